@@ -1,0 +1,252 @@
+/*
+ * mipt.h -- C ABI of libmipt.so, the MI355X-native wavefront path tracer that
+ * replaces the optixTrace / raygen / closest-hit / miss pipeline of
+ * SDK/optixPathTracer (and, later, SDK/imgui_test) of awegsche/OptiX_Raytracer.
+ *
+ * Plain C: pointers, sizes, PODs.  No torch / HIP types in any signature
+ * (a stream is passed as `void*` holding a hipStream_t; NULL = default stream).
+ * Every entry point returns a MiptResult (0 = success), like OptixResult
+ * (reference: include/optix_types.h, OPTIX_CHECK in SDK/sutil/Exception.h:82-112).
+ * Contexts are not thread safe (same as the reference samples: one host thread,
+ * one stream per state, SDK/optixPathTracer/optixPathTracer.cpp:442).
+ *
+ * File:line citations are relative to /root/reference.
+ */
+#ifndef MIPT_H
+#define MIPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPT_ABI_VERSION 1
+
+typedef enum MiptResult {
+    MIPT_SUCCESS                 = 0,
+    MIPT_ERROR_INVALID_VALUE     = 1,
+    MIPT_ERROR_OUT_OF_MEMORY     = 2,
+    MIPT_ERROR_HIP               = 3,   /* a HIP runtime call failed; see mipt_last_error_string */
+    MIPT_ERROR_NO_DEVICE         = 4,
+    MIPT_ERROR_INVALID_HANDLE    = 5,   /* traversable handle unknown to this context */
+    MIPT_ERROR_NOT_CONFIGURED    = 6,   /* launch before hit-group records / accel were set */
+    MIPT_ERROR_BVH_TOO_DEEP      = 7,
+    MIPT_ERROR_INTERNAL          = 8
+} MiptResult;
+
+typedef struct MiptContext MiptContext;
+
+/* same signature as the OptiX log callback used by the samples
+ * (SDK/optixPathTracer/optixPathTracer.cpp:530-533) */
+typedef void (*MiptLogCallback)(unsigned int level, const char* tag, const char* message, void* cbdata);
+
+/* ---------------------------------------------------------------------------
+ * Structs kept bit-for-bit from the reference
+ * ------------------------------------------------------------------------- */
+
+/* ParallelogramLight, SDK/optixPathTracer/optixPathTracer.h:82-88 (60 bytes) */
+typedef struct MiptParallelogramLight {
+    float corner[3];
+    float v1[3], v2[3];
+    float normal[3];
+    float emission[3];
+} MiptParallelogramLight;
+
+/* Params, SDK/optixPathTracer/optixPathTracer.h:91-107 -- 152 bytes, align 8:
+ * subframe_index 0, accum_buffer 8, frame_buffer 16, width 24, height 28,
+ * samples_per_launch 32, eye 36, U 48, V 60, W 72, light 84, handle 144.
+ * accum_buffer: width*height float4 (device), index y*width+x, row 0 = bottom.
+ * frame_buffer: width*height uchar4 (device), sRGB8, alpha 255. */
+typedef struct MiptParams {
+    unsigned int           subframe_index;
+    void*                  accum_buffer;
+    void*                  frame_buffer;
+    unsigned int           width;
+    unsigned int           height;
+    unsigned int           samples_per_launch;
+    float                  eye[3];
+    float                  U[3];
+    float                  V[3];
+    float                  W[3];
+    MiptParallelogramLight light;
+    unsigned long long     handle;      /* OptixTraversableHandle stays an opaque u64 */
+} MiptParams;
+
+/* MissData, optixPathTracer.h:115-118 */
+typedef struct MiptMissData {
+    float bg_color[4];
+} MiptMissData;
+
+/* HitGroupData, optixPathTracer.h:121-126 (32 bytes).  `vertices` is a DEVICE
+ * pointer to float4-strided vertices, 3 per primitive, owned by the caller and
+ * kept alive until the context is destroyed (optixPathTracer.cpp:877). */
+typedef struct MiptHitGroupData {
+    float       emission_color[3];
+    float       diffuse_color[3];
+    const void* vertices;
+} MiptHitGroupData;
+
+/* ---------------------------------------------------------------------------
+ * BVH memory layout (device and export): linear arrays, 64-byte nodes.
+ * ------------------------------------------------------------------------- */
+
+/* inner node: both children's boxes + references.
+ * ref >= 0 : inner node index;  ref < 0 : leaf, ~ref = (first_tri << 4) | count */
+typedef struct MiptBvhNode {
+    float    c0x[2], c0y[2];   /* child0 lo.x hi.x lo.y hi.y */
+    float    c1x[2], c1y[2];   /* child1 lo.x hi.x lo.y hi.y */
+    float    c0z[2], c1z[2];   /* child0 lo.z hi.z | child1 lo.z hi.z */
+    int32_t  c0, c1;
+    uint32_t pad0, pad1;
+} MiptBvhNode;
+
+/* triangle in leaf order: v0, e1 = v1 - v0, e2 = v2 - v0 (fp32), original index */
+typedef struct MiptBvhTri {
+    float v0[3]; uint32_t prim;
+    float e1[3]; uint32_t pad1;
+    float e2[3]; uint32_t pad2;
+} MiptBvhTri;
+
+typedef struct MiptAccelInfo {
+    uint32_t num_nodes;
+    uint32_t num_triangles;
+    uint32_t depth;            /* deepest leaf; traversal stack needs <= depth entries */
+    uint32_t leaf_max;
+    uint64_t device_bytes;
+    double   build_seconds;
+} MiptAccelInfo;
+
+/* one triangle build input == OptixBuildInputTriangleArray as the samples use it
+ * (optixPathTracer.cpp:610-621; sutil/Scene.cpp:900-960; imgui_test/triangle_gas.cpp:196-214) */
+typedef struct MiptBuildInput {
+    const void*     vertices;            /* host or device pointer (detected) */
+    uint32_t        num_vertices;
+    uint32_t        vertex_stride_bytes; /* 0 => 12 (packed float3) */
+    const void*     indices;             /* NULL => non-indexed, 3 consecutive vertices per triangle */
+    uint32_t        index_format;        /* 0 none, 2 = uint16 triplets, 4 = uint32 triplets */
+    uint32_t        index_stride_bytes;  /* bytes between triplets; 0 => 3*index_format */
+    uint32_t        num_triangles;       /* indexed: number of triplets; else num_vertices/3 */
+    const uint32_t* sbt_index_offsets;   /* per-triangle hit-group record index (host or device), NULL => 0 */
+    const float*    transform3x4;        /* optional row-major 3x4 object->world (host), NULL => identity */
+} MiptBuildInput;
+
+typedef struct MiptLaunchStats {
+    uint64_t closest_rays;     /* primary + continuation rays traced by the last launch */
+    uint64_t shadow_rays;      /* occlusion rays traced by the last launch */
+    uint64_t node_visits;      /* only counted when mipt_set_option(MIPT_OPT_COUNT_VISITS, 1) */
+    uint64_t tri_tests;
+    uint32_t bounces;          /* wavefront iterations executed */
+    uint32_t reserved;
+} MiptLaunchStats;
+
+typedef enum MiptOption {
+    MIPT_OPT_MAX_DEPTH    = 1, /* 0 = unbounded (reference behaviour, Russian roulette only);
+                                  k = at most k closest-hit queries per path (build extension) */
+    MIPT_OPT_COUNT_VISITS = 2, /* 1 = traversal kernels count node visits / triangle tests */
+    MIPT_OPT_TRACE_GRID   = 3, /* persistent-kernel workgroups per CU (0 = default) */
+    MIPT_OPT_PERSISTENT   = 4, /* 1 (default) persistent traversal kernels, 0 = one thread per ray */
+    MIPT_OPT_PROFILE      = 5  /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings) */
+} MiptOption;
+
+/* per-kernel device time of the last launch, summed over its wavefront iterations (ms);
+ * only filled when MIPT_OPT_PROFILE is on */
+typedef struct MiptLaunchTimings {
+    float    ms_raygen, ms_trace_closest, ms_shade, ms_trace_any, ms_resolve;
+    uint32_t n_trace_closest, n_trace_any;   /* kernel launches behind the sums */
+} MiptLaunchTimings;
+
+/* ---------------------------------------------------------------------------
+ * Context   (replaces createContext, optixPathTracer.cpp:555-573)
+ * ------------------------------------------------------------------------- */
+int         mipt_abi_version(void);
+int         mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int log_level, MiptContext** out);
+int         mipt_context_destroy(MiptContext* ctx);
+const char* mipt_error_name(int result);
+const char* mipt_last_error_string(const MiptContext* ctx);
+int         mipt_set_option(MiptContext* ctx, int option, uint64_t value);
+int         mipt_get_option(const MiptContext* ctx, int option, uint64_t* value);
+
+/* ---------------------------------------------------------------------------
+ * Acceleration structure   (replaces buildMeshAccel / optixAccelBuild+Compact,
+ * optixPathTracer.cpp:576-684; library owns BVH memory)
+ * ------------------------------------------------------------------------- */
+int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs,
+                     unsigned long long* handle_out);
+int mipt_accel_destroy(MiptContext* ctx, unsigned long long handle);
+int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccelInfo* info);
+/* copies the linear BVH to host arrays sized from mipt_accel_info (inspection, external checkers) */
+int mipt_accel_export(const MiptContext* ctx, unsigned long long handle,
+                      MiptBvhNode* nodes_out, MiptBvhTri* tris_out);
+
+/* Host-only build (no device needed): the same builder, for inspection and for checking the BVH
+ * without a GPU.  vertices9: num_triangles * 9 floats (v0 v1 v2, world space). */
+typedef struct MiptHostBvh MiptHostBvh;
+int mipt_host_bvh_create(const float* vertices9, uint32_t num_triangles, MiptHostBvh** out);
+int mipt_host_bvh_info(const MiptHostBvh* bvh, MiptAccelInfo* info);
+int mipt_host_bvh_copy(const MiptHostBvh* bvh, MiptBvhNode* nodes_out, MiptBvhTri* tris_out);
+int mipt_host_bvh_destroy(MiptHostBvh* bvh);
+
+/* ---------------------------------------------------------------------------
+ * Shader binding table   (replaces createSBT, optixPathTracer.cpp:829-898;
+ * the programs themselves are fixed-function kernels of this library)
+ * ------------------------------------------------------------------------- */
+int mipt_sbt_set_hitgroups(MiptContext* ctx, const MiptHitGroupData* records, uint32_t count);
+int mipt_sbt_set_miss(MiptContext* ctx, const MiptMissData* miss);
+
+/* ---------------------------------------------------------------------------
+ * Launch   (replaces cudaMemcpyAsync(params) + optixLaunch in launchSubframe,
+ * optixPathTracer.cpp:488-511).  `params` is a HOST pointer to the 152-byte
+ * struct; width/height/depth as optixLaunch (depth must be 1).
+ * ------------------------------------------------------------------------- */
+int mipt_launch(MiptContext* ctx, void* stream, const MiptParams* params,
+                unsigned int width, unsigned int height, unsigned int depth);
+int mipt_sync(MiptContext* ctx);
+int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats);
+int mipt_get_launch_timings(MiptContext* ctx, MiptLaunchTimings* timings);
+
+/* ---------------------------------------------------------------------------
+ * Ray-buffer queries (precedent: SDK/optixRaycasting, Ray/Hit buffers,
+ * optixRaycastingKernels.h:35-47).  rays: n * {ox,oy,oz,tmin, dx,dy,dz,tmax}
+ * (device).  hits: n * {t, prim(as bits), u, v} (device); miss => t = -1, prim = ~0.
+ * occluded: n * uint32 (device), 1 = any hit in (tmin,tmax).
+ * ------------------------------------------------------------------------- */
+int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle,
+                       const void* rays, uint32_t n, void* hits);
+int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle,
+                   const void* rays, uint32_t n, void* occluded);
+
+/* ---------------------------------------------------------------------------
+ * Multi-GPU image-tile sharding (precedent: SDK/optixMultiGPU +
+ * StaticWorkDistribution, sutil/WorkDistribution.h:34-91: 8x4 tiles, strip of
+ * `world` tiles, tile->rank rotated per strip row).  Each rank renders its
+ * pixels into a compact float4 buffer of mipt_shard_num_samples() entries;
+ * the caller all-gathers the shards (RCCL) and calls mipt_unpermute.
+ * ------------------------------------------------------------------------- */
+int mipt_shard_num_samples(unsigned int width, unsigned int height, unsigned int world, uint32_t* n_out);
+int mipt_shard_pixel(unsigned int width, unsigned int height, unsigned int world, unsigned int rank,
+                     uint32_t sample_idx, int32_t* px, int32_t* py);
+/* params->accum_buffer / frame_buffer are ignored; compact_accum (device, in/out) holds
+ * this rank's running average, indexed by sample index. */
+int mipt_launch_shard(MiptContext* ctx, void* stream, const MiptParams* params,
+                      unsigned int width, unsigned int height,
+                      unsigned int rank, unsigned int world, void* compact_accum);
+/* gathered: world * num_samples float4 (device), rank-major; writes canonical accum + frame */
+int mipt_unpermute(MiptContext* ctx, void* stream, const void* gathered, unsigned int world,
+                   unsigned int width, unsigned int height, void* accum_buffer, void* frame_buffer);
+
+/* ---------------------------------------------------------------------------
+ * Host helpers mirroring sutil (kept API: SDK/sutil/Camera.h:38-76)
+ * ------------------------------------------------------------------------- */
+/* Camera::UVWFrame, SDK/sutil/Camera.cpp:34-46 (fod = m_fod, the fork's focal scale) */
+void mipt_camera_uvw(const float eye[3], const float lookat[3], const float up[3],
+                     float fovY_deg, float aspect, float fod, float U[3], float V[3], float W[3]);
+/* deterministic synthetic scene of SURVEY.md 8(d) "C4": n triangles in the unit cube,
+ * written as 3 float4 {x,y,z,0} per triangle (the reference's Vertex layout) to host memory */
+int  mipt_scene_random_triangles(uint32_t n, uint32_t seed_tag, float edge_scale, float* vertices4_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPT_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libmipt.so -- the C ABI declared in include/mipt.h.
+
+The library must exist (built in-tree by `__graft_entry__.build()` or
+`make -C optix_raytracer_amd/csrc`); there is no fallback path: a missing
+library raises ImportError-like RuntimeError on first use.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmipt.so")
+
+
+class MiptParallelogramLight(C.Structure):
+    _fields_ = [("corner", C.c_float * 3), ("v1", C.c_float * 3), ("v2", C.c_float * 3),
+                ("normal", C.c_float * 3), ("emission", C.c_float * 3)]
+
+
+class MiptParams(C.Structure):
+    """`struct Params`, SDK/optixPathTracer/optixPathTracer.h:91-107 (152 bytes)."""
+    _fields_ = [("subframe_index", C.c_uint), ("accum_buffer", C.c_void_p), ("frame_buffer", C.c_void_p),
+                ("width", C.c_uint), ("height", C.c_uint), ("samples_per_launch", C.c_uint),
+                ("eye", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3),
+                ("light", MiptParallelogramLight), ("handle", C.c_ulonglong)]
+
+
+class MiptMissData(C.Structure):
+    _fields_ = [("bg_color", C.c_float * 4)]
+
+
+class MiptHitGroupData(C.Structure):
+    _fields_ = [("emission_color", C.c_float * 3), ("diffuse_color", C.c_float * 3), ("vertices", C.c_void_p)]
+
+
+class MiptAccelInfo(C.Structure):
+    _fields_ = [("num_nodes", C.c_uint32), ("num_triangles", C.c_uint32), ("depth", C.c_uint32),
+                ("leaf_max", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double)]
+
+
+class MiptBuildInput(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("num_vertices", C.c_uint32), ("vertex_stride_bytes", C.c_uint32),
+                ("indices", C.c_void_p), ("index_format", C.c_uint32), ("index_stride_bytes", C.c_uint32),
+                ("num_triangles", C.c_uint32), ("sbt_index_offsets", C.c_void_p), ("transform3x4", C.c_void_p)]
+
+
+class MiptLaunchStats(C.Structure):
+    _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("bounces", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class MiptLaunchTimings(C.Structure):
+    _fields_ = [("ms_raygen", C.c_float), ("ms_trace_closest", C.c_float), ("ms_shade", C.c_float),
+                ("ms_trace_any", C.c_float), ("ms_resolve", C.c_float),
+                ("n_trace_closest", C.c_uint32), ("n_trace_any", C.c_uint32)]
+
+
+LOG_CALLBACK = C.CFUNCTYPE(None, C.c_uint, C.c_char_p, C.c_char_p, C.c_void_p)
+
+OPT_MAX_DEPTH, OPT_COUNT_VISITS, OPT_TRACE_GRID, OPT_PERSISTENT, OPT_PROFILE = 1, 2, 3, 4, 5
+
+# every symbol include/mipt.h declares: (name, restype, argtypes)
+_vp, _u32, _u64 = C.c_void_p, C.c_uint32, C.c_uint64
+_fp = C.POINTER(C.c_float)
+SYMBOLS = [
+    ("mipt_abi_version", C.c_int, []),
+    ("mipt_context_create", C.c_int, [C.c_int, LOG_CALLBACK, _vp, C.c_int, C.POINTER(_vp)]),
+    ("mipt_context_destroy", C.c_int, [_vp]),
+    ("mipt_error_name", C.c_char_p, [C.c_int]),
+    ("mipt_last_error_string", C.c_char_p, [_vp]),
+    ("mipt_set_option", C.c_int, [_vp, C.c_int, _u64]),
+    ("mipt_get_option", C.c_int, [_vp, C.c_int, C.POINTER(_u64)]),
+    ("mipt_accel_build", C.c_int, [_vp, C.POINTER(MiptBuildInput), _u32, C.POINTER(C.c_ulonglong)]),
+    ("mipt_accel_destroy", C.c_int, [_vp, C.c_ulonglong]),
+    ("mipt_accel_info", C.c_int, [_vp, C.c_ulonglong, C.POINTER(MiptAccelInfo)]),
+    ("mipt_accel_export", C.c_int, [_vp, C.c_ulonglong, _vp, _vp]),
+    ("mipt_host_bvh_create", C.c_int, [_vp, _u32, C.POINTER(_vp)]),
+    ("mipt_host_bvh_info", C.c_int, [_vp, C.POINTER(MiptAccelInfo)]),
+    ("mipt_host_bvh_copy", C.c_int, [_vp, _vp, _vp]),
+    ("mipt_host_bvh_destroy", C.c_int, [_vp]),
+    ("mipt_sbt_set_hitgroups", C.c_int, [_vp, C.POINTER(MiptHitGroupData), _u32]),
+    ("mipt_sbt_set_miss", C.c_int, [_vp, C.POINTER(MiptMissData)]),
+    ("mipt_launch", C.c_int, [_vp, _vp, C.POINTER(MiptParams), C.c_uint, C.c_uint, C.c_uint]),
+    ("mipt_sync", C.c_int, [_vp]),
+    ("mipt_get_launch_stats", C.c_int, [_vp, C.POINTER(MiptLaunchStats)]),
+    ("mipt_get_launch_timings", C.c_int, [_vp, C.POINTER(MiptLaunchTimings)]),
+    ("mipt_trace_closest", C.c_int, [_vp, _vp, C.c_ulonglong, _vp, _u32, _vp]),
+    ("mipt_trace_any", C.c_int, [_vp, _vp, C.c_ulonglong, _vp, _u32, _vp]),
+    ("mipt_shard_num_samples", C.c_int, [C.c_uint, C.c_uint, C.c_uint, C.POINTER(_u32)]),
+    ("mipt_shard_pixel", C.c_int, [C.c_uint, C.c_uint, C.c_uint, C.c_uint, _u32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("mipt_launch_shard", C.c_int, [_vp, _vp, C.POINTER(MiptParams), C.c_uint, C.c_uint, C.c_uint, C.c_uint, _vp]),
+    ("mipt_unpermute", C.c_int, [_vp, _vp, _vp, C.c_uint, C.c_uint, C.c_uint, _vp, _vp]),
+    ("mipt_camera_uvw", None, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp]),
+    ("mipt_scene_random_triangles", C.c_int, [_u32, _u32, C.c_float, _vp]),
+]
+
+_lib = None
+
+
+def load():
+    """Loads libmipt.so.  torch is imported first so that the process has ONE HIP runtime
+    (the one bundled with PyTorch-ROCm, same SONAME libamdhip64.so.7) shared by torch tensors,
+    RCCL and this library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libmipt.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C optix_raytracer_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if L.mipt_abi_version() != 1:
+        raise RuntimeError("libmipt.so ABI version mismatch")
+    _lib = L
+    return L

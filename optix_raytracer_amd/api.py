@@ -1,0 +1,208 @@
+"""Thin object layer over the C ABI (include/mipt.h).  Errors raise MiptError, the
+counterpart of sutil::Exception thrown by OPTIX_CHECK (SDK/sutil/Exception.h:82-112)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class MiptError(RuntimeError):
+    def __init__(self, code, name, detail):
+        super().__init__("%s (%d): %s" % (name, code, detail))
+        self.code = code
+        self.name = name
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def camera_uvw(eye, lookat, up, fov_y, aspect, fod=1.0):
+    """sutil::Camera::UVWFrame (SDK/sutil/Camera.cpp:34-46) evaluated by the library's host code."""
+    U, V, W = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    L.load().mipt_camera_uvw(_f3(eye), _f3(lookat), _f3(up), fov_y, aspect, fod, U, V, W)
+    return np.array(U, np.float32), np.array(V, np.float32), np.array(W, np.float32)
+
+
+def random_triangles(n, seed_tag=0x5EED, edge_scale=0.01):
+    """Synthetic scene of SURVEY.md 8(d): returns (n*3, 4) float32 vertices (float4 stride)."""
+    out = np.empty((n * 3, 4), np.float32)
+    rc = L.load().mipt_scene_random_triangles(n, seed_tag, edge_scale, out.ctypes.data)
+    if rc:
+        raise MiptError(rc, "mipt_scene_random_triangles", "failed")
+    return out
+
+
+def shard_num_samples(width, height, world):
+    n = C.c_uint32()
+    rc = L.load().mipt_shard_num_samples(width, height, world, C.byref(n))
+    if rc:
+        raise MiptError(rc, "MIPT_ERROR_INVALID_VALUE", "shard_num_samples")
+    return n.value
+
+
+def shard_pixel(width, height, world, rank, sample):
+    x, y = C.c_int32(), C.c_int32()
+    rc = L.load().mipt_shard_pixel(width, height, world, rank, sample, C.byref(x), C.byref(y))
+    if rc:
+        raise MiptError(rc, "MIPT_ERROR_INVALID_VALUE", "shard_pixel")
+    return x.value, y.value
+
+
+def host_bvh(vertices4):
+    """Builds the BVH on the host only (no GPU): returns (nodes (n,16) f32 view of 64-B nodes,
+    tris (m,12) f32 view of 48-B triangles, info dict).  vertices4: (n*3, 4) float32."""
+    lib = L.load()
+    v = np.ascontiguousarray(np.asarray(vertices4, np.float32).reshape(-1, 4)[:, :3]).reshape(-1, 9)
+    h = C.c_void_p()
+    rc = lib.mipt_host_bvh_create(v.ctypes.data, v.shape[0], C.byref(h))
+    if rc:
+        raise MiptError(rc, lib.mipt_error_name(rc).decode(), "mipt_host_bvh_create")
+    try:
+        info = L.MiptAccelInfo()
+        lib.mipt_host_bvh_info(h, C.byref(info))
+        nodes = np.zeros((info.num_nodes, 16), np.float32)
+        tris = np.zeros((max(info.num_triangles, 1), 12), np.float32)
+        lib.mipt_host_bvh_copy(h, nodes.ctypes.data, tris.ctypes.data)
+    finally:
+        lib.mipt_host_bvh_destroy(h)
+    return nodes, tris[:info.num_triangles], {k: getattr(info, k) for k, _ in info._fields_}
+
+
+class Context:
+    """A device context (createContext, optixPathTracer.cpp:555-573)."""
+
+    def __init__(self, device=0, log=None, log_level=0):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        self._log_py = log
+
+        def _cb(level, tag, msg, _):
+            if self._log_py:
+                self._log_py(level, tag.decode(), msg.decode())
+        self._cb = L.LOG_CALLBACK(_cb)
+        rc = self._lib.mipt_context_create(device, self._cb, None, log_level, C.byref(self._h))
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_context_create(device=%d)" % device)
+        self.device = device
+
+    def _check(self, rc):
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(),
+                            self._lib.mipt_last_error_string(self._h).decode())
+
+    def destroy(self):
+        if self._h:
+            self._lib.mipt_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # ---- options
+    def set_option(self, opt, value):
+        self._check(self._lib.mipt_set_option(self._h, opt, int(value)))
+
+    def get_option(self, opt):
+        v = C.c_uint64()
+        self._check(self._lib.mipt_get_option(self._h, opt, C.byref(v)))
+        return v.value
+
+    # ---- accel
+    def accel_build(self, inputs):
+        """inputs: list of dicts {vertices(ptr|ndarray), num_vertices, stride, indices, index_format,
+        num_triangles, sbt_index_offsets, transform}"""
+        arr = (L.MiptBuildInput * len(inputs))()
+        keep = []
+        for i, d in enumerate(inputs):
+            bi = arr[i]
+
+            def ptr(x):
+                if x is None:
+                    return None
+                if isinstance(x, np.ndarray):
+                    x = np.ascontiguousarray(x)
+                    keep.append(x)
+                    return x.ctypes.data
+                return int(x)
+            bi.vertices = ptr(d["vertices"])
+            bi.num_vertices = int(d["num_vertices"])
+            bi.vertex_stride_bytes = int(d.get("stride", 0))
+            bi.indices = ptr(d.get("indices"))
+            bi.index_format = int(d.get("index_format", 0))
+            bi.index_stride_bytes = int(d.get("index_stride", 0))
+            bi.num_triangles = int(d.get("num_triangles", 0))
+            bi.sbt_index_offsets = ptr(d.get("sbt_index_offsets"))
+            t = d.get("transform")
+            if t is not None:
+                t = np.ascontiguousarray(t, dtype=np.float32).reshape(12)
+                keep.append(t)
+                bi.transform3x4 = t.ctypes.data
+        h = C.c_ulonglong()
+        self._check(self._lib.mipt_accel_build(self._h, arr, len(inputs), C.byref(h)))
+        return h.value
+
+    def accel_destroy(self, handle):
+        self._check(self._lib.mipt_accel_destroy(self._h, handle))
+
+    def accel_info(self, handle):
+        info = L.MiptAccelInfo()
+        self._check(self._lib.mipt_accel_info(self._h, handle, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_}
+
+    def accel_export(self, handle):
+        info = self.accel_info(handle)
+        nodes = np.zeros((info["num_nodes"], 16), np.float32)
+        tris = np.zeros((max(info["num_triangles"], 1), 12), np.float32)
+        self._check(self._lib.mipt_accel_export(self._h, handle, nodes.ctypes.data, tris.ctypes.data))
+        return nodes, tris[:info["num_triangles"]]
+
+    # ---- SBT
+    def sbt_set_hitgroups(self, records):
+        """records: list of (emission3, diffuse3, device_vertices_ptr)"""
+        arr = (L.MiptHitGroupData * max(len(records), 1))()
+        for i, (em, df, vp) in enumerate(records):
+            arr[i].emission_color = _f3(em)
+            arr[i].diffuse_color = _f3(df)
+            arr[i].vertices = int(vp) if vp else None
+        self._check(self._lib.mipt_sbt_set_hitgroups(self._h, arr, len(records)))
+
+    def sbt_set_miss(self, bg):
+        m = L.MiptMissData()
+        m.bg_color = (C.c_float * 4)(*[float(x) for x in bg])
+        self._check(self._lib.mipt_sbt_set_miss(self._h, C.byref(m)))
+
+    # ---- launch
+    def launch(self, params, width, height, depth=1, stream=None):
+        self._check(self._lib.mipt_launch(self._h, stream, C.byref(params), width, height, depth))
+
+    def launch_shard(self, params, width, height, rank, world, compact_accum_ptr, stream=None):
+        self._check(self._lib.mipt_launch_shard(self._h, stream, C.byref(params), width, height, rank, world,
+                                                compact_accum_ptr))
+
+    def unpermute(self, gathered_ptr, world, width, height, accum_ptr, frame_ptr, stream=None):
+        self._check(self._lib.mipt_unpermute(self._h, stream, gathered_ptr, world, width, height, accum_ptr, frame_ptr))
+
+    def sync(self):
+        self._check(self._lib.mipt_sync(self._h))
+
+    def launch_stats(self):
+        s = L.MiptLaunchStats()
+        self._check(self._lib.mipt_get_launch_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+
+    def launch_timings(self):
+        t = L.MiptLaunchTimings()
+        self._check(self._lib.mipt_get_launch_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    # ---- ray-buffer queries
+    def trace_closest(self, handle, rays_ptr, n, hits_ptr, stream=None):
+        self._check(self._lib.mipt_trace_closest(self._h, stream, handle, rays_ptr, n, hits_ptr))
+
+    def trace_any(self, handle, rays_ptr, n, occluded_ptr, stream=None):
+        self._check(self._lib.mipt_trace_any(self._h, stream, handle, rays_ptr, n, occluded_ptr))

@@ -1,0 +1,81 @@
+// kernels.h -- host-visible launch interface of the HIP kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mipt.h"
+
+namespace mipt {
+
+constexpr int      kStackEntries  = 32;     // LDS traversal stack entries per lane == builder depth cap
+constexpr uint32_t kInvalidSlot   = 0xffffffffu;
+constexpr int      kNumSegments   = 8;      // one ray-range segment per XCD
+constexpr int      kCursorStride  = 32;     // uint32 words between cursors (own 128-B line each)
+constexpr uint32_t kChunk         = 256;    // rays a wave takes from a segment cursor at a time
+
+// device-resident queue counters + statistics (one per context)
+struct DeviceCounters {
+    uint32_t n_cur;            // live paths entering this bounce
+    uint32_t n_next;           // continuation rays emitted by shade
+    uint32_t n_shadow;         // shadow rays emitted by shade
+    uint32_t bounce;
+    uint32_t cursor_closest[kNumSegments * kCursorStride];
+    uint32_t cursor_shadow[kNumSegments * kCursorStride];
+    unsigned long long closest_rays, shadow_rays, node_visits, tri_tests;
+};
+
+struct DeviceBvh {
+    const float4* nodes;       // 4 x float4 per MiptBvhNode
+    const float4* tris;        // 3 x float4 per MiptBvhTri
+    const uint32_t* mat_index; // per ORIGINAL primitive: hit-group record index
+};
+
+// SoA path queues, capacity `cap` entries each
+struct PathQueue {
+    float4* ray_o;             // origin.xyz, tmin
+    float4* ray_d;             // direction.xyz, tmax
+    float4* state_a;           // attenuation.xyz, seed (bits)
+    uint2*  state_b;           // result slot, depth
+};
+
+struct ShadowQueue {
+    float4* ray_o;
+    float4* ray_d;
+    float4* contrib;           // radiance*attenuation .xyz, result slot (bits)
+};
+
+struct FrameConsts {           // the by-value part of Params (optixPathTracer.h:91-107)
+    uint32_t width, height, subframe_index, samples_per_launch;
+    float eye[3], U[3], V[3], W[3];
+    MiptParallelogramLight light;
+    float bg[4];
+    uint32_t max_depth;
+    // sharding: world == 0 -> full frame (slot = pixel index, 8x8-tile path order)
+    uint32_t world, rank, n_paths;   // n_paths: padded path count launched per sample
+};
+
+struct TraceOpts {
+    int  persistent;           // 1: persistent waves + refill, 0: one thread per ray
+    int  count_visits;
+    int  blocks;               // persistent grid size (workgroups of 64)
+};
+
+// ---- launches (all asynchronous on `st`) ----
+void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths);
+void launch_advance(hipStream_t st, DeviceCounters* ctr);
+void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result);
+void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
+                          const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o);
+// mode 1: occluded flags (uint32 per ray); mode 2: accumulate contrib into result when unoccluded
+void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
+                      const uint32_t* n_ptr, uint32_t n_max, uint32_t* occluded, const float4* contrib, float4* result,
+                      DeviceCounters* ctr, const TraceOpts& o);
+void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
+                  uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
+                  float4* result, DeviceCounters* ctr, uint32_t n_max);
+void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots);
+void launch_unpermute(hipStream_t st, const float4* gathered, uint32_t world, uint32_t width, uint32_t height,
+                      float4* accum, uint32_t* frame);
+
+}  // namespace mipt

@@ -1,0 +1,621 @@
+// kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, wave64).
+//
+// Wavefront replacement of the OptiX megakernel that optixLaunch runs in
+// SDK/optixPathTracer (file:line below relative to /root/reference):
+//
+//   k_raygen        <- __raygen__rg prologue            optixPathTracer.cu:249-281
+//   k_trace<0>      <- optixTraverse closest hit        optixPathTracer.cu:184-197   (driver-internal BVH walk)
+//   k_shade         <- __closesthit__radiance / __miss__radiance + the raygen bounce loop body
+//                                                         optixPathTracer.cu:291-303, 323-413
+//   k_trace<2>      <- traceOcclusion (any hit)         optixPathTracer.cu:218-240 + radiance add :292
+//   k_resolve       <- raygen epilogue                  optixPathTracer.cu:308-319
+//   k_unpermute     <- multi-GPU merge                  optixMultiGPU.cu:282-292 (scatter by StaticWorkDistribution)
+//
+// Traversal is HBM/cache-latency bound pointer chasing (64-B nodes, 48-B triangles); MFMA is not used.
+// One ray per lane, per-lane traversal stack in LDS ([entry][lane] -> conflict free), persistent waves
+// that refill idle lanes from per-XCD ray-range cursors, wave-ballot compaction of the output queues.
+// Floating point: -ffp-contract=off, explicit fmaf only where the specification says so.
+#include "kernels.h"
+#include "detmath.h"
+
+namespace mipt {
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers (wave64)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// compacting append: lanes with `push` get consecutive indices in a queue whose length lives at `counter`
+__device__ __forceinline__ uint32_t wave_append(bool push, uint32_t* counter)
+{
+    const unsigned long long m = __ballot(push);
+    if (m == 0ull) return 0u;
+    const int leader = __builtin_ctzll(m);
+    uint32_t base = 0u;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    return base + lane_rank(m);
+}
+
+__device__ __forceinline__ void wave_add64(unsigned long long* dst, uint32_t v)
+{
+    // wave reduction by DPP-free shuffles, one atomic per wave
+    uint32_t s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += (uint32_t)__shfl_down((int)s, off, 64);
+    if ((threadIdx.x & 63u) == 0u && s) atomicAdd(dst, (unsigned long long)s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// traversal core (build-defined conventions, identical sequence in oracle/pt_oracle.c):
+//   hit iff tmin < t < tmax; double sided; det == 0 rejected; u >= 0, v >= 0, u + v <= 1;
+//   closest-hit tie -> lowest original primitive index; near child first, tie -> child 0 first.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fdot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3    fcross(f3 a, f3 b)
+{
+    return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+               __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+constexpr int kSentinel = (int)0x80000000;
+
+struct Trav {
+    f3       o, d, idir, nood;   // nood = -(o * idir)
+    float    tmin, tmax, tbest;
+    float    u, v;
+    uint32_t prim;
+    int      node, sp;
+};
+
+__device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd)
+{
+    T.o = mk3(ro.x, ro.y, ro.z);
+    T.d = mk3(rd.x, rd.y, rd.z);
+    T.tmin = ro.w; T.tmax = rd.w; T.tbest = rd.w;
+    const float eps = 8.27180613e-25f;   // 2^-80: keeps 1/d finite for axis-parallel rays
+    const float dx = __builtin_fabsf(T.d.x) > eps ? T.d.x : __builtin_copysignf(eps, T.d.x);
+    const float dy = __builtin_fabsf(T.d.y) > eps ? T.d.y : __builtin_copysignf(eps, T.d.y);
+    const float dz = __builtin_fabsf(T.d.z) > eps ? T.d.z : __builtin_copysignf(eps, T.d.z);
+    T.idir = mk3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    T.nood = mk3(-(T.o.x * T.idir.x), -(T.o.y * T.idir.y), -(T.o.z * T.idir.z));
+    T.u = 0.0f; T.v = 0.0f; T.prim = 0xffffffffu;
+    T.node = 0; T.sp = 0;
+}
+
+__device__ __forceinline__ int stack_pop(Trav& T, const uint32_t* stk, int lane)
+{
+    if (T.sp == 0) return kSentinel;
+    --T.sp;
+    return (int)stk[T.sp * 64 + lane];
+}
+
+// one inner-node step: fetch 64 B, slab-test both children, descend into the nearer, push the other
+__device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ nodes, uint32_t* stk, int lane)
+{
+    const float4* np = nodes + (size_t)(uint32_t)T.node * 4u;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
+    const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
+    const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
+    const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
+    const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
+    const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
+    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                      __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
+    const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                      __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
+    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                      __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
+    const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                      __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
+    const bool h0 = tn0 <= tf0;
+    const bool h1 = tn1 <= tf1;
+    int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+    if (!h0 && !h1) {
+        T.node = stack_pop(T, stk, lane);
+    } else if (h0 && h1) {
+        const bool swp = tn1 < tn0;
+        const int nearc = swp ? c1 : c0;
+        const int farc  = swp ? c0 : c1;
+        stk[T.sp * 64 + lane] = (uint32_t)farc;
+        ++T.sp;
+        T.node = nearc;
+    } else {
+        T.node = h0 ? c0 : c1;
+    }
+}
+
+// leaf step: Moeller-Trumbore on (v0, e1, e2); returns true when ANY mode may terminate
+template <bool ANY>
+__device__ __forceinline__ bool visit_leaf(Trav& T, const float4* __restrict__ tris, uint32_t& n_tests)
+{
+    const uint32_t desc = ~(uint32_t)T.node;
+    const uint32_t first = desc >> 4, cnt = desc & 15u;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const float4* tp = tris + (size_t)(first + i) * 3u;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        ++n_tests;
+        const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+        const f3 p  = fcross(T.d, e2);
+        const float det = fdot(e1, p);
+        if (det == 0.0f) continue;
+        const float inv = 1.0f / det;
+        const f3 tv = T.o - mk3(a.x, a.y, a.z);
+        const float u = fdot(tv, p) * inv;
+        const f3 q = fcross(tv, e1);
+        const float v = fdot(T.d, q) * inv;
+        const float t = fdot(e2, q) * inv;
+        if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) continue;
+        if (!(t > T.tmin && t < T.tmax)) continue;
+        const uint32_t prim = f2u(a.w);
+        if (ANY) { T.tbest = t; T.prim = prim; return true; }
+        if (t < T.tbest || (t == T.tbest && prim < T.prim)) { T.tbest = t; T.prim = prim; T.u = u; T.v = v; }
+    }
+    return false;
+}
+
+struct TraceArgs {
+    DeviceBvh       bvh;
+    const float4*   ray_o;
+    const float4*   ray_d;
+    uint32_t        stride;       // float4 elements between consecutive rays (1 = SoA planes, 2 = interleaved)
+    const uint32_t* n_ptr;        // device-side ray count (may be null)
+    uint32_t        n_max;
+    float4*         hits;         // MODE 0
+    uint32_t*       occluded;     // MODE 1
+    const float4*   contrib;      // MODE 2
+    float4*         result;       // MODE 2
+    uint32_t*       cursors;      // kNumSegments cursors, kCursorStride apart
+    DeviceCounters* ctr;
+};
+
+template <int MODE>
+__device__ __forceinline__ void finish_ray(const TraceArgs& a, const Trav& T, uint32_t ray, bool hit)
+{
+    if (MODE == 0) {
+        a.hits[ray] = hit ? make_float4(T.tbest, u2f(T.prim), T.u, T.v) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+    } else if (MODE == 1) {
+        a.occluded[ray] = hit ? 1u : 0u;
+    } else {
+        if (!hit) {
+            // result += radiance * attenuation (optixPathTracer.cu:292); one path per slot is in flight
+            const float4 c = a.contrib[ray];
+            const uint32_t slot = f2u(c.w);
+            float4 r = a.result[slot];
+            r.x += c.x; r.y += c.y; r.z += c.z;
+            a.result[slot] = r;
+        }
+    }
+}
+
+// ---- persistent waves: 64 lanes, each lane owns one ray; idle lanes are refilled from the ray range ----
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(64) void k_trace_persistent(TraceArgs a)
+{
+    __shared__ uint32_t stk[kStackEntries * 64];
+    const int lane = (int)threadIdx.x;
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    // segment s covers [s*seg_len, min((s+1)*seg_len, n)); blocks with equal blockIdx%8 share an XCD (speed only)
+    const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
+    uint32_t seg = blockIdx.x & (kNumSegments - 1);
+    uint32_t tried = 0;
+    uint32_t pool_next = 0, pool_end = 0;
+    bool     active = false;
+    uint32_t ray = 0;
+    uint32_t n_visits = 0, n_tests = 0;
+    Trav T;
+    T.node = kSentinel; T.sp = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------------ refill
+        const unsigned long long idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        const bool exhausted = tried >= (uint32_t)kNumSegments && pool_next == pool_end;
+        if (n_idle == 64 || (n_idle >= 24 && !exhausted)) {
+            const uint32_t rank = lane_rank(idle);
+            uint32_t given = 0;
+            while (given < (uint32_t)n_idle) {
+                if (pool_next == pool_end) {
+                    if (tried >= (uint32_t)kNumSegments) break;
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(&a.cursors[seg * kCursorStride], kChunk);
+                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                    const uint32_t lo = seg * seg_len;
+                    uint32_t hi = lo + seg_len; hi = hi < n ? hi : n;
+                    if (lo >= hi || c >= hi - lo) { seg = (seg + 1u) & (kNumSegments - 1); ++tried; continue; }
+                    pool_next = lo + c;
+                    pool_end  = pool_next + kChunk < hi ? pool_next + kChunk : hi;
+                }
+                const uint32_t avail = pool_end - pool_next;
+                const uint32_t want  = (uint32_t)n_idle - given;
+                const uint32_t take  = avail < want ? avail : want;
+                if (!active && rank >= given && rank < given + take) {
+                    ray = pool_next + (rank - given);
+                    const float4 ro = a.ray_o[(size_t)ray * a.stride];
+                    const float4 rd = a.ray_d[(size_t)ray * a.stride];
+                    trav_init(T, ro, rd);
+                    active = true;
+                }
+                pool_next += take;
+                given += take;
+            }
+            if (__ballot(active) == 0ull) break;
+        }
+        // ------------------------------------------------------------------ traverse (while-while)
+        while (active && T.node >= 0) {
+            if (COUNT) ++n_visits;
+            visit_inner(T, a.bvh.nodes, stk, lane);
+        }
+        if (active && T.node != kSentinel) {          // a leaf reference
+            const bool stop = visit_leaf<(MODE != 0)>(T, a.bvh.tris, n_tests);
+            if (stop) { finish_ray<MODE>(a, T, ray, true); active = false; T.node = kSentinel; }
+            else T.node = stack_pop(T, stk, lane);
+        }
+        if (active && T.node == kSentinel) {
+            finish_ray<MODE>(a, T, ray, MODE == 0 ? (T.prim != 0xffffffffu) : false);
+            active = false;
+        }
+    }
+    if (COUNT) {
+        wave_add64(&a.ctr->node_visits, n_visits);
+        wave_add64(&a.ctr->tri_tests, n_tests);
+    }
+}
+
+// ---- one thread per ray (no refill); same per-ray visiting order ----
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
+{
+    __shared__ uint32_t stk[kStackEntries * 64];
+    const int lane = (int)threadIdx.x;
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    const uint32_t ray = blockIdx.x * 64u + threadIdx.x;
+    uint32_t n_visits = 0, n_tests = 0;
+    if (ray < n) {
+        Trav T;
+        trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+        bool hit = false;
+        while (T.node != kSentinel) {
+            while (T.node >= 0) {
+                if (COUNT) ++n_visits;
+                visit_inner(T, a.bvh.nodes, stk, lane);
+            }
+            if (T.node != kSentinel) {
+                if (visit_leaf<(MODE != 0)>(T, a.bvh.tris, n_tests)) { hit = true; break; }
+                T.node = stack_pop(T, stk, lane);
+            }
+        }
+        if (MODE == 0) hit = T.prim != 0xffffffffu;
+        finish_ray<MODE>(a, T, ray, hit);
+    }
+    if (COUNT) {
+        wave_add64(&a.ctr->node_visits, n_visits);
+        wave_add64(&a.ctr->tri_tests, n_tests);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// queue bookkeeping
+// ------------------------------------------------------------------------------------------------
+__global__ void k_begin_sample(DeviceCounters* c, uint32_t n_paths)
+{
+    const uint32_t i = threadIdx.x;
+    if (i == 0) { c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; }
+    if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
+}
+
+__global__ void k_advance(DeviceCounters* c)
+{
+    const uint32_t i = threadIdx.x;
+    if (i == 0) { c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce += 1; }
+    if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// raygen: optixPathTracer.cu:249-281.  Path i -> pixel by 8x8 tiles (one wave = one tile) for full
+// frames, or by the StaticWorkDistribution map for a rank's shard.  The raygen-local seed advances
+// by the two jitter draws only (the path's own stream is discarded, :260-278), so it is kept per slot.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fc.n_paths) return;
+    int px, py; uint32_t slot; bool valid;
+    if (fc.world == 0u) {
+        const uint32_t tiles_x = (fc.width + 7u) >> 3;
+        const uint32_t tile = i >> 6, in = i & 63u;
+        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        px = (int)(tx * 8u + (in & 7u));
+        py = (int)(ty * 8u + (in >> 3));
+        valid = (uint32_t)px < fc.width && (uint32_t)py < fc.height;
+        slot = (uint32_t)py * fc.width + (uint32_t)px;
+    } else {
+        shard_pixel(fc.width, fc.world, fc.rank, i, px, py);
+        valid = (uint32_t)px < fc.width && (uint32_t)py < fc.height;
+        slot = i;
+    }
+    if (!valid) {
+        // padding lane: a ray with an empty interval, killed by shade
+        q.ray_o[i]   = make_float4(0.f, 0.f, 0.f, 1.0f);
+        q.ray_d[i]   = make_float4(0.f, 0.f, 1.f, 0.0f);
+        q.state_a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q.state_b[i] = make_uint2(kInvalidSlot, 0u);
+        if (fc.world != 0u && sample == 0u) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    uint32_t seed = sample == 0u ? tea4((uint32_t)py * fc.width + (uint32_t)px, fc.subframe_index) : rg_seed[slot];
+    const float jx = rnd(seed);
+    const float jy = rnd(seed);
+    rg_seed[slot] = seed;
+    const float dx = 2.0f * (((float)px + jx) / (float)fc.width) - 1.0f;
+    const float dy = 2.0f * (((float)py + jy) / (float)fc.height) - 1.0f;
+    const f3 U = mk3(fc.U[0], fc.U[1], fc.U[2]), V = mk3(fc.V[0], fc.V[1], fc.V[2]), W = mk3(fc.W[0], fc.W[1], fc.W[2]);
+    const f3 dir = normalize(dx * U + dy * V + W);
+    q.ray_o[i]   = make_float4(fc.eye[0], fc.eye[1], fc.eye[2], 0.01f);
+    q.ray_d[i]   = make_float4(dir.x, dir.y, dir.z, 1e16f);
+    q.state_a[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
+    q.state_b[i] = make_uint2(slot, 0u);
+    if (sample == 0u) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// shade: __closesthit__radiance (optixPathTracer.cu:338-413), __miss__radiance (:323-335) and the
+// caller's per-bounce bookkeeping (:291-303).  Emits the NEE shadow ray and the continuation ray
+// into compacted queues.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cosine_sample_hemisphere(float u1, float u2, f3& p)
+{
+    const float r   = __builtin_sqrtf(u1);
+    const float phi = (2.0f * 3.14159265358979323846f) * u2;
+    float sn, cs;
+    det_sincos(phi, sn, cs);
+    p.x = r * cs;
+    p.y = r * sn;
+    p.z = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
+}
+
+__device__ __forceinline__ f3 onb_inverse_transform(f3 n, f3 p)
+{
+    f3 b;
+    if (__builtin_fabsf(n.x) > __builtin_fabsf(n.z)) b = mk3(-n.y, n.x, 0.0f);
+    else                                             b = mk3(0.0f, -n.z, n.y);
+    b = normalize(b);
+    const f3 t = cross(b, n);
+    return p.x * t + p.y * b + p.z * n;
+}
+
+struct ShadeArgs {
+    FrameConsts             fc;
+    DeviceBvh               bvh;
+    const MiptHitGroupData* hitgroups;
+    uint32_t                n_hitgroups;
+    PathQueue               cur;
+    const float4*           hits;
+    PathQueue               next;
+    ShadowQueue             shadow;
+    float4*                 result;
+    DeviceCounters*         ctr;
+    uint32_t                n_max;
+};
+
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
+{
+    uint32_t n = a.ctr->n_cur;
+    n = n < a.n_max ? n : a.n_max;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (n + 63u) & ~63u;      // whole waves take part in the ballots
+    uint32_t my_closest = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        bool push_next = false, push_shadow = false;
+        float4 nro, nrd, nsa; uint2 nsb;
+        float4 sro, srd, sc;
+        if (i < n) {
+            const uint2 sb = a.cur.state_b[i];
+            const uint32_t slot = sb.x, depth = sb.y;
+            if (slot != kInvalidSlot) {
+                ++my_closest;
+                const float4 hit = a.hits[i];
+                const float4 sa = a.cur.state_a[i];
+                f3 att = mk3(sa.x, sa.y, sa.z);
+                uint32_t seed = f2u(sa.w);
+                float4 res = a.result[slot];
+                if (hit.x < 0.0f) {
+                    // miss: radiance = bg, emitted = 0, done (optixPathTracer.cu:323-335)
+                    const f3 rad = mk3(a.fc.bg[0], a.fc.bg[1], a.fc.bg[2]) * att;
+                    res.x += 0.0f; res.y += 0.0f; res.z += 0.0f;
+                    res.x += rad.x; res.y += rad.y; res.z += rad.z;
+                    a.result[slot] = res;
+                } else {
+                    const float4 ro4 = a.cur.ray_o[i], rd4 = a.cur.ray_d[i];
+                    const f3 ray_o = mk3(ro4.x, ro4.y, ro4.z), ray_d = mk3(rd4.x, rd4.y, rd4.z);
+                    const uint32_t prim = f2u(hit.y);
+                    uint32_t m = a.bvh.mat_index[prim];
+                    m = m < a.n_hitgroups ? m : a.n_hitgroups - 1u;
+                    const MiptHitGroupData rec = a.hitgroups[m];
+                    const float4* vb = reinterpret_cast<const float4*>(rec.vertices) + (size_t)prim * 3u;
+                    const float4 a0 = vb[0], a1 = vb[1], a2 = vb[2];
+                    const f3 v0 = mk3(a0.x, a0.y, a0.z), v1 = mk3(a1.x, a1.y, a1.z), v2 = mk3(a2.x, a2.y, a2.z);
+                    const f3 N0 = normalize(cross(v1 - v0, v2 - v0));
+                    const f3 N  = faceforward(N0, -ray_d, N0);
+                    const f3 P  = ray_o + hit.x * ray_d;
+
+                    // emitted only for camera rays (:352-355); added before the radiance term (:291)
+                    if (depth == 0u) { res.x += rec.emission_color[0]; res.y += rec.emission_color[1]; res.z += rec.emission_color[2]; }
+                    else             { res.x += 0.0f; res.y += 0.0f; res.z += 0.0f; }
+                    a.result[slot] = res;
+
+                    const float z1 = rnd(seed);
+                    const float z2 = rnd(seed);
+                    f3 w_in;
+                    cosine_sample_hemisphere(z1, z2, w_in);
+                    const f3 new_dir = onb_inverse_transform(N, w_in);
+                    att = att * mk3(rec.diffuse_color[0], rec.diffuse_color[1], rec.diffuse_color[2]);
+
+                    const float l1 = rnd(seed);
+                    const float l2 = rnd(seed);
+                    const MiptParallelogramLight& lt = a.fc.light;
+                    const f3 lv1 = mk3(lt.v1[0], lt.v1[1], lt.v1[2]), lv2 = mk3(lt.v2[0], lt.v2[1], lt.v2[2]);
+                    const f3 light_pos = mk3(lt.corner[0], lt.corner[1], lt.corner[2]) + lv1 * l1 + lv2 * l2;
+                    const f3 toL = light_pos - P;
+                    const float Ldist = length(toL);
+                    const f3 L = normalize(toL);
+                    const float nDl  = dot(N, L);
+                    const float LnDl = -dot(mk3(lt.normal[0], lt.normal[1], lt.normal[2]), L);
+                    if (nDl > 0.0f && LnDl > 0.0f) {
+                        const float A = length(cross(lv1, lv2));
+                        const float weight = nDl * LnDl * A / (3.14159265358979323846f * Ldist * Ldist);
+                        const f3 radiance = mk3(lt.emission[0], lt.emission[1], lt.emission[2]) * weight;
+                        const f3 c = radiance * att;
+                        push_shadow = true;
+                        sro = make_float4(P.x, P.y, P.z, 0.01f);
+                        srd = make_float4(L.x, L.y, L.z, Ldist - 0.01f);
+                        sc  = make_float4(c.x, c.y, c.z, u2f(slot));
+                    }
+                    // Russian roulette + continuation (:294-303)
+                    const float lum = dot(att, mk3(0.30f, 0.59f, 0.11f));
+                    const bool done = rnd(seed) > lum;
+                    const bool capped = a.fc.max_depth != 0u && depth + 1u >= a.fc.max_depth;
+                    if (!done && !capped) {
+                        const float inv = 1.0f / lum;
+                        att = att * inv;
+                        push_next = true;
+                        nro = make_float4(P.x, P.y, P.z, 0.01f);
+                        nrd = make_float4(new_dir.x, new_dir.y, new_dir.z, 1e16f);
+                        nsa = make_float4(att.x, att.y, att.z, u2f(seed));
+                        nsb = make_uint2(slot, depth + 1u);
+                    }
+                }
+            }
+        }
+        const uint32_t js = wave_append(push_shadow, &a.ctr->n_shadow);
+        if (push_shadow) { a.shadow.ray_o[js] = sro; a.shadow.ray_d[js] = srd; a.shadow.contrib[js] = sc; }
+        const uint32_t jn = wave_append(push_next, &a.ctr->n_next);
+        if (push_next) { a.next.ray_o[jn] = nro; a.next.ray_d[jn] = nrd; a.next.state_a[jn] = nsa; a.next.state_b[jn] = nsb; }
+        const unsigned long long ms = __ballot(push_shadow);
+        if ((threadIdx.x & 63u) == 0u && ms) atomicAdd(&a.ctr->shadow_rays, (unsigned long long)__popcll(ms));
+    }
+    wave_add64(&a.ctr->closest_rays, my_closest);
+}
+
+// ------------------------------------------------------------------------------------------------
+// resolve: optixPathTracer.cu:308-319
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve(FrameConsts fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const float4 r = result[i];
+    const float inv_spp = 1.0f / (float)fc.samples_per_launch;
+    f3 c = mk3(r.x, r.y, r.z) * inv_spp;
+    if (fc.subframe_index > 0u) {
+        const float a = 1.0f / (float)(fc.subframe_index + 1u);
+        const float4 p = accum[i];
+        c = lerp3(mk3(p.x, p.y, p.z), c, a);
+    }
+    accum[i] = make_float4(c.x, c.y, c.z, 1.0f);
+    if (frame) frame[i] = make_color(c);
+}
+
+__global__ __launch_bounds__(256) void k_unpermute(const float4* gathered, uint32_t world, uint32_t width, uint32_t height,
+                                                   uint32_t ns, float4* accum, uint32_t* frame)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= world * ns) return;
+    const uint32_t rank = i / ns, s = i - rank * ns;
+    int px, py;
+    shard_pixel(width, world, rank, s, px, py);
+    if ((uint32_t)px >= width || (uint32_t)py >= height) return;
+    const float4 v = gathered[i];
+    const uint32_t p = (uint32_t)py * width + (uint32_t)px;
+    accum[p] = v;
+    if (frame) frame[p] = make_color(mk3(v.x, v.y, v.z));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths)
+{
+    hipLaunchKernelGGL(k_begin_sample, dim3(1), dim3(64), 0, st, ctr, n_paths);
+}
+
+void launch_advance(hipStream_t st, DeviceCounters* ctr)
+{
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctr);
+}
+
+void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result)
+{
+    const uint32_t blocks = (fc.n_paths + 255u) / 256u;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, fc, sample, q, rg_seed, result);
+}
+
+template <int MODE>
+static void launch_trace(hipStream_t st, const TraceArgs& a, const TraceOpts& o)
+{
+    if (a.n_max == 0) return;
+    if (o.persistent) {
+        const int blocks = o.blocks > 0 ? o.blocks : 4096;
+        if (o.count_visits) hipLaunchKernelGGL((k_trace_persistent<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
+        else                hipLaunchKernelGGL((k_trace_persistent<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
+    } else {
+        const uint32_t blocks = (a.n_max + 63u) / 64u;
+        if (o.count_visits) hipLaunchKernelGGL((k_trace_simple<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
+        else                hipLaunchKernelGGL((k_trace_simple<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
+    }
+}
+
+void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
+                          const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o)
+{
+    TraceArgs a{};
+    a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
+    a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr;
+    launch_trace<0>(st, a, o);
+}
+
+void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
+                      const uint32_t* n_ptr, uint32_t n_max, uint32_t* occluded, const float4* contrib, float4* result,
+                      DeviceCounters* ctr, const TraceOpts& o)
+{
+    TraceArgs a{};
+    a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
+    a.occluded = occluded; a.contrib = contrib; a.result = result; a.cursors = ctr->cursor_shadow; a.ctr = ctr;
+    if (occluded) launch_trace<1>(st, a, o);
+    else          launch_trace<2>(st, a, o);
+}
+
+void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
+                  uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
+                  float4* result, DeviceCounters* ctr, uint32_t n_max)
+{
+    ShadeArgs a{};
+    a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur; a.hits = hits;
+    a.next = next; a.shadow = shadow; a.result = result; a.ctr = ctr; a.n_max = n_max;
+    uint32_t blocks = (n_max + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    if (blocks == 0u) blocks = 1u;
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots)
+{
+    const uint32_t blocks = (n_slots + 255u) / 256u;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, st, fc, result, accum, frame, n_slots);
+}
+
+void launch_unpermute(hipStream_t st, const float4* gathered, uint32_t world, uint32_t width, uint32_t height,
+                      float4* accum, uint32_t* frame)
+{
+    const uint32_t ns = shard_num_samples(width, height, world);
+    const uint32_t total = world * ns;
+    hipLaunchKernelGGL(k_unpermute, dim3((total + 255u) / 256u), dim3(256), 0, st, gathered, world, width, height, ns, accum, frame);
+}
+
+}  // namespace mipt

@@ -1,0 +1,773 @@
+// mipt_api.cpp -- the C ABI of libmipt.so (include/mipt.h): context, acceleration structures,
+// hit-group records, and the host side of the wavefront launch.
+//
+// Mirrors the per-sample "state" functions of the reference (SDK/optixPathTracer/optixPathTracer.cpp):
+//   createContext :555-573   -> mipt_context_create
+//   buildMeshAccel :576-684  -> mipt_accel_build          (BVH owned by the library)
+//   createSBT :829-898       -> mipt_sbt_set_hitgroups / mipt_sbt_set_miss
+//   launchSubframe :488-511  -> mipt_launch               (params passed by value to the kernels,
+//                                                          no cudaMemcpyAsync of Params needed)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mipt.h"
+#include "bvh_build.h"
+#include "detmath.h"
+#include "kernels.h"
+
+using namespace mipt;
+
+static_assert(sizeof(MiptParams) == 152, "Params layout must match optixPathTracer.h:91-107");
+static_assert(offsetof(MiptParams, accum_buffer) == 8 && offsetof(MiptParams, frame_buffer) == 16, "Params layout");
+static_assert(offsetof(MiptParams, width) == 24 && offsetof(MiptParams, samples_per_launch) == 32, "Params layout");
+static_assert(offsetof(MiptParams, eye) == 36 && offsetof(MiptParams, U) == 48 && offsetof(MiptParams, W) == 72, "Params layout");
+static_assert(offsetof(MiptParams, light) == 84 && offsetof(MiptParams, handle) == 144, "Params layout");
+static_assert(sizeof(MiptParallelogramLight) == 60, "ParallelogramLight layout");
+static_assert(sizeof(MiptHitGroupData) == 32, "HitGroupData layout");
+static_assert(sizeof(MiptBvhNode) == 64 && sizeof(MiptBvhTri) == 48, "BVH layout");
+
+namespace {
+
+struct Accel {
+    HostBvh   host;
+    float4*   d_nodes = nullptr;
+    float4*   d_tris  = nullptr;
+    uint32_t* d_mat   = nullptr;
+    uint32_t  n_prims = 0;
+    uint64_t  bytes   = 0;
+};
+
+enum TimedKind { T_RAYGEN = 0, T_CLOSEST, T_SHADE, T_ANY, T_RESOLVE, T_KINDS };
+
+}  // namespace
+
+struct MiptContext {
+    int             device = 0;
+    int             num_cus = 256;
+    MiptLogCallback cb = nullptr;
+    void*           cbdata = nullptr;
+    int             log_level = 0;
+    std::string     last_error;
+
+    std::unordered_map<unsigned long long, Accel*> accels;
+    unsigned long long next_handle = 0x4d495054ull << 16;   // "MIPT"
+
+    MiptHitGroupData* d_hitgroups = nullptr;
+    uint32_t          n_hitgroups = 0;
+    MiptMissData      miss{};
+
+    // options
+    uint32_t max_depth = 0;
+    int      count_visits = 0;
+    int      blocks_per_cu = 0;
+    int      persistent = 1;
+    int      profile = 0;
+
+    // launch buffers
+    size_t          cap_paths = 0, cap_slots = 0;
+    PathQueue       q[2]{};
+    ShadowQueue     sq{};
+    float4*         hits = nullptr;
+    float4*         result = nullptr;
+    uint32_t*       rg_seed = nullptr;
+    DeviceCounters* d_ctr = nullptr;
+    uint32_t*       h_pinned = nullptr;
+    hipStream_t     last_stream = nullptr;
+    uint32_t        last_bounces = 0;
+
+    // per-kernel timing (MIPT_OPT_PROFILE)
+    struct Timed { hipEvent_t a, b; int kind; };
+    std::vector<Timed>      timed;
+    std::vector<hipEvent_t> event_pool;
+    size_t                  events_used = 0;
+
+    void log(unsigned level, const char* tag, const char* fmt, ...)
+    {
+        if (!cb || (int)level > log_level) return;
+        char buf[1024];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        cb(level, tag, buf, cbdata);
+    }
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[1024];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        last_error = buf;
+        if (cb && log_level >= 2) cb(2, "ERROR", buf, cbdata);
+        return code;
+    }
+    hipEvent_t get_event()
+    {
+        if (events_used == event_pool.size()) {
+            hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            event_pool.push_back(e);
+        }
+        return event_pool[events_used++];
+    }
+};
+
+#define HIPCHK(ctx, call)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return (ctx)->fail(e_ == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, \
+                               "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+namespace {
+
+struct TimedScope {
+    MiptContext* c; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr;
+    TimedScope(MiptContext* c_, hipStream_t st_, int kind_) : c(c_), st(st_), kind(kind_)
+    {
+        if (c->profile) { a = c->get_event(); b = c->get_event(); if (a) (void)hipEventRecord(a, st); }
+    }
+    ~TimedScope()
+    {
+        if (c->profile && a && b) { (void)hipEventRecord(b, st); c->timed.push_back({ a, b, kind }); }
+    }
+};
+
+bool is_device_pointer(const void* p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof attr);
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// copies `bytes` from a host-or-device pointer into host storage
+int fetch_to_host(MiptContext* ctx, const void* src, size_t bytes, std::vector<uint8_t>& dst)
+{
+    dst.resize(bytes);
+    if (bytes == 0) return MIPT_SUCCESS;
+    if (is_device_pointer(src)) HIPCHK(ctx, hipMemcpy(dst.data(), src, bytes, hipMemcpyDeviceToHost));
+    else                        std::memcpy(dst.data(), src, bytes);
+    return MIPT_SUCCESS;
+}
+
+void free_accel(Accel* a)
+{
+    if (!a) return;
+    if (a->d_nodes) (void)hipFree(a->d_nodes);
+    if (a->d_tris) (void)hipFree(a->d_tris);
+    if (a->d_mat) (void)hipFree(a->d_mat);
+    delete a;
+}
+
+void free_launch_buffers(MiptContext* c)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (c->q[i].ray_o) (void)hipFree(c->q[i].ray_o);
+        if (c->q[i].state_a) (void)hipFree(c->q[i].state_a);
+        if (c->q[i].state_b) (void)hipFree(c->q[i].state_b);
+        c->q[i] = PathQueue{};
+    }
+    if (c->sq.ray_o) (void)hipFree(c->sq.ray_o);
+    if (c->sq.contrib) (void)hipFree(c->sq.contrib);
+    c->sq = ShadowQueue{};
+    if (c->hits) (void)hipFree(c->hits);
+    if (c->result) (void)hipFree(c->result);
+    if (c->rg_seed) (void)hipFree(c->rg_seed);
+    c->hits = nullptr; c->result = nullptr; c->rg_seed = nullptr;
+    c->cap_paths = 0; c->cap_slots = 0;
+}
+
+// SoA queues: ray_o and ray_d are two planes of one allocation
+int ensure_capacity(MiptContext* c, size_t n_paths, size_t n_slots)
+{
+    if (n_paths <= c->cap_paths && n_slots <= c->cap_slots) return MIPT_SUCCESS;
+    const size_t np = std::max(n_paths, c->cap_paths), ns = std::max(n_slots, c->cap_slots);
+    free_launch_buffers(c);
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, hipMalloc((void**)&c->q[i].ray_o, np * 2 * sizeof(float4)));
+        c->q[i].ray_d = c->q[i].ray_o + np;
+        HIPCHK(c, hipMalloc((void**)&c->q[i].state_a, np * sizeof(float4)));
+        HIPCHK(c, hipMalloc((void**)&c->q[i].state_b, np * sizeof(uint2)));
+    }
+    HIPCHK(c, hipMalloc((void**)&c->sq.ray_o, np * 2 * sizeof(float4)));
+    c->sq.ray_d = c->sq.ray_o + np;
+    HIPCHK(c, hipMalloc((void**)&c->sq.contrib, np * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->hits, np * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->result, ns * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->rg_seed, ns * sizeof(uint32_t)));
+    c->cap_paths = np; c->cap_slots = ns;
+    c->log(4, "LAUNCH", "queues sized for %zu paths / %zu slots (%.1f MB)", np, ns,
+           (double)(np * (2 * (32 + 16 + 8) + 32 + 16 + 16) + ns * 20) / 1e6);
+    return MIPT_SUCCESS;
+}
+
+TraceOpts trace_opts(const MiptContext* c)
+{
+    TraceOpts o{};
+    o.persistent = c->persistent;
+    o.count_visits = c->count_visits;
+    o.blocks = c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 16);
+    return o;
+}
+
+int default_build_threads()
+{
+    int threads = (int)std::thread::hardware_concurrency();
+    return threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+}
+
+Accel* find_accel(const MiptContext* c, unsigned long long h)
+{
+    auto it = c->accels.find(h);
+    return it == c->accels.end() ? nullptr : it->second;
+}
+
+DeviceBvh device_bvh(const Accel* a)
+{
+    DeviceBvh b{};
+    b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat;
+    return b;
+}
+
+int check_launch(MiptContext* ctx, const MiptParams* p, unsigned width, unsigned height, unsigned depth, Accel** acc)
+{
+    if (!p) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "params is null");
+    if (depth != 1) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "launch depth must be 1 (got %u)", depth);
+    if (width == 0 || height == 0 || width != p->width || height != p->height)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "launch size %ux%u does not match params %ux%u", width, height, p->width, p->height);
+    if ((uint64_t)width * height > (1ull << 30)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "launch too large");
+    if (p->samples_per_launch == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "samples_per_launch must be >= 1");
+    *acc = find_accel(ctx, p->handle);
+    if (!*acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
+    if (!ctx->d_hitgroups || ctx->n_hitgroups == 0) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "no hit-group records set (mipt_sbt_set_hitgroups)");
+    return MIPT_SUCCESS;
+}
+
+FrameConsts make_consts(const MiptContext* c, const MiptParams* p)
+{
+    FrameConsts fc{};
+    fc.width = p->width; fc.height = p->height; fc.subframe_index = p->subframe_index;
+    fc.samples_per_launch = p->samples_per_launch;
+    std::memcpy(fc.eye, p->eye, 12); std::memcpy(fc.U, p->U, 12); std::memcpy(fc.V, p->V, 12); std::memcpy(fc.W, p->W, 12);
+    fc.light = p->light;
+    std::memcpy(fc.bg, c->miss.bg_color, 16);
+    fc.max_depth = c->max_depth;
+    return fc;
+}
+
+// the wavefront loop shared by full-frame and shard launches
+int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc, const Accel* acc, size_t n_slots,
+                  float4* accum_out, uint32_t* frame_out)
+{
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_paths = fc.n_paths;
+    int rc = ensure_capacity(ctx, n_paths, n_slots);
+    if (rc) return rc;
+    ctx->last_stream = st;
+    ctx->events_used = 0; ctx->timed.clear();
+    const DeviceBvh bvh = device_bvh(acc);
+    const TraceOpts opts = trace_opts(ctx);
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 4 * sizeof(unsigned long long), st));
+    uint32_t bounces_total = 0;
+    for (uint32_t s = 0; s < fc.samples_per_launch; ++s) {
+        launch_begin_sample(st, ctx->d_ctr, n_paths);
+        { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result); }
+        int cur = 0;
+        for (uint32_t bounce = 0;; ++bounce) {
+            { TimedScope t(ctx, st, T_CLOSEST);
+              launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, n_paths, ctx->hits, ctx->d_ctr, opts); }
+            { TimedScope t(ctx, st, T_SHADE);
+              launch_shade(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->hits, ctx->q[cur ^ 1], ctx->sq,
+                           ctx->result, ctx->d_ctr, n_paths); }
+            { TimedScope t(ctx, st, T_ANY);
+              launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, n_paths, nullptr, ctx->sq.contrib,
+                               ctx->result, ctx->d_ctr, opts); }
+            launch_advance(st, ctx->d_ctr);
+            cur ^= 1;
+            ++bounces_total;
+            if (fc.max_depth != 0u) {
+                if (bounce + 1u >= fc.max_depth) break;
+                continue;             // bounded paths: no host round trip, empty queues make the kernels exit at once
+            }
+            // unbounded (reference behaviour): stop when Russian roulette has ended every path
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, &ctx->d_ctr->n_cur, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            if (*ctx->h_pinned == 0u) break;
+            if (bounce > 100000u) return ctx->fail(MIPT_ERROR_INTERNAL, "path length runaway");
+        }
+    }
+    { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots); }
+    ctx->last_bounces = bounces_total;
+    HIPCHK(ctx, hipGetLastError());
+    return MIPT_SUCCESS;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int mipt_abi_version(void) { return MIPT_ABI_VERSION; }
+
+const char* mipt_error_name(int r)
+{
+    switch (r) {
+    case MIPT_SUCCESS: return "MIPT_SUCCESS";
+    case MIPT_ERROR_INVALID_VALUE: return "MIPT_ERROR_INVALID_VALUE";
+    case MIPT_ERROR_OUT_OF_MEMORY: return "MIPT_ERROR_OUT_OF_MEMORY";
+    case MIPT_ERROR_HIP: return "MIPT_ERROR_HIP";
+    case MIPT_ERROR_NO_DEVICE: return "MIPT_ERROR_NO_DEVICE";
+    case MIPT_ERROR_INVALID_HANDLE: return "MIPT_ERROR_INVALID_HANDLE";
+    case MIPT_ERROR_NOT_CONFIGURED: return "MIPT_ERROR_NOT_CONFIGURED";
+    case MIPT_ERROR_BVH_TOO_DEEP: return "MIPT_ERROR_BVH_TOO_DEEP";
+    case MIPT_ERROR_INTERNAL: return "MIPT_ERROR_INTERNAL";
+    default: return "MIPT_ERROR_UNKNOWN";
+    }
+}
+
+int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int log_level, MiptContext** out)
+{
+    if (!out) return MIPT_ERROR_INVALID_VALUE;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return MIPT_ERROR_NO_DEVICE; }
+    if (hip_device < 0 || hip_device >= n) return MIPT_ERROR_INVALID_VALUE;
+    if (hipSetDevice(hip_device) != hipSuccess) return MIPT_ERROR_HIP;
+    if (hipFree(nullptr) != hipSuccess) return MIPT_ERROR_HIP;     // same idiom as cudaFree(0), optixPathTracer.cpp:558
+    MiptContext* c = new MiptContext();
+    c->device = hip_device; c->cb = cb; c->cbdata = cbdata; c->log_level = log_level;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) {
+        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        c->log(4, "CONTEXT", "device %d: %s, %d CUs, arch %s", hip_device, prop.name, c->num_cus, prop.gcnArchName);
+    }
+    if (hipMalloc((void**)&c->d_ctr, sizeof(DeviceCounters)) != hipSuccess ||
+        hipMemset(c->d_ctr, 0, sizeof(DeviceCounters)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_pinned, 64) != hipSuccess) {
+        delete c;
+        return MIPT_ERROR_OUT_OF_MEMORY;
+    }
+    *out = c;
+    return MIPT_SUCCESS;
+}
+
+int mipt_context_destroy(MiptContext* c)
+{
+    if (!c) return MIPT_ERROR_INVALID_VALUE;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : c->accels) free_accel(kv.second);
+    free_launch_buffers(c);
+    if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
+    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    delete c;
+    return MIPT_SUCCESS;
+}
+
+const char* mipt_last_error_string(const MiptContext* c) { return c ? c->last_error.c_str() : "null context"; }
+
+int mipt_set_option(MiptContext* c, int option, uint64_t value)
+{
+    if (!c) return MIPT_ERROR_INVALID_VALUE;
+    switch (option) {
+    case MIPT_OPT_MAX_DEPTH: c->max_depth = (uint32_t)value; return MIPT_SUCCESS;
+    case MIPT_OPT_COUNT_VISITS: c->count_visits = value ? 1 : 0; return MIPT_SUCCESS;
+    case MIPT_OPT_TRACE_GRID:
+        if (value > 32) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 32 single-wave workgroups fit a CU");
+        c->blocks_per_cu = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_PERSISTENT: c->persistent = value ? 1 : 0; return MIPT_SUCCESS;
+    case MIPT_OPT_PROFILE: c->profile = value ? 1 : 0; return MIPT_SUCCESS;
+    default: return c->fail(MIPT_ERROR_INVALID_VALUE, "unknown option %d", option);
+    }
+}
+
+int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
+{
+    if (!c || !value) return MIPT_ERROR_INVALID_VALUE;
+    switch (option) {
+    case MIPT_OPT_MAX_DEPTH: *value = c->max_depth; return MIPT_SUCCESS;
+    case MIPT_OPT_COUNT_VISITS: *value = (uint64_t)c->count_visits; return MIPT_SUCCESS;
+    case MIPT_OPT_TRACE_GRID: *value = (uint64_t)c->blocks_per_cu; return MIPT_SUCCESS;
+    case MIPT_OPT_PERSISTENT: *value = (uint64_t)c->persistent; return MIPT_SUCCESS;
+    case MIPT_OPT_PROFILE: *value = (uint64_t)c->profile; return MIPT_SUCCESS;
+    default: return MIPT_ERROR_INVALID_VALUE;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs, unsigned long long* handle_out)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!inputs || num_inputs == 0 || !handle_out) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_build: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<float>    world;     // 9 floats per triangle
+    std::vector<uint32_t> mats;
+    for (uint32_t k = 0; k < num_inputs; ++k) {
+        const MiptBuildInput& in = inputs[k];
+        const uint32_t stride = in.vertex_stride_bytes ? in.vertex_stride_bytes : 12u;
+        if (stride < 12u || (stride & 3u)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: vertex stride %u", k, stride);
+        if (in.num_vertices && !in.vertices) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: null vertices", k);
+        uint32_t n_tris = in.num_triangles;
+        if (!in.indices || in.index_format == 0) {
+            if (n_tris == 0) n_tris = in.num_vertices / 3u;
+            if ((uint64_t)n_tris * 3u > in.num_vertices) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: %u triangles need %u vertices, got %u", k, n_tris, n_tris * 3u, in.num_vertices);
+        } else if (in.index_format != 2u && in.index_format != 4u) {
+            return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: index format %u (expected 0, 2 or 4)", k, in.index_format);
+        }
+        std::vector<uint8_t> vbuf, ibuf, mbuf;
+        int rc = fetch_to_host(ctx, in.vertices, in.num_vertices ? (size_t)(in.num_vertices - 1) * stride + 12u : 0u, vbuf);
+        if (rc) return rc;
+        const bool indexed = in.indices && in.index_format != 0;
+        const uint32_t istride = indexed ? (in.index_stride_bytes ? in.index_stride_bytes : 3u * in.index_format) : 0u;
+        if (indexed) { rc = fetch_to_host(ctx, in.indices, n_tris ? (size_t)(n_tris - 1) * istride + 3u * in.index_format : 0u, ibuf); if (rc) return rc; }
+        if (in.sbt_index_offsets) { rc = fetch_to_host(ctx, in.sbt_index_offsets, (size_t)n_tris * 4u, mbuf); if (rc) return rc; }
+        const size_t base = world.size() / 9;
+        world.resize((base + n_tris) * 9);
+        mats.resize(base + n_tris);
+        for (uint32_t t = 0; t < n_tris; ++t) {
+            uint32_t vi[3];
+            if (indexed) {
+                const uint8_t* ip = ibuf.data() + (size_t)t * istride;
+                for (int c = 0; c < 3; ++c) {
+                    if (in.index_format == 2u) { uint16_t v; std::memcpy(&v, ip + 2 * c, 2); vi[c] = v; }
+                    else                       { std::memcpy(&vi[c], ip + 4 * c, 4); }
+                    if (vi[c] >= in.num_vertices) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: index %u out of range (%u vertices)", k, vi[c], in.num_vertices);
+                }
+            } else {
+                vi[0] = 3 * t; vi[1] = 3 * t + 1; vi[2] = 3 * t + 2;
+            }
+            float* w = world.data() + (base + t) * 9;
+            for (int c = 0; c < 3; ++c) {
+                float v[3];
+                std::memcpy(v, vbuf.data() + (size_t)vi[c] * stride, 12);
+                if (in.transform3x4) {
+                    const float* m = in.transform3x4;
+                    for (int r = 0; r < 3; ++r) w[3 * c + r] = ((m[4 * r] * v[0] + m[4 * r + 1] * v[1]) + m[4 * r + 2] * v[2]) + m[4 * r + 3];
+                } else {
+                    w[3 * c] = v[0]; w[3 * c + 1] = v[1]; w[3 * c + 2] = v[2];
+                }
+            }
+            uint32_t m = 0;
+            if (in.sbt_index_offsets) std::memcpy(&m, mbuf.data() + (size_t)t * 4, 4);
+            mats[base + t] = m;
+        }
+    }
+    const uint32_t n_tris = (uint32_t)(world.size() / 9);
+    Accel* a = new Accel();
+    a->n_prims = n_tris;
+    if (!build_bvh(world.data(), n_tris, 4, kStackEntries, default_build_threads(), a->host)) {
+        delete a;
+        return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "BVH over %u triangles does not fit a %d-entry traversal stack", n_tris, kStackEntries);
+    }
+    const size_t nb = a->host.nodes.size() * sizeof(MiptBvhNode);
+    const size_t tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
+    const size_t mb = std::max<size_t>(n_tris, 1) * sizeof(uint32_t);
+    hipError_t e = hipMalloc((void**)&a->d_nodes, nb);
+    if (e == hipSuccess) e = hipMalloc((void**)&a->d_tris, tb);
+    if (e == hipSuccess) e = hipMalloc((void**)&a->d_mat, mb);
+    if (e == hipSuccess) e = hipMemcpy(a->d_nodes, a->host.nodes.data(), nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !a->host.tris.empty()) e = hipMemcpy(a->d_tris, a->host.tris.data(), a->host.tris.size() * sizeof(MiptBvhTri), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_tris) e = hipMemcpy(a->d_mat, mats.data(), (size_t)n_tris * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        free_accel(a);
+        return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "accel upload failed: %s", hipGetErrorString(e));
+    }
+    a->bytes = nb + tb + mb;
+    const unsigned long long h = ++ctx->next_handle;
+    ctx->accels[h] = a;
+    *handle_out = h;
+    ctx->log(4, "ACCEL", "built BVH2: %u tris, %zu nodes, depth %u, %.1f MB, %.3f s", n_tris, a->host.nodes.size(), a->host.depth,
+             (double)a->bytes / 1e6, a->host.seconds);
+    return MIPT_SUCCESS;
+}
+
+int mipt_accel_destroy(MiptContext* ctx, unsigned long long handle)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    auto it = ctx->accels.find(handle);
+    if (it == ctx->accels.end()) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_accel(it->second);
+    ctx->accels.erase(it);
+    return MIPT_SUCCESS;
+}
+
+int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccelInfo* info)
+{
+    if (!ctx || !info) return MIPT_ERROR_INVALID_VALUE;
+    const Accel* a = find_accel(ctx, handle);
+    if (!a) return MIPT_ERROR_INVALID_HANDLE;
+    info->num_nodes = (uint32_t)a->host.nodes.size();
+    info->num_triangles = (uint32_t)a->host.tris.size();
+    info->depth = a->host.depth;
+    info->leaf_max = a->host.leaf_max;
+    info->device_bytes = a->bytes;
+    info->build_seconds = a->host.seconds;
+    return MIPT_SUCCESS;
+}
+
+int mipt_accel_export(const MiptContext* ctx, unsigned long long handle, MiptBvhNode* nodes_out, MiptBvhTri* tris_out)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    const Accel* a = find_accel(ctx, handle);
+    if (!a) return MIPT_ERROR_INVALID_HANDLE;
+    // exported from DEVICE memory, so the checker sees what the kernels read
+    (void)hipSetDevice(ctx->device);
+    if (nodes_out && hipMemcpy(nodes_out, a->d_nodes, a->host.nodes.size() * sizeof(MiptBvhNode), hipMemcpyDeviceToHost) != hipSuccess) return MIPT_ERROR_HIP;
+    if (tris_out && !a->host.tris.empty() &&
+        hipMemcpy(tris_out, a->d_tris, a->host.tris.size() * sizeof(MiptBvhTri), hipMemcpyDeviceToHost) != hipSuccess) return MIPT_ERROR_HIP;
+    return MIPT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct MiptHostBvh { HostBvh bvh; };
+
+int mipt_host_bvh_create(const float* vertices9, uint32_t num_triangles, MiptHostBvh** out)
+{
+    if (!out || (num_triangles && !vertices9)) return MIPT_ERROR_INVALID_VALUE;
+    MiptHostBvh* h = new MiptHostBvh();
+    if (!build_bvh(vertices9, num_triangles, 4, kStackEntries, default_build_threads(), h->bvh)) { delete h; return MIPT_ERROR_BVH_TOO_DEEP; }
+    *out = h;
+    return MIPT_SUCCESS;
+}
+
+int mipt_host_bvh_info(const MiptHostBvh* h, MiptAccelInfo* info)
+{
+    if (!h || !info) return MIPT_ERROR_INVALID_VALUE;
+    info->num_nodes = (uint32_t)h->bvh.nodes.size();
+    info->num_triangles = (uint32_t)h->bvh.tris.size();
+    info->depth = h->bvh.depth;
+    info->leaf_max = h->bvh.leaf_max;
+    info->device_bytes = 0;
+    info->build_seconds = h->bvh.seconds;
+    return MIPT_SUCCESS;
+}
+
+int mipt_host_bvh_copy(const MiptHostBvh* h, MiptBvhNode* nodes_out, MiptBvhTri* tris_out)
+{
+    if (!h) return MIPT_ERROR_INVALID_VALUE;
+    if (nodes_out) std::memcpy(nodes_out, h->bvh.nodes.data(), h->bvh.nodes.size() * sizeof(MiptBvhNode));
+    if (tris_out && !h->bvh.tris.empty()) std::memcpy(tris_out, h->bvh.tris.data(), h->bvh.tris.size() * sizeof(MiptBvhTri));
+    return MIPT_SUCCESS;
+}
+
+int mipt_host_bvh_destroy(MiptHostBvh* h)
+{
+    delete h;
+    return MIPT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mipt_sbt_set_hitgroups(MiptContext* ctx, const MiptHitGroupData* records, uint32_t count)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!records || count == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "sbt_set_hitgroups: no records");
+    for (uint32_t i = 0; i < count; ++i)
+        if (!records[i].vertices) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "hit-group record %u has a null vertex pointer", i);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    if (ctx->d_hitgroups) { (void)hipFree(ctx->d_hitgroups); ctx->d_hitgroups = nullptr; ctx->n_hitgroups = 0; }
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_hitgroups, (size_t)count * sizeof(MiptHitGroupData)));
+    HIPCHK(ctx, hipMemcpy(ctx->d_hitgroups, records, (size_t)count * sizeof(MiptHitGroupData), hipMemcpyHostToDevice));
+    ctx->n_hitgroups = count;
+    return MIPT_SUCCESS;
+}
+
+int mipt_sbt_set_miss(MiptContext* ctx, const MiptMissData* miss)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!miss) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "sbt_set_miss: null");
+    ctx->miss = *miss;
+    return MIPT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mipt_launch(MiptContext* ctx, void* stream, const MiptParams* p, unsigned int width, unsigned int height, unsigned int depth)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    Accel* acc = nullptr;
+    int rc = check_launch(ctx, p, width, height, depth, &acc);
+    if (rc) return rc;
+    if (!p->accum_buffer) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "params.accum_buffer is null");
+    FrameConsts fc = make_consts(ctx, p);
+    fc.world = 0; fc.rank = 0;
+    const uint32_t tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
+    fc.n_paths = tiles * 64u;
+    return run_wavefront(ctx, (hipStream_t)stream, fc, acc, (size_t)width * height, (float4*)p->accum_buffer, (uint32_t*)p->frame_buffer);
+}
+
+int mipt_launch_shard(MiptContext* ctx, void* stream, const MiptParams* p, unsigned int width, unsigned int height,
+                      unsigned int rank, unsigned int world, void* compact_accum)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    Accel* acc = nullptr;
+    int rc = check_launch(ctx, p, width, height, 1, &acc);
+    if (rc) return rc;
+    if (world == 0 || rank >= world) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "rank %u / world %u", rank, world);
+    if (!compact_accum) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "compact_accum is null");
+    FrameConsts fc = make_consts(ctx, p);
+    fc.world = world; fc.rank = rank;
+    fc.n_paths = shard_num_samples(width, height, world);
+    return run_wavefront(ctx, (hipStream_t)stream, fc, acc, fc.n_paths, (float4*)compact_accum, nullptr);
+}
+
+int mipt_unpermute(MiptContext* ctx, void* stream, const void* gathered, unsigned int world, unsigned int width,
+                   unsigned int height, void* accum_buffer, void* frame_buffer)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!gathered || !accum_buffer || world == 0 || width == 0 || height == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "unpermute: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->last_stream = (hipStream_t)stream;
+    launch_unpermute((hipStream_t)stream, (const float4*)gathered, world, width, height, (float4*)accum_buffer, (uint32_t*)frame_buffer);
+    HIPCHK(ctx, hipGetLastError());
+    return MIPT_SUCCESS;
+}
+
+int mipt_shard_num_samples(unsigned int width, unsigned int height, unsigned int world, uint32_t* n_out)
+{
+    if (!n_out || world == 0) return MIPT_ERROR_INVALID_VALUE;
+    *n_out = shard_num_samples(width, height, world);
+    return MIPT_SUCCESS;
+}
+
+int mipt_shard_pixel(unsigned int width, unsigned int height, unsigned int world, unsigned int rank, uint32_t sample_idx,
+                     int32_t* px, int32_t* py)
+{
+    (void)height;
+    if (!px || !py || world == 0 || rank >= world) return MIPT_ERROR_INVALID_VALUE;
+    int x, y;
+    shard_pixel(width, world, rank, sample_idx, x, y);
+    *px = x; *py = y;
+    return MIPT_SUCCESS;
+}
+
+int mipt_sync(MiptContext* ctx)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
+    return MIPT_SUCCESS;
+}
+
+int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
+{
+    if (!ctx || !stats) return MIPT_ERROR_INVALID_VALUE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
+    DeviceCounters h;
+    HIPCHK(ctx, hipMemcpy(&h, ctx->d_ctr, sizeof h, hipMemcpyDeviceToHost));
+    stats->closest_rays = h.closest_rays; stats->shadow_rays = h.shadow_rays;
+    stats->node_visits = h.node_visits; stats->tri_tests = h.tri_tests;
+    stats->bounces = ctx->last_bounces; stats->reserved = 0;
+    return MIPT_SUCCESS;
+}
+
+int mipt_get_launch_timings(MiptContext* ctx, MiptLaunchTimings* out)
+{
+    if (!ctx || !out) return MIPT_ERROR_INVALID_VALUE;
+    std::memset(out, 0, sizeof *out);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
+    for (const auto& t : ctx->timed) {
+        float ms = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, t.a, t.b));
+        switch (t.kind) {
+        case T_RAYGEN: out->ms_raygen += ms; break;
+        case T_CLOSEST: out->ms_trace_closest += ms; out->n_trace_closest++; break;
+        case T_SHADE: out->ms_shade += ms; break;
+        case T_ANY: out->ms_trace_any += ms; out->n_trace_any++; break;
+        case T_RESOLVE: out->ms_resolve += ms; break;
+        default: break;
+        }
+    }
+    return MIPT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle, const void* rays, uint32_t n, void* hits)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    const Accel* a = find_accel(ctx, handle);
+    if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
+    if (n == 0) return MIPT_SUCCESS;
+    if (!rays || !hits) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "trace_closest: null buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    ctx->last_stream = st;
+    ctx->events_used = 0; ctx->timed.clear();
+    launch_begin_sample(st, ctx->d_ctr, n);
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 4 * sizeof(unsigned long long), st));
+    const float4* r = (const float4*)rays;
+    { TimedScope t(ctx, st, T_CLOSEST);
+      launch_trace_closest(st, device_bvh(a), r, r + 1, 2, nullptr, n, (float4*)hits, ctx->d_ctr, trace_opts(ctx)); }
+    HIPCHK(ctx, hipGetLastError());
+    return MIPT_SUCCESS;
+}
+
+int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, const void* rays, uint32_t n, void* occluded)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    const Accel* a = find_accel(ctx, handle);
+    if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
+    if (n == 0) return MIPT_SUCCESS;
+    if (!rays || !occluded) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "trace_any: null buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    ctx->last_stream = st;
+    ctx->events_used = 0; ctx->timed.clear();
+    launch_begin_sample(st, ctx->d_ctr, n);
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 4 * sizeof(unsigned long long), st));
+    const float4* r = (const float4*)rays;
+    { TimedScope t(ctx, st, T_ANY);
+      launch_trace_any(st, device_bvh(a), r, r + 1, 2, nullptr, n, (uint32_t*)occluded, nullptr, nullptr, ctx->d_ctr, trace_opts(ctx)); }
+    HIPCHK(ctx, hipGetLastError());
+    return MIPT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------------
+void mipt_camera_uvw(const float eye[3], const float lookat[3], const float up[3], float fovY_deg, float aspect, float fod,
+                     float U[3], float V[3], float W[3])
+{
+    // sutil::Camera::UVWFrame, SDK/sutil/Camera.cpp:34-46
+    f3 w = (mk3(lookat[0], lookat[1], lookat[2]) - mk3(eye[0], eye[1], eye[2])) * fod;
+    const float wlen = length(w);
+    f3 u = normalize(cross(w, mk3(up[0], up[1], up[2])));
+    f3 v = normalize(cross(u, w));
+    const float vlen = wlen * tanf(0.5f * fovY_deg * 3.14159265358979323846f / 180.0f);
+    v = v * vlen;
+    const float ulen = vlen * aspect;
+    u = u * ulen;
+    U[0] = u.x; U[1] = u.y; U[2] = u.z;
+    V[0] = v.x; V[1] = v.y; V[2] = v.z;
+    W[0] = w.x; W[1] = w.y; W[2] = w.z;
+}
+
+int mipt_scene_random_triangles(uint32_t n, uint32_t seed_tag, float edge_scale, float* out)
+{
+    if (!out && n) return MIPT_ERROR_INVALID_VALUE;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t seed = tea4(i, seed_tag);
+        float c[3], e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) c[k] = rnd(seed);
+        for (int k = 0; k < 3; ++k) e1[k] = (rnd(seed) - 0.5f) * 2.0f * edge_scale;
+        for (int k = 0; k < 3; ++k) e2[k] = (rnd(seed) - 0.5f) * 2.0f * edge_scale;
+        float* v = out + (size_t)i * 12;
+        for (int k = 0; k < 3; ++k) { v[k] = c[k]; v[4 + k] = c[k] + e1[k]; v[8 + k] = c[k] + e2[k]; }
+        v[3] = 0.0f; v[7] = 0.0f; v[11] = 0.0f;
+    }
+    return MIPT_SUCCESS;
+}
+
+}  // extern "C"

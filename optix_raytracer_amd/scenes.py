@@ -1,0 +1,93 @@
+"""Scene data of the path-tracer sample and the benchmark scene.
+
+cornell_box(): the hard-coded scene of SDK/optixPathTracer/optixPathTracer.cpp:144-314 (32 triangles,
+4 materials), kept here as quads (v0,v1,v2,v3 -> triangles (v0,v1,v2),(v0,v2,v3), the order the
+reference lists them in), light :435-439, camera :538-541, background :852.
+
+random_soup(): SURVEY.md 8(d) "C4" -- n small random triangles in the unit cube, one Lambert material.
+"""
+import numpy as np
+
+from . import api
+
+_W, _H, _D = 556.0, 548.8, 559.2
+
+# (material, quad corners)
+_CORNELL_QUADS = [
+    (0, [(0, 0, 0), (0, 0, _D), (_W, 0, _D), (_W, 0, 0)]),                       # floor
+    (0, [(0, _H, 0), (_W, _H, 0), (_W, _H, _D), (0, _H, _D)]),                   # ceiling
+    (0, [(0, 0, _D), (0, _H, _D), (_W, _H, _D), (_W, 0, _D)]),                   # back wall
+    (1, [(0, 0, 0), (0, _H, 0), (0, _H, _D), (0, 0, _D)]),                       # right wall (green)
+    (2, [(_W, 0, 0), (_W, 0, _D), (_W, _H, _D), (_W, _H, 0)]),                   # left wall (red)
+    # short block
+    (0, [(130, 165, 65), (82, 165, 225), (242, 165, 274), (290, 165, 114)]),
+    (0, [(290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272)]),
+    (0, [(130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114)]),
+    (0, [(82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65)]),
+    (0, [(240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225)]),
+    # tall block
+    (0, [(423, 330, 247), (265, 330, 296), (314, 330, 455), (472, 330, 406)]),
+    (0, [(423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)]),
+    (0, [(472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)]),
+    (0, [(314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)]),
+    (0, [(265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)]),
+    # ceiling light
+    (3, [(343, 548.6, 227), (213, 548.6, 227), (213, 548.6, 332), (343, 548.6, 332)]),
+]
+
+_CORNELL_EMISSION = [(0, 0, 0), (0, 0, 0), (0, 0, 0), (15, 15, 5)]
+_CORNELL_DIFFUSE = [(0.80, 0.80, 0.80), (0.05, 0.80, 0.05), (0.80, 0.05, 0.05), (0.50, 0.00, 0.00)]
+
+
+def _light(corner, v1, v2, emission):
+    corner, v1, v2 = (np.asarray(x, np.float32) for x in (corner, v1, v2))
+    # normalize(cross(v1, v2)) in float32, operation order of SDK/sutil/vec_math.h:533,545
+    f = np.float32
+    c = np.array([f(f(v1[1] * v2[2]) - f(v1[2] * v2[1])), f(f(v1[2] * v2[0]) - f(v1[0] * v2[2])),
+                  f(f(v1[0] * v2[1]) - f(v1[1] * v2[0]))], np.float32)
+    d = f(f(f(c[0] * c[0]) + f(c[1] * c[1])) + f(c[2] * c[2]))
+    n = (c * np.float32(np.float32(1.0) / np.sqrt(d, dtype=np.float32))).astype(np.float32)
+    return {"corner": corner, "v1": v1, "v2": v2, "normal": n, "emission": np.asarray(emission, np.float32)}
+
+
+def cornell_box():
+    verts, mats = [], []
+    for m, q in _CORNELL_QUADS:
+        for tri in ((0, 1, 2), (0, 2, 3)):
+            for k in tri:
+                verts.append((q[k][0], q[k][1], q[k][2], 0.0))
+            mats.append(m)
+    return {
+        "name": "cornell",
+        "vertices": np.asarray(verts, np.float32),
+        "mat_index": np.asarray(mats, np.uint32),
+        "emission": np.asarray(_CORNELL_EMISSION, np.float32),
+        "diffuse": np.asarray(_CORNELL_DIFFUSE, np.float32),
+        "bg": np.zeros(4, np.float32),
+        "light": _light((343.0, 548.5, 227.0), (0.0, 0.0, 105.0), (-130.0, 0.0, 0.0), (15.0, 15.0, 5.0)),
+        "camera": {"eye": (278.0, 273.0, -900.0), "lookat": (278.0, 273.0, 330.0), "up": (0.0, 1.0, 0.0), "fovY": 35.0},
+    }
+
+
+def random_soup(n_tris=1_000_000, seed_tag=0x5EED, edge_scale=0.01):
+    return {
+        "name": "soup%d" % n_tris,
+        "vertices": api.random_triangles(n_tris, seed_tag, edge_scale),
+        "mat_index": np.zeros(n_tris, np.uint32),
+        "emission": np.zeros((1, 3), np.float32),
+        "diffuse": np.asarray([(0.8, 0.8, 0.8)], np.float32),
+        "bg": np.zeros(4, np.float32),
+        "light": _light((0.25, 1.5, 0.25), (0.0, 0.0, 0.5), (0.5, 0.0, 0.0), (15.0, 15.0, 5.0)),
+        "camera": {"eye": (0.5, 0.5, -1.5), "lookat": (0.5, 0.5, 0.5), "up": (0.0, 1.0, 0.0), "fovY": 35.0},
+    }
+
+
+def launch_desc(scene, width, height, spp=1, subframe=0):
+    """Host-side launch description (what initLaunchParams + handleCameraUpdate put into Params)."""
+    from .camera import Camera
+    c = scene["camera"]
+    cam = Camera(c["eye"], c["lookat"], c["up"], c["fovY"], 1.0)
+    cam.setAspectRatio(np.float32(width) / np.float32(height))
+    U, V, W = cam.UVWFrame()
+    return {"width": width, "height": height, "spp": spp, "subframe": subframe,
+            "eye": np.asarray(c["eye"], np.float32), "U": U, "V": V, "W": W, "light": scene["light"]}

@@ -1,0 +1,896 @@
+/*
+ * pt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See pt_oracle.h for scope and parity status.
+ *
+ * Build: gcc -O2 -mfma -ffp-contract=off -fno-fast-math -shared -fPIC
+ * (fmaf must be a single fused op; no implicit contraction anywhere.)
+ *
+ * Each function cites the reference lines it restates (paths relative to
+ * /root/reference).  Nothing here is copied: the reference is C++/CUDA on
+ * float3 operator overloads, this is scalar C.
+ */
+#include "pt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* small float helpers; operation ORDER follows SDK/sutil/vec_math.h          */
+/* ------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } v3;
+
+static inline v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v3_ld(const float* p) { return v3_make(p[0], p[1], p[2]); }
+static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }   /* vec_math.h:411 */
+static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }   /* vec_math.h:432 */
+static inline v3 v3_mul(v3 a, v3 b) { return v3_make(a.x * b.x, a.y * b.y, a.z * b.z); }   /* vec_math.h:453 */
+static inline v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }    /* vec_math.h:457 */
+/* vec_math.h:527  a.x*b.x + a.y*b.y + a.z*b.z, left to right, no fma */
+static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* vec_math.h:533 */
+static inline v3 v3_cross(v3 a, v3 b)
+{
+    return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* vec_math.h:539 */
+static inline float v3_length(v3 v) { return sqrtf(v3_dot(v, v)); }
+/* vec_math.h:545  v * (1/sqrt(dot)) */
+static inline v3 v3_normalize(v3 v)
+{
+    float inv = 1.0f / sqrtf(v3_dot(v, v));
+    return v3_scale(v, inv);
+}
+/* NaN-ignoring min/max, same result as C fminf/fmaxf (vec_math.h:119 clamp) */
+static inline float f_min(float a, float b) { return (a < b || b != b) ? a : b; }
+static inline float f_max(float a, float b) { return (a > b || b != b) ? a : b; }
+static inline float f_clamp(float f, float a, float b) { return f_max(a, f_min(f, b)); }
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* KAT hook for the helpers above: out = dot, length, normalize[3], cross[3],
+ * faceforward(normalize(a), -b, normalize(a))[3], lerp(a,b,t)[3], a/t[3] */
+void orc_vec_kat(const float a[3], const float b[3], float t, float out[17])
+{
+    v3 A = v3_ld(a), B = v3_ld(b);
+    out[0] = v3_dot(A, B);
+    out[1] = v3_length(A);
+    v3 n = v3_normalize(A);
+    out[2] = n.x; out[3] = n.y; out[4] = n.z;
+    v3 c = v3_cross(A, B);
+    out[5] = c.x; out[6] = c.y; out[7] = c.z;
+    v3 nb = v3_make(-B.x, -B.y, -B.z);
+    v3 ff = v3_scale(n, copysignf(1.0f, v3_dot(nb, n)));            /* vec_math.h:567 */
+    out[8] = ff.x; out[9] = ff.y; out[10] = ff.z;
+    v3 l = v3_add(A, v3_scale(v3_sub(B, A), t));                      /* vec_math.h:500 */
+    out[11] = l.x; out[12] = l.y; out[13] = l.z;
+    float inv = 1.0f / t;                                             /* vec_math.h:483 */
+    v3 d = v3_scale(A, inv);
+    out[14] = d.x; out[15] = d.y; out[16] = d.z;
+}
+
+/* ------------------------------------------------------------------------- */
+/* RNG -- SDK/cuda/random.h:31-67                                             */
+/* ------------------------------------------------------------------------- */
+uint32_t orc_tea4(uint32_t val0, uint32_t val1)
+{
+    uint32_t a = val0, b = val1, sum = 0;
+    for (int round = 0; round < 4; ++round) {
+        sum += 0x9e3779b9u;
+        a += ((b << 4) + 0xa341316cu) ^ (b + sum) ^ ((b >> 5) + 0xc8013ea4u);
+        b += ((a << 4) + 0xad90777du) ^ (a + sum) ^ ((a >> 5) + 0x7e95761eu);
+    }
+    return a;
+}
+
+uint32_t orc_lcg(uint32_t* prev)
+{
+    *prev = 1664525u * (*prev) + 1013904223u;
+    return *prev & 0x00FFFFFFu;
+}
+
+float orc_rnd(uint32_t* prev)
+{
+    return (float)orc_lcg(prev) / (float)0x01000000;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Deterministic transcendental math (build-defined; DESIGN.md "detmath").    */
+/* The reference calls cosf/sinf/powf under nvcc --use_fast_math              */
+/* (SDK/CMakeLists.txt:267); those are not reproducible across devices, so    */
+/* CPU and GPU both evaluate these fixed polynomials with explicit fmaf.      */
+/* ------------------------------------------------------------------------- */
+void orc_det_sincos(float x, float* s_out, float* c_out)
+{
+    /* quadrant reduction, Cody-Waite 3-term pi/2 */
+    float kf = rintf(x * 0.636619772f);
+    int   k  = (int)kf;
+    float r  = fmaf(kf, -1.5703125f, x);
+    r        = fmaf(kf, -4.837512969970703125e-4f, r);
+    r        = fmaf(kf, -7.54978995489188216e-8f, r);
+    float z  = r * r;
+    /* sin(r), |r| <= pi/4 */
+    float sp = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    sp       = fmaf(sp, z, -1.6666654611e-1f);
+    sp       = fmaf(sp, z * r, r);
+    /* cos(r) */
+    float cp = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    cp       = fmaf(cp, z, 4.166664568298827e-2f);
+    cp       = fmaf(cp, z * z, fmaf(-0.5f, z, 1.0f));
+    switch (k & 3) {
+    case 0:  *s_out = sp;  *c_out = cp;  break;
+    case 1:  *s_out = cp;  *c_out = -sp; break;
+    case 2:  *s_out = -sp; *c_out = -cp; break;
+    default: *s_out = -cp; *c_out = sp;  break;
+    }
+}
+
+/* x^(1/2.4) for normal positive x <= ~2; log2 via fdlibm-style series, exp2 via
+ * degree-7 polynomial.  ~2 ulp. */
+float orc_det_pow_inv24(float x)
+{
+    uint32_t ix = f2u(x);
+    int      e  = (int)(ix >> 23) - 127;
+    float    m  = u2f((ix & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m *= 0.5f; e += 1; }
+    float f    = m - 1.0f;
+    float s    = f / (2.0f + f);
+    float z    = s * s;
+    float w    = z * z;
+    float t1   = w * fmaf(w, 0.24279078841f, 0.40000972152f);
+    float t2   = z * fmaf(w, 0.28498786688f, 0.66666662693f);
+    float R    = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float lnm  = f - (hfsq - s * (hfsq + R));
+    float lg2  = fmaf(lnm, 1.44269502f, (float)e);
+    float y    = lg2 * 0.416666657f;
+    float n    = rintf(y);
+    float g    = y - n;
+    float p    = fmaf(1.52527338e-5f, g, 1.54035304e-4f);
+    p          = fmaf(p, g, 1.33335581e-3f);
+    p          = fmaf(p, g, 9.61812911e-3f);
+    p          = fmaf(p, g, 5.55041087e-2f);
+    p          = fmaf(p, g, 2.40226507e-1f);
+    p          = fmaf(p, g, 6.93147182e-1f);
+    p          = fmaf(p, g, 1.0f);
+    return u2f(f2u(p) + ((uint32_t)(int)n << 23));
+}
+
+/* ------------------------------------------------------------------------- */
+/* Camera -- SDK/sutil/Camera.cpp:34-46 (fod = author's m_fod, Camera.h:64,75) */
+/* ------------------------------------------------------------------------- */
+void orc_camera_uvw(const float eye[3], const float lookat[3], const float up[3],
+                    float fovY_deg, float aspect, float fod, float U[3], float V[3], float W[3])
+{
+    v3    w    = v3_scale(v3_sub(v3_ld(lookat), v3_ld(eye)), fod);
+    float wlen = v3_length(w);
+    v3    u    = v3_normalize(v3_cross(w, v3_ld(up)));
+    v3    v    = v3_normalize(v3_cross(u, w));
+    float vlen = wlen * tanf(0.5f * fovY_deg * 3.14159265358979323846f / 180.0f);
+    v          = v3_scale(v, vlen);
+    float ulen = vlen * aspect;
+    u          = v3_scale(u, ulen);
+    U[0] = u.x; U[1] = u.y; U[2] = u.z;
+    V[0] = v.x; V[1] = v.y; V[2] = v.z;
+    W[0] = w.x; W[1] = w.y; W[2] = w.z;
+}
+
+/* ------------------------------------------------------------------------- */
+/* sRGB + 8-bit quantisation -- SDK/cuda/helpers.h:35-66                      */
+/* ------------------------------------------------------------------------- */
+static inline float srgb_channel(float c)
+{
+    return c < 0.0031308f ? 12.92f * c : 1.055f * orc_det_pow_inv24(c) - 0.055f;
+}
+
+static inline uint8_t quantize8(float x)
+{
+    x = f_clamp(x, 0.0f, 1.0f);
+    uint32_t q = (uint32_t)(x * 256.0f);
+    return (uint8_t)(q < 255u ? q : 255u);
+}
+
+void orc_make_color(const float c[3], uint8_t out[4])
+{
+    for (int k = 0; k < 3; ++k)
+        out[k] = quantize8(srgb_channel(f_clamp(c[k], 0.0f, 1.0f)));
+    out[3] = 255u;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Hemisphere sampling + ONB -- optixPathTracer.cu:47-78, 149-159             */
+/* ------------------------------------------------------------------------- */
+void orc_cosine_sample_hemisphere(float u1, float u2, float p[3])
+{
+    float r   = sqrtf(u1);
+    float phi = (2.0f * 3.14159265358979323846f) * u2;
+    float sn, cs;
+    orc_det_sincos(phi, &sn, &cs);
+    p[0] = r * cs;
+    p[1] = r * sn;
+    p[2] = sqrtf(f_max(0.0f, 1.0f - p[0] * p[0] - p[1] * p[1]));
+}
+
+void orc_onb_inverse_transform(const float nrm[3], float p[3])
+{
+    v3 n = v3_ld(nrm), b;
+    if (fabsf(n.x) > fabsf(n.z)) b = v3_make(-n.y, n.x, 0.0f);
+    else                         b = v3_make(0.0f, -n.z, n.y);
+    b    = v3_normalize(b);
+    v3 t = v3_cross(b, n);
+    v3 r = v3_add(v3_add(v3_scale(t, p[0]), v3_scale(b, p[1])), v3_scale(n, p[2]));
+    p[0] = r.x; p[1] = r.y; p[2] = r.z;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU tile map -- SDK/sutil/WorkDistribution.h:50-81 (8x4 tiles)       */
+/* ------------------------------------------------------------------------- */
+enum { TILE_W = 8, TILE_H = 4 };
+
+int orc_work_num_samples(int width, int height, int num_gpus)
+{
+    int strip_w = TILE_W * num_gpus;
+    int cols    = (width + strip_w - 1) / strip_w;
+    int rows    = (height + TILE_H - 1) / TILE_H;
+    return rows * cols * TILE_W * TILE_H;
+}
+
+void orc_work_pixel(int width, int height, int num_gpus, int gpu, int sample_idx, int* px, int* py)
+{
+    (void)height;
+    int strip_w = TILE_W * num_gpus;
+    int cols    = (width + strip_w - 1) / strip_w;
+    int tile    = sample_idx / (TILE_W * TILE_H);
+    int in_tile = sample_idx % (TILE_W * TILE_H);
+    int srow    = tile / cols;
+    int scol    = tile % cols;
+    int rot     = (gpu + srow % num_gpus) % num_gpus;
+    *px         = scol * strip_w + rot * TILE_W + in_tile % TILE_W;
+    *py         = srow * TILE_H + in_tile / TILE_W;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Scene + BVH                                                                */
+/* ------------------------------------------------------------------------- */
+/* 64-byte node, two children with their boxes (layout = include/mipt.h)      */
+typedef struct {
+    float   c0x[2], c0y[2];     /* child0 lo.x hi.x lo.y hi.y */
+    float   c1x[2], c1y[2];     /* child1 lo.x hi.x lo.y hi.y */
+    float   c0z[2], c1z[2];     /* child0 lo.z hi.z, child1 lo.z hi.z */
+    int32_t c0, c1;             /* >=0 inner node index; <0 leaf: ~((first<<4)|count) */
+    uint32_t pad0, pad1;
+} Node64;
+
+/* 48-byte triangle in leaf order */
+typedef struct {
+    float    v0[3]; uint32_t prim;  /* original primitive index */
+    float    e1[3]; uint32_t pad1;  /* v1 - v0 */
+    float    e2[3]; uint32_t pad2;  /* v2 - v0 */
+} Tri48;
+
+struct OrcScene {
+    uint32_t  n_tris, n_mat;
+    float*    verts;       /* n_tris*3 float4 (caller layout, optixPathTracer.cpp:96-99) */
+    uint32_t* mat;         /* per-prim material (optixPathTracer.cpp:285-294) */
+    float*    emission;    /* n_mat*3 */
+    float*    diffuse;     /* n_mat*3 */
+    float     bg[4];       /* MissData (optixPathTracer.h:115-118) */
+    Tri48*    brute;       /* all triangles, prim order, for brute force */
+    Node64*   nodes; uint32_t n_nodes;
+    Tri48*    tris;  uint32_t n_leaf_tris;
+    int       depth;
+};
+
+#define LEAF_REF(first, count) (~(int32_t)(((uint32_t)(first) << 4) | (uint32_t)(count)))
+#define STACK_MAX 64
+#define SENTINEL 0x7fffffff
+
+static void make_tri(const float* verts, uint32_t prim, Tri48* t)
+{
+    const float* a = verts + (size_t)prim * 12;
+    const float* b = a + 4;
+    const float* c = a + 8;
+    for (int k = 0; k < 3; ++k) {
+        t->v0[k] = a[k];
+        t->e1[k] = b[k] - a[k];
+        t->e2[k] = c[k] - a[k];
+    }
+    t->prim = prim; t->pad1 = 0; t->pad2 = 0;
+}
+
+OrcScene* orc_scene_create(const float* vertices4, uint32_t n_tris, const uint32_t* mat_index,
+                           const float* emission3, const float* diffuse3, uint32_t n_mat,
+                           const float bg[4])
+{
+    OrcScene* s = (OrcScene*)calloc(1, sizeof(OrcScene));
+    s->n_tris = n_tris; s->n_mat = n_mat;
+    s->verts = (float*)malloc((size_t)n_tris * 12 * sizeof(float));
+    memcpy(s->verts, vertices4, (size_t)n_tris * 12 * sizeof(float));
+    s->mat = (uint32_t*)calloc(n_tris ? n_tris : 1, sizeof(uint32_t));
+    if (mat_index) memcpy(s->mat, mat_index, (size_t)n_tris * sizeof(uint32_t));
+    s->emission = (float*)malloc((size_t)n_mat * 3 * sizeof(float));
+    s->diffuse  = (float*)malloc((size_t)n_mat * 3 * sizeof(float));
+    memcpy(s->emission, emission3, (size_t)n_mat * 3 * sizeof(float));
+    memcpy(s->diffuse, diffuse3, (size_t)n_mat * 3 * sizeof(float));
+    memcpy(s->bg, bg, 4 * sizeof(float));
+    s->brute = (Tri48*)malloc((size_t)(n_tris ? n_tris : 1) * sizeof(Tri48));
+    for (uint32_t i = 0; i < n_tris; ++i) make_tri(s->verts, i, &s->brute[i]);
+    return s;
+}
+
+void orc_scene_destroy(OrcScene* s)
+{
+    if (!s) return;
+    free(s->verts); free(s->mat); free(s->emission); free(s->diffuse);
+    free(s->brute); free(s->nodes); free(s->tris); free(s);
+}
+
+uint32_t orc_scene_num_nodes(const OrcScene* s) { return s->n_nodes; }
+int      orc_scene_bvh_depth(const OrcScene* s) { return s->depth; }
+
+/* ---- binned SAH builder (own definition; OptiX's builder is closed) ---- */
+typedef struct { float lo[3], hi[3]; } Box;
+
+static inline void box_empty(Box* b)
+{
+    for (int k = 0; k < 3; ++k) { b->lo[k] = INFINITY; b->hi[k] = -INFINITY; }
+}
+static inline void box_grow_pt(Box* b, const float* p)
+{
+    for (int k = 0; k < 3; ++k) { if (p[k] < b->lo[k]) b->lo[k] = p[k]; if (p[k] > b->hi[k]) b->hi[k] = p[k]; }
+}
+static inline void box_grow(Box* b, const Box* o)
+{
+    for (int k = 0; k < 3; ++k) { if (o->lo[k] < b->lo[k]) b->lo[k] = o->lo[k]; if (o->hi[k] > b->hi[k]) b->hi[k] = o->hi[k]; }
+}
+static inline float box_half_area(const Box* b)
+{
+    float dx = b->hi[0] - b->lo[0], dy = b->hi[1] - b->lo[1], dz = b->hi[2] - b->lo[2];
+    if (!(dx >= 0.0f)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+typedef struct {
+    const OrcScene* s;
+    Box*      tbox;     /* per prim */
+    float*    cent;     /* per prim * 3 */
+    uint32_t* idx;      /* permutation */
+    Node64*   nodes; uint32_t n_nodes, cap_nodes;
+    Tri48*    tris;  uint32_t n_out;
+    int       leaf_max, max_depth, depth_seen;
+} Builder;
+
+static void store_child(Node64* n, int which, const Box* b, int32_t ref)
+{
+    if (which == 0) {
+        n->c0x[0] = b->lo[0]; n->c0x[1] = b->hi[0]; n->c0y[0] = b->lo[1]; n->c0y[1] = b->hi[1];
+        n->c0z[0] = b->lo[2]; n->c0z[1] = b->hi[2]; n->c0 = ref;
+    } else {
+        n->c1x[0] = b->lo[0]; n->c1x[1] = b->hi[0]; n->c1y[0] = b->lo[1]; n->c1y[1] = b->hi[1];
+        n->c1z[0] = b->lo[2]; n->c1z[1] = b->hi[2]; n->c1 = ref;
+    }
+}
+
+static Box range_box(const Builder* B, uint32_t lo, uint32_t hi)
+{
+    Box b; box_empty(&b);
+    for (uint32_t i = lo; i < hi; ++i) box_grow(&b, &B->tbox[B->idx[i]]);
+    return b;
+}
+
+static int32_t emit_leaf(Builder* B, uint32_t lo, uint32_t hi)
+{
+    uint32_t first = B->n_out;
+    for (uint32_t i = lo; i < hi; ++i) make_tri(B->s->verts, B->idx[i], &B->tris[B->n_out++]);
+    return LEAF_REF(first, hi - lo);
+}
+
+static int cmp_axis; static const float* cmp_cent;
+static int cmp_idx(const void* a, const void* b)
+{
+    uint32_t ia = *(const uint32_t*)a, ib = *(const uint32_t*)b;
+    float ca = cmp_cent[ia * 3 + cmp_axis], cb = cmp_cent[ib * 3 + cmp_axis];
+    if (ca < cb) return -1;
+    if (ca > cb) return 1;
+    return ia < ib ? -1 : (ia > ib ? 1 : 0);
+}
+
+/* returns split position mid in (lo,hi) after partitioning idx[lo,hi) */
+static uint32_t split_range(Builder* B, uint32_t lo, uint32_t hi, int rem_depth)
+{
+    enum { NB = 16 };
+    uint32_t n = hi - lo;
+    Box cb; box_empty(&cb);
+    for (uint32_t i = lo; i < hi; ++i) box_grow_pt(&cb, &B->cent[B->idx[i] * 3]);
+    uint64_t cap = (uint64_t)B->leaf_max << (rem_depth - 1 > 40 ? 40 : rem_depth - 1);
+    float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+    for (int ax = 0; ax < 3; ++ax) {
+        float ext = cb.hi[ax] - cb.lo[ax];
+        if (!(ext > 0.0f)) continue;
+        Box bb[NB]; uint32_t cnt[NB];
+        for (int b = 0; b < NB; ++b) { box_empty(&bb[b]); cnt[b] = 0; }
+        float scale = (float)NB / ext;
+        for (uint32_t i = lo; i < hi; ++i) {
+            uint32_t p = B->idx[i];
+            int b = (int)((B->cent[p * 3 + ax] - cb.lo[ax]) * scale);
+            if (b < 0) b = 0; if (b > NB - 1) b = NB - 1;
+            cnt[b]++; box_grow(&bb[b], &B->tbox[p]);
+        }
+        float rarea[NB]; uint32_t rcnt[NB];
+        Box acc; box_empty(&acc); uint32_t c = 0;
+        for (int b = NB - 1; b > 0; --b) { box_grow(&acc, &bb[b]); c += cnt[b]; rarea[b] = box_half_area(&acc); rcnt[b] = c; }
+        box_empty(&acc); c = 0;
+        for (int b = 0; b < NB - 1; ++b) {
+            box_grow(&acc, &bb[b]); c += cnt[b];
+            uint32_t nl = c, nr = rcnt[b + 1];
+            if (nl == 0 || nr == 0) continue;
+            if (nl > cap || nr > cap) continue;
+            float cost = box_half_area(&acc) * (float)nl + rarea[b + 1] * (float)nr;
+            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+        }
+    }
+    if (best_axis >= 0) {
+        float ext = cb.hi[best_axis] - cb.lo[best_axis];
+        float scale = (float)NB / ext;
+        uint32_t i = lo, j = hi;
+        while (i < j) {
+            uint32_t p = B->idx[i];
+            int b = (int)((B->cent[p * 3 + best_axis] - cb.lo[best_axis]) * scale);
+            if (b < 0) b = 0; if (b > NB - 1) b = NB - 1;
+            if (b <= best_bin) ++i;
+            else { --j; B->idx[i] = B->idx[j]; B->idx[j] = p; }
+        }
+        if (i > lo && i < hi) return i;
+    }
+    /* fallback: object median on the widest centroid axis (also enforces depth cap) */
+    int ax = 0; float w = -1.0f;
+    for (int k = 0; k < 3; ++k) { float e = cb.hi[k] - cb.lo[k]; if (e > w) { w = e; ax = k; } }
+    cmp_axis = ax; cmp_cent = B->cent;
+    qsort(B->idx + lo, n, sizeof(uint32_t), cmp_idx);
+    return lo + n / 2;
+}
+
+/* builds the subtree for idx[lo,hi), returns its reference */
+static int32_t build_range(Builder* B, uint32_t lo, uint32_t hi, int depth)
+{
+    if (depth > B->depth_seen) B->depth_seen = depth;
+    uint32_t n = hi - lo;
+    if (n <= (uint32_t)B->leaf_max) return emit_leaf(B, lo, hi);
+    uint32_t me = B->n_nodes++;
+    uint32_t mid = split_range(B, lo, hi, B->max_depth - depth);
+    Box b0 = range_box(B, lo, mid), b1 = range_box(B, mid, hi);
+    int32_t r0 = build_range(B, lo, mid, depth + 1);
+    int32_t r1 = build_range(B, mid, hi, depth + 1);
+    store_child(&B->nodes[me], 0, &b0, r0);
+    store_child(&B->nodes[me], 1, &b1, r1);
+    return (int32_t)me;
+}
+
+int orc_scene_build_bvh(OrcScene* s, int leaf_max, int max_depth)
+{
+    if (leaf_max < 1 || leaf_max > 15 || max_depth < 2 || max_depth > STACK_MAX - 2) return -1;
+    { uint64_t cap = (uint64_t)leaf_max << (max_depth - 1 > 40 ? 40 : max_depth - 1); if (s->n_tris > cap) return -2; }
+    free(s->nodes); free(s->tris); s->nodes = NULL; s->tris = NULL;
+    Builder B; memset(&B, 0, sizeof B);
+    B.s = s; B.leaf_max = leaf_max; B.max_depth = max_depth;
+    uint32_t n = s->n_tris;
+    B.tbox = (Box*)malloc((size_t)(n ? n : 1) * sizeof(Box));
+    B.cent = (float*)malloc((size_t)(n ? n : 1) * 3 * sizeof(float));
+    B.idx  = (uint32_t*)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* v = s->verts + (size_t)i * 12;
+        box_empty(&B.tbox[i]);
+        box_grow_pt(&B.tbox[i], v); box_grow_pt(&B.tbox[i], v + 4); box_grow_pt(&B.tbox[i], v + 8);
+        for (int k = 0; k < 3; ++k) B.cent[i * 3 + k] = 0.5f * (B.tbox[i].lo[k] + B.tbox[i].hi[k]);
+        B.idx[i] = i;
+    }
+    B.cap_nodes = n + 2;
+    B.nodes = (Node64*)calloc(B.cap_nodes, sizeof(Node64));
+    B.tris  = (Tri48*)malloc((size_t)(n ? n : 1) * sizeof(Tri48));
+    if (n <= (uint32_t)leaf_max) {
+        /* root must be an inner node: child0 = everything, child1 = empty leaf */
+        Box b0 = range_box(&B, 0, n), bz; memset(&bz, 0, sizeof bz);
+        B.n_nodes = 1;
+        int32_t r0 = emit_leaf(&B, 0, n);
+        store_child(&B.nodes[0], 0, &b0, r0);
+        store_child(&B.nodes[0], 1, &bz, LEAF_REF(n, 0));
+        B.depth_seen = 1;
+    } else {
+        build_range(&B, 0, n, 0);
+    }
+    s->nodes = B.nodes; s->n_nodes = B.n_nodes;
+    s->tris = B.tris;   s->n_leaf_tris = B.n_out;
+    s->depth = B.depth_seen;
+    free(B.tbox); free(B.cent); free(B.idx);
+    return 0;
+}
+
+int orc_scene_set_bvh(OrcScene* s, const void* nodes, uint32_t n_nodes, const void* tris, uint32_t n_tris)
+{
+    free(s->nodes); free(s->tris);
+    s->nodes = (Node64*)malloc((size_t)n_nodes * sizeof(Node64));
+    s->tris  = (Tri48*)malloc((size_t)(n_tris ? n_tris : 1) * sizeof(Tri48));
+    memcpy(s->nodes, nodes, (size_t)n_nodes * sizeof(Node64));
+    memcpy(s->tris, tris, (size_t)n_tris * sizeof(Tri48));
+    s->n_nodes = n_nodes; s->n_leaf_tris = n_tris;
+    s->depth = -1;
+    return orc_scene_validate_bvh(s);
+}
+
+/* every prim appears exactly once, child boxes contain their triangles, refs in range,
+ * depth < STACK_MAX.  Returns 0 when sound. */
+static int validate_rec(const OrcScene* s, int32_t ref, const Box* bound, uint8_t* seen, int depth, int* maxd)
+{
+    if (depth > *maxd) *maxd = depth;
+    if (depth >= STACK_MAX - 1) return -10;
+    if (ref < 0) {
+        uint32_t d = (uint32_t)~ref, first = d >> 4, cnt = d & 15u;
+        if (first + cnt > s->n_leaf_tris) return -11;
+        for (uint32_t i = first; i < first + cnt; ++i) {
+            const Tri48* t = &s->tris[i];
+            if (t->prim >= s->n_tris || seen[t->prim]) return -12;
+            seen[t->prim] = 1;
+            const float* v = s->verts + (size_t)t->prim * 12;
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 3; ++k) {
+                    float x = v[c * 4 + k];
+                    if (x < bound->lo[k] || x > bound->hi[k]) return -13;
+                }
+            for (int k = 0; k < 3; ++k) {
+                if (t->v0[k] != v[k] || t->e1[k] != v[4 + k] - v[k] || t->e2[k] != v[8 + k] - v[k]) return -14;
+            }
+        }
+        return 0;
+    }
+    if ((uint32_t)ref >= s->n_nodes) return -15;
+    const Node64* n = &s->nodes[ref];
+    Box b0 = { { n->c0x[0], n->c0y[0], n->c0z[0] }, { n->c0x[1], n->c0y[1], n->c0z[1] } };
+    Box b1 = { { n->c1x[0], n->c1y[0], n->c1z[0] }, { n->c1x[1], n->c1y[1], n->c1z[1] } };
+    int r = validate_rec(s, n->c0, &b0, seen, depth + 1, maxd);
+    if (r) return r;
+    return validate_rec(s, n->c1, &b1, seen, depth + 1, maxd);
+}
+
+int orc_scene_validate_bvh(const OrcScene* cs)
+{
+    OrcScene* s = (OrcScene*)cs;
+    if (!s->nodes || s->n_nodes == 0) return -1;
+    uint8_t* seen = (uint8_t*)calloc(s->n_tris ? s->n_tris : 1, 1);
+    Box all = { { -INFINITY, -INFINITY, -INFINITY }, { INFINITY, INFINITY, INFINITY } };
+    int maxd = 0;
+    int r = validate_rec(s, 0, &all, seen, 0, &maxd);
+    if (!r) for (uint32_t i = 0; i < s->n_tris; ++i) if (!seen[i]) { r = -16; break; }
+    free(seen);
+    if (!r) s->depth = maxd;
+    return r;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Ray / triangle and ray / box -- BUILD-DEFINED conventions:   */
+/*   hit iff tmin < t < tmax; double sided; det == 0 rejected; u>=0, v>=0,    */
+/*   u+v<=1 inclusive; closest-hit tie -> lowest primitive index.             */
+/* Moeller-Trumbore on (v0, e1, e2) with explicit fmaf (same sequence in the  */
+/* HIP kernel).  Replaces optixTraverse (optixPathTracer.cu:184-197,227-238). */
+/* ------------------------------------------------------------------------- */
+typedef struct { v3 o, d; float tmin, tmax; v3 idir, ood; } Ray;
+
+static inline float fdot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 fcross(v3 a, v3 b)
+{
+    return v3_make(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+static inline void ray_prepare(Ray* r)
+{
+    const float eps = 8.27180613e-25f; /* 2^-80 */
+    float dx = fabsf(r->d.x) > eps ? r->d.x : copysignf(eps, r->d.x);
+    float dy = fabsf(r->d.y) > eps ? r->d.y : copysignf(eps, r->d.y);
+    float dz = fabsf(r->d.z) > eps ? r->d.z : copysignf(eps, r->d.z);
+    r->idir = v3_make(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    r->ood  = v3_make(r->o.x * r->idir.x, r->o.y * r->idir.y, r->o.z * r->idir.z);
+}
+
+/* returns 1 and writes t,u,v when the triangle is hit inside (tmin, tmax) */
+static inline int tri_test(const Tri48* T, const Ray* r, float tmax, float* t_out, float* u_out, float* v_out)
+{
+    v3    e1 = v3_ld(T->e1), e2 = v3_ld(T->e2);
+    v3    p   = fcross(r->d, e2);
+    float det = fdot(e1, p);
+    if (det == 0.0f) return 0;
+    float inv = 1.0f / det;
+    v3    tv  = v3_sub(r->o, v3_ld(T->v0));
+    float u   = fdot(tv, p) * inv;
+    v3    q   = fcross(tv, e1);
+    float v   = fdot(r->d, q) * inv;
+    float t   = fdot(e2, q) * inv;
+    if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) return 0;
+    if (!(t > r->tmin && t < tmax)) return 0;
+    *t_out = t; *u_out = u; *v_out = v;
+    return 1;
+}
+
+/* slab test of one child box; returns entry distance, hit flag through *hit */
+static inline float box_test(const float x[2], const float y[2], const float z[2], const Ray* r, float tfar_limit, int* hit)
+{
+    float x0 = fmaf(x[0], r->idir.x, -r->ood.x), x1 = fmaf(x[1], r->idir.x, -r->ood.x);
+    float y0 = fmaf(y[0], r->idir.y, -r->ood.y), y1 = fmaf(y[1], r->idir.y, -r->ood.y);
+    float z0 = fmaf(z[0], r->idir.z, -r->ood.z), z1 = fmaf(z[1], r->idir.z, -r->ood.z);
+    float tn = f_max(f_max(f_min(x0, x1), f_min(y0, y1)), f_max(f_min(z0, z1), r->tmin));
+    float tf = f_min(f_min(f_max(x0, x1), f_max(y0, y1)), f_min(f_max(z0, z1), tfar_limit));
+    *hit = tn <= tf;
+    return tn;
+}
+
+typedef struct { int hit; float t, u, v; uint32_t prim; } HitRec;
+
+static inline void consider(HitRec* h, float t, float u, float v, uint32_t prim)
+{
+    if (!h->hit || t < h->t || (t == h->t && prim < h->prim)) {
+        h->hit = 1; h->t = t; h->u = u; h->v = v; h->prim = prim;
+    }
+}
+
+static void brute_force(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats* st)
+{
+    h->hit = 0; h->t = r->tmax; h->prim = 0xffffffffu; h->u = h->v = 0.0f;
+    for (uint32_t i = 0; i < s->n_tris; ++i) {
+        float t, u, v;
+        if (st) st->tri_tests++;
+        if (tri_test(&s->brute[i], r, r->tmax, &t, &u, &v)) {
+            if (any) { h->hit = 1; h->t = t; h->prim = i; return; }
+            consider(h, t, u, v, i);
+        }
+    }
+}
+
+/* per-ray stack traversal, near child first; identical visiting order to the HIP kernel */
+static void bvh_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats* st)
+{
+    int32_t stack[STACK_MAX];
+    int     sp = 0;
+    h->hit = 0; h->t = r->tmax; h->prim = 0xffffffffu; h->u = h->v = 0.0f;
+    stack[sp++] = SENTINEL;
+    int32_t node = 0;
+    while (node != SENTINEL) {
+        if (node >= 0) {
+            const Node64* n = &s->nodes[node];
+            if (st) st->node_visits++;
+            int   h0, h1;
+            /* prune with the current best t (inclusive, so equal-t candidates are still visited) */
+            float lim = h->t;
+            float t0 = box_test(n->c0x, n->c0y, n->c0z, r, lim, &h0);
+            float t1 = box_test(n->c1x, n->c1y, n->c1z, r, lim, &h1);
+            if (!h0 && !h1) { node = stack[--sp]; continue; }
+            int32_t a = n->c0, b = n->c1;
+            if (h0 && h1) {
+                if (t1 < t0) { int32_t tmp = a; a = b; b = tmp; }
+                stack[sp++] = b;
+                node = a;
+            } else {
+                node = h0 ? a : b;
+            }
+        } else {
+            uint32_t d = (uint32_t)~node, first = d >> 4, cnt = d & 15u;
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                float t, u, v;
+                if (st) st->tri_tests++;
+                if (tri_test(&s->tris[i], r, r->tmax, &t, &u, &v)) {
+                    if (any) { h->hit = 1; h->t = t; h->prim = s->tris[i].prim; return; }
+                    consider(h, t, u, v, s->tris[i].prim);
+                }
+            }
+            node = stack[--sp];
+        }
+    }
+}
+
+static inline void trace(const OrcScene* s, int mode, v3 o, v3 d, float tmin, float tmax, int any,
+                         HitRec* h, OrcStats* st)
+{
+    Ray r; r.o = o; r.d = d; r.tmin = tmin; r.tmax = tmax;
+    ray_prepare(&r);
+    if (st) { if (any) st->shadow_rays++; else st->closest_rays++; }
+    if (mode == ORC_MODE_BVH) bvh_traverse(s, &r, any, h, st);
+    else                      brute_force(s, &r, any, h, st);
+}
+
+void orc_trace_closest(const OrcScene* s, int mode, const float* rays, uint32_t n,
+                       float* hit_t, uint32_t* hit_prim, float* hit_u, float* hit_v, OrcStats* st)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* q = rays + (size_t)i * 8;
+        HitRec h;
+        trace(s, mode, v3_ld(q), v3_ld(q + 4), q[3], q[7], 0, &h, st);
+        hit_t[i]    = h.hit ? h.t : -1.0f;
+        hit_prim[i] = h.hit ? h.prim : 0xffffffffu;
+        if (hit_u) hit_u[i] = h.u;
+        if (hit_v) hit_v[i] = h.v;
+    }
+}
+
+void orc_trace_any(const OrcScene* s, int mode, const float* rays, uint32_t n, uint8_t* occluded, OrcStats* st)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* q = rays + (size_t)i * 8;
+        HitRec h;
+        trace(s, mode, v3_ld(q), v3_ld(q + 4), q[3], q[7], 1, &h, st);
+        occluded[i] = (uint8_t)h.hit;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Path tracer -- optixPathTracer.cu:249-413                                  */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    v3 attenuation; uint32_t seed; int depth;       /* optixPathTracer.h:35-49 RadiancePRD */
+    v3 emitted, radiance, origin, direction; int done;
+} PRD;
+
+/* __miss__radiance, optixPathTracer.cu:323-335 */
+static void miss_radiance(const OrcScene* s, PRD* prd)
+{
+    prd->radiance = v3_make(s->bg[0], s->bg[1], s->bg[2]);
+    prd->emitted  = v3_make(0.0f, 0.0f, 0.0f);
+    prd->done     = 1;
+}
+
+/* __closesthit__radiance, optixPathTracer.cu:338-413 */
+static void closesthit_radiance(const OrcScene* s, int mode, const OrcLight* light, v3 ray_o, v3 ray_d,
+                                const HitRec* h, PRD* prd, OrcStats* st)
+{
+    const float* vb = s->verts + (size_t)h->prim * 12;
+    v3 v0 = v3_ld(vb), v1 = v3_ld(vb + 4), v2 = v3_ld(vb + 8);
+    v3 N0 = v3_normalize(v3_cross(v3_sub(v1, v0), v3_sub(v2, v0)));
+    v3 neg_d = v3_make(-ray_d.x, -ray_d.y, -ray_d.z);
+    v3 N  = v3_scale(N0, copysignf(1.0f, v3_dot(neg_d, N0)));        /* faceforward, vec_math.h:567 */
+    v3 P  = v3_add(ray_o, v3_scale(ray_d, h->t));
+    uint32_t m = s->mat[h->prim];
+    const float* em = s->emission + 3 * m;
+    const float* df = s->diffuse + 3 * m;
+
+    prd->emitted = prd->depth == 0 ? v3_ld(em) : v3_make(0.0f, 0.0f, 0.0f);
+
+    uint32_t seed = prd->seed;
+    {
+        float z1 = orc_rnd(&seed);
+        float z2 = orc_rnd(&seed);
+        float w_in[3];
+        orc_cosine_sample_hemisphere(z1, z2, w_in);
+        float nn[3] = { N.x, N.y, N.z };
+        orc_onb_inverse_transform(nn, w_in);
+        prd->direction   = v3_ld(w_in);
+        prd->origin      = P;
+        prd->attenuation = v3_mul(prd->attenuation, v3_ld(df));
+    }
+    float z1 = orc_rnd(&seed);
+    float z2 = orc_rnd(&seed);
+    prd->seed = seed;
+
+    v3 lv1 = v3_ld(light->v1), lv2 = v3_ld(light->v2);
+    v3 light_pos = v3_add(v3_add(v3_ld(light->corner), v3_scale(lv1, z1)), v3_scale(lv2, z2));
+    v3    toL   = v3_sub(light_pos, P);
+    float Ldist = v3_length(toL);
+    v3    L     = v3_normalize(toL);
+    float nDl   = v3_dot(N, L);
+    float LnDl  = -v3_dot(v3_ld(light->normal), L);
+
+    float weight = 0.0f;
+    if (nDl > 0.0f && LnDl > 0.0f) {
+        HitRec sh;
+        trace(s, mode, P, L, 0.01f, Ldist - 0.01f, 1, &sh, st);       /* traceOcclusion, :218-240 */
+        if (!sh.hit) {
+            float A = v3_length(v3_cross(lv1, lv2));
+            weight  = nDl * LnDl * A / (3.14159265358979323846f * Ldist * Ldist);
+        }
+    }
+    prd->radiance = v3_scale(v3_ld(light->emission), weight);
+    prd->done     = 0;
+}
+
+/* one pixel of __raygen__rg (optixPathTracer.cu:249-320); returns the spp-averaged colour */
+static v3 raygen_pixel(const OrcScene* s, int mode, const OrcParams* p, uint32_t max_depth,
+                       uint32_t px, uint32_t py, OrcStats* st)
+{
+    const int w = (int)p->width, hgt = (int)p->height;
+    v3 eye = v3_ld(p->eye), U = v3_ld(p->U), V = v3_ld(p->V), W = v3_ld(p->W);
+    uint32_t seed = orc_tea4(py * (uint32_t)w + px, p->subframe_index);
+    v3 result = v3_make(0.0f, 0.0f, 0.0f);
+    int i = (int)p->samples_per_launch;
+    do {
+        float jx = orc_rnd(&seed);
+        float jy = orc_rnd(&seed);
+        float dx = 2.0f * (((float)px + jx) / (float)w) - 1.0f;
+        float dy = 2.0f * (((float)py + jy) / (float)hgt) - 1.0f;
+        v3 ray_d = v3_normalize(v3_add(v3_add(v3_scale(U, dx), v3_scale(V, dy)), W));
+        v3 ray_o = eye;
+
+        PRD prd;
+        prd.attenuation = v3_make(1.0f, 1.0f, 1.0f);
+        prd.seed        = seed;
+        prd.depth       = 0;
+        for (;;) {
+            HitRec h;
+            trace(s, mode, ray_o, ray_d, 0.01f, 1e16f, 0, &h, st);
+            if (h.hit) closesthit_radiance(s, mode, &p->light, ray_o, ray_d, &h, &prd, st);
+            else       miss_radiance(s, &prd);
+            if (st && (uint64_t)prd.depth > st->max_depth_seen) st->max_depth_seen = (uint64_t)prd.depth;
+
+            result = v3_add(result, prd.emitted);
+            result = v3_add(result, v3_mul(prd.radiance, prd.attenuation));
+
+            float lum = v3_dot(prd.attenuation, v3_make(0.30f, 0.59f, 0.11f));
+            int done = prd.done || orc_rnd(&prd.seed) > lum;
+            if (done) break;
+            /* build extension: bounded path length (0 = reference behaviour) */
+            if (max_depth && (uint32_t)(prd.depth + 1) >= max_depth) break;
+            float inv = 1.0f / lum;
+            prd.attenuation = v3_scale(prd.attenuation, inv);
+            ray_o = prd.origin;
+            ray_d = prd.direction;
+            ++prd.depth;
+        }
+    } while (--i);
+    float inv_spp = 1.0f / (float)p->samples_per_launch;
+    return v3_scale(result, inv_spp);
+}
+
+static void resolve_pixel(const OrcParams* p, v3 c, const float* prev4, float* out4, uint8_t* out_rgba)
+{
+    if (p->subframe_index > 0) {
+        float a = 1.0f / (float)(p->subframe_index + 1);
+        v3 pr = v3_ld(prev4);
+        c = v3_add(pr, v3_scale(v3_sub(c, pr), a));          /* lerp, vec_math.h:500 */
+    }
+    out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = 1.0f;
+    if (out_rgba) { float cc[3] = { c.x, c.y, c.z }; orc_make_color(cc, out_rgba); }
+}
+
+int orc_render_rows(const OrcScene* s, int mode, const OrcParams* p, uint32_t max_depth,
+                    uint32_t y0, uint32_t y1, OrcStats* st)
+{
+    if (mode == ORC_MODE_BVH && !s->nodes) return -1;
+    if (!p->samples_per_launch) return -2;
+    for (uint32_t y = y0; y < y1 && y < p->height; ++y)
+        for (uint32_t x = 0; x < p->width; ++x) {
+            size_t idx = (size_t)y * p->width + x;
+            v3 c = raygen_pixel(s, mode, p, max_depth, x, y, st);
+            resolve_pixel(p, c, p->accum_buffer + idx * 4, p->accum_buffer + idx * 4,
+                          p->frame_buffer ? p->frame_buffer + idx * 4 : NULL);
+        }
+    return 0;
+}
+
+int orc_render_pixels(const OrcScene* s, int mode, const OrcParams* p, uint32_t max_depth,
+                      const uint32_t* pixel_index, uint32_t n, float* compact_accum4,
+                      const float* compact_prev4, OrcStats* st)
+{
+    if (mode == ORC_MODE_BVH && !s->nodes) return -1;
+    if (!p->samples_per_launch) return -2;
+    float zero[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t idx = pixel_index[i];
+        float* out = compact_accum4 + (size_t)i * 4;
+        if (idx >= p->width * p->height) { out[0] = out[1] = out[2] = out[3] = 0.0f; continue; }
+        v3 c = raygen_pixel(s, mode, p, max_depth, idx % p->width, idx / p->width, st);
+        resolve_pixel(p, c, compact_prev4 ? compact_prev4 + (size_t)i * 4 : zero, out, NULL);
+    }
+    return 0;
+}
+
+void orc_primary_rays(const OrcParams* p, uint32_t y0, uint32_t y1, float* rays8)
+{
+    v3 eye = v3_ld(p->eye), U = v3_ld(p->U), V = v3_ld(p->V), W = v3_ld(p->W);
+    size_t k = 0;
+    for (uint32_t y = y0; y < y1; ++y)
+        for (uint32_t x = 0; x < p->width; ++x, ++k) {
+            uint32_t seed = orc_tea4(y * p->width + x, p->subframe_index);
+            float jx = orc_rnd(&seed), jy = orc_rnd(&seed);
+            float dx = 2.0f * (((float)x + jx) / (float)p->width) - 1.0f;
+            float dy = 2.0f * (((float)y + jy) / (float)p->height) - 1.0f;
+            v3 d = v3_normalize(v3_add(v3_add(v3_scale(U, dx), v3_scale(V, dy)), W));
+            float* q = rays8 + k * 8;
+            q[0] = eye.x; q[1] = eye.y; q[2] = eye.z; q[3] = 0.01f;
+            q[4] = d.x;   q[5] = d.y;   q[6] = d.z;   q[7] = 1e16f;
+        }
+}

@@ -1,0 +1,112 @@
+/*
+ * pt_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's path-tracer hot path
+ * (SDK/optixPathTracer/optixPathTracer.cu:249-413 and the headers it uses),
+ * plus a CPU BVH2 builder / traversal that stands in for the closed-source
+ * OptiX traversal (optixTraverse, optixPathTracer.cu:184-197, 227-238).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (libmipt.so) never links or calls it.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - RNG, camera frame, sRGB quantisation, float3 helpers: PINNED by known
+ *     answer vectors generated from the reference's own headers
+ *     (oracle/ref_kat.cpp -> tests/golden/ref_kat.json).
+ *   - raygen / closest-hit / miss control flow: restated from the reference
+ *     source; the reference has no tests or golden images.
+ *   - BVH traversal + ray/triangle test: PARITY UNPINNED -- the reference's
+ *     arithmetic lives in libnvoptix / RT cores and is not in the tree.  The
+ *     conventions used here are this build's own definition.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- launch parameters: same field order as `struct Params`
+ *      (SDK/optixPathTracer/optixPathTracer.h:91-107), host pointers. ---- */
+typedef struct OrcLight {
+    float corner[3], v1[3], v2[3], normal[3], emission[3];
+} OrcLight;
+
+typedef struct OrcParams {
+    uint32_t subframe_index;
+    float*   accum_buffer;   /* width*height float4, row 0 = bottom */
+    uint8_t* frame_buffer;   /* width*height uchar4 */
+    uint32_t width, height, samples_per_launch;
+    float    eye[3], U[3], V[3], W[3];
+    OrcLight light;
+    uint64_t handle;         /* unused by the oracle */
+} OrcParams;
+
+typedef struct OrcStats {
+    uint64_t closest_rays;   /* primary + continuation rays   */
+    uint64_t shadow_rays;    /* occlusion rays actually traced */
+    uint64_t node_visits;    /* 64-byte inner nodes fetched    */
+    uint64_t tri_tests;      /* 48-byte triangles fetched      */
+    uint64_t max_depth_seen; /* deepest bounce index reached   */
+} OrcStats;
+
+typedef struct OrcScene OrcScene;
+
+enum { ORC_MODE_BRUTE = 0, ORC_MODE_BVH = 1 };
+
+/* ---- scalar pieces (each pinned by a KAT) ---- */
+uint32_t orc_tea4(uint32_t v0, uint32_t v1);
+uint32_t orc_lcg(uint32_t* prev);
+float    orc_rnd(uint32_t* prev);
+void     orc_camera_uvw(const float eye[3], const float lookat[3], const float up[3],
+                        float fovY_deg, float aspect, float fod,
+                        float U[3], float V[3], float W[3]);
+void     orc_make_color(const float c[3], uint8_t out[4]);
+void     orc_vec_kat(const float a[3], const float b[3], float t, float out[17]);
+void     orc_det_sincos(float x, float* s, float* c);
+float    orc_det_pow_inv24(float x);
+void     orc_cosine_sample_hemisphere(float u1, float u2, float p[3]);
+void     orc_onb_inverse_transform(const float n[3], float p[3]);
+void     orc_work_pixel(int width, int height, int num_gpus, int gpu, int sample_idx, int* px, int* py);
+int      orc_work_num_samples(int width, int height, int num_gpus);
+
+/* ---- scene ---- */
+OrcScene* orc_scene_create(const float* vertices4 /* n_tris*3 float4 */, uint32_t n_tris,
+                           const uint32_t* mat_index /* n_tris or NULL */,
+                           const float* emission3, const float* diffuse3, uint32_t n_mat,
+                           const float bg[4]);
+void      orc_scene_destroy(OrcScene*);
+/* own binned-SAH builder */
+int       orc_scene_build_bvh(OrcScene*, int leaf_max, int max_depth);
+/* adopt a BVH in the layout of include/mipt.h (MiptBvhNode / MiptBvhTri) */
+int       orc_scene_set_bvh(OrcScene*, const void* nodes, uint32_t n_nodes,
+                            const void* tris, uint32_t n_tris);
+uint32_t  orc_scene_num_nodes(const OrcScene*);
+int       orc_scene_bvh_depth(const OrcScene*);
+/* structural validation of the adopted/built BVH; 0 = ok */
+int       orc_scene_validate_bvh(const OrcScene*);
+
+/* ---- traversal: rays = n * 8 floats (ox,oy,oz,tmin, dx,dy,dz,tmax) ---- */
+void orc_trace_closest(const OrcScene*, int mode, const float* rays, uint32_t n,
+                       float* hit_t, uint32_t* hit_prim, float* hit_u, float* hit_v, OrcStats* stats);
+void orc_trace_any(const OrcScene*, int mode, const float* rays, uint32_t n,
+                   uint8_t* occluded, OrcStats* stats);
+
+/* ---- full render of rows [y0,y1) (or of an explicit pixel list) ----
+ * max_depth: 0 = unbounded (the reference's behaviour: Russian roulette only),
+ *            k>0 = stop after k closest-hit queries per path (build extension). */
+int orc_render_rows(const OrcScene*, int mode, const OrcParams* p, uint32_t max_depth,
+                    uint32_t y0, uint32_t y1, OrcStats* stats);
+int orc_render_pixels(const OrcScene*, int mode, const OrcParams* p, uint32_t max_depth,
+                      const uint32_t* pixel_index, uint32_t n, float* compact_accum4,
+                      const float* compact_prev4, OrcStats* stats);
+
+/* primary rays exactly as raygen emits them for sample 0 (for traversal tests) */
+void orc_primary_rays(const OrcParams* p, uint32_t y0, uint32_t y1, float* rays8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,266 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU ORACLE (checker only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It never touches /root/reference at run time.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+MODE_BRUTE, MODE_BVH = 0, 1
+
+
+class OrcLight(C.Structure):
+    _fields_ = [("corner", C.c_float * 3), ("v1", C.c_float * 3), ("v2", C.c_float * 3),
+                ("normal", C.c_float * 3), ("emission", C.c_float * 3)]
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("subframe_index", C.c_uint32), ("accum_buffer", C.c_void_p), ("frame_buffer", C.c_void_p),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("samples_per_launch", C.c_uint32),
+                ("eye", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3),
+                ("light", OrcLight), ("handle", C.c_uint64)]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("max_depth_seen", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def _build():
+    src = os.path.join(ORACLE_DIR, "pt_oracle.c")
+    if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(ORACLE_DIR, "pt_oracle.h"))):
+        return
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    _build()
+    L = C.CDLL(LIB_PATH)
+    fp, u32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    L.orc_tea4.restype = C.c_uint32
+    L.orc_tea4.argtypes = [C.c_uint32, C.c_uint32]
+    L.orc_lcg.restype = C.c_uint32
+    L.orc_lcg.argtypes = [u32p]
+    L.orc_rnd.restype = C.c_float
+    L.orc_rnd.argtypes = [u32p]
+    L.orc_camera_uvw.restype = None
+    L.orc_camera_uvw.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, fp, fp, fp]
+    L.orc_make_color.restype = None
+    L.orc_make_color.argtypes = [fp, u8p]
+    L.orc_vec_kat.restype = None
+    L.orc_vec_kat.argtypes = [fp, fp, C.c_float, fp]
+    L.orc_det_sincos.restype = None
+    L.orc_det_sincos.argtypes = [C.c_float, fp, fp]
+    L.orc_det_pow_inv24.restype = C.c_float
+    L.orc_det_pow_inv24.argtypes = [C.c_float]
+    L.orc_cosine_sample_hemisphere.restype = None
+    L.orc_cosine_sample_hemisphere.argtypes = [C.c_float, C.c_float, fp]
+    L.orc_onb_inverse_transform.restype = None
+    L.orc_onb_inverse_transform.argtypes = [fp, fp]
+    L.orc_work_pixel.restype = None
+    L.orc_work_pixel.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)] * 2
+    L.orc_work_num_samples.restype = C.c_int
+    L.orc_work_num_samples.argtypes = [C.c_int] * 3
+    L.orc_scene_create.restype = C.c_void_p
+    L.orc_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_scene_destroy.restype = None
+    L.orc_scene_destroy.argtypes = [C.c_void_p]
+    L.orc_scene_build_bvh.restype = C.c_int
+    L.orc_scene_build_bvh.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_scene_set_bvh.restype = C.c_int
+    L.orc_scene_set_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.orc_scene_num_nodes.restype = C.c_uint32
+    L.orc_scene_num_nodes.argtypes = [C.c_void_p]
+    L.orc_scene_bvh_depth.restype = C.c_int
+    L.orc_scene_bvh_depth.argtypes = [C.c_void_p]
+    L.orc_scene_validate_bvh.restype = C.c_int
+    L.orc_scene_validate_bvh.argtypes = [C.c_void_p]
+    L.orc_trace_closest.restype = None
+    L.orc_trace_closest.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.POINTER(OrcStats)]
+    L.orc_trace_any.restype = None
+    L.orc_trace_any.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(OrcStats)]
+    L.orc_render_rows.restype = C.c_int
+    L.orc_render_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.POINTER(OrcStats)]
+    L.orc_render_pixels.restype = C.c_int
+    L.orc_render_pixels.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcParams), C.c_uint32, C.c_void_p, C.c_uint32,
+                                    C.c_void_p, C.c_void_p, C.POINTER(OrcStats)]
+    L.orc_primary_rays.restype = None
+    L.orc_primary_rays.argtypes = [C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def camera_uvw(eye, lookat, up, fov_y, aspect, fod=1.0):
+    U, V, W = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    lib().orc_camera_uvw(_f3(eye), _f3(lookat), _f3(up), fov_y, aspect, fod, U, V, W)
+    return (np.array(U, dtype=np.float32), np.array(V, dtype=np.float32), np.array(W, dtype=np.float32))
+
+
+class Scene:
+    """Owns an OrcScene.  `scene` is a dict as produced by optix_raytracer_amd.scenes.* :
+    vertices (n*3,4) f32, mat_index (n,) u32, emission (m,3), diffuse (m,3), bg (4,)"""
+
+    def __init__(self, scene):
+        self.verts = np.ascontiguousarray(scene["vertices"], dtype=np.float32).reshape(-1, 4)
+        assert self.verts.shape[0] % 3 == 0
+        self.n_tris = self.verts.shape[0] // 3
+        mat = np.ascontiguousarray(scene["mat_index"], dtype=np.uint32)
+        em = np.ascontiguousarray(scene["emission"], dtype=np.float32).reshape(-1, 3)
+        df = np.ascontiguousarray(scene["diffuse"], dtype=np.float32).reshape(-1, 3)
+        bg = np.ascontiguousarray(scene.get("bg", np.zeros(4)), dtype=np.float32)
+        self._h = lib().orc_scene_create(self.verts.ctypes.data, self.n_tris, mat.ctypes.data, em.ctypes.data,
+                                         df.ctypes.data, em.shape[0], bg.ctypes.data)
+        self.has_bvh = False
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_scene_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def build_bvh(self, leaf_max=4, max_depth=48):
+        rc = lib().orc_scene_build_bvh(self._h, leaf_max, max_depth)
+        if rc:
+            raise RuntimeError("orc_scene_build_bvh failed: %d" % rc)
+        self.has_bvh = True
+        return self
+
+    def set_bvh(self, nodes, tris):
+        nodes = np.ascontiguousarray(nodes)
+        tris = np.ascontiguousarray(tris)
+        assert nodes.nbytes % 64 == 0 and tris.nbytes % 48 == 0
+        rc = lib().orc_scene_set_bvh(self._h, nodes.ctypes.data, nodes.nbytes // 64, tris.ctypes.data,
+                                     tris.nbytes // 48)
+        if rc:
+            raise RuntimeError("orc_scene_set_bvh: BVH failed validation: %d" % rc)
+        self.has_bvh = True
+        return self
+
+    def validate(self):
+        return lib().orc_scene_validate_bvh(self._h)
+
+    @property
+    def num_nodes(self):
+        return lib().orc_scene_num_nodes(self._h)
+
+    @property
+    def depth(self):
+        return lib().orc_scene_bvh_depth(self._h)
+
+    def trace_closest(self, rays, mode=MODE_BVH, stats=None):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        t = np.empty(n, np.float32)
+        prim = np.empty(n, np.uint32)
+        u = np.empty(n, np.float32)
+        v = np.empty(n, np.float32)
+        lib().orc_trace_closest(self._h, mode, rays.ctypes.data, n, t.ctypes.data, prim.ctypes.data, u.ctypes.data,
+                                v.ctypes.data, C.byref(stats) if stats is not None else None)
+        return t, prim, u, v
+
+    def trace_any(self, rays, mode=MODE_BVH, stats=None):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        occ = np.empty(n, np.uint8)
+        lib().orc_trace_any(self._h, mode, rays.ctypes.data, n, occ.ctypes.data,
+                            C.byref(stats) if stats is not None else None)
+        return occ
+
+    def make_params(self, launch, accum=None, frame=None):
+        """launch: dict with width,height,spp,subframe,eye,U,V,W,light{corner,v1,v2,normal,emission}"""
+        p = OrcParams()
+        p.subframe_index = int(launch.get("subframe", 0))
+        p.width, p.height = int(launch["width"]), int(launch["height"])
+        p.samples_per_launch = int(launch.get("spp", 1))
+        for k in ("eye", "U", "V", "W"):
+            setattr(p, k, _f3(launch[k]))
+        for k in ("corner", "v1", "v2", "normal", "emission"):
+            setattr(p.light, k, _f3(launch["light"][k]))
+        if accum is not None:
+            p.accum_buffer = accum.ctypes.data
+        if frame is not None:
+            p.frame_buffer = frame.ctypes.data
+        return p
+
+    def render(self, launch, mode=MODE_BVH, max_depth=0, accum=None, threads=1, rows=None, want_frame=True):
+        """Renders rows [y0,y1) (default: all).  Returns (accum HxWx4 f32, frame HxWx4 u8, stats dict)."""
+        w, h = int(launch["width"]), int(launch["height"])
+        if accum is None:
+            accum = np.zeros((h, w, 4), np.float32)
+        frame = np.zeros((h, w, 4), np.uint8) if want_frame else None
+        p = self.make_params(launch, accum, frame)
+        y0, y1 = rows if rows is not None else (0, h)
+        L = lib()
+        if threads <= 1:
+            st = OrcStats()
+            rc = L.orc_render_rows(self._h, mode, C.byref(p), max_depth, y0, y1, C.byref(st))
+            if rc:
+                raise RuntimeError("orc_render_rows: %d" % rc)
+            return accum, frame, st.as_dict()
+        import threading
+        # interleaved small bands so every thread sees a similar mix of the image
+        band = 4
+        bands = [(y, min(y + band, y1)) for y in range(y0, y1, band)]
+        stats = [OrcStats() for _ in range(threads)]
+        errs = []
+
+        def work(tid):
+            for b in bands[tid::threads]:
+                rc = L.orc_render_rows(self._h, mode, C.byref(p), max_depth, b[0], b[1], C.byref(stats[tid]))
+                if rc:
+                    errs.append(rc)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        if errs:
+            raise RuntimeError("orc_render_rows: %s" % errs)
+        tot = {k: 0 for k, _ in OrcStats._fields_}
+        for s in stats:
+            for k, v in s.as_dict().items():
+                tot[k] = max(tot[k], v) if k == "max_depth_seen" else tot[k] + v
+        return accum, frame, tot
+
+    def render_pixels(self, launch, pixel_index, mode=MODE_BVH, max_depth=0, prev=None):
+        pix = np.ascontiguousarray(pixel_index, dtype=np.uint32)
+        out = np.zeros((pix.shape[0], 4), np.float32)
+        p = self.make_params(launch)
+        st = OrcStats()
+        prevp = np.ascontiguousarray(prev, dtype=np.float32).ctypes.data if prev is not None else None
+        rc = lib().orc_render_pixels(self._h, mode, C.byref(p), max_depth, pix.ctypes.data, pix.shape[0],
+                                     out.ctypes.data, prevp, C.byref(st))
+        if rc:
+            raise RuntimeError("orc_render_pixels: %d" % rc)
+        return out, st.as_dict()
+
+    def primary_rays(self, launch, rows=None):
+        w, h = int(launch["width"]), int(launch["height"])
+        y0, y1 = rows if rows is not None else (0, h)
+        rays = np.empty(((y1 - y0) * w, 8), np.float32)
+        p = self.make_params(launch)
+        lib().orc_primary_rays(C.byref(p), y0, y1, rays.ctypes.data)
+        return rays
