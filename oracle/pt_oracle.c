@@ -470,7 +470,7 @@ static int32_t build_range(Builder* B, uint32_t lo, uint32_t hi, int depth)
 int orc_scene_build_bvh(OrcScene* s, int leaf_max, int max_depth)
 {
     if (leaf_max < 1 || leaf_max > 15 || max_depth < 2 || max_depth > STACK_MAX - 2) return -1;
-    { uint64_t cap = (uint64_t)leaf_max << (max_depth - 1 > 40 ? 40 : max_depth - 1); if (s->n_tris > cap) return -2; }
+    { uint64_t cap = (uint64_t)leaf_max << (max_depth > 40 ? 40 : max_depth); if (s->n_tris > cap) return -2; }
     free(s->nodes); free(s->tris); s->nodes = NULL; s->tris = NULL;
     Builder B; memset(&B, 0, sizeof B);
     B.s = s; B.leaf_max = leaf_max; B.max_depth = max_depth;

@@ -1,0 +1,271 @@
+"""GPU parity tests (run on an MI355X with `-m gpu`): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded inputs and the SAME BVH (exported from device memory).
+
+Bars (BASELINE.json north_star): traversal records (t, prim, u, v) and occlusion flags bit-exact;
+ray counters and node/triangle visit counts equal; accum float4 within 1e-5 relative (they are in
+fact bit-identical, asserted where stated); frame uchar4 exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5          # north_star tolerance for pixel RGB
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _state(scene, w, h, spp=1, max_depth=0):
+    from optix_raytracer_amd import pathtracer as PT
+    st = PT.make_state(scene, w, h, spp, 0, max_depth)
+    return PT, st
+
+
+def _oracle_scene(scene, st):
+    nodes, tris = st.context.accel_export(st.gas_handle)
+    return O.Scene(scene).set_bvh(nodes, tris)
+
+
+def _render_gpu(PT, st, subframe=0):
+    st.params.subframe_index = subframe
+    ob = getattr(st, "_ob", None)
+    if ob is None:
+        ob = PT.OutputBuffer(st.params.width, st.params.height, st.device)
+        st._ob = ob
+    PT.launchSubframe(ob, st)
+    return st.accum.cpu().numpy(), ob.getHostPointer(), st.context.launch_stats()
+
+
+def _assert_pixels(acc_gpu, acc_cpu, exact=True):
+    if exact:
+        bad = np.argwhere(acc_gpu.view(np.uint32) != acc_cpu.view(np.uint32))
+        assert bad.size == 0, "first differing pixel %s: gpu %s cpu %s" % (bad[0], acc_gpu[tuple(bad[0][:2])], acc_cpu[tuple(bad[0][:2])])
+    denom = np.maximum(np.abs(acc_cpu), 1e-6)
+    assert (np.abs(acc_gpu - acc_cpu) / denom).max() <= REL_TOL
+
+
+# ------------------------------------------------------------------------------------------------
+def test_library_is_native_and_loaded():
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    L.load()
+    maps = open("/proc/self/maps").read()
+    assert "optix_raytracer_amd/lib/libmipt.so" in maps
+    assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
+
+
+@pytest.mark.parametrize("persistent", [1, 0])
+def test_traversal_records_bit_exact(persistent):
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import scenes
+    for scene, (w, h) in ((scenes.cornell_box(), (160, 96)), (scenes.random_soup(30000), (200, 120))):
+        PT, st = _state(scene, w, h)
+        st.context.set_option(L.OPT_PERSISTENT, persistent)
+        st.context.set_option(L.OPT_COUNT_VISITS, 1)
+        osc = _oracle_scene(scene, st)
+        launch = scenes.launch_desc(scene, w, h)
+        rays = osc.primary_rays(launch)
+        # add incoherent rays + empty-interval rays + axis-parallel rays
+        rng = np.random.default_rng(7)
+        lo, hi = (0, 556) if scene["name"] == "cornell" else (-0.2, 1.2)
+        extra = np.zeros((5000, 8), np.float32)
+        extra[:, :3] = rng.uniform(lo, hi, (5000, 3))
+        extra[:, 4:7] = rng.normal(size=(5000, 3))
+        extra[:, 3], extra[:, 7] = 0.01, 1e16
+        extra[:50, 7] = 0.0                       # tmax < tmin
+        extra[50:100, 4:6] = 0.0                  # parallel to z
+        rays = np.concatenate([rays, extra])
+        n = rays.shape[0]
+        d_rays = torch.from_numpy(rays).cuda()
+        d_hits = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), n, d_hits.data_ptr())
+        stats = st.context.launch_stats()
+        hits = d_hits.cpu().numpy()
+        ost = O.OrcStats()
+        t, prim, u, v = osc.trace_closest(rays, O.MODE_BVH, ost)
+        assert np.array_equal(hits[:, 1].view(np.uint32), prim)
+        assert np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
+        hit = prim != 0xffffffff
+        assert np.array_equal(hits[hit, 2].view(np.uint32), u[hit].view(np.uint32))
+        assert np.array_equal(hits[hit, 3].view(np.uint32), v[hit].view(np.uint32))
+        assert stats["node_visits"] == ost.node_visits and stats["tri_tests"] == ost.tri_tests
+        # occlusion
+        seg = rays.copy()
+        seg[:, 7] = np.where(seg[:, 7] > 1.0, 250.0 if scene["name"] == "cornell" else 0.4, seg[:, 7])
+        d_seg = torch.from_numpy(seg).cuda()
+        d_occ = torch.zeros(n, dtype=torch.int32, device="cuda")
+        st.context.trace_any(st.gas_handle, d_seg.data_ptr(), n, d_occ.data_ptr())
+        occ = osc.trace_any(seg, O.MODE_BVH)
+        assert np.array_equal(d_occ.cpu().numpy().astype(np.uint8), occ)
+        PT.cleanupState(st)
+
+
+def test_cornell_config1_512_spp1():
+    """BASELINE config 1: Cornell 512x512 spp 1 (CPU reference) vs the GPU path, unbounded depth"""
+    _torch()
+    from optix_raytracer_amd import scenes
+    scene = scenes.cornell_box()
+    PT, st = _state(scene, 512, 512, 1)
+    acc, frame, stats = _render_gpu(PT, st)
+    osc = _oracle_scene(scene, st)
+    a, f, ost = osc.render(scenes.launch_desc(scene, 512, 512, 1), threads=8)
+    _assert_pixels(acc, a)
+    assert np.array_equal(frame, f)
+    assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"]
+    assert stats["bounces"] == ost["max_depth_seen"] + 1
+    PT.cleanupState(st)
+
+
+@pytest.mark.parametrize("w,h,spp,max_depth", [(96, 64, 4, 0), (100, 37, 3, 0), (64, 64, 16, 8), (33, 9, 1, 1)])
+def test_cornell_multi_sample_and_ragged_sizes(w, h, spp, max_depth):
+    _torch()
+    from optix_raytracer_amd import scenes
+    scene = scenes.cornell_box()
+    PT, st = _state(scene, w, h, spp, max_depth)
+    acc, frame, stats = _render_gpu(PT, st)
+    osc = _oracle_scene(scene, st)
+    a, f, ost = osc.render(scenes.launch_desc(scene, w, h, spp), max_depth=max_depth, threads=4)
+    _assert_pixels(acc, a)
+    assert np.array_equal(frame, f)
+    assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"]
+    PT.cleanupState(st)
+
+
+def test_progressive_subframes():
+    _torch()
+    from optix_raytracer_amd import scenes
+    scene = scenes.cornell_box()
+    PT, st = _state(scene, 80, 48, 2)
+    osc = _oracle_scene(scene, st)
+    acc_cpu = None
+    for sub in range(3):
+        acc, frame, _ = _render_gpu(PT, st, sub)
+        acc_cpu, f, _ = osc.render(scenes.launch_desc(scene, 80, 48, 2, subframe=sub), accum=acc_cpu)
+        _assert_pixels(acc, acc_cpu)
+        assert np.array_equal(frame, f)
+    PT.cleanupState(st)
+
+
+@pytest.mark.parametrize("n_tris,max_depth", [(100000, 1), (100000, 8), (20000, 0)])
+def test_soup_scene_parity(n_tris, max_depth):
+    """the benchmark scene family at a size the oracle renders in seconds"""
+    _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import scenes
+    scene = scenes.random_soup(n_tris)
+    w, h = 320, 180
+    PT, st = _state(scene, w, h, 1, max_depth)
+    st.context.set_option(L.OPT_COUNT_VISITS, 1)
+    acc, frame, stats = _render_gpu(PT, st)
+    osc = _oracle_scene(scene, st)
+    a, f, ost = osc.render(scenes.launch_desc(scene, w, h, 1), max_depth=max_depth, threads=8)
+    _assert_pixels(acc, a)
+    assert np.array_equal(frame, f)
+    for k in ("closest_rays", "shadow_rays", "node_visits", "tri_tests"):
+        assert stats[k] == ost[k], k
+    PT.cleanupState(st)
+
+
+def test_shards_reassemble_to_the_full_frame():
+    """multi-GPU path on one GPU: every rank's shard rendered in turn, gathered buffer un-permuted"""
+    torch = _torch()
+    from optix_raytracer_amd import api, scenes
+    scene = scenes.cornell_box()
+    w, h, spp = 104, 44, 2          # not a multiple of the 8*world strip: padded samples must be ignored
+    PT, st = _state(scene, w, h, spp)
+    full, full_frame, _ = _render_gpu(PT, st)
+    for world in (1, 2, 3, 8):
+        ns = api.shard_num_samples(w, h, world)
+        gathered = torch.zeros((world, ns, 4), dtype=torch.float32, device="cuda")
+        for r in range(world):
+            st.context.launch_shard(st.params, w, h, r, world, gathered[r].data_ptr(), stream=st.stream.cuda_stream)
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        st.context.unpermute(gathered.data_ptr(), world, w, h, acc.data_ptr(), frame.data_ptr(), stream=st.stream.cuda_stream)
+        st.context.sync()
+        assert np.array_equal(acc.cpu().numpy().view(np.uint32), full.view(np.uint32)), world
+        assert np.array_equal(frame.cpu().numpy(), full_frame), world
+    PT.cleanupState(st)
+
+
+def test_error_behaviour():
+    torch = _torch()
+    from optix_raytracer_amd import api, scenes
+    from optix_raytracer_amd import pathtracer as PT
+    scene = scenes.cornell_box()
+    st = PT.PathTracerState()
+    PT.createContext(st)
+    PT.buildMeshAccel(st, scene)
+    PT.initLaunchParams(st, 32, 32, 1)
+    with pytest.raises(api.MiptError) as e:        # no hit-group records yet
+        st.context.launch(st.params, 32, 32, 1)
+    assert e.value.code == 6
+    PT.createSBT(st)
+    with pytest.raises(api.MiptError) as e:        # launch size must match params
+        st.context.launch(st.params, 64, 32, 1)
+    assert e.value.code == 1
+    with pytest.raises(api.MiptError) as e:
+        st.context.launch(st.params, 32, 32, 2)
+    assert e.value.code == 1
+    st.params.handle = 12345
+    with pytest.raises(api.MiptError) as e:
+        st.context.launch(st.params, 32, 32, 1)
+    assert e.value.code == 5
+    st.params.handle = st.gas_handle
+    st.params.samples_per_launch = 0
+    with pytest.raises(api.MiptError):
+        st.context.launch(st.params, 32, 32, 1)
+    with pytest.raises(api.MiptError):
+        st.context.accel_build([{"vertices": None, "num_vertices": 3}])
+    with pytest.raises(api.MiptError):             # indexed input with an out-of-range index
+        st.context.accel_build([{"vertices": np.zeros((3, 3), np.float32), "num_vertices": 3,
+                                 "indices": np.array([0, 1, 7], np.uint32), "index_format": 4, "num_triangles": 1}])
+    PT.cleanupState(st)
+
+
+def test_indexed_strided_and_transformed_inputs():
+    """build inputs as sutil::Scene feeds them: u16/u32 indices, byte strides, a 3x4 instance transform"""
+    torch = _torch()
+    from optix_raytracer_amd import api, scenes
+    scene = scenes.random_soup(500, edge_scale=0.1)
+    v = scene["vertices"].reshape(-1, 4)[:, :3].copy()
+    # weld nothing, but index in reverse order and interleave vertices with 8 bytes of padding
+    packed = np.zeros((v.shape[0], 5), np.float32)
+    packed[:, :3] = v
+    idx32 = np.arange(v.shape[0], dtype=np.uint32).reshape(-1, 3)[::-1].copy()
+    idx16 = idx32.astype(np.uint16)
+    xf = np.array([[0, -2, 0, 1], [2, 0, 0, -3], [0, 0, 2, 0.5]], np.float32)
+    ctx = api.Context(0)
+    handles = [
+        ctx.accel_build([{"vertices": packed, "num_vertices": v.shape[0], "stride": 20, "indices": idx32,
+                          "index_format": 4, "num_triangles": idx32.shape[0], "transform": xf}]),
+        ctx.accel_build([{"vertices": torch.from_numpy(packed).cuda().data_ptr(), "num_vertices": v.shape[0], "stride": 20,
+                          "indices": idx16, "index_format": 2, "num_triangles": idx16.shape[0], "transform": xf}]),
+    ]
+    world = (v[idx32.reshape(-1)] @ xf[:, :3].T + xf[:, 3]).astype(np.float32)
+    sc2 = dict(scene, vertices=np.concatenate([world, np.zeros((world.shape[0], 1), np.float32)], axis=1))
+    rng = np.random.default_rng(0)
+    rays = np.zeros((3000, 8), np.float32)
+    rays[:, :3] = rng.uniform(-4, 4, (3000, 3))
+    rays[:, 4:7] = np.array([0.0, -2.0, 1.5]) - rays[:, :3] + rng.normal(size=(3000, 3))
+    rays[:, 3], rays[:, 7] = 0.01, 1e16
+    d_rays = torch.from_numpy(rays).cuda()
+    for hnd in handles:
+        nodes, tris = ctx.accel_export(hnd)
+        osc = O.Scene(sc2).set_bvh(nodes, tris)
+        d_hits = torch.zeros((3000, 4), dtype=torch.float32, device="cuda")
+        ctx.trace_closest(hnd, d_rays.data_ptr(), 3000, d_hits.data_ptr())
+        ctx.sync()
+        t, prim, _, _ = osc.trace_closest(rays, O.MODE_BRUTE)
+        hits = d_hits.cpu().numpy()
+        assert np.array_equal(hits[:, 1].view(np.uint32), prim) and np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
+        assert (prim != 0xffffffff).sum() > 100
+    ctx.destroy()
