@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's headline configuration.
+
+Workload (configs[3], SURVEY.md 8d "C4"): 1,000,000 random triangles in the unit cube, 1920x1080,
+spp = 1, subframe 0, max depth 1 (the primary ray and its next-event-estimation shadow ray).
+A "step" is one frame: raygen -> trace_closest -> shade -> trace_any -> resolve.  With N > 1 ranks
+(one process per GPU, launched by torch.distributed.run) every rank renders its interleaved 8x4-tile
+shard of the SAME frame, the compact float4 shards are all-gathered over RCCL and un-permuted
+(strong scaling: the total work is the frame).
+
+Prints ONE JSON line on rank 0:  value = (closest + shadow rays actually traced by all ranks) / time.
+Scene generation and the BVH build are outside the timed region; inputs are resident
+in HBM when the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, N_TRIS, MAX_DEPTH = 1920, 1080, 1, 1_000_000, 1
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tris", type=int, default=N_TRIS, help="debug only: any other value is not the headline workload")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--max-depth", type=int, default=MAX_DEPTH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(st, scene, width, height, max_depth, budget_s):
+    """The CPU oracle (oracle/pt_oracle.c, kind "port": this build's C restatement, single-threaded
+    traversal per core) rendering a bounded sample of the same frame over the same BVH."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    from optix_raytracer_amd import scenes
+    nodes, tris = st.context.accel_export(st.gas_handle)
+    osc = O.Scene(scene).set_bvh(nodes, tris)
+    launch = scenes.launch_desc(scene, width, height, SPP)
+    cores = max(1, len(os.sched_getaffinity(0)))
+    # calibrate on a few scattered bands, then size the sample to the budget
+    import numpy as np
+    rng = np.random.default_rng(0)
+    n_bands = height // 4
+
+    def run(bands):
+        import threading
+        stats = [O.OrcStats() for _ in range(cores)]
+        p = osc.make_params(launch, np.zeros((height, width, 4), np.float32), None)
+        L = O.lib()
+
+        def work(tid):
+            import ctypes as C
+            for b in bands[tid::cores]:
+                L.orc_render_rows(osc._h, O.MODE_BVH, C.byref(p), max_depth, int(b) * 4, int(b) * 4 + 4, C.byref(stats[tid]))
+        t0 = time.perf_counter()
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        dt = time.perf_counter() - t0
+        rays = sum(s.closest_rays + s.shadow_rays for s in stats)
+        return rays, dt
+    probe = rng.permutation(n_bands)[:max(cores, 8)]
+    rays, dt = run(probe)
+    per_band = dt / max(len(probe) / cores, 1.0) / cores          # seconds of one core per band (approx)
+    want = int(min(n_bands, max(cores, budget_s * cores / max(per_band * cores, 1e-9) / cores)))
+    bands = rng.permutation(n_bands)[:want]
+    rays, dt = run(bands)
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d 4-row bands of the same %dx%d frame (%d rays) in %.1f s, %d threads, one band per task" % (
+                len(bands), n_bands, width, height, rays, dt, cores)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import api, scenes
+    from optix_raytracer_amd import pathtracer as PT
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h = args.width, args.height
+    scene = scenes.random_soup(args.tris)
+    t0 = time.perf_counter()
+    st = PT.make_state(scene, w, h, SPP, local_rank, max_depth=args.max_depth)
+    build_s = time.perf_counter() - t0
+    info = st.context.accel_info(st.gas_handle)
+    stream = torch.cuda.current_stream()
+    frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=st.device)
+    st.params.frame_buffer = frame.data_ptr()
+    st.params.subframe_index = 0
+    if world > 1:
+        ns = api.shard_num_samples(w, h, world)
+        compact = torch.zeros((ns, 4), dtype=torch.float32, device=st.device)
+        gathered = torch.zeros((world * ns, 4), dtype=torch.float32, device=st.device)
+
+    def step():
+        if world == 1:
+            st.context.launch(st.params, w, h, 1, stream=stream.cuda_stream)
+        else:
+            st.context.launch_shard(st.params, w, h, rank, world, compact.data_ptr(), stream=stream.cuda_stream)
+            dist.all_gather_into_tensor(gathered, compact)
+            st.context.unpermute(gathered.data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=stream.cuda_stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- one counting launch (outside the timed region): rays, node visits, triangle tests per frame
+    st.context.set_option(L.OPT_COUNT_VISITS, 1)
+    step()
+    torch.cuda.synchronize()
+    counts = st.context.launch_stats()
+    st.context.set_option(L.OPT_COUNT_VISITS, 0)
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps between barrier + synchronize
+    st.context.set_option(L.OPT_PROFILE, 1)       # HIP events around each kernel, on the launch stream
+    k_closest = k_any = k_shade = k_other = 0.0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tm = st.context.launch_timings()              # event sums over all K timed steps (read after the fence)
+    k_closest, k_any, k_shade = (tm[k] / args.steps for k in ("ms_trace_closest", "ms_trace_any", "ms_shade"))
+    k_other = (tm["ms_raygen"] + tm["ms_resolve"]) / args.steps
+    st.context.set_option(L.OPT_PROFILE, 0)
+
+    rays_local = counts["closest_rays"] + counts["shadow_rays"]
+    t_max = elapsed
+    rays_total = rays_local
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=st.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_max = float(tt.item())
+        rr = torch.tensor([rays_local], dtype=torch.int64, device=st.device)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays_total = int(rr.item())
+
+    if rank == 0:
+        ms_per_step = t_max / args.steps * 1e3
+        value = rays_total * args.steps / t_max / 1e6
+        # ---- roofline of the dominant kernel (algorithmic bytes: SURVEY.md 8d / DESIGN.md)
+        nv_c = counts["node_visits"] - counts["shadow_node_visits"]
+        tt_c = counts["tri_tests"] - counts["shadow_tri_tests"]
+        bytes_closest = 64 * nv_c + 48 * tt_c + (32 + 16) * counts["closest_rays"]
+        bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
+        if k_closest >= k_any:
+            kname, kbytes, kms, klaunches = "k_trace_persistent<closest>", bytes_closest, k_closest, tm["n_trace_closest"]
+        else:
+            kname, kbytes, kms, klaunches = "k_trace_persistent<any>", bytes_any, k_any, tm["n_trace_any"]
+        launches_per_step = max(klaunches // args.steps, 1)
+        kms_avg = kms / launches_per_step          # average duration of one launch of that kernel
+        kbytes_launch = kbytes / launches_per_step
+        achieved = kbytes_launch / (kms_avg * 1e-3) / 1e9 if kms_avg > 0 else 0.0
+        out = {
+            "metric": "Mray/s (primary+shadow), 1920x1080 spp=1, 1M-tri scene",
+            "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: %d random triangles in the unit cube, %dx%d spp=%d, max depth %d "
+                                   "(primary + NEE shadow ray), BVH2 %d nodes depth %d" % (
+                                       args.tris, w, h, SPP, args.max_depth, info["num_nodes"], info["depth"]),
+                       "rays_per_frame": rays_total, "closest_rays": counts["closest_rays"] if world == 1 else None,
+                       "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather" % world,
+                       "bvh_build_s": round(info["build_seconds"], 3), "setup_s": round(build_s, 3)},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(kbytes_launch),
+                         "kernel_ms_avg": round(kms_avg, 4),
+                         "per_frame_ms": {"trace_closest": round(k_closest, 4), "trace_any": round(k_any, 4),
+                                          "shade": round(k_shade, 4), "raygen+resolve": round(k_other, 4)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(st, scene, w, h, args.max_depth, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    PT.cleanupState(st)
+
+
+if __name__ == "__main__":
+    main()

@@ -135,8 +135,10 @@ typedef struct MiptBuildInput {
 typedef struct MiptLaunchStats {
     uint64_t closest_rays;     /* primary + continuation rays traced by the last launch */
     uint64_t shadow_rays;      /* occlusion rays traced by the last launch */
-    uint64_t node_visits;      /* only counted when mipt_set_option(MIPT_OPT_COUNT_VISITS, 1) */
-    uint64_t tri_tests;
+    uint64_t node_visits;      /* 64-B nodes fetched by both traversal kernels; only counted when */
+    uint64_t tri_tests;        /* 48-B triangles fetched;  MIPT_OPT_COUNT_VISITS is on           */
+    uint64_t shadow_node_visits; /* the any-hit kernel's share of node_visits */
+    uint64_t shadow_tri_tests;   /* the any-hit kernel's share of tri_tests   */
     uint32_t bounces;          /* wavefront iterations executed */
     uint32_t reserved;
 } MiptLaunchStats;
@@ -150,8 +152,9 @@ typedef enum MiptOption {
     MIPT_OPT_PROFILE      = 5  /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings) */
 } MiptOption;
 
-/* per-kernel device time of the last launch, summed over its wavefront iterations (ms);
- * only filled when MIPT_OPT_PROFILE is on */
+/* per-kernel device time (ms), summed over every kernel launched since the previous
+ * mipt_get_launch_timings call (or since MIPT_OPT_PROFILE was switched on); only filled
+ * while MIPT_OPT_PROFILE is on.  Reading the timings synchronises the stream and resets the sums. */
 typedef struct MiptLaunchTimings {
     float    ms_raygen, ms_trace_closest, ms_shade, ms_trace_any, ms_resolve;
     uint32_t n_trace_closest, n_trace_any;   /* kernel launches behind the sums */

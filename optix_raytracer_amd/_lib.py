@@ -45,7 +45,8 @@ class MiptBuildInput(C.Structure):
 
 class MiptLaunchStats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
-                ("tri_tests", C.c_uint64), ("bounces", C.c_uint32), ("reserved", C.c_uint32)]
+                ("tri_tests", C.c_uint64), ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
+                ("bounces", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MiptLaunchTimings(C.Structure):

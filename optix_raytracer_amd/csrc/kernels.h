@@ -22,7 +22,8 @@ struct DeviceCounters {
     uint32_t bounce;
     uint32_t cursor_closest[kNumSegments * kCursorStride];
     uint32_t cursor_shadow[kNumSegments * kCursorStride];
-    unsigned long long closest_rays, shadow_rays, node_visits, tri_tests;
+    unsigned long long closest_rays, shadow_rays;
+    unsigned long long node_visits[2], tri_tests[2];   // [0] closest-hit kernel, [1] any-hit kernel
 };
 
 struct DeviceBvh {

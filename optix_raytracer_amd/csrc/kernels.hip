@@ -83,7 +83,8 @@ __device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd)
     T.idir = mk3(1.0f / dx, 1.0f / dy, 1.0f / dz);
     T.nood = mk3(-(T.o.x * T.idir.x), -(T.o.y * T.idir.y), -(T.o.z * T.idir.z));
     T.u = 0.0f; T.v = 0.0f; T.prim = 0xffffffffu;
-    T.node = 0; T.sp = 0;
+    T.node = T.tmax > T.tmin ? 0 : kSentinel;   // empty interval: a miss without touching the BVH
+    T.sp = 0;
 }
 
 __device__ __forceinline__ int stack_pop(Trav& T, const uint32_t* stk, int lane)
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(64) void k_trace_persistent(TraceArgs a)
         }
     }
     if (COUNT) {
-        wave_add64(&a.ctr->node_visits, n_visits);
-        wave_add64(&a.ctr->tri_tests, n_tests);
+        wave_add64(&a.ctr->node_visits[MODE != 0], n_visits);
+        wave_add64(&a.ctr->tri_tests[MODE != 0], n_tests);
     }
 }
 
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
         finish_ray<MODE>(a, T, ray, hit);
     }
     if (COUNT) {
-        wave_add64(&a.ctr->node_visits, n_visits);
-        wave_add64(&a.ctr->tri_tests, n_tests);
+        wave_add64(&a.ctr->node_visits[MODE != 0], n_visits);
+        wave_add64(&a.ctr->tri_tests[MODE != 0], n_tests);
     }
 }
 

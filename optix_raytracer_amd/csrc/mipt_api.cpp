@@ -271,10 +271,9 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc, const
     int rc = ensure_capacity(ctx, n_paths, n_slots);
     if (rc) return rc;
     ctx->last_stream = st;
-    ctx->events_used = 0; ctx->timed.clear();
     const DeviceBvh bvh = device_bvh(acc);
     const TraceOpts opts = trace_opts(ctx);
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 6 * sizeof(unsigned long long), st));
     uint32_t bounces_total = 0;
     for (uint32_t s = 0; s < fc.samples_per_launch; ++s) {
         launch_begin_sample(st, ctx->d_ctr, n_paths);
@@ -385,7 +384,9 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value > 32) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 32 single-wave workgroups fit a CU");
         c->blocks_per_cu = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PERSISTENT: c->persistent = value ? 1 : 0; return MIPT_SUCCESS;
-    case MIPT_OPT_PROFILE: c->profile = value ? 1 : 0; return MIPT_SUCCESS;
+    case MIPT_OPT_PROFILE:
+        if (c->last_stream || c->timed.size()) (void)hipStreamSynchronize(c->last_stream);
+        c->profile = value ? 1 : 0; c->timed.clear(); c->events_used = 0; return MIPT_SUCCESS;
     default: return c->fail(MIPT_ERROR_INVALID_VALUE, "unknown option %d", option);
     }
 }
@@ -667,7 +668,8 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     DeviceCounters h;
     HIPCHK(ctx, hipMemcpy(&h, ctx->d_ctr, sizeof h, hipMemcpyDeviceToHost));
     stats->closest_rays = h.closest_rays; stats->shadow_rays = h.shadow_rays;
-    stats->node_visits = h.node_visits; stats->tri_tests = h.tri_tests;
+    stats->node_visits = h.node_visits[0] + h.node_visits[1]; stats->tri_tests = h.tri_tests[0] + h.tri_tests[1];
+    stats->shadow_node_visits = h.node_visits[1]; stats->shadow_tri_tests = h.tri_tests[1];
     stats->bounces = ctx->last_bounces; stats->reserved = 0;
     return MIPT_SUCCESS;
 }
@@ -690,6 +692,7 @@ int mipt_get_launch_timings(MiptContext* ctx, MiptLaunchTimings* out)
         default: break;
         }
     }
+    ctx->timed.clear(); ctx->events_used = 0;      // sums cover every launch since the previous call
     return MIPT_SUCCESS;
 }
 
@@ -704,9 +707,8 @@ int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    ctx->events_used = 0; ctx->timed.clear();
     launch_begin_sample(st, ctx->d_ctr, n);
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 6 * sizeof(unsigned long long), st));
     const float4* r = (const float4*)rays;
     { TimedScope t(ctx, st, T_CLOSEST);
       launch_trace_closest(st, device_bvh(a), r, r + 1, 2, nullptr, n, (float4*)hits, ctx->d_ctr, trace_opts(ctx)); }
@@ -724,9 +726,8 @@ int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, co
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    ctx->events_used = 0; ctx->timed.clear();
     launch_begin_sample(st, ctx->d_ctr, n);
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 6 * sizeof(unsigned long long), st));
     const float4* r = (const float4*)rays;
     { TimedScope t(ctx, st, T_ANY);
       launch_trace_any(st, device_bvh(a), r, r + 1, 2, nullptr, n, (uint32_t*)occluded, nullptr, nullptr, ctx->d_ctr, trace_opts(ctx)); }

@@ -636,7 +636,7 @@ static void brute_force(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats*
     h->hit = 0; h->t = r->tmax; h->prim = 0xffffffffu; h->u = h->v = 0.0f;
     for (uint32_t i = 0; i < s->n_tris; ++i) {
         float t, u, v;
-        if (st) st->tri_tests++;
+        if (st) { st->tri_tests++; if (any) st->shadow_tri_tests++; }
         if (tri_test(&s->brute[i], r, r->tmax, &t, &u, &v)) {
             if (any) { h->hit = 1; h->t = t; h->prim = i; return; }
             consider(h, t, u, v, i);
@@ -651,11 +651,12 @@ static void bvh_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats
     int     sp = 0;
     h->hit = 0; h->t = r->tmax; h->prim = 0xffffffffu; h->u = h->v = 0.0f;
     stack[sp++] = SENTINEL;
+    if (!(r->tmax > r->tmin)) return;          /* empty interval: a miss without touching the BVH */
     int32_t node = 0;
     while (node != SENTINEL) {
         if (node >= 0) {
             const Node64* n = &s->nodes[node];
-            if (st) st->node_visits++;
+            if (st) { st->node_visits++; if (any) st->shadow_node_visits++; }
             int   h0, h1;
             /* prune with the current best t (inclusive, so equal-t candidates are still visited) */
             float lim = h->t;
@@ -674,7 +675,7 @@ static void bvh_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats
             uint32_t d = (uint32_t)~node, first = d >> 4, cnt = d & 15u;
             for (uint32_t i = first; i < first + cnt; ++i) {
                 float t, u, v;
-                if (st) st->tri_tests++;
+                if (st) { st->tri_tests++; if (any) st->shadow_tri_tests++; }
                 if (tri_test(&s->tris[i], r, r->tmax, &t, &u, &v)) {
                     if (any) { h->hit = 1; h->t = t; h->prim = s->tris[i].prim; return; }
                     consider(h, t, u, v, s->tris[i].prim);

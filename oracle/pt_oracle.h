@@ -47,9 +47,11 @@ typedef struct OrcParams {
 typedef struct OrcStats {
     uint64_t closest_rays;   /* primary + continuation rays   */
     uint64_t shadow_rays;    /* occlusion rays actually traced */
-    uint64_t node_visits;    /* 64-byte inner nodes fetched    */
-    uint64_t tri_tests;      /* 48-byte triangles fetched      */
+    uint64_t node_visits;    /* 64-byte inner nodes fetched (closest + shadow) */
+    uint64_t tri_tests;      /* 48-byte triangles fetched   (closest + shadow) */
     uint64_t max_depth_seen; /* deepest bounce index reached   */
+    uint64_t shadow_node_visits; /* the occlusion rays' share of node_visits */
+    uint64_t shadow_tri_tests;   /* the occlusion rays' share of tri_tests   */
 } OrcStats;
 
 typedef struct OrcScene OrcScene;

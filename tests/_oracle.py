@@ -30,7 +30,8 @@ class OrcParams(C.Structure):
 
 class OrcStats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
-                ("tri_tests", C.c_uint64), ("max_depth_seen", C.c_uint64)]
+                ("tri_tests", C.c_uint64), ("max_depth_seen", C.c_uint64),
+                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

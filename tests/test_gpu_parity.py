@@ -169,7 +169,7 @@ def test_soup_scene_parity(n_tris, max_depth):
     a, f, ost = osc.render(scenes.launch_desc(scene, w, h, 1), max_depth=max_depth, threads=8)
     _assert_pixels(acc, a)
     assert np.array_equal(frame, f)
-    for k in ("closest_rays", "shadow_rays", "node_visits", "tri_tests"):
+    for k in ("closest_rays", "shadow_rays", "node_visits", "tri_tests", "shadow_node_visits", "shadow_tri_tests"):
         assert stats[k] == ost[k], k
     PT.cleanupState(st)
 
