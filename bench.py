@@ -57,7 +57,8 @@ def cpu_baseline(st, scene, width, height, max_depth, budget_s):
     def run(bands):
         import threading
         stats = [O.OrcStats() for _ in range(cores)]
-        p = osc.make_params(launch, np.zeros((height, width, 4), np.float32), None)
+        accum = np.zeros((height, width, 4), np.float32)      # must outlive the render calls
+        p = osc.make_params(launch, accum, None)
         L = O.lib()
 
         def work(tid):
@@ -70,6 +71,7 @@ def cpu_baseline(st, scene, width, height, max_depth, budget_s):
         [t.join() for t in ts]
         dt = time.perf_counter() - t0
         rays = sum(s.closest_rays + s.shadow_rays for s in stats)
+        del accum
         return rays, dt
     probe = rng.permutation(n_bands)[:max(cores, 8)]
     rays, dt = run(probe)

@@ -77,7 +77,10 @@ def random_soup(n_tris=1_000_000, seed_tag=0x5EED, edge_scale=0.01):
         "emission": np.zeros((1, 3), np.float32),
         "diffuse": np.asarray([(0.8, 0.8, 0.8)], np.float32),
         "bg": np.zeros(4, np.float32),
-        "light": _light((0.25, 1.5, 0.25), (0.0, 0.0, 0.5), (0.5, 0.0, 0.0), (15.0, 15.0, 5.0)),
+        # SURVEY.md 8(d) lists v1 = (0,0,.5), v2 = (.5,0,0) and states normal = (0,-1,0); normalize(v1 x v2)
+        # of those is (0,+1,0) (facing away from the cube: no shadow ray would ever be cast), so the
+        # two edges are swapped here -- same parallelogram, normal (0,-1,0) as the survey intends.
+        "light": _light((0.25, 1.5, 0.25), (0.5, 0.0, 0.0), (0.0, 0.0, 0.5), (15.0, 15.0, 5.0)),
         "camera": {"eye": (0.5, 0.5, -1.5), "lookat": (0.5, 0.5, 0.5), "up": (0.0, 1.0, 0.0), "fovY": 35.0},
     }
 
