@@ -148,8 +148,15 @@ typedef enum MiptOption {
                                   k = at most k closest-hit queries per path (build extension) */
     MIPT_OPT_COUNT_VISITS = 2, /* 1 = traversal kernels count node visits / triangle tests */
     MIPT_OPT_TRACE_GRID   = 3, /* persistent-kernel workgroups per CU (0 = default) */
-    MIPT_OPT_PERSISTENT   = 4, /* 1 (default) persistent traversal kernels, 0 = one thread per ray */
-    MIPT_OPT_PROFILE      = 5  /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings) */
+    MIPT_OPT_PERSISTENT   = 4, /* traversal kernel: 2 (default) streaming waves, 1 persistent while-while waves,
+                                  0 one thread per ray.  All three visit the BVH in the same per-ray order. */
+    MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings) */
+    MIPT_OPT_LDS_STACK    = 6, /* traversal-stack entries kept in LDS: 16 (default, rest spills to global) or 32 */
+    MIPT_OPT_REFILL_MIN   = 7, /* streaming waves: idle lanes that trigger a swap-in/prefetch round (default 8) */
+    MIPT_OPT_LEAF_MIN     = 8, /* streaming waves: lanes waiting at a leaf that trigger a triangle step (default 1) */
+    MIPT_OPT_ABANDON_MIN  = 9  /* streaming waves: once no fresh rays are left, a wave with fewer live rays than this
+                                  hands them to the one-ray-per-lane kernel and exits (default 0 = never: measured slower,
+                                  64 long rays packed into one wave serialise; kept for experiments) */
 } MiptOption;
 
 /* per-kernel device time (ms), summed over every kernel launched since the previous

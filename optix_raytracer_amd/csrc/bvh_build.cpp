@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -20,7 +21,7 @@ namespace mipt {
 namespace {
 
 constexpr int   kBins     = 32;
-constexpr float kNodeCost = 1.2f;   // cost of one more inner node relative to one triangle test
+float kNodeCost = 1.2f;             // cost of one more inner node relative to one triangle test
 
 struct Box {
     float lo[3], hi[3];
@@ -209,6 +210,8 @@ void put_child(MiptBvhNode& n, int which, const Box& b, int32_t ref)
 bool build_bvh(const float* world_verts, uint32_t n_tris, int leaf_max, int depth_cap, int n_threads, HostBvh& out)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    if (const char* e = std::getenv("MIPT_BVH_NODE_COST")) kNodeCost = (float)std::atof(e);   // experiments only
+    if (const char* e = std::getenv("MIPT_BVH_LEAF_MAX")) leaf_max = std::atoi(e);
     if (leaf_max < 1 || leaf_max > 15 || depth_cap < 1) return false;
     if (n_tris >= (1u << 27)) return false;
     Builder B;

@@ -8,11 +8,15 @@
 
 namespace mipt {
 
-constexpr int      kStackEntries  = 32;     // LDS traversal stack entries per lane == builder depth cap
+constexpr int      kStackEntries  = 32;     // traversal stack entries per lane == builder depth cap
+constexpr int      kLdsStackEntries = 16;   // of which in LDS (4 KB per wave -> 8 waves/SIMD); the rest spill to global
+constexpr int      kMaxTraceBlocks = 256 * 32 * 2;
 constexpr uint32_t kInvalidSlot   = 0xffffffffu;
 constexpr int      kNumSegments   = 8;      // one ray-range segment per XCD
 constexpr int      kCursorStride  = 32;     // uint32 words between cursors (own 128-B line each)
-constexpr uint32_t kChunk         = 256;    // rays a wave takes from a segment cursor at a time
+constexpr uint32_t kChunk         = 256;    // rays a wave takes from a segment cursor at a time (k_trace_persistent)
+constexpr uint32_t kStreamChunk   = 64;     // same, k_trace_stream
+constexpr uint32_t kShadeBlock    = 512;    // threads per shade workgroup == paths per queue-append atomic
 
 // device-resident queue counters + statistics (one per context)
 struct DeviceCounters {
@@ -20,16 +24,21 @@ struct DeviceCounters {
     uint32_t n_next;           // continuation rays emitted by shade
     uint32_t n_shadow;         // shadow rays emitted by shade
     uint32_t bounce;
+    uint32_t n_left[2];        // rays handed over by the streaming kernel: [0] closest, [1] shadow
+    uint32_t pad_left[2];
     uint32_t cursor_closest[kNumSegments * kCursorStride];
     uint32_t cursor_shadow[kNumSegments * kCursorStride];
     unsigned long long closest_rays, shadow_rays;
     unsigned long long node_visits[2], tri_tests[2];   // [0] closest-hit kernel, [1] any-hit kernel
+    unsigned long long dbg[8];                          // schedule counters of k_trace_stream (COUNT builds)
 };
 
 struct DeviceBvh {
     const float4* nodes;       // 4 x float4 per MiptBvhNode
     const float4* tris;        // 3 x float4 per MiptBvhTri
     const uint32_t* mat_index; // per ORIGINAL primitive: hit-group record index
+    uint32_t tri_byte_off;     // tris == (char*)nodes + tri_byte_off (one allocation); 0 if that offset needs > 32 bits
+    uint32_t blob_bytes;       // size of that allocation (buffer-descriptor range)
 };
 
 // SoA path queues, capacity `cap` entries each
@@ -57,13 +66,19 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
 };
 
 struct TraceOpts {
-    int  persistent;           // 1: persistent waves + refill, 0: one thread per ray
+    int  persistent;           // 2: streaming waves (default), 1: persistent while-while waves, 0: one thread per ray
+    int  refill_min, leaf_min; // k_trace_stream thresholds
+    int  abandon_min;          // k_trace_stream: hand-over threshold (0 = waves drain by themselves)
+    uint32_t* leftover;        // 2 * leftover_cap ray indices (closest | shadow), or null
+    uint32_t  leftover_cap;
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
+    int  lds_stack;            // kLdsStackEntries (default) or kStackEntries (all of the stack in LDS)
+    uint32_t* spill;           // blocks * (kStackEntries - kLdsStackEntries) * 64 words
 };
 
 // ---- launches (all asynchronous on `st`) ----
-void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths);
+void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, uint32_t n_valid);
 void launch_advance(hipStream_t st, DeviceCounters* ctr);
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result);
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
@@ -74,7 +89,7 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
                       DeviceCounters* ctr, const TraceOpts& o);
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
-                  float4* result, DeviceCounters* ctr, uint32_t n_max);
+                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices);
 void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots);
 void launch_unpermute(hipStream_t st, const float4* gathered, uint32_t world, uint32_t width, uint32_t height,
                       float4* accum, uint32_t* frame);

@@ -87,15 +87,32 @@ __device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd)
     T.sp = 0;
 }
 
-__device__ __forceinline__ int stack_pop(Trav& T, const uint32_t* stk, int lane)
-{
-    if (T.sp == 0) return kSentinel;
-    --T.sp;
-    return (int)stk[T.sp * 64 + lane];
-}
+// Per-lane traversal stack: the first LDS_N entries live in LDS ([entry][lane]: bank = lane, conflict
+// free), deeper entries -- rare -- spill to a per-wave slab in global memory.  LDS_N = 16 keeps a wave at
+// 4 KB of LDS so that 8 waves per SIMD fit; the builder caps the tree depth at kStackEntries.
+template <int LDS_N>
+struct Stack {
+    uint32_t* lds;       // LDS_N * 64 words
+    uint32_t* spill;     // (kStackEntries - LDS_N) * 64 words of global memory for this wave
+    int       lane;
+    __device__ __forceinline__ void push(int& sp, uint32_t v) const
+    {
+        if (LDS_N >= kStackEntries || sp < LDS_N) lds[sp * 64 + lane] = v;
+        else                                      spill[(sp - LDS_N) * 64 + lane] = v;
+        ++sp;
+    }
+    __device__ __forceinline__ int pop(int& sp) const
+    {
+        if (sp == 0) return kSentinel;
+        --sp;
+        if (LDS_N >= kStackEntries || sp < LDS_N) return (int)lds[sp * 64 + lane];
+        return (int)spill[(sp - LDS_N) * 64 + lane];
+    }
+};
 
 // one inner-node step: fetch 64 B, slab-test both children, descend into the nearer, push the other
-__device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ nodes, uint32_t* stk, int lane)
+template <int LDS_N>
+__device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ nodes, const Stack<LDS_N>& stk)
 {
     const float4* np = nodes + (size_t)(uint32_t)T.node * 4u;
     const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
@@ -117,13 +134,12 @@ __device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ 
     const bool h1 = tn1 <= tf1;
     int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
     if (!h0 && !h1) {
-        T.node = stack_pop(T, stk, lane);
+        T.node = stk.pop(T.sp);
     } else if (h0 && h1) {
         const bool swp = tn1 < tn0;
         const int nearc = swp ? c1 : c0;
         const int farc  = swp ? c0 : c1;
-        stk[T.sp * 64 + lane] = (uint32_t)farc;
-        ++T.sp;
+        stk.push(T.sp, (uint32_t)farc);
         T.node = nearc;
     } else {
         T.node = h0 ? c0 : c1;
@@ -172,6 +188,14 @@ struct TraceArgs {
     float4*         result;       // MODE 2
     uint32_t*       cursors;      // kNumSegments cursors, kCursorStride apart
     DeviceCounters* ctr;
+    uint32_t*       spill;        // gridDim.x * (kStackEntries - LDS_N) * 64 words (stack overflow slabs)
+    int             refill_min;   // k_trace_stream: idle lanes that trigger a swap-in / prefetch round
+    int             leaf_min;     // k_trace_stream: lanes waiting at a leaf that trigger a triangle step
+    int             abandon_min;  // k_trace_stream: once the ray range is exhausted, a wave with fewer live rays
+                                  // than this hands them to the leftover list and exits (0 = never)
+    const uint32_t* index_list;   // optional indirection: the i-th work item is ray index_list[i]
+    uint32_t*       leftover;     // rays handed over by k_trace_stream (ray indices)
+    uint32_t*       leftover_n;   // their count
 };
 
 template <int MODE>
@@ -194,11 +218,12 @@ __device__ __forceinline__ void finish_ray(const TraceArgs& a, const Trav& T, ui
 }
 
 // ---- persistent waves: 64 lanes, each lane owns one ray; idle lanes are refilled from the ray range ----
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, int LDS_N>
 __global__ __launch_bounds__(64) void k_trace_persistent(TraceArgs a)
 {
-    __shared__ uint32_t stk[kStackEntries * 64];
+    __shared__ uint32_t stk_lds[LDS_N * 64];
     const int lane = (int)threadIdx.x;
+    const Stack<LDS_N> stk{ stk_lds, a.spill + (size_t)blockIdx.x * (size_t)((kStackEntries - LDS_N) * 64), lane };
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     // segment s covers [s*seg_len, min((s+1)*seg_len, n)); blocks with equal blockIdx%8 share an XCD (speed only)
@@ -250,12 +275,12 @@ __global__ __launch_bounds__(64) void k_trace_persistent(TraceArgs a)
         // ------------------------------------------------------------------ traverse (while-while)
         while (active && T.node >= 0) {
             if (COUNT) ++n_visits;
-            visit_inner(T, a.bvh.nodes, stk, lane);
+            visit_inner(T, a.bvh.nodes, stk);
         }
         if (active && T.node != kSentinel) {          // a leaf reference
             const bool stop = visit_leaf<(MODE != 0)>(T, a.bvh.tris, n_tests);
             if (stop) { finish_ray<MODE>(a, T, ray, true); active = false; T.node = kSentinel; }
-            else T.node = stack_pop(T, stk, lane);
+            else T.node = stk.pop(T.sp);
         }
         if (active && T.node == kSentinel) {
             finish_ray<MODE>(a, T, ray, MODE == 0 ? (T.prim != 0xffffffffu) : false);
@@ -268,28 +293,225 @@ __global__ __launch_bounds__(64) void k_trace_persistent(TraceArgs a)
     }
 }
 
+
+// ---- streaming waves: the default traversal kernel -------------------------------------------
+// Every lane is a small state machine (at an inner node | at a leaf with k triangles left | idle) and
+// the wave runs ONE loop.  Per iteration: the lanes at inner nodes issue their 64-B node load and --
+// only when enough lanes wait at a leaf -- those lanes issue their 48-B triangle load; after ONE wait
+// the inner lanes do a slab step and the leaf lanes one branch-free triangle test.  Lanes never sit
+// out a whole inner or leaf phase as in the classic while-while loop (measured there: 19-27 % VALU
+// lane utilisation, profiles/r01_*; tools/sim_divergence.py models the schedules).  A finished lane
+// is swapped onto a ray that was prefetched into registers while it was still traversing, in batches,
+// so refilling exposes no memory latency.  The per-ray visiting order is unchanged (a lane never
+// takes an inner step while it owes a triangle test), so hit records and visit counters equal the
+// oracle's.  Loads use a uniform base + 32-bit lane offset (saddr form).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: uniform base in SGPRs + 32-bit lane offset, hardware
+// range check (an out-of-range offset reads zeros instead of faulting), never split by the compiler
+__device__ __forceinline__ float4 ld16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(u2f(v.x), u2f(v.y), u2f(v.z), u2f(v.w));
+}
+
+template <int MODE, bool COUNT, int LDS_N>
+__global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
+{
+    __shared__ uint32_t stk_lds[LDS_N * 64];
+    const int lane = (int)threadIdx.x;
+    const Stack<LDS_N> stk{ stk_lds, a.spill + (size_t)blockIdx.x * (size_t)((kStackEntries - LDS_N) * 64), lane };
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
+    uint32_t seg = blockIdx.x & (kNumSegments - 1);
+    uint32_t tried = 0;
+    uint32_t pool_next = 0, pool_end = 0;
+    const int refill_min = a.refill_min, leaf_min = a.leaf_min;
+    // nodes, then triangles at tri_byte_off, in one allocation
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+
+    bool     has_ray = false, nxt_valid = false;
+    uint32_t ray = 0, nxt_idx = 0;
+    float4   nxt_o = make_float4(0.f, 0.f, 0.f, 0.f), nxt_d = nxt_o;
+    uint32_t n_visits = 0, n_tests = 0;
+    uint32_t rv = 0, rt = 0;          // this ray's share; only counted when the ray completes here
+    uint32_t dbg_iter = 0, dbg_inner = 0, dbg_leaf = 0, dbg_leafnow = 0, dbg_idle = 0, dbg_leafiter = 0, dbg_refills = 0;
+    Trav T;
+    T.node = kSentinel; T.sp = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------ swap in prefetched rays, prefetch more
+        const unsigned long long idle = __ballot(!has_ray);
+        const int n_idle = __popcll(idle);
+        const bool dry = tried >= (uint32_t)kNumSegments && pool_next == pool_end;
+        // the long tail: when no fresh rays are left, a mostly empty wave would keep issuing whole-wave
+        // instructions for a handful of long rays.  Hand them over (they restart in the tight kernel,
+        // densely packed) and retire the wave.
+        if (dry && a.abandon_min > 0 && 64 - n_idle < a.abandon_min && __ballot(nxt_valid) == 0ull) {
+            const uint32_t j = wave_append(has_ray, a.leftover_n);
+            if (has_ray) a.leftover[j] = ray;
+            break;
+        }
+        if (n_idle == 64 || (n_idle >= refill_min && (!dry || __ballot(nxt_valid && !has_ray) != 0ull))) {
+            if (COUNT) ++dbg_refills;
+            if (!has_ray && nxt_valid) {
+                ray = nxt_idx;
+                rv = 0; rt = 0;
+                trav_init(T, nxt_o, nxt_d);
+                has_ray = T.node != kSentinel;
+                if (!has_ray) finish_ray<MODE>(a, T, ray, false);      // empty interval: a miss, no BVH access
+                nxt_valid = false;
+            }
+            const unsigned long long want = __ballot(!nxt_valid);
+            const uint32_t n_want = (uint32_t)__popcll(want);
+            const uint32_t rank = lane_rank(want);
+            uint32_t given = 0;
+            while (given < n_want) {
+                if (pool_next == pool_end) {
+                    if (tried >= (uint32_t)kNumSegments) break;
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(&a.cursors[seg * kCursorStride], kStreamChunk);
+                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                    const uint32_t lo = seg * seg_len;
+                    uint32_t hi = lo + seg_len; hi = hi < n ? hi : n;
+                    if (lo >= hi || c >= hi - lo) { seg = (seg + 1u) & (kNumSegments - 1); ++tried; continue; }
+                    pool_next = lo + c;
+                    pool_end  = pool_next + kStreamChunk < hi ? pool_next + kStreamChunk : hi;
+                }
+                const uint32_t avail = pool_end - pool_next;
+                const uint32_t need  = n_want - given;
+                const uint32_t take  = avail < need ? avail : need;
+                if (!nxt_valid && rank >= given && rank < given + take) {
+                    nxt_idx = pool_next + (rank - given);
+                    if (a.index_list) nxt_idx = a.index_list[nxt_idx];
+                    nxt_o = a.ray_o[(size_t)nxt_idx * a.stride];      // lands while this lane keeps traversing
+                    nxt_d = a.ray_d[(size_t)nxt_idx * a.stride];
+                    nxt_valid = true;
+                }
+                pool_next += take;
+                given += take;
+            }
+            if (__ballot(has_ray || nxt_valid) == 0ull) break;
+        }
+        // ------------------------------------------------------------ this iteration's load: 64 B per lane
+        // nodes and triangles live in one allocation, so one uniform base + a 32-bit lane offset serves
+        // both kinds of lane with the same four instructions (a triangle uses the first 48 B)
+        const bool inner   = has_ray && T.node >= 0;
+        const bool at_leaf = has_ray && T.node < 0;                    // has_ray implies node != sentinel here
+        const unsigned long long im = __ballot(inner), lm = __ballot(at_leaf);
+        const bool do_leaf = lm != 0ull && (__popcll(lm) >= leaf_min || im == 0ull);
+        const bool leaf_now = at_leaf && do_leaf;
+        if (COUNT && lane == 0) {
+            dbg_iter += 1; dbg_inner += (uint32_t)__popcll(im); dbg_leaf += (uint32_t)__popcll(lm);
+            dbg_leafnow += do_leaf ? (uint32_t)__popcll(lm) : 0u; dbg_idle += (uint32_t)n_idle;
+            dbg_leafiter += do_leaf ? 1u : 0u;
+        }
+        const uint32_t ldesc = ~(uint32_t)T.node;
+        const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
+        uint32_t off = 0u;                                             // idle lanes re-read node 0 (a broadcast)
+        if (inner) off = (uint32_t)T.node << 6;
+        if (at_leaf && lcnt != 0u) off = a.bvh.tri_byte_off + lfirst * 48u;
+        const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------------------ one inner-node step
+        if (inner) {
+            if (COUNT) ++rv;
+            const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
+            const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
+            const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
+            const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
+            const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
+            const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
+            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                              __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
+            const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                              __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
+            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                              __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
+            const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                              __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+            if (h0 && h1) {
+                const bool swp = tn1 < tn0;
+                stk.push(T.sp, (uint32_t)(swp ? c0 : c1));
+                T.node = swp ? c1 : c0;
+            } else if (h0 || h1) {
+                T.node = h0 ? c0 : c1;
+            } else {
+                T.node = stk.pop(T.sp);
+            }
+        }
+        // ------------------------------------------------------------ one triangle test (branch free)
+        if (leaf_now) {
+            bool stop = false;
+            if (lcnt != 0u) {
+                if (COUNT) ++rt;
+                const float4 ta = n0, tb = n1, tc = n2;
+                const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
+                const f3 p = fcross(T.d, e2);
+                const float det = fdot(e1, p);
+                const float inv = 1.0f / det;
+                const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
+                const float u = fdot(tv, p) * inv;
+                const f3 q = fcross(tv, e1);
+                const float v = fdot(T.d, q) * inv;
+                const float t = fdot(e2, q) * inv;
+                const uint32_t prim = f2u(ta.w);
+                const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax;
+                if (MODE != 0) {
+                    stop = ok;
+                } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
+                    T.tbest = t; T.prim = prim; T.u = u; T.v = v;
+                }
+            }
+            if (stop) { finish_ray<MODE>(a, T, ray, true); has_ray = false; T.node = kSentinel; n_visits += rv; n_tests += rt; }
+            else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
+            else T.node = stk.pop(T.sp);
+        }
+        // ------------------------------------------------------------ retire
+        if (has_ray && T.node == kSentinel) {
+            finish_ray<MODE>(a, T, ray, MODE == 0 ? (T.prim != 0xffffffffu) : false);
+            has_ray = false;
+            n_visits += rv; n_tests += rt;
+        }
+    }
+    if (COUNT) {
+        wave_add64(&a.ctr->node_visits[MODE != 0], n_visits);
+        wave_add64(&a.ctr->tri_tests[MODE != 0], n_tests);
+        if (lane == 0 && MODE == 0) {
+            atomicAdd(&a.ctr->dbg[0], (unsigned long long)dbg_iter);  atomicAdd(&a.ctr->dbg[1], (unsigned long long)dbg_inner);
+            atomicAdd(&a.ctr->dbg[2], (unsigned long long)dbg_leaf);  atomicAdd(&a.ctr->dbg[3], (unsigned long long)dbg_leafnow);
+            atomicAdd(&a.ctr->dbg[4], (unsigned long long)dbg_idle);  atomicAdd(&a.ctr->dbg[5], (unsigned long long)dbg_leafiter);
+            atomicAdd(&a.ctr->dbg[6], (unsigned long long)dbg_refills);
+        }
+    }
+}
+
 // ---- one thread per ray (no refill); same per-ray visiting order ----
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
 {
-    __shared__ uint32_t stk[kStackEntries * 64];
+    __shared__ uint32_t stk_lds[kStackEntries * 64];
     const int lane = (int)threadIdx.x;
+    const Stack<kStackEntries> stk{ stk_lds, nullptr, lane };
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
-    const uint32_t ray = blockIdx.x * 64u + threadIdx.x;
     uint32_t n_visits = 0, n_tests = 0;
-    if (ray < n) {
+    for (uint32_t item = blockIdx.x * 64u + threadIdx.x; item < n; item += gridDim.x * 64u) {
+        const uint32_t ray = a.index_list ? a.index_list[item] : item;
         Trav T;
         trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
         bool hit = false;
         while (T.node != kSentinel) {
             while (T.node >= 0) {
                 if (COUNT) ++n_visits;
-                visit_inner(T, a.bvh.nodes, stk, lane);
+                visit_inner(T, a.bvh.nodes, stk);
             }
             if (T.node != kSentinel) {
                 if (visit_leaf<(MODE != 0)>(T, a.bvh.tris, n_tests)) { hit = true; break; }
-                T.node = stack_pop(T, stk, lane);
+                T.node = stk.pop(T.sp);
             }
         }
         if (MODE == 0) hit = T.prim != 0xffffffffu;
@@ -304,17 +526,17 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
 // ------------------------------------------------------------------------------------------------
 // queue bookkeeping
 // ------------------------------------------------------------------------------------------------
-__global__ void k_begin_sample(DeviceCounters* c, uint32_t n_paths)
+__global__ void k_begin_sample(DeviceCounters* c, uint32_t n_paths, uint32_t n_valid)
 {
     const uint32_t i = threadIdx.x;
-    if (i == 0) { c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; }
+    if (i == 0) { c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; c->n_left[0] = 0; c->n_left[1] = 0; }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
 __global__ void k_advance(DeviceCounters* c)
 {
     const uint32_t i = threadIdx.x;
-    if (i == 0) { c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce += 1; }
+    if (i == 0) { c->closest_rays += c->n_next; c->shadow_rays += c->n_shadow; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce += 1; c->n_left[0] = 0; c->n_left[1] = 0; }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
@@ -403,16 +625,21 @@ struct ShadeArgs {
     float4*                 result;
     DeviceCounters*         ctr;
     uint32_t                n_max;
+    const void*             common_vertices;   // non-null when every hit-group record points at the same vertex buffer
 };
 
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
+// One global atomic per 512-path tile and queue (not per wave): the queue-length words are single
+// addresses, and ~32 k returning atomics on one word serialise at ~88 per microsecond (measured: the
+// per-wave version spent 0.37 of its 0.44 ms there).
+__global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a)
 {
+    __shared__ uint32_t s_cnt[2], s_base[2];
     uint32_t n = a.ctr->n_cur;
     n = n < a.n_max ? n : a.n_max;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_round = (n + 63u) & ~63u;      // whole waves take part in the ballots
-    uint32_t my_closest = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t tile = blockIdx.x; tile * kShadeBlock < n; tile += gridDim.x) {
+        const uint32_t i = tile * kShadeBlock + threadIdx.x;
         bool push_next = false, push_shadow = false;
         float4 nro, nrd, nsa; uint2 nsb;
         float4 sro, srd, sc;
@@ -420,7 +647,6 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
             const uint2 sb = a.cur.state_b[i];
             const uint32_t slot = sb.x, depth = sb.y;
             if (slot != kInvalidSlot) {
-                ++my_closest;
                 const float4 hit = a.hits[i];
                 const float4 sa = a.cur.state_a[i];
                 f3 att = mk3(sa.x, sa.y, sa.z);
@@ -438,8 +664,11 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
                     const uint32_t prim = f2u(hit.y);
                     uint32_t m = a.bvh.mat_index[prim];
                     m = m < a.n_hitgroups ? m : a.n_hitgroups - 1u;
+                    // all records usually share one vertex buffer (optixPathTracer.cpp:877): then the fetch
+                    // does not have to wait for the record
+                    const float4* vb0 = reinterpret_cast<const float4*>(a.common_vertices);
                     const MiptHitGroupData rec = a.hitgroups[m];
-                    const float4* vb = reinterpret_cast<const float4*>(rec.vertices) + (size_t)prim * 3u;
+                    const float4* vb = (vb0 ? vb0 : reinterpret_cast<const float4*>(rec.vertices)) + (size_t)prim * 3u;
                     const float4 a0 = vb[0], a1 = vb[1], a2 = vb[2];
                     const f3 v0 = mk3(a0.x, a0.y, a0.z), v1 = mk3(a1.x, a1.y, a1.z), v2 = mk3(a2.x, a2.y, a2.z);
                     const f3 N0 = normalize(cross(v1 - v0, v2 - v0));
@@ -494,14 +723,31 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a)
                 }
             }
         }
-        const uint32_t js = wave_append(push_shadow, &a.ctr->n_shadow);
-        if (push_shadow) { a.shadow.ray_o[js] = sro; a.shadow.ray_d[js] = srd; a.shadow.contrib[js] = sc; }
-        const uint32_t jn = wave_append(push_next, &a.ctr->n_next);
-        if (push_next) { a.next.ray_o[jn] = nro; a.next.ray_d[jn] = nrd; a.next.state_a[jn] = nsa; a.next.state_b[jn] = nsb; }
-        const unsigned long long ms = __ballot(push_shadow);
-        if ((threadIdx.x & 63u) == 0u && ms) atomicAdd(&a.ctr->shadow_rays, (unsigned long long)__popcll(ms));
+        // ---- compacting appends, aggregated over the block
+        const unsigned long long ms = __ballot(push_shadow), mn = __ballot(push_next);
+        uint32_t wo_s = 0, wo_n = 0;
+        if ((threadIdx.x & 63u) == 0u) {
+            if (ms) wo_s = atomicAdd(&s_cnt[0], (uint32_t)__popcll(ms));
+            if (mn) wo_n = atomicAdd(&s_cnt[1], (uint32_t)__popcll(mn));
+        }
+        wo_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wo_s);
+        wo_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)wo_n);
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const uint32_t c = s_cnt[threadIdx.x];
+            s_base[threadIdx.x] = c ? atomicAdd(threadIdx.x == 0 ? &a.ctr->n_shadow : &a.ctr->n_next, c) : 0u;
+            s_cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        if (push_shadow) {
+            const uint32_t js = s_base[0] + wo_s + lane_rank(ms);
+            a.shadow.ray_o[js] = sro; a.shadow.ray_d[js] = srd; a.shadow.contrib[js] = sc;
+        }
+        if (push_next) {
+            const uint32_t jn = s_base[1] + wo_n + lane_rank(mn);
+            a.next.ray_o[jn] = nro; a.next.ray_d[jn] = nrd; a.next.state_a[jn] = nsa; a.next.state_b[jn] = nsb;
+        }
     }
-    wave_add64(&a.ctr->closest_rays, my_closest);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,9 +787,9 @@ __global__ __launch_bounds__(256) void k_unpermute(const float4* gathered, uint3
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
-void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths)
+void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, uint32_t n_valid)
 {
-    hipLaunchKernelGGL(k_begin_sample, dim3(1), dim3(64), 0, st, ctr, n_paths);
+    hipLaunchKernelGGL(k_begin_sample, dim3(1), dim3(64), 0, st, ctr, n_paths, n_valid);
 }
 
 void launch_advance(hipStream_t st, DeviceCounters* ctr)
@@ -558,17 +804,45 @@ void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQ
 }
 
 template <int MODE>
-static void launch_trace(hipStream_t st, const TraceArgs& a, const TraceOpts& o)
+static void launch_simple(hipStream_t st, const TraceArgs& a, const TraceOpts& o)
+{
+    uint32_t blocks = (a.n_max + 63u) / 64u;
+    if (blocks > 16384u) blocks = 16384u;
+    if (o.count_visits) hipLaunchKernelGGL((k_trace_simple<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
+    else                hipLaunchKernelGGL((k_trace_simple<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
+}
+
+template <int MODE>
+static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
 {
     if (a.n_max == 0) return;
-    if (o.persistent) {
+    if (o.persistent == 2 && a.bvh.tri_byte_off != 0u) {
         const int blocks = o.blocks > 0 ? o.blocks : 4096;
-        if (o.count_visits) hipLaunchKernelGGL((k_trace_persistent<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
-        else                hipLaunchKernelGGL((k_trace_persistent<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
+        // pass 1: streaming waves; waves that run out of fresh rays hand their long rays over
+        a.abandon_min = o.leftover ? o.abandon_min : 0;
+        a.leftover = o.leftover ? o.leftover + (MODE != 0 ? o.leftover_cap : 0) : nullptr;
+        a.leftover_n = &a.ctr->n_left[MODE != 0];
+        if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true, kLdsStackEntries>), dim3(blocks), dim3(64), 0, st, a);
+        else                hipLaunchKernelGGL((k_trace_stream<MODE, false, kLdsStackEntries>), dim3(blocks), dim3(64), 0, st, a);
+        if (a.abandon_min > 0) {
+            // pass 2: the handed-over rays, one per lane, tight while-while loop (lowest latency per step)
+            TraceArgs b = a;
+            b.index_list = a.leftover; b.n_ptr = a.leftover_n;
+            b.n_max = a.n_max < o.leftover_cap ? a.n_max : o.leftover_cap;
+            b.leftover = nullptr; b.leftover_n = nullptr; b.abandon_min = 0;
+            launch_simple<MODE>(st, b, o);
+        }
+    } else if (o.persistent == 1) {
+        const int blocks = o.blocks > 0 ? o.blocks : 4096;
+        if (o.lds_stack >= kStackEntries) {
+            if (o.count_visits) hipLaunchKernelGGL((k_trace_persistent<MODE, true, kStackEntries>), dim3(blocks), dim3(64), 0, st, a);
+            else                hipLaunchKernelGGL((k_trace_persistent<MODE, false, kStackEntries>), dim3(blocks), dim3(64), 0, st, a);
+        } else {
+            if (o.count_visits) hipLaunchKernelGGL((k_trace_persistent<MODE, true, kLdsStackEntries>), dim3(blocks), dim3(64), 0, st, a);
+            else                hipLaunchKernelGGL((k_trace_persistent<MODE, false, kLdsStackEntries>), dim3(blocks), dim3(64), 0, st, a);
+        }
     } else {
-        const uint32_t blocks = (a.n_max + 63u) / 64u;
-        if (o.count_visits) hipLaunchKernelGGL((k_trace_simple<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
-        else                hipLaunchKernelGGL((k_trace_simple<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
+        launch_simple<MODE>(st, a, o);
     }
 }
 
@@ -577,7 +851,8 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
 {
     TraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
-    a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr;
+    a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr; a.spill = o.spill;
+    a.refill_min = o.refill_min; a.leaf_min = o.leaf_min;
     launch_trace<0>(st, a, o);
 }
 
@@ -588,21 +863,22 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
     TraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.occluded = occluded; a.contrib = contrib; a.result = result; a.cursors = ctr->cursor_shadow; a.ctr = ctr;
+    a.spill = o.spill; a.refill_min = o.refill_min; a.leaf_min = o.leaf_min;
     if (occluded) launch_trace<1>(st, a, o);
     else          launch_trace<2>(st, a, o);
 }
 
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
-                  float4* result, DeviceCounters* ctr, uint32_t n_max)
+                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices)
 {
     ShadeArgs a{};
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur; a.hits = hits;
-    a.next = next; a.shadow = shadow; a.result = result; a.ctr = ctr; a.n_max = n_max;
-    uint32_t blocks = (n_max + 255u) / 256u;
-    if (blocks > 4096u) blocks = 4096u;
+    a.next = next; a.shadow = shadow; a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
+    uint32_t blocks = (n_max + kShadeBlock - 1u) / kShadeBlock;
+    if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0u) blocks = 1u;
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, st, a);
 }
 
 void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots)

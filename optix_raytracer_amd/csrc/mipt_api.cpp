@@ -39,8 +39,10 @@ namespace {
 
 struct Accel {
     HostBvh   host;
-    float4*   d_nodes = nullptr;
-    float4*   d_tris  = nullptr;
+    float4*   d_nodes = nullptr;   // one allocation: nodes | triangles | 64 B pad
+    float4*   d_tris  = nullptr;   // = d_nodes + num_nodes * 4
+    uint32_t  tri_byte_off = 0;    // 0 when the blob does not fit 32-bit offsets (then no streaming kernel)
+    uint32_t  blob_bytes = 0;
     uint32_t* d_mat   = nullptr;
     uint32_t  n_prims = 0;
     uint64_t  bytes   = 0;
@@ -63,14 +65,20 @@ struct MiptContext {
 
     MiptHitGroupData* d_hitgroups = nullptr;
     uint32_t          n_hitgroups = 0;
+    const void*       common_vertices = nullptr;   // set when all records share one vertex pointer
     MiptMissData      miss{};
 
     // options
     uint32_t max_depth = 0;
     int      count_visits = 0;
     int      blocks_per_cu = 0;
-    int      persistent = 1;
+    int      persistent = 2;
+    int      refill_min = 8, leaf_min = 1, abandon_min = 0;
+    uint32_t* d_leftover = nullptr;
+    size_t    cap_leftover = 0;
     int      profile = 0;
+    int      lds_stack = kLdsStackEntries;
+    uint32_t* d_spill = nullptr;
 
     // launch buffers
     size_t          cap_paths = 0, cap_slots = 0;
@@ -161,7 +169,6 @@ void free_accel(Accel* a)
 {
     if (!a) return;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
-    if (a->d_tris) (void)hipFree(a->d_tris);
     if (a->d_mat) (void)hipFree(a->d_mat);
     delete a;
 }
@@ -184,6 +191,16 @@ void free_launch_buffers(MiptContext* c)
     c->cap_paths = 0; c->cap_slots = 0;
 }
 
+// ray-index lists for the streaming kernel's hand-over (closest | shadow)
+int ensure_leftover(MiptContext* c, size_t n)
+{
+    if (n <= c->cap_leftover) return MIPT_SUCCESS;
+    if (c->d_leftover) { (void)hipDeviceSynchronize(); (void)hipFree(c->d_leftover); c->d_leftover = nullptr; c->cap_leftover = 0; }
+    HIPCHK(c, hipMalloc((void**)&c->d_leftover, n * 2 * sizeof(uint32_t)));
+    c->cap_leftover = n;
+    return MIPT_SUCCESS;
+}
+
 // SoA queues: ray_o and ray_d are two planes of one allocation
 int ensure_capacity(MiptContext* c, size_t n_paths, size_t n_slots)
 {
@@ -203,6 +220,7 @@ int ensure_capacity(MiptContext* c, size_t n_paths, size_t n_slots)
     HIPCHK(c, hipMalloc((void**)&c->result, ns * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->rg_seed, ns * sizeof(uint32_t)));
     c->cap_paths = np; c->cap_slots = ns;
+    { const int rc = ensure_leftover(c, np); if (rc) return rc; }
     c->log(4, "LAUNCH", "queues sized for %zu paths / %zu slots (%.1f MB)", np, ns,
            (double)(np * (2 * (32 + 16 + 8) + 32 + 16 + 16) + ns * 20) / 1e6);
     return MIPT_SUCCESS;
@@ -213,7 +231,12 @@ TraceOpts trace_opts(const MiptContext* c)
     TraceOpts o{};
     o.persistent = c->persistent;
     o.count_visits = c->count_visits;
-    o.blocks = c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 16);
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (c->persistent == 2 ? 24 : (c->lds_stack >= kStackEntries ? 20 : 32));
+    o.blocks = std::min(c->num_cus * per_cu, kMaxTraceBlocks);
+    o.lds_stack = c->lds_stack;
+    o.spill = c->d_spill;
+    o.refill_min = c->refill_min; o.leaf_min = c->leaf_min;
+    o.abandon_min = c->abandon_min; o.leftover = c->d_leftover; o.leftover_cap = (uint32_t)c->cap_leftover;
     return o;
 }
 
@@ -232,7 +255,7 @@ Accel* find_accel(const MiptContext* c, unsigned long long h)
 DeviceBvh device_bvh(const Accel* a)
 {
     DeviceBvh b{};
-    b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat;
+    b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes;
     return b;
 }
 
@@ -263,9 +286,26 @@ FrameConsts make_consts(const MiptContext* c, const MiptParams* p)
 }
 
 // the wavefront loop shared by full-frame and shard launches
+// pixels of the frame that a rank owns under the 8x4 interleaved tile map
+uint32_t shard_valid_pixels(uint32_t w, uint32_t h, uint32_t world, uint32_t rank)
+{
+    const uint32_t ns = shard_num_samples(w, h, world);
+    uint32_t valid = 0;
+    for (uint32_t tile = 0; tile < ns / 32u; ++tile) {
+        int px, py;
+        shard_pixel(w, world, rank, tile * 32u, px, py);
+        if ((uint32_t)px >= w || (uint32_t)py >= h) continue;
+        const uint32_t cols = w - (uint32_t)px < 8u ? w - (uint32_t)px : 8u;
+        const uint32_t rows = h - (uint32_t)py < 4u ? h - (uint32_t)py : 4u;
+        valid += cols * rows;
+    }
+    return valid;
+}
+
 int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc, const Accel* acc, size_t n_slots,
                   float4* accum_out, uint32_t* frame_out)
 {
+    const uint32_t n_valid = fc.world == 0u ? fc.width * fc.height : shard_valid_pixels(fc.width, fc.height, fc.world, fc.rank);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t n_paths = fc.n_paths;
     int rc = ensure_capacity(ctx, n_paths, n_slots);
@@ -273,10 +313,10 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc, const
     ctx->last_stream = st;
     const DeviceBvh bvh = device_bvh(acc);
     const TraceOpts opts = trace_opts(ctx);
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 6 * sizeof(unsigned long long), st));
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     uint32_t bounces_total = 0;
     for (uint32_t s = 0; s < fc.samples_per_launch; ++s) {
-        launch_begin_sample(st, ctx->d_ctr, n_paths);
+        launch_begin_sample(st, ctx->d_ctr, n_paths, n_valid);
         { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result); }
         int cur = 0;
         for (uint32_t bounce = 0;; ++bounce) {
@@ -284,7 +324,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc, const
               launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, n_paths, ctx->hits, ctx->d_ctr, opts); }
             { TimedScope t(ctx, st, T_SHADE);
               launch_shade(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->hits, ctx->q[cur ^ 1], ctx->sq,
-                           ctx->result, ctx->d_ctr, n_paths); }
+                           ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices); }
             { TimedScope t(ctx, st, T_ANY);
               launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, n_paths, nullptr, ctx->sq.contrib,
                                ctx->result, ctx->d_ctr, opts); }
@@ -349,7 +389,8 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     }
     if (hipMalloc((void**)&c->d_ctr, sizeof(DeviceCounters)) != hipSuccess ||
         hipMemset(c->d_ctr, 0, sizeof(DeviceCounters)) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_pinned, 64) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_pinned, 64) != hipSuccess ||
+        hipMalloc((void**)&c->d_spill, (size_t)kMaxTraceBlocks * (kStackEntries - kLdsStackEntries) * 64 * sizeof(uint32_t)) != hipSuccess) {
         delete c;
         return MIPT_ERROR_OUT_OF_MEMORY;
     }
@@ -366,6 +407,8 @@ int mipt_context_destroy(MiptContext* c)
     free_launch_buffers(c);
     if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->d_spill) (void)hipFree(c->d_spill);
+    if (c->d_leftover) (void)hipFree(c->d_leftover);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     delete c;
@@ -383,7 +426,22 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_TRACE_GRID:
         if (value > 32) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 32 single-wave workgroups fit a CU");
         c->blocks_per_cu = (int)value; return MIPT_SUCCESS;
-    case MIPT_OPT_PERSISTENT: c->persistent = value ? 1 : 0; return MIPT_SUCCESS;
+    case MIPT_OPT_PERSISTENT:
+        if (value > 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "traversal kernel variant must be 0, 1 or 2");
+        c->persistent = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_REFILL_MIN:
+        if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
+        c->refill_min = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_LEAF_MIN:
+        if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "leaf threshold must be 1..64");
+        c->leaf_min = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_ABANDON_MIN:
+        if (value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "hand-over threshold must be 0..64");
+        c->abandon_min = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_LDS_STACK:
+        if (value != (uint64_t)kLdsStackEntries && value != (uint64_t)kStackEntries)
+            return c->fail(MIPT_ERROR_INVALID_VALUE, "LDS stack entries must be %d or %d", kLdsStackEntries, kStackEntries);
+        c->lds_stack = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PROFILE:
         if (c->last_stream || c->timed.size()) (void)hipStreamSynchronize(c->last_stream);
         c->profile = value ? 1 : 0; c->timed.clear(); c->events_used = 0; return MIPT_SUCCESS;
@@ -400,6 +458,10 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_TRACE_GRID: *value = (uint64_t)c->blocks_per_cu; return MIPT_SUCCESS;
     case MIPT_OPT_PERSISTENT: *value = (uint64_t)c->persistent; return MIPT_SUCCESS;
     case MIPT_OPT_PROFILE: *value = (uint64_t)c->profile; return MIPT_SUCCESS;
+    case MIPT_OPT_LDS_STACK: *value = (uint64_t)c->lds_stack; return MIPT_SUCCESS;
+    case MIPT_OPT_REFILL_MIN: *value = (uint64_t)c->refill_min; return MIPT_SUCCESS;
+    case MIPT_OPT_LEAF_MIN: *value = (uint64_t)c->leaf_min; return MIPT_SUCCESS;
+    case MIPT_OPT_ABANDON_MIN: *value = (uint64_t)c->abandon_min; return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;
     }
 }
@@ -472,8 +534,13 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     const size_t nb = a->host.nodes.size() * sizeof(MiptBvhNode);
     const size_t tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
     const size_t mb = std::max<size_t>(n_tris, 1) * sizeof(uint32_t);
-    hipError_t e = hipMalloc((void**)&a->d_nodes, nb);
-    if (e == hipSuccess) e = hipMalloc((void**)&a->d_tris, tb);
+    hipError_t e = hipMalloc((void**)&a->d_nodes, nb + tb + 64);
+    if (e == hipSuccess) {
+        a->d_tris = a->d_nodes + nb / sizeof(float4);
+        a->tri_byte_off = (nb + tb + 64 < (1ull << 31)) ? (uint32_t)nb : 0u;
+        a->blob_bytes = a->tri_byte_off ? (uint32_t)(nb + tb + 64) : 0u;
+        e = hipMemset((char*)a->d_nodes + nb + tb, 0, 64);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&a->d_mat, mb);
     if (e == hipSuccess) e = hipMemcpy(a->d_nodes, a->host.nodes.data(), nb, hipMemcpyHostToDevice);
     if (e == hipSuccess && !a->host.tris.empty()) e = hipMemcpy(a->d_tris, a->host.tris.data(), a->host.tris.size() * sizeof(MiptBvhTri), hipMemcpyHostToDevice);
@@ -581,6 +648,8 @@ int mipt_sbt_set_hitgroups(MiptContext* ctx, const MiptHitGroupData* records, ui
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_hitgroups, (size_t)count * sizeof(MiptHitGroupData)));
     HIPCHK(ctx, hipMemcpy(ctx->d_hitgroups, records, (size_t)count * sizeof(MiptHitGroupData), hipMemcpyHostToDevice));
     ctx->n_hitgroups = count;
+    ctx->common_vertices = records[0].vertices;
+    for (uint32_t i = 1; i < count; ++i) if (records[i].vertices != records[0].vertices) ctx->common_vertices = nullptr;
     return MIPT_SUCCESS;
 }
 
@@ -671,6 +740,9 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     stats->node_visits = h.node_visits[0] + h.node_visits[1]; stats->tri_tests = h.tri_tests[0] + h.tri_tests[1];
     stats->shadow_node_visits = h.node_visits[1]; stats->shadow_tri_tests = h.tri_tests[1];
     stats->bounces = ctx->last_bounces; stats->reserved = 0;
+    if (ctx->log_level >= 4)
+        ctx->log(4, "SCHED", "stream<closest>: iterations %llu, inner lanes %llu, leaf lanes %llu (tested %llu in %llu iterations), idle lanes %llu, refill rounds %llu",
+                 h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[5], h.dbg[4], h.dbg[6]);
     return MIPT_SUCCESS;
 }
 
@@ -707,8 +779,9 @@ int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    launch_begin_sample(st, ctx->d_ctr, n);
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 6 * sizeof(unsigned long long), st));
+    { const int rc = ensure_leftover(ctx, n); if (rc) return rc; }
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    launch_begin_sample(st, ctx->d_ctr, n, n);
     const float4* r = (const float4*)rays;
     { TimedScope t(ctx, st, T_CLOSEST);
       launch_trace_closest(st, device_bvh(a), r, r + 1, 2, nullptr, n, (float4*)hits, ctx->d_ctr, trace_opts(ctx)); }
@@ -726,8 +799,9 @@ int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, co
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    launch_begin_sample(st, ctx->d_ctr, n);
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 6 * sizeof(unsigned long long), st));
+    { const int rc = ensure_leftover(ctx, n); if (rc) return rc; }
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    launch_begin_sample(st, ctx->d_ctr, n, 0);
     const float4* r = (const float4*)rays;
     { TimedScope t(ctx, st, T_ANY);
       launch_trace_any(st, device_bvh(a), r, r + 1, 2, nullptr, n, (uint32_t*)occluded, nullptr, nullptr, ctx->d_ctr, trace_opts(ctx)); }

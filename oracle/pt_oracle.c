@@ -710,6 +710,49 @@ void orc_trace_closest(const OrcScene* s, int mode, const float* rays, uint32_t 
     }
 }
 
+/* step profile of one closest-hit traversal: pairs (inner steps before the leaf, triangles in the leaf);
+ * a final pair (k, 0xffff) holds the inner steps after the last leaf.  For scheduling studies only. */
+uint32_t orc_trace_profile(const OrcScene* s, const float* ray8, int any, uint16_t* pairs, uint32_t max_pairs)
+{
+    Ray r; r.o = v3_ld(ray8); r.d = v3_ld(ray8 + 4); r.tmin = ray8[3]; r.tmax = ray8[7];
+    ray_prepare(&r);
+    int32_t stack[STACK_MAX]; int sp = 0;
+    HitRec h; h.hit = 0; h.t = r.tmax; h.prim = 0xffffffffu; h.u = h.v = 0.0f;
+    uint32_t np = 0; uint16_t inner = 0;
+    stack[sp++] = SENTINEL;
+    int32_t node = (r.tmax > r.tmin) ? 0 : SENTINEL;
+    while (node != SENTINEL) {
+        if (node >= 0) {
+            const Node64* n = &s->nodes[node];
+            inner++;
+            int h0, h1;
+            float t0 = box_test(n->c0x, n->c0y, n->c0z, &r, h.t, &h0);
+            float t1 = box_test(n->c1x, n->c1y, n->c1z, &r, h.t, &h1);
+            if (!h0 && !h1) { node = stack[--sp]; continue; }
+            int32_t a = n->c0, b = n->c1;
+            if (h0 && h1) { if (t1 < t0) { int32_t tmp = a; a = b; b = tmp; } stack[sp++] = b; node = a; }
+            else node = h0 ? a : b;
+        } else {
+            uint32_t d = (uint32_t)~node, first = d >> 4, cnt = d & 15u;
+            uint32_t tested = 0; int stop = 0;
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                float t, u, v;
+                tested++;
+                if (tri_test(&s->tris[i], &r, r.tmax, &t, &u, &v)) {
+                    if (any) { stop = 1; break; }
+                    consider(&h, t, u, v, s->tris[i].prim);
+                }
+            }
+            if (np < max_pairs) { pairs[2 * np] = inner; pairs[2 * np + 1] = (uint16_t)tested; }
+            np++; inner = 0;
+            if (stop) return np;
+            node = stack[--sp];
+        }
+    }
+    if (np < max_pairs) { pairs[2 * np] = inner; pairs[2 * np + 1] = 0xffff; }
+    return np + 1;
+}
+
 void orc_trace_any(const OrcScene* s, int mode, const float* rays, uint32_t n, uint8_t* occluded, OrcStats* st)
 {
     for (uint32_t i = 0; i < n; ++i) {

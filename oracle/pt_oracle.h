@@ -96,6 +96,8 @@ void orc_trace_closest(const OrcScene*, int mode, const float* rays, uint32_t n,
 void orc_trace_any(const OrcScene*, int mode, const float* rays, uint32_t n,
                    uint8_t* occluded, OrcStats* stats);
 
+uint32_t orc_trace_profile(const OrcScene*, const float* ray8, int any, uint16_t* pairs, uint32_t max_pairs);
+
 /* ---- full render of rows [y0,y1) (or of an explicit pixel list) ----
  * max_depth: 0 = unbounded (the reference's behaviour: Russian roulette only),
  *            k>0 = stop after k closest-hit queries per path (build extension). */

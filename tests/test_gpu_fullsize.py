@@ -48,15 +48,21 @@ def test_headline_determinism_and_kernel_variants(big):
     a0, f0, s0 = _render(PT, st, ob)
     a1, f1, s1 = _render(PT, st, ob)
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and s0 == s1          # idempotent relaunch
-    st.context.set_option(L.OPT_PERSISTENT, 0)
-    a2, f2, s2 = _render(PT, st, ob)
-    st.context.set_option(L.OPT_PERSISTENT, 1)
-    assert np.array_equal(a0.view(np.uint32), a2.view(np.uint32)) and np.array_equal(f0, f2)
-    for grid in (4, 20):
+    for variant in (0, 1):                      # one-thread-per-ray and while-while kernels
+        st.context.set_option(L.OPT_PERSISTENT, variant)
+        a2, f2, s2 = _render(PT, st, ob)
+        assert np.array_equal(a0.view(np.uint32), a2.view(np.uint32)) and np.array_equal(f0, f2), variant
+    st.context.set_option(L.OPT_PERSISTENT, 2)
+    defaults = [st.context.get_option(o) for o in (L.OPT_TRACE_GRID, L.OPT_REFILL_MIN, L.OPT_LEAF_MIN, L.OPT_ABANDON_MIN)]
+    for grid, refill, leaf, aband in ((4, 1, 1, 0), (20, 32, 64, 64), (32, 64, 8, 16), (8, 8, 1, 40)):
         st.context.set_option(L.OPT_TRACE_GRID, grid)
+        st.context.set_option(L.OPT_REFILL_MIN, refill)
+        st.context.set_option(L.OPT_LEAF_MIN, leaf)
+        st.context.set_option(L.OPT_ABANDON_MIN, aband)
         a3, _, _ = _render(PT, st, ob)
-        assert np.array_equal(a0.view(np.uint32), a3.view(np.uint32)), grid
-    st.context.set_option(L.OPT_TRACE_GRID, 0)
+        assert np.array_equal(a0.view(np.uint32), a3.view(np.uint32)), (grid, refill, leaf, aband)
+    for o, v in zip((L.OPT_TRACE_GRID, L.OPT_REFILL_MIN, L.OPT_LEAF_MIN, L.OPT_ABANDON_MIN), defaults):
+        st.context.set_option(o, v)
 
 
 def test_headline_shards_equal_full_frame(big):

@@ -61,14 +61,15 @@ def test_library_is_native_and_loaded():
     assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
 
 
-@pytest.mark.parametrize("persistent", [1, 0])
-def test_traversal_records_bit_exact(persistent):
+@pytest.mark.parametrize("persistent,abandon", [(2, 24), (2, 0), (2, 64), (1, 0), (0, 0)])
+def test_traversal_records_bit_exact(persistent, abandon):
     torch = _torch()
     from optix_raytracer_amd import _lib as L
     from optix_raytracer_amd import scenes
     for scene, (w, h) in ((scenes.cornell_box(), (160, 96)), (scenes.random_soup(30000), (200, 120))):
         PT, st = _state(scene, w, h)
         st.context.set_option(L.OPT_PERSISTENT, persistent)
+        st.context.set_option(L.OPT_ABANDON_MIN, abandon)
         st.context.set_option(L.OPT_COUNT_VISITS, 1)
         osc = _oracle_scene(scene, st)
         launch = scenes.launch_desc(scene, w, h)
