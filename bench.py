@@ -162,7 +162,7 @@ def main():
             st.context.launch(st.params, w, h, 1, stream=stream.cuda_stream)
         else:
             st.context.launch_shard(st.params, w, h, rank, world, compact.data_ptr(), stream=stream.cuda_stream)
-            dist.all_gather_into_tensor(gathered, compact)
+            dist.all_gather_into_tensor(gathered, compact)      # the path's one exchange (RCCL over xGMI)
             st.context.unpermute(gathered.data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=stream.cuda_stream)
 
     def fence():
