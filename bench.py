@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--persistent", type=int, default=-1, help="tuning: 1/0 forces the persistent / one-thread-per-ray traversal kernels")
     ap.add_argument("--grid", type=int, default=0, help="tuning: persistent workgroups per CU")
     ap.add_argument("--refill-min", type=int, default=0)
-    ap.add_argument("--leaf-min", type=int, default=0)
+    ap.add_argument("--steal-min", type=int, default=0)
     ap.add_argument("--lds-stack", type=int, default=0, help="tuning: 16 or 32 LDS stack entries")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -146,8 +146,8 @@ def main():
         st.context.set_option(L.OPT_LDS_STACK, args.lds_stack)
     if args.refill_min:
         st.context.set_option(L.OPT_REFILL_MIN, args.refill_min)
-    if args.leaf_min:
-        st.context.set_option(L.OPT_LEAF_MIN, args.leaf_min)
+    if args.steal_min:
+        st.context.set_option(L.OPT_STEAL_MIN, args.steal_min)
     stream = torch.cuda.current_stream()
     frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=st.device)
     st.params.frame_buffer = frame.data_ptr()

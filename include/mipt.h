@@ -153,10 +153,8 @@ typedef enum MiptOption {
     MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings) */
     MIPT_OPT_LDS_STACK    = 6, /* traversal-stack entries kept in LDS: 16 (default, rest spills to global) or 32 */
     MIPT_OPT_REFILL_MIN   = 7, /* streaming waves: idle lanes that trigger a swap-in/prefetch round (default 8) */
-    MIPT_OPT_LEAF_MIN     = 8, /* streaming waves: lanes waiting at a leaf that trigger a triangle step (default 1) */
-    MIPT_OPT_ABANDON_MIN  = 9  /* streaming waves: once no fresh rays are left, a wave with fewer live rays than this
-                                  hands them to the one-ray-per-lane kernel and exits (default 0 = never: measured slower,
-                                  64 long rays packed into one wave serialise; kept for experiments) */
+    MIPT_OPT_STEAL_MIN    = 8  /* streaming waves: once the ray range is exhausted, this many idle lanes trigger a
+                                  round in which they take stack entries (subtrees) of busy rays (default 32, 65 = never) */
 } MiptOption;
 
 /* per-kernel device time (ms), summed over every kernel launched since the previous

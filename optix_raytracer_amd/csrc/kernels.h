@@ -10,6 +10,7 @@ namespace mipt {
 
 constexpr int      kStackEntries  = 32;     // traversal stack entries per lane == builder depth cap
 constexpr int      kLdsStackEntries = 16;   // of which in LDS (4 KB per wave -> 8 waves/SIMD); the rest spill to global
+constexpr int      kStreamStack = 24;       // k_trace_stream keeps its whole stack in LDS (6 KB per wave); deeper trees use the other kernels
 constexpr int      kMaxTraceBlocks = 256 * 32 * 2;
 constexpr uint32_t kInvalidSlot   = 0xffffffffu;
 constexpr int      kNumSegments   = 8;      // one ray-range segment per XCD
@@ -24,8 +25,6 @@ struct DeviceCounters {
     uint32_t n_next;           // continuation rays emitted by shade
     uint32_t n_shadow;         // shadow rays emitted by shade
     uint32_t bounce;
-    uint32_t n_left[2];        // rays handed over by the streaming kernel: [0] closest, [1] shadow
-    uint32_t pad_left[2];
     uint32_t cursor_closest[kNumSegments * kCursorStride];
     uint32_t cursor_shadow[kNumSegments * kCursorStride];
     unsigned long long closest_rays, shadow_rays;
@@ -39,6 +38,7 @@ struct DeviceBvh {
     const uint32_t* mat_index; // per ORIGINAL primitive: hit-group record index
     uint32_t tri_byte_off;     // tris == (char*)nodes + tri_byte_off (one allocation); 0 if that offset needs > 32 bits
     uint32_t blob_bytes;       // size of that allocation (buffer-descriptor range)
+    uint32_t depth;            // deepest leaf (stack entries a ray can need)
 };
 
 // SoA path queues, capacity `cap` entries each
@@ -67,10 +67,7 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
 
 struct TraceOpts {
     int  persistent;           // 2: streaming waves (default), 1: persistent while-while waves, 0: one thread per ray
-    int  refill_min, leaf_min; // k_trace_stream thresholds
-    int  abandon_min;          // k_trace_stream: hand-over threshold (0 = waves drain by themselves)
-    uint32_t* leftover;        // 2 * leftover_cap ray indices (closest | shadow), or null
-    uint32_t  leftover_cap;
+    int  refill_min, steal_min; // k_trace_stream thresholds
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
     int  lds_stack;            // kLdsStackEntries (default) or kStackEntries (all of the stack in LDS)

@@ -190,12 +190,7 @@ struct TraceArgs {
     DeviceCounters* ctr;
     uint32_t*       spill;        // gridDim.x * (kStackEntries - LDS_N) * 64 words (stack overflow slabs)
     int             refill_min;   // k_trace_stream: idle lanes that trigger a swap-in / prefetch round
-    int             leaf_min;     // k_trace_stream: lanes waiting at a leaf that trigger a triangle step
-    int             abandon_min;  // k_trace_stream: once the ray range is exhausted, a wave with fewer live rays
-                                  // than this hands them to the leftover list and exits (0 = never)
-    const uint32_t* index_list;   // optional indirection: the i-th work item is ray index_list[i]
-    uint32_t*       leftover;     // rays handed over by k_trace_stream (ray indices)
-    uint32_t*       leftover_n;   // their count
+    int             steal_min;    // k_trace_stream: idle lanes that trigger a steal round once the ray range is exhausted
 };
 
 template <int MODE>
@@ -296,15 +291,23 @@ __global__ __launch_bounds__(64) void k_trace_persistent(TraceArgs a)
 
 // ---- streaming waves: the default traversal kernel -------------------------------------------
 // Every lane is a small state machine (at an inner node | at a leaf with k triangles left | idle) and
-// the wave runs ONE loop.  Per iteration: the lanes at inner nodes issue their 64-B node load and --
-// only when enough lanes wait at a leaf -- those lanes issue their 48-B triangle load; after ONE wait
-// the inner lanes do a slab step and the leaf lanes one branch-free triangle test.  Lanes never sit
-// out a whole inner or leaf phase as in the classic while-while loop (measured there: 19-27 % VALU
-// lane utilisation, profiles/r01_*; tools/sim_divergence.py models the schedules).  A finished lane
-// is swapped onto a ray that was prefetched into registers while it was still traversing, in batches,
-// so refilling exposes no memory latency.  The per-ray visiting order is unchanged (a lane never
-// takes an inner step while it owes a triangle test), so hit records and visit counters equal the
-// oracle's.  Loads use a uniform base + 32-bit lane offset (saddr form).
+// the wave runs ONE loop.  Per iteration every lane loads 64 bytes -- its node, or its next triangle
+// (nodes and triangles share one allocation, so inner lanes and leaf lanes execute the same four
+// buffer loads: uniform descriptor + 32-bit lane offset) -- then, after ONE wait, inner lanes do a slab
+// step and leaf lanes one branch-free triangle test.  Lanes never sit out a whole inner or leaf phase
+// as in the classic while-while loop (measured there: 19-27 % VALU lane utilisation, profiles/r01_*;
+// tools/sim_divergence.py models the schedules).
+//   * Refill: a finished lane is swapped onto a ray that was prefetched into registers while it was
+//     still traversing, in batches, so refilling exposes no memory latency.
+//   * Drain (STEAL): once the ray range is exhausted the frame time is the dependent-load chain of the
+//     few longest rays (hundreds of steps).  Idle lanes then take the BOTTOM entry of a busy lane's
+//     traversal stack -- an independent subtree of the same ray -- and traverse it with their own
+//     running best; a per-ray slot in LDS merges the partial results (min t, tie -> lowest primitive)
+//     and the last participant writes the hit record.  Sequential traversal visits a subset of what the
+//     participants visit, so the result is the same; visit counters are only exact without stealing,
+//     hence COUNT builds do not steal.
+// The per-ray visiting order of a non-shared ray is unchanged (a lane never takes an inner step while
+// it owes a triangle test), so hit records and visit counters equal the oracle's.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // 16-byte load through a buffer descriptor: uniform base in SGPRs + 32-bit lane offset, hardware
@@ -315,50 +318,48 @@ __device__ __forceinline__ float4 ld16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byt
     return make_float4(u2f(v.x), u2f(v.y), u2f(v.z), u2f(v.w));
 }
 
-template <int MODE, bool COUNT, int LDS_N>
+__device__ __forceinline__ float shfl_f(float v, uint32_t src) { return __shfl(v, (int)src, 64); }
+__device__ __forceinline__ uint32_t shfl_u(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
+
+template <int MODE, bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
 {
-    __shared__ uint32_t stk_lds[LDS_N * 64];
+    constexpr bool STEAL = !COUNT;
+    __shared__ uint32_t stk[kStreamStack * 64];          // [entry][lane]: bank = lane
+    __shared__ float    sh_t[64], sh_u[64], sh_v[64];    // per-ray merge slots, indexed by the owner's lane
+    __shared__ uint32_t sh_prim[64], sh_ray[64];
+    __shared__ int      sh_pending[64];
+    __shared__ uint32_t sh_src[64], sh_node[64];         // steal round: donor lane / donated reference per pair
     const int lane = (int)threadIdx.x;
-    const Stack<LDS_N> stk{ stk_lds, a.spill + (size_t)blockIdx.x * (size_t)((kStackEntries - LDS_N) * 64), lane };
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
     uint32_t seg = blockIdx.x & (kNumSegments - 1);
     uint32_t tried = 0;
     uint32_t pool_next = 0, pool_end = 0;
-    const int refill_min = a.refill_min, leaf_min = a.leaf_min;
+    const int refill_min = a.refill_min, steal_min = a.steal_min;
     // nodes, then triangles at tri_byte_off, in one allocation
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
 
-    bool     has_ray = false, nxt_valid = false;
-    uint32_t ray = 0, nxt_idx = 0;
+    bool     has_ray = false, nxt_valid = false, shared = false;
+    uint32_t ray = 0, nxt_idx = 0, own = (uint32_t)lane;
+    int      sb = 0;                                      // stack bottom (entries below were given away)
     float4   nxt_o = make_float4(0.f, 0.f, 0.f, 0.f), nxt_d = nxt_o;
     uint32_t n_visits = 0, n_tests = 0;
-    uint32_t rv = 0, rt = 0;          // this ray's share; only counted when the ray completes here
-    uint32_t dbg_iter = 0, dbg_inner = 0, dbg_leaf = 0, dbg_leafnow = 0, dbg_idle = 0, dbg_leafiter = 0, dbg_refills = 0;
     Trav T;
     T.node = kSentinel; T.sp = 0;
+    sh_pending[lane] = 0;
 
     for (;;) {
         // ------------------------------------------------------------ swap in prefetched rays, prefetch more
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle = __popcll(idle);
         const bool dry = tried >= (uint32_t)kNumSegments && pool_next == pool_end;
-        // the long tail: when no fresh rays are left, a mostly empty wave would keep issuing whole-wave
-        // instructions for a handful of long rays.  Hand them over (they restart in the tight kernel,
-        // densely packed) and retire the wave.
-        if (dry && a.abandon_min > 0 && 64 - n_idle < a.abandon_min && __ballot(nxt_valid) == 0ull) {
-            const uint32_t j = wave_append(has_ray, a.leftover_n);
-            if (has_ray) a.leftover[j] = ray;
-            break;
-        }
         if (n_idle == 64 || (n_idle >= refill_min && (!dry || __ballot(nxt_valid && !has_ray) != 0ull))) {
-            if (COUNT) ++dbg_refills;
             if (!has_ray && nxt_valid) {
                 ray = nxt_idx;
-                rv = 0; rt = 0;
                 trav_init(T, nxt_o, nxt_d);
+                sb = 0; shared = false; own = (uint32_t)lane;
                 has_ray = T.node != kSentinel;
                 if (!has_ray) finish_ray<MODE>(a, T, ray, false);      // empty interval: a miss, no BVH access
                 nxt_valid = false;
@@ -384,7 +385,6 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
                 const uint32_t take  = avail < need ? avail : need;
                 if (!nxt_valid && rank >= given && rank < given + take) {
                     nxt_idx = pool_next + (rank - given);
-                    if (a.index_list) nxt_idx = a.index_list[nxt_idx];
                     nxt_o = a.ray_o[(size_t)nxt_idx * a.stride];      // lands while this lane keeps traversing
                     nxt_d = a.ray_d[(size_t)nxt_idx * a.stride];
                     nxt_valid = true;
@@ -394,19 +394,53 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
             }
             if (__ballot(has_ray || nxt_valid) == 0ull) break;
         }
-        // ------------------------------------------------------------ this iteration's load: 64 B per lane
-        // nodes and triangles live in one allocation, so one uniform base + a 32-bit lane offset serves
-        // both kinds of lane with the same four instructions (a triangle uses the first 48 B)
-        const bool inner   = has_ray && T.node >= 0;
-        const bool at_leaf = has_ray && T.node < 0;                    // has_ray implies node != sentinel here
-        const unsigned long long im = __ballot(inner), lm = __ballot(at_leaf);
-        const bool do_leaf = lm != 0ull && (__popcll(lm) >= leaf_min || im == 0ull);
-        const bool leaf_now = at_leaf && do_leaf;
-        if (COUNT && lane == 0) {
-            dbg_iter += 1; dbg_inner += (uint32_t)__popcll(im); dbg_leaf += (uint32_t)__popcll(lm);
-            dbg_leafnow += do_leaf ? (uint32_t)__popcll(lm) : 0u; dbg_idle += (uint32_t)n_idle;
-            dbg_leafiter += do_leaf ? 1u : 0u;
+        // ------------------------------------------------------------ drain: idle lanes take subtrees of busy rays
+        if (STEAL && dry && n_idle >= steal_min) {
+            const bool thief  = !has_ray && !nxt_valid;
+            // a lane's merge slot may still belong to an earlier ray of this lane whose helpers are not done:
+            // such a lane does not donate from a new, not yet shared ray
+            const bool victim = has_ray && T.sp > sb && (shared || sh_pending[lane] == 0);
+            const unsigned long long tm = __ballot(thief), vm = __ballot(victim);
+            const uint32_t nt = (uint32_t)__popcll(tm), nv = (uint32_t)__popcll(vm);
+            const uint32_t np = nt < nv ? nt : nv;
+            if (np != 0u) {
+                const uint32_t rt = lane_rank(tm), rv = lane_rank(vm);
+                const bool donate = victim && rv < np, receive = thief && rt < np;
+                if (donate) {
+                    if (!shared) {          // first donation of this ray: open its merge slot
+                        sh_t[lane] = 0.0f; sh_u[lane] = 0.0f; sh_v[lane] = 0.0f;
+                        sh_prim[lane] = 0xffffffffu; sh_ray[lane] = ray; sh_pending[lane] = 1;
+                        shared = true;      // own == lane already
+                    }
+                    sh_src[rv]  = (uint32_t)lane;
+                    sh_node[rv] = stk[sb * 64 + lane];
+                    ++sb;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (donate) atomicAdd(&sh_pending[own], 1);
+                uint32_t src = (uint32_t)lane, got = 0u;
+                if (receive) { src = sh_src[rt]; got = sh_node[rt]; }
+                // the thief copies the donor's ray; all lanes take part in the shuffles
+                const float ox = shfl_f(T.o.x, src), oy = shfl_f(T.o.y, src), oz = shfl_f(T.o.z, src);
+                const float dx = shfl_f(T.d.x, src), dy = shfl_f(T.d.y, src), dz = shfl_f(T.d.z, src);
+                const float ix = shfl_f(T.idir.x, src), iy = shfl_f(T.idir.y, src), iz = shfl_f(T.idir.z, src);
+                const float nx = shfl_f(T.nood.x, src), ny = shfl_f(T.nood.y, src), nz = shfl_f(T.nood.z, src);
+                const float tmn = shfl_f(T.tmin, src), tmx = shfl_f(T.tmax, src), tbs = shfl_f(T.tbest, src);
+                const uint32_t ow = shfl_u(own, src);
+                if (receive) {
+                    T.o = mk3(ox, oy, oz); T.d = mk3(dx, dy, dz); T.idir = mk3(ix, iy, iz); T.nood = mk3(nx, ny, nz);
+                    T.tmin = tmn; T.tmax = tmx; T.tbest = tbs;
+                    T.u = 0.0f; T.v = 0.0f; T.prim = 0xffffffffu;
+                    T.node = (int)got; T.sp = 0; sb = 0;
+                    own = ow; shared = true; has_ray = true;
+                }
+            }
         }
+        // any-hit: a participant stops as soon as another one has found an occluder
+        if (STEAL && MODE != 0 && has_ray && shared && sh_prim[own] != 0xffffffffu) T.node = kSentinel;
+        // ------------------------------------------------------------ this iteration's load: 64 B per lane
+        const bool inner   = has_ray && T.node >= 0;
+        const bool at_leaf = has_ray && T.node < 0 && T.node != kSentinel;
         const uint32_t ldesc = ~(uint32_t)T.node;
         const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
         uint32_t off = 0u;                                             // idle lanes re-read node 0 (a broadcast)
@@ -416,7 +450,7 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
         asm volatile("" ::: "memory");
         // ------------------------------------------------------------ one inner-node step
         if (inner) {
-            if (COUNT) ++rv;
+            if (COUNT) ++n_visits;
             const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
             const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
             const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
@@ -435,19 +469,23 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
             const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
             if (h0 && h1) {
                 const bool swp = tn1 < tn0;
-                stk.push(T.sp, (uint32_t)(swp ? c0 : c1));
+                stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
+                ++T.sp;
                 T.node = swp ? c1 : c0;
             } else if (h0 || h1) {
                 T.node = h0 ? c0 : c1;
+            } else if (T.sp == sb) {
+                T.node = kSentinel;
             } else {
-                T.node = stk.pop(T.sp);
+                --T.sp;
+                T.node = (int)stk[T.sp * 64 + lane];
             }
         }
         // ------------------------------------------------------------ one triangle test (branch free)
-        if (leaf_now) {
+        if (at_leaf) {
             bool stop = false;
             if (lcnt != 0u) {
-                if (COUNT) ++rt;
+                if (COUNT) ++n_tests;
                 const float4 ta = n0, tb = n1, tc = n2;
                 const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
                 const f3 p = fcross(T.d, e2);
@@ -462,30 +500,49 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
                 const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax;
                 if (MODE != 0) {
                     stop = ok;
+                    if (ok) { T.tbest = t; T.prim = prim; }
                 } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
                     T.tbest = t; T.prim = prim; T.u = u; T.v = v;
                 }
             }
-            if (stop) { finish_ray<MODE>(a, T, ray, true); has_ray = false; T.node = kSentinel; n_visits += rv; n_tests += rt; }
+            if (stop) T.node = kSentinel;
             else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
-            else T.node = stk.pop(T.sp);
+            else if (T.sp == sb) T.node = kSentinel;
+            else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
         }
         // ------------------------------------------------------------ retire
-        if (has_ray && T.node == kSentinel) {
-            finish_ray<MODE>(a, T, ray, MODE == 0 ? (T.prim != 0xffffffffu) : false);
-            has_ray = false;
-            n_visits += rv; n_tests += rt;
+        const bool done = has_ray && T.node == kSentinel;
+        if (done && !shared) finish_ray<MODE>(a, T, ray, T.prim != 0xffffffffu);
+        if (STEAL) {
+            // participants of a shared ray merge into its slot one after the other (same wave: program order)
+            unsigned long long fm = __ballot(done && shared);
+            while (fm != 0ull) {
+                const int l = __builtin_ctzll(fm);
+                if (lane == l) {
+                    if (T.prim != 0xffffffffu) {
+                        const uint32_t sp_ = sh_prim[own];
+                        const float st_ = sh_t[own];
+                        if (MODE != 0 || sp_ == 0xffffffffu || T.tbest < st_ || (T.tbest == st_ && T.prim < sp_)) {
+                            sh_t[own] = T.tbest; sh_prim[own] = T.prim; sh_u[own] = T.u; sh_v[own] = T.v;
+                        }
+                    }
+                    const int left = sh_pending[own] - 1;
+                    sh_pending[own] = left;
+                    if (left == 0) {
+                        Trav R = T;
+                        R.tbest = sh_t[own]; R.prim = sh_prim[own]; R.u = sh_u[own]; R.v = sh_v[own];
+                        finish_ray<MODE>(a, R, sh_ray[own], R.prim != 0xffffffffu);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                fm &= fm - 1ull;
+            }
         }
+        if (done) has_ray = false;
     }
     if (COUNT) {
         wave_add64(&a.ctr->node_visits[MODE != 0], n_visits);
         wave_add64(&a.ctr->tri_tests[MODE != 0], n_tests);
-        if (lane == 0 && MODE == 0) {
-            atomicAdd(&a.ctr->dbg[0], (unsigned long long)dbg_iter);  atomicAdd(&a.ctr->dbg[1], (unsigned long long)dbg_inner);
-            atomicAdd(&a.ctr->dbg[2], (unsigned long long)dbg_leaf);  atomicAdd(&a.ctr->dbg[3], (unsigned long long)dbg_leafnow);
-            atomicAdd(&a.ctr->dbg[4], (unsigned long long)dbg_idle);  atomicAdd(&a.ctr->dbg[5], (unsigned long long)dbg_leafiter);
-            atomicAdd(&a.ctr->dbg[6], (unsigned long long)dbg_refills);
-        }
     }
 }
 
@@ -500,7 +557,7 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     uint32_t n_visits = 0, n_tests = 0;
     for (uint32_t item = blockIdx.x * 64u + threadIdx.x; item < n; item += gridDim.x * 64u) {
-        const uint32_t ray = a.index_list ? a.index_list[item] : item;
+        const uint32_t ray = item;
         Trav T;
         trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
         bool hit = false;
@@ -529,14 +586,14 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
 __global__ void k_begin_sample(DeviceCounters* c, uint32_t n_paths, uint32_t n_valid)
 {
     const uint32_t i = threadIdx.x;
-    if (i == 0) { c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; c->n_left[0] = 0; c->n_left[1] = 0; }
+    if (i == 0) { c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
 __global__ void k_advance(DeviceCounters* c)
 {
     const uint32_t i = threadIdx.x;
-    if (i == 0) { c->closest_rays += c->n_next; c->shadow_rays += c->n_shadow; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce += 1; c->n_left[0] = 0; c->n_left[1] = 0; }
+    if (i == 0) { c->closest_rays += c->n_next; c->shadow_rays += c->n_shadow; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce += 1; }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
@@ -816,22 +873,10 @@ template <int MODE>
 static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
 {
     if (a.n_max == 0) return;
-    if (o.persistent == 2 && a.bvh.tri_byte_off != 0u) {
+    if (o.persistent == 2 && a.bvh.tri_byte_off != 0u && a.bvh.depth <= (uint32_t)kStreamStack) {
         const int blocks = o.blocks > 0 ? o.blocks : 4096;
-        // pass 1: streaming waves; waves that run out of fresh rays hand their long rays over
-        a.abandon_min = o.leftover ? o.abandon_min : 0;
-        a.leftover = o.leftover ? o.leftover + (MODE != 0 ? o.leftover_cap : 0) : nullptr;
-        a.leftover_n = &a.ctr->n_left[MODE != 0];
-        if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true, kLdsStackEntries>), dim3(blocks), dim3(64), 0, st, a);
-        else                hipLaunchKernelGGL((k_trace_stream<MODE, false, kLdsStackEntries>), dim3(blocks), dim3(64), 0, st, a);
-        if (a.abandon_min > 0) {
-            // pass 2: the handed-over rays, one per lane, tight while-while loop (lowest latency per step)
-            TraceArgs b = a;
-            b.index_list = a.leftover; b.n_ptr = a.leftover_n;
-            b.n_max = a.n_max < o.leftover_cap ? a.n_max : o.leftover_cap;
-            b.leftover = nullptr; b.leftover_n = nullptr; b.abandon_min = 0;
-            launch_simple<MODE>(st, b, o);
-        }
+        if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
+        else                hipLaunchKernelGGL((k_trace_stream<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
     } else if (o.persistent == 1) {
         const int blocks = o.blocks > 0 ? o.blocks : 4096;
         if (o.lds_stack >= kStackEntries) {
@@ -852,7 +897,7 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
     TraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr; a.spill = o.spill;
-    a.refill_min = o.refill_min; a.leaf_min = o.leaf_min;
+    a.refill_min = o.refill_min; a.steal_min = o.steal_min;
     launch_trace<0>(st, a, o);
 }
 
@@ -863,7 +908,7 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
     TraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.occluded = occluded; a.contrib = contrib; a.result = result; a.cursors = ctr->cursor_shadow; a.ctr = ctr;
-    a.spill = o.spill; a.refill_min = o.refill_min; a.leaf_min = o.leaf_min;
+    a.spill = o.spill; a.refill_min = o.refill_min; a.steal_min = o.steal_min;
     if (occluded) launch_trace<1>(st, a, o);
     else          launch_trace<2>(st, a, o);
 }

@@ -73,9 +73,7 @@ struct MiptContext {
     int      count_visits = 0;
     int      blocks_per_cu = 0;
     int      persistent = 2;
-    int      refill_min = 8, leaf_min = 1, abandon_min = 0;
-    uint32_t* d_leftover = nullptr;
-    size_t    cap_leftover = 0;
+    int      refill_min = 8, steal_min = 32;
     int      profile = 0;
     int      lds_stack = kLdsStackEntries;
     uint32_t* d_spill = nullptr;
@@ -191,16 +189,6 @@ void free_launch_buffers(MiptContext* c)
     c->cap_paths = 0; c->cap_slots = 0;
 }
 
-// ray-index lists for the streaming kernel's hand-over (closest | shadow)
-int ensure_leftover(MiptContext* c, size_t n)
-{
-    if (n <= c->cap_leftover) return MIPT_SUCCESS;
-    if (c->d_leftover) { (void)hipDeviceSynchronize(); (void)hipFree(c->d_leftover); c->d_leftover = nullptr; c->cap_leftover = 0; }
-    HIPCHK(c, hipMalloc((void**)&c->d_leftover, n * 2 * sizeof(uint32_t)));
-    c->cap_leftover = n;
-    return MIPT_SUCCESS;
-}
-
 // SoA queues: ray_o and ray_d are two planes of one allocation
 int ensure_capacity(MiptContext* c, size_t n_paths, size_t n_slots)
 {
@@ -220,7 +208,6 @@ int ensure_capacity(MiptContext* c, size_t n_paths, size_t n_slots)
     HIPCHK(c, hipMalloc((void**)&c->result, ns * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->rg_seed, ns * sizeof(uint32_t)));
     c->cap_paths = np; c->cap_slots = ns;
-    { const int rc = ensure_leftover(c, np); if (rc) return rc; }
     c->log(4, "LAUNCH", "queues sized for %zu paths / %zu slots (%.1f MB)", np, ns,
            (double)(np * (2 * (32 + 16 + 8) + 32 + 16 + 16) + ns * 20) / 1e6);
     return MIPT_SUCCESS;
@@ -231,12 +218,11 @@ TraceOpts trace_opts(const MiptContext* c)
     TraceOpts o{};
     o.persistent = c->persistent;
     o.count_visits = c->count_visits;
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (c->persistent == 2 ? 24 : (c->lds_stack >= kStackEntries ? 20 : 32));
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (c->persistent == 2 ? 20 : (c->lds_stack >= kStackEntries ? 20 : 32));
     o.blocks = std::min(c->num_cus * per_cu, kMaxTraceBlocks);
     o.lds_stack = c->lds_stack;
     o.spill = c->d_spill;
-    o.refill_min = c->refill_min; o.leaf_min = c->leaf_min;
-    o.abandon_min = c->abandon_min; o.leftover = c->d_leftover; o.leftover_cap = (uint32_t)c->cap_leftover;
+    o.refill_min = c->refill_min; o.steal_min = c->steal_min;
     return o;
 }
 
@@ -255,7 +241,7 @@ Accel* find_accel(const MiptContext* c, unsigned long long h)
 DeviceBvh device_bvh(const Accel* a)
 {
     DeviceBvh b{};
-    b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes;
+    b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes; b.depth = a->host.depth;
     return b;
 }
 
@@ -408,7 +394,6 @@ int mipt_context_destroy(MiptContext* c)
     if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_spill) (void)hipFree(c->d_spill);
-    if (c->d_leftover) (void)hipFree(c->d_leftover);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     delete c;
@@ -432,12 +417,9 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
         c->refill_min = (int)value; return MIPT_SUCCESS;
-    case MIPT_OPT_LEAF_MIN:
-        if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "leaf threshold must be 1..64");
-        c->leaf_min = (int)value; return MIPT_SUCCESS;
-    case MIPT_OPT_ABANDON_MIN:
-        if (value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "hand-over threshold must be 0..64");
-        c->abandon_min = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_STEAL_MIN:
+        if (value < 1 || value > 65) return c->fail(MIPT_ERROR_INVALID_VALUE, "steal threshold must be 1..65 (65 = never)");
+        c->steal_min = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_LDS_STACK:
         if (value != (uint64_t)kLdsStackEntries && value != (uint64_t)kStackEntries)
             return c->fail(MIPT_ERROR_INVALID_VALUE, "LDS stack entries must be %d or %d", kLdsStackEntries, kStackEntries);
@@ -460,8 +442,7 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_PROFILE: *value = (uint64_t)c->profile; return MIPT_SUCCESS;
     case MIPT_OPT_LDS_STACK: *value = (uint64_t)c->lds_stack; return MIPT_SUCCESS;
     case MIPT_OPT_REFILL_MIN: *value = (uint64_t)c->refill_min; return MIPT_SUCCESS;
-    case MIPT_OPT_LEAF_MIN: *value = (uint64_t)c->leaf_min; return MIPT_SUCCESS;
-    case MIPT_OPT_ABANDON_MIN: *value = (uint64_t)c->abandon_min; return MIPT_SUCCESS;
+    case MIPT_OPT_STEAL_MIN: *value = (uint64_t)c->steal_min; return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;
     }
 }
@@ -779,7 +760,6 @@ int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    { const int rc = ensure_leftover(ctx, n); if (rc) return rc; }
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, n);
     const float4* r = (const float4*)rays;
@@ -799,7 +779,6 @@ int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, co
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    { const int rc = ensure_leftover(ctx, n); if (rc) return rc; }
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, 0);
     const float4* r = (const float4*)rays;

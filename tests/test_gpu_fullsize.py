@@ -53,15 +53,14 @@ def test_headline_determinism_and_kernel_variants(big):
         a2, f2, s2 = _render(PT, st, ob)
         assert np.array_equal(a0.view(np.uint32), a2.view(np.uint32)) and np.array_equal(f0, f2), variant
     st.context.set_option(L.OPT_PERSISTENT, 2)
-    defaults = [st.context.get_option(o) for o in (L.OPT_TRACE_GRID, L.OPT_REFILL_MIN, L.OPT_LEAF_MIN, L.OPT_ABANDON_MIN)]
-    for grid, refill, leaf, aband in ((4, 1, 1, 0), (20, 32, 64, 64), (32, 64, 8, 16), (8, 8, 1, 40)):
-        st.context.set_option(L.OPT_TRACE_GRID, grid)
-        st.context.set_option(L.OPT_REFILL_MIN, refill)
-        st.context.set_option(L.OPT_LEAF_MIN, leaf)
-        st.context.set_option(L.OPT_ABANDON_MIN, aband)
-        a3, _, _ = _render(PT, st, ob)
-        assert np.array_equal(a0.view(np.uint32), a3.view(np.uint32)), (grid, refill, leaf, aband)
-    for o, v in zip((L.OPT_TRACE_GRID, L.OPT_REFILL_MIN, L.OPT_LEAF_MIN, L.OPT_ABANDON_MIN), defaults):
+    opts = (L.OPT_TRACE_GRID, L.OPT_REFILL_MIN, L.OPT_STEAL_MIN)
+    defaults = [st.context.get_option(o) for o in opts]
+    for vals in ((4, 1, 1), (20, 32, 65), (32, 64, 16), (8, 8, 40)):     # incl. stealing on every idle lane / never
+        for o, v in zip(opts, vals):
+            st.context.set_option(o, v)
+        a3, f3, _ = _render(PT, st, ob)
+        assert np.array_equal(a0.view(np.uint32), a3.view(np.uint32)) and np.array_equal(f0, f3), vals
+    for o, v in zip(opts, defaults):
         st.context.set_option(o, v)
 
 

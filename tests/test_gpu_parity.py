@@ -61,15 +61,15 @@ def test_library_is_native_and_loaded():
     assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
 
 
-@pytest.mark.parametrize("persistent,abandon", [(2, 24), (2, 0), (2, 64), (1, 0), (0, 0)])
-def test_traversal_records_bit_exact(persistent, abandon):
+@pytest.mark.parametrize("persistent,steal", [(2, 8), (2, 1), (2, 65), (1, 8), (0, 8)])
+def test_traversal_records_bit_exact(persistent, steal):
     torch = _torch()
     from optix_raytracer_amd import _lib as L
     from optix_raytracer_amd import scenes
     for scene, (w, h) in ((scenes.cornell_box(), (160, 96)), (scenes.random_soup(30000), (200, 120))):
         PT, st = _state(scene, w, h)
         st.context.set_option(L.OPT_PERSISTENT, persistent)
-        st.context.set_option(L.OPT_ABANDON_MIN, abandon)
+        st.context.set_option(L.OPT_STEAL_MIN, steal)
         st.context.set_option(L.OPT_COUNT_VISITS, 1)
         osc = _oracle_scene(scene, st)
         launch = scenes.launch_desc(scene, w, h)
@@ -87,9 +87,16 @@ def test_traversal_records_bit_exact(persistent, abandon):
         n = rays.shape[0]
         d_rays = torch.from_numpy(rays).cuda()
         d_hits = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        st.context.set_option(L.OPT_COUNT_VISITS, 0)       # the production build of the kernels (steals subtrees)
+        st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), n, d_hits.data_ptr())
+        st.context.sync()
+        hits_fast = d_hits.cpu().numpy()
+        d_hits.zero_()
+        st.context.set_option(L.OPT_COUNT_VISITS, 1)       # the counting build (exact per-ray order)
         st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), n, d_hits.data_ptr())
         stats = st.context.launch_stats()
         hits = d_hits.cpu().numpy()
+        assert np.array_equal(hits.view(np.uint32), hits_fast.view(np.uint32))
         ost = O.OrcStats()
         t, prim, u, v = osc.trace_closest(rays, O.MODE_BVH, ost)
         assert np.array_equal(hits[:, 1].view(np.uint32), prim)
@@ -103,9 +110,12 @@ def test_traversal_records_bit_exact(persistent, abandon):
         seg[:, 7] = np.where(seg[:, 7] > 1.0, 250.0 if scene["name"] == "cornell" else 0.4, seg[:, 7])
         d_seg = torch.from_numpy(seg).cuda()
         d_occ = torch.zeros(n, dtype=torch.int32, device="cuda")
-        st.context.trace_any(st.gas_handle, d_seg.data_ptr(), n, d_occ.data_ptr())
         occ = osc.trace_any(seg, O.MODE_BVH)
-        assert np.array_equal(d_occ.cpu().numpy().astype(np.uint8), occ)
+        for counting in (0, 1):
+            st.context.set_option(L.OPT_COUNT_VISITS, counting)
+            d_occ.zero_()
+            st.context.trace_any(st.gas_handle, d_seg.data_ptr(), n, d_occ.data_ptr())
+            assert np.array_equal(d_occ.cpu().numpy().astype(np.uint8), occ), counting
         PT.cleanupState(st)
 
 

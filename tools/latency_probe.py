@@ -41,7 +41,6 @@ print("longest rays (nodes, tris):", [(c[0], c[1]) for c in cand[:8]])
 st.context.set_option(L.OPT_PROFILE, 1)
 for variant in (0, 2):
     st.context.set_option(L.OPT_PERSISTENT, variant)
-    st.context.set_option(L.OPT_ABANDON_MIN, 0)
     for label, rays in (("1 longest ray", np.stack([cand[0][2]])),
                         ("64 x longest ray", np.stack([cand[0][2]] * 64)),
                         ("64 longest rays", np.stack([c[2] for c in cand[:64]])),
