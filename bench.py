@@ -44,6 +44,18 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by tools/prof_traffic.sh + tools/traffic_json.py): 2*FETCH_SIZE + WRITE_SIZE, in bytes -- FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when no profile of this kernel is on file."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        e = d["kernels"][kernel]
+        return int((2.0 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024)
+    except Exception:
+        return None
+
+
 def effective_cpus():
     """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box
     shows every host thread in the mask but grants a share of them)."""
@@ -212,10 +224,11 @@ def main():
         tt_c = counts["tri_tests"] - counts["shadow_tri_tests"]
         bytes_closest = 64 * nv_c + 48 * tt_c + (32 + 16) * counts["closest_rays"]
         bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
+        variant = {2: "k_trace_stream", 1: "k_trace_persistent", 0: "k_trace_simple"}[int(st.context.get_option(L.OPT_PERSISTENT))]
         if k_closest >= k_any:
-            kname, kbytes, kms, klaunches = "k_trace_persistent<closest>", bytes_closest, k_closest, tm["n_trace_closest"]
+            kname, kbytes, kms, klaunches = variant + "<0, false>", bytes_closest, k_closest, tm["n_trace_closest"]
         else:
-            kname, kbytes, kms, klaunches = "k_trace_persistent<any>", bytes_any, k_any, tm["n_trace_any"]
+            kname, kbytes, kms, klaunches = variant + "<2, false>", bytes_any, k_any, tm["n_trace_any"]
         launches_per_step = max(klaunches // args.steps, 1)
         kms_avg = kms / launches_per_step          # average duration of one launch of that kernel
         kbytes_launch = kbytes / launches_per_step
@@ -232,7 +245,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather" % world,
                        "bvh_build_s": round(info["build_seconds"], 3), "setup_s": round(build_s, 3)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname),
                          "algorithmic_bytes_per_launch": int(kbytes_launch),
                          "kernel_ms_avg": round(kms_avg, 4),
                          "per_frame_ms": {"trace_closest": round(k_closest, 4), "trace_any": round(k_any, 4),
