@@ -153,8 +153,10 @@ typedef enum MiptOption {
     MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings) */
     MIPT_OPT_LDS_STACK    = 6, /* traversal-stack entries kept in LDS: 16 (default, rest spills to global) or 32 */
     MIPT_OPT_REFILL_MIN   = 7, /* streaming waves: idle lanes that trigger a swap-in/prefetch round (default 8) */
-    MIPT_OPT_STEAL_MIN    = 8  /* streaming waves: once the ray range is exhausted, this many idle lanes trigger a
+    MIPT_OPT_STEAL_MIN    = 8, /* streaming waves: once the ray range is exhausted, this many idle lanes trigger a
                                   round in which they take stack entries (subtrees) of busy rays (default 32, 65 = never) */
+    MIPT_OPT_DRAIN_MAX    = 9  /* streaming waves: with at most this many rays left (and no fresh ones), a wave finishes
+                                  them in tight per-lane loops without bookkeeping (0 = off) */
 } MiptOption;
 
 /* per-kernel device time (ms), summed over every kernel launched since the previous

@@ -73,7 +73,7 @@ struct MiptContext {
     int      count_visits = 0;
     int      blocks_per_cu = 0;
     int      persistent = 2;
-    int      refill_min = 8, steal_min = 32;
+    int      refill_min = 8, steal_min = 32, drain_max = 0;   // drain_max: measured no gain next to stealing
     int      profile = 0;
     int      lds_stack = kLdsStackEntries;
     uint32_t* d_spill = nullptr;
@@ -222,7 +222,7 @@ TraceOpts trace_opts(const MiptContext* c)
     o.blocks = std::min(c->num_cus * per_cu, kMaxTraceBlocks);
     o.lds_stack = c->lds_stack;
     o.spill = c->d_spill;
-    o.refill_min = c->refill_min; o.steal_min = c->steal_min;
+    o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.drain_max = c->drain_max;
     return o;
 }
 
@@ -417,6 +417,9 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
         c->refill_min = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_DRAIN_MAX:
+        if (value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "drain threshold must be 0..64");
+        c->drain_max = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_STEAL_MIN:
         if (value < 1 || value > 65) return c->fail(MIPT_ERROR_INVALID_VALUE, "steal threshold must be 1..65 (65 = never)");
         c->steal_min = (int)value; return MIPT_SUCCESS;
@@ -443,6 +446,7 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_LDS_STACK: *value = (uint64_t)c->lds_stack; return MIPT_SUCCESS;
     case MIPT_OPT_REFILL_MIN: *value = (uint64_t)c->refill_min; return MIPT_SUCCESS;
     case MIPT_OPT_STEAL_MIN: *value = (uint64_t)c->steal_min; return MIPT_SUCCESS;
+    case MIPT_OPT_DRAIN_MAX: *value = (uint64_t)c->drain_max; return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;
     }
 }

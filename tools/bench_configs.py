@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Times the BASELINE.json configurations that fit one GPU (besides the headline one that bench.py owns) and
+prints one line each: ms per launch, Mray/s (closest + shadow rays actually traced)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from optix_raytracer_amd import _lib as L, pathtracer as PT, scenes
+
+def run(name, scene, w, h, spp, max_depth, reps):
+    st = PT.make_state(scene, w, h, spp, 0, max_depth=max_depth)
+    ob = PT.OutputBuffer(w, h, st.device)
+    PT.launchSubframe(ob, st)
+    stats = st.context.launch_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        PT.launchSubframe(ob, st)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    rays = stats["closest_rays"] + stats["shadow_rays"]
+    print("%-44s %9.3f ms/launch  %9.1f Mray/s  (%d closest + %d shadow rays, %d wavefront iterations)" % (
+        name, ms, rays / ms / 1e3, stats["closest_rays"], stats["shadow_rays"], stats["bounces"]), flush=True)
+    PT.cleanupState(st)
+
+run("C1 Cornell 512x512 spp1 (RR depth)", scenes.cornell_box(), 512, 512, 1, 0, 5)
+run("C2 Cornell 1920x1080 spp16 (RR depth)", scenes.cornell_box(), 1920, 1080, 16, 0, 2)
+run("C4 soup 1M 1920x1080 spp1 depth 1", scenes.random_soup(1_000_000), 1920, 1080, 1, 1, 10)
+run("C4 soup 1M 1920x1080 spp1 depth 8", scenes.random_soup(1_000_000), 1920, 1080, 1, 8, 5)
