@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--max-depth", type=int, default=MAX_DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", type=str, default="nccl", help="debug: 'gloo' lets several ranks share one GPU (functional check only)")
     ap.add_argument("--persistent", type=int, default=-1, help="tuning: 1/0 forces the persistent / one-thread-per-ray traversal kernels")
     ap.add_argument("--grid", type=int, default=0, help="tuning: persistent workgroups per CU")
     ap.add_argument("--refill-min", type=int, default=0)
@@ -129,6 +130,7 @@ def main():
     import torch.distributed as dist
     from optix_raytracer_amd import _lib as L
     from optix_raytracer_amd import api, scenes
+    from optix_raytracer_amd import dist as D
     from optix_raytracer_amd import pathtracer as PT
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,9 +142,14 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()      # debug: ranks may share a device
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+        else:
+            dist.init_process_group(args.backend)
 
     w, h = args.width, args.height
     scene = scenes.random_soup(args.tris)
@@ -174,7 +181,10 @@ def main():
             st.context.launch(st.params, w, h, 1, stream=stream.cuda_stream)
         else:
             st.context.launch_shard(st.params, w, h, rank, world, compact.data_ptr(), stream=stream.cuda_stream)
-            dist.all_gather_into_tensor(gathered, compact)      # the path's one exchange (RCCL over xGMI)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, compact)      # the path's one exchange (RCCL over xGMI)
+            else:
+                gathered.copy_(D.all_gather_shards(compact.cpu(), world))   # debug backend: staged through the host
             st.context.unpermute(gathered.data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=stream.cuda_stream)
 
     def fence():
@@ -209,10 +219,11 @@ def main():
     t_max = elapsed
     rays_total = rays_local
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=st.device)
+        red_dev = st.device if args.backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_max = float(tt.item())
-        rr = torch.tensor([rays_local], dtype=torch.int64, device=st.device)
+        rr = torch.tensor([rays_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays_total = int(rr.item())
 
