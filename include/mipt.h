@@ -247,6 +247,39 @@ int mipt_unpermute(MiptContext* ctx, void* stream, const void* gathered, unsigne
                    unsigned int width, unsigned int height, void* accum_buffer, void* frame_buffer);
 
 /* ---------------------------------------------------------------------------
+ * glTF scenes   (replaces sutil::loadScene + the host data of sutil::Scene,
+ * SDK/sutil/Scene.cpp:267-550, Scene.h:53-159; host only, no device needed).
+ * Instances are flattened to world-space triangles instead of GAS/IAS builds.
+ * ------------------------------------------------------------------------- */
+typedef struct MiptScene MiptScene;
+
+typedef struct MiptSceneInfo {
+    uint32_t num_buffers, num_images, num_textures, num_materials;
+    uint32_t num_meshes, num_instances, num_cameras, num_triangles;   /* triangles after flattening */
+    float    aabb_min[3], aabb_max[3];                                 /* union of the instances' world boxes */
+} MiptSceneInfo;
+
+/* the factors of MaterialData (SDK/cuda/MaterialData.h:33-130) that do not need texture objects */
+typedef struct MiptMaterialData {
+    float   base_color[4];
+    float   metallic, roughness;
+    float   emissive_factor[3];
+    float   alpha_cutoff;
+    int32_t alpha_mode;           /* 0 OPAQUE, 1 MASK, 2 BLEND */
+    int32_t double_sided;
+    int32_t base_color_texture;   /* glTF texture index or -1 (not decoded yet) */
+} MiptMaterialData;
+
+int mipt_scene_load(const char* filename, MiptScene** out, char* errbuf, size_t errlen);   /* .gltf (+ .bin / data: URIs) or .glb */
+int mipt_scene_destroy(MiptScene* scene);
+int mipt_scene_info(const MiptScene* scene, MiptSceneInfo* info);
+/* Scene::camera() (Scene.cpp:777-791): first glTF camera (lookat = scene aabb centre, :687-688) or the default camera */
+int mipt_scene_camera(const MiptScene* scene, float eye[3], float lookat[3], float up[3], float* fovY_deg, float* aspect);
+int mipt_scene_material(const MiptScene* scene, uint32_t index, MiptMaterialData* out);
+/* vertices4_out: num_triangles*3 float4 {x,y,z,0}; material_index_out: num_triangles (0xffffffff = none) */
+int mipt_scene_flatten(const MiptScene* scene, float* vertices4_out, uint32_t* material_index_out);
+
+/* ---------------------------------------------------------------------------
  * Host helpers mirroring sutil (kept API: SDK/sutil/Camera.h:38-76)
  * ------------------------------------------------------------------------- */
 /* Camera::UVWFrame, SDK/sutil/Camera.cpp:34-46 (fod = m_fod, the fork's focal scale) */

@@ -43,6 +43,19 @@ class MiptBuildInput(C.Structure):
                 ("num_triangles", C.c_uint32), ("sbt_index_offsets", C.c_void_p), ("transform3x4", C.c_void_p)]
 
 
+class MiptSceneInfo(C.Structure):
+    _fields_ = [("num_buffers", C.c_uint32), ("num_images", C.c_uint32), ("num_textures", C.c_uint32),
+                ("num_materials", C.c_uint32), ("num_meshes", C.c_uint32), ("num_instances", C.c_uint32),
+                ("num_cameras", C.c_uint32), ("num_triangles", C.c_uint32),
+                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3)]
+
+
+class MiptMaterialData(C.Structure):
+    _fields_ = [("base_color", C.c_float * 4), ("metallic", C.c_float), ("roughness", C.c_float),
+                ("emissive_factor", C.c_float * 3), ("alpha_cutoff", C.c_float), ("alpha_mode", C.c_int32),
+                ("double_sided", C.c_int32), ("base_color_texture", C.c_int32)]
+
+
 class MiptLaunchStats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
@@ -91,6 +104,12 @@ SYMBOLS = [
     ("mipt_shard_pixel", C.c_int, [C.c_uint, C.c_uint, C.c_uint, C.c_uint, _u32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("mipt_launch_shard", C.c_int, [_vp, _vp, C.POINTER(MiptParams), C.c_uint, C.c_uint, C.c_uint, C.c_uint, _vp]),
     ("mipt_unpermute", C.c_int, [_vp, _vp, _vp, C.c_uint, C.c_uint, C.c_uint, _vp, _vp]),
+    ("mipt_scene_load", C.c_int, [C.c_char_p, C.POINTER(_vp), C.c_char_p, C.c_size_t]),
+    ("mipt_scene_destroy", C.c_int, [_vp]),
+    ("mipt_scene_info", C.c_int, [_vp, C.POINTER(MiptSceneInfo)]),
+    ("mipt_scene_camera", C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp]),
+    ("mipt_scene_material", C.c_int, [_vp, _u32, C.POINTER(MiptMaterialData)]),
+    ("mipt_scene_flatten", C.c_int, [_vp, _vp, _vp]),
     ("mipt_camera_uvw", None, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp]),
     ("mipt_scene_random_triangles", C.c_int, [_u32, _u32, C.c_float, _vp]),
 ]

@@ -70,6 +70,64 @@ def host_bvh(vertices4):
     return nodes, tris[:info.num_triangles], {k: getattr(info, k) for k, _ in info._fields_}
 
 
+class Scene:
+    """Host scene loaded from glTF: the data side of sutil::Scene (SDK/sutil/Scene.h:53-159) behind
+    sutil::loadScene (Scene.cpp:267).  Raises MiptError on a malformed file, like the reference throws."""
+
+    def __init__(self, filename):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self._lib.mipt_scene_load(str(filename).encode(), C.byref(self._h), err, 512)
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), err.value.decode() or "mipt_scene_load")
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.mipt_scene_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def info(self):
+        i = L.MiptSceneInfo()
+        self._lib.mipt_scene_info(self._h, C.byref(i))
+        d = {k: getattr(i, k) for k, _ in i._fields_}
+        d["aabb_min"] = np.array(i.aabb_min, np.float32)
+        d["aabb_max"] = np.array(i.aabb_max, np.float32)
+        return d
+
+    def camera(self):
+        """Scene::camera(): dict(eye, lookat, up, fovY, aspect)"""
+        e, l, u = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+        f, a = C.c_float(), C.c_float()
+        self._lib.mipt_scene_camera(self._h, e, l, u, C.byref(f), C.byref(a))
+        return {"eye": np.array(e, np.float32), "lookat": np.array(l, np.float32), "up": np.array(u, np.float32),
+                "fovY": f.value, "aspect": a.value}
+
+    def materials(self):
+        out = []
+        for k in range(self.info()["num_materials"]):
+            m = L.MiptMaterialData()
+            self._lib.mipt_scene_material(self._h, k, C.byref(m))
+            out.append({"base_color": np.array(m.base_color, np.float32), "metallic": m.metallic, "roughness": m.roughness,
+                        "emissive_factor": np.array(m.emissive_factor, np.float32), "alpha_mode": m.alpha_mode,
+                        "alpha_cutoff": m.alpha_cutoff, "double_sided": bool(m.double_sided),
+                        "base_color_texture": m.base_color_texture})
+        return out
+
+    def flatten(self):
+        """(n*3, 4) float32 world-space vertices, (n,) uint32 material indices"""
+        n = self.info()["num_triangles"]
+        v = np.zeros((max(n, 1) * 3, 4), np.float32)
+        m = np.zeros(max(n, 1), np.uint32)
+        rc = self._lib.mipt_scene_flatten(self._h, v.ctypes.data, m.ctypes.data)
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_flatten")
+        return v[:n * 3], m[:n]
+
+
 class Context:
     """A device context (createContext, optixPathTracer.cpp:555-573)."""
 

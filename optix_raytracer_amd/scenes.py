@@ -94,3 +94,33 @@ def launch_desc(scene, width, height, spp=1, subframe=0):
     U, V, W = cam.UVWFrame()
     return {"width": width, "height": height, "spp": spp, "subframe": subframe,
             "eye": np.asarray(c["eye"], np.float32), "U": U, "V": V, "W": W, "light": scene["light"]}
+
+
+def from_gltf(filename):
+    """BASELINE config 3/5 scenes: a glTF file through the sutil::Scene-compatible loader.  The reference has no
+    path tracer over sutil::Scene (only the Whitted PBR programs), so the shading here is build-defined
+    (SURVEY.md 8d): Lambert with diffuse = pbr.base_color.rgb (textures ignored for now), no emission, camera
+    from Scene::camera(), one downward parallelogram light of side 0.5*maxExtent centred 1.0*maxExtent above the
+    scene aabb centre, emission (15,15,5)."""
+    sc = api.Scene(filename)
+    info = sc.info()
+    verts, mat = sc.flatten()
+    mats = sc.materials()
+    diffuse = np.asarray([m["base_color"][:3] for m in mats] + [(0.8, 0.8, 0.8)], np.float32)   # last = "no material"
+    mat = np.where(mat == 0xFFFFFFFF, len(mats), mat).astype(np.uint32)
+    lo, hi = info["aabb_min"], info["aabb_max"]
+    f = np.float32
+    centre = ((lo + hi) * f(0.5)).astype(np.float32)
+    ext = f(max(hi - lo))
+    side = f(0.5) * ext
+    corner = np.array([centre[0] - side * f(0.5), centre[1] + ext, centre[2] - side * f(0.5)], np.float32)
+    cam = sc.camera()
+    return {
+        "name": "gltf:" + str(filename).rsplit("/", 1)[-1],
+        "vertices": verts, "mat_index": mat,
+        "emission": np.zeros((diffuse.shape[0], 3), np.float32), "diffuse": diffuse,
+        "bg": np.zeros(4, np.float32),
+        "light": _light(corner, (side, 0.0, 0.0), (0.0, 0.0, side), (15.0, 15.0, 5.0)),
+        "camera": {"eye": cam["eye"], "lookat": cam["lookat"], "up": cam["up"], "fovY": cam["fovY"]},
+        "info": info,
+    }

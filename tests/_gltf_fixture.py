@@ -1,0 +1,175 @@
+"""Writes a small synthetic glTF 2.0 scene (and its .glb twin) that exercises what sutil::loadScene handles:
+u16 / u32 / no indices, a strided vertex view, a data: URI buffer and an external .bin, nested nodes with
+matrix + TRS, two instances of one mesh, a perspective camera node, a non-triangle primitive that must be
+ignored, materials with and without factors.  Also returns the expected world-space triangles computed with
+float32 numpy in the operation order of SDK/sutil/Matrix.h."""
+import base64
+import json
+import struct
+
+import numpy as np
+
+f32 = np.float32
+
+
+def m4_mul(a, b):
+    out = np.zeros((4, 4), f32)
+    for i in range(4):
+        for j in range(4):
+            s = f32(0)
+            for k in range(4):
+                s = f32(s + f32(a[i, k] * b[k, j]))
+            out[i, j] = s
+    return out
+
+
+def m4_apply(a, v):
+    out = np.zeros(4, f32)
+    for i in range(4):
+        s = f32(0)
+        for j in range(4):
+            s = f32(s + f32(a[i, j] * v[j]))
+        out[i] = s
+    return out
+
+
+def trs(t=None, r=None, s=None, matrix=None):
+    T = np.eye(4, dtype=f32)
+    if t is not None:
+        T[:3, 3] = np.asarray(t, f32)
+    R = np.eye(4, dtype=f32)
+    if r is not None:
+        qx, qy, qz, qw = [f32(x) for x in r]
+        two = f32(2)
+        R[0, 0] = f32(f32(f32(1) - f32(f32(two * qy) * qy)) - f32(f32(two * qz) * qz)); R[0, 1] = f32(f32(f32(two * qx) * qy) - f32(f32(two * qz) * qw)); R[0, 2] = f32(f32(f32(two * qx) * qz) + f32(f32(two * qy) * qw))
+        R[1, 0] = f32(f32(f32(two * qx) * qy) + f32(f32(two * qz) * qw)); R[1, 1] = f32(f32(f32(1) - f32(f32(two * qx) * qx)) - f32(f32(two * qz) * qz)); R[1, 2] = f32(f32(f32(two * qy) * qz) - f32(f32(two * qx) * qw))
+        R[2, 0] = f32(f32(f32(two * qx) * qz) - f32(f32(two * qy) * qw)); R[2, 1] = f32(f32(f32(two * qy) * qz) + f32(f32(two * qx) * qw)); R[2, 2] = f32(f32(f32(1) - f32(f32(two * qx) * qx)) - f32(f32(two * qy) * qy))
+    S = np.eye(4, dtype=f32)
+    if s is not None:
+        S[0, 0], S[1, 1], S[2, 2] = [f32(x) for x in s]
+    M = np.eye(4, dtype=f32)
+    if matrix is not None:
+        M = np.asarray(matrix, f32).reshape(4, 4).T.copy()      # glTF stores column-major
+    return M, T, R, S
+
+
+def node_xform(parent, t=None, r=None, s=None, matrix=None):
+    M, T, R, S = trs(t, r, s, matrix)
+    return m4_mul(m4_mul(m4_mul(m4_mul(parent, M), T), R), S)
+
+
+def write(tmpdir, n_grid=6):
+    rng = np.random.default_rng(11)
+    # mesh 0, primitive 0: a bumpy grid, u16 indices, positions interleaved with normals (stride 24)
+    g = n_grid
+    xs, zs = np.meshgrid(np.linspace(-1, 1, g), np.linspace(-1, 1, g))
+    pos0 = np.stack([xs.ravel(), 0.15 * rng.standard_normal(g * g), zs.ravel()], 1).astype(f32)
+    inter = np.zeros((g * g, 6), f32)
+    inter[:, :3] = pos0
+    inter[:, 3:] = (0, 1, 0)
+    idx0 = []
+    for j in range(g - 1):
+        for i in range(g - 1):
+            a = j * g + i
+            idx0 += [a, a + 1, a + g, a + 1, a + g + 1, a + g]
+    idx0 = np.asarray(idx0, np.uint16)
+    # mesh 0, primitive 1: 4 loose triangles, no indices
+    pos1 = (rng.uniform(-1, 1, (12, 3)) * (1, 0.5, 1) + (0, 1.0, 0)).astype(f32)
+    # mesh 1: a box-ish blob, u32 indices
+    pos2 = rng.uniform(-0.4, 0.4, (20, 3)).astype(f32)
+    idx2 = rng.integers(0, 20, (14, 3)).astype(np.uint32)
+    idx2 = idx2[(idx2[:, 0] != idx2[:, 1]) & (idx2[:, 1] != idx2[:, 2]) & (idx2[:, 0] != idx2[:, 2])]
+    # a line primitive that must be ignored
+    idx_lines = np.asarray([0, 1, 1, 2], np.uint16)
+
+    bin0 = inter.tobytes() + idx0.tobytes()
+    bin0 += b"\0" * (-len(bin0) % 4)
+    off_pos1 = len(bin0)
+    bin0 += pos1.tobytes()
+    off_lines = len(bin0)
+    bin0 += idx_lines.tobytes()
+    bin1 = pos2.tobytes() + idx2.tobytes()
+
+    def mm(a):
+        return [float(x) for x in a.min(0)], [float(x) for x in a.max(0)]
+
+    root_matrix = [0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.5, 0, 0.1, 0.2, -0.3, 1]        # column-major: scale 0.5 + translate
+    q = np.asarray([0.1, 0.7, -0.2, 0.68], np.float64)
+    q /= np.linalg.norm(q)
+    doc = {
+        "asset": {"version": "2.0"},
+        "buffers": [{"byteLength": len(bin0), "uri": "fixture0.bin"},
+                    {"byteLength": len(bin1), "uri": "data:application/octet-stream;base64," + base64.b64encode(bin1).decode()}],
+        "bufferViews": [
+            {"buffer": 0, "byteOffset": 0, "byteLength": inter.nbytes, "byteStride": 24},
+            {"buffer": 0, "byteOffset": inter.nbytes, "byteLength": idx0.nbytes},
+            {"buffer": 0, "byteOffset": off_pos1, "byteLength": pos1.nbytes},
+            {"buffer": 1, "byteOffset": 0, "byteLength": pos2.nbytes},
+            {"buffer": 1, "byteOffset": pos2.nbytes, "byteLength": idx2.nbytes},
+            {"buffer": 0, "byteOffset": off_lines, "byteLength": idx_lines.nbytes},
+        ],
+        "accessors": [
+            {"bufferView": 0, "byteOffset": 0, "componentType": 5126, "count": g * g, "type": "VEC3", "min": mm(pos0)[0], "max": mm(pos0)[1]},
+            {"bufferView": 1, "componentType": 5123, "count": int(idx0.size), "type": "SCALAR"},
+            {"bufferView": 2, "componentType": 5126, "count": 12, "type": "VEC3", "min": mm(pos1)[0], "max": mm(pos1)[1]},
+            {"bufferView": 3, "componentType": 5126, "count": 20, "type": "VEC3", "min": mm(pos2)[0], "max": mm(pos2)[1]},
+            {"bufferView": 4, "componentType": 5125, "count": int(idx2.size), "type": "SCALAR"},
+            {"bufferView": 5, "componentType": 5123, "count": 4, "type": "SCALAR"},
+        ],
+        "materials": [
+            {"name": "red", "pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.1, 0.1, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.5}},
+            {"name": "defaults", "emissiveFactor": [0.0, 0.0, 0.0], "alphaMode": "MASK", "alphaCutoff": 0.25, "doubleSided": True},
+        ],
+        "meshes": [
+            {"name": "ground", "primitives": [
+                {"attributes": {"POSITION": 0}, "indices": 1, "material": 0, "mode": 4},
+                {"attributes": {"POSITION": 2}, "material": 1},
+                {"attributes": {"POSITION": 0}, "indices": 5, "mode": 1}]},
+            {"name": "blob", "primitives": [{"attributes": {"POSITION": 3}, "indices": 4}]},
+        ],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 0.7, "aspectRatio": 1.25, "znear": 0.1}}],
+        "nodes": [
+            {"children": [1, 3], "matrix": root_matrix},
+            {"mesh": 0, "translation": [0.0, -0.5, 0.0], "scale": [2.0, 1.0, 2.0], "children": [2]},
+            {"mesh": 1, "rotation": [float(x) for x in q], "translation": [0.3, 1.2, 0.1]},
+            {"mesh": 1, "translation": [-1.0, 0.8, 0.5], "scale": [1.5, 1.5, 1.5]},
+            {"camera": 0, "translation": [0.2, 1.5, 4.0]},
+        ],
+        "scenes": [{"nodes": [0, 4]}], "scene": 0,
+    }
+    gltf = tmpdir / "fixture.gltf"
+    gltf.write_text(json.dumps(doc))
+    (tmpdir / "fixture0.bin").write_bytes(bin0)
+    # GLB twin: one embedded BIN chunk holding both buffers' bytes would change buffer indices, so the twin keeps
+    # buffer 1 as a data URI and embeds buffer 0
+    doc_glb = json.loads(json.dumps(doc))
+    del doc_glb["buffers"][0]["uri"]
+    js = json.dumps(doc_glb).encode()
+    js += b" " * (-len(js) % 4)
+    glb = tmpdir / "fixture.glb"
+    body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(bin0), 0x004E4942) + bin0
+    glb.write_bytes(b"glTF" + struct.pack("<II", 2, 12 + len(body)) + body)
+
+    # ---- expected flattening, instance order = node traversal order (roots in index order, depth first)
+    I = np.eye(4, dtype=f32)
+    x0 = node_xform(I, matrix=root_matrix)
+    x1 = node_xform(x0, t=[0.0, -0.5, 0.0], s=[2.0, 1.0, 2.0])
+    x2 = node_xform(x1, t=[0.3, 1.2, 0.1], r=[float(x) for x in q])
+    x3 = node_xform(x0, t=[-1.0, 0.8, 0.5], s=[1.5, 1.5, 1.5])
+    x4 = node_xform(I, t=[0.2, 1.5, 4.0])
+    tris, mats = [], []
+
+    def emit(xf, pos, idx, mat):
+        ids = np.arange(pos.shape[0]) if idx is None else idx.reshape(-1)
+        for v in ids[: (len(ids) // 3) * 3]:
+            w = m4_apply(xf, np.array([pos[v, 0], pos[v, 1], pos[v, 2], 1.0], f32))
+            tris.append((w[0], w[1], w[2], f32(0)))
+        mats.extend([mat] * (len(ids) // 3))
+    emit(x1, pos0, idx0, 0); emit(x1, pos1, None, 1)
+    emit(x2, pos2, idx2, 0xFFFFFFFF)
+    emit(x3, pos2, idx2, 0xFFFFFFFF)
+    eye = m4_apply(x4, np.array([0, 0, 0, 1], f32))[:3]
+    up = m4_apply(x4, np.array([0, 1, 0, 0], f32))[:3]
+    expect = {"vertices": np.asarray(tris, f32), "mat_index": np.asarray(mats, np.uint32), "eye": eye, "up": up,
+              "fovY": f32(f32(0.7) * f32(180.0) / f32(np.pi)), "aspect": f32(1.25), "n_instances": 3, "n_meshes": 2}
+    return gltf, glb, expect
