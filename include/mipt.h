@@ -247,6 +247,58 @@ int mipt_unpermute(MiptContext* ctx, void* stream, const void* gathered, unsigne
                    unsigned int width, unsigned int height, void* accum_buffer, void* frame_buffer);
 
 /* ---------------------------------------------------------------------------
+ * SDK/imgui_test (the fork author's interactive tracer): the same traversal kernels under its own
+ * raygen / closest-hit / miss programs (imgui_test/optixTriangle.cu:103-268).  The structs keep the
+ * layouts of the sample's device objects, so its host code can upload them unchanged.
+ * ------------------------------------------------------------------------- */
+
+/* class Camera, imgui_test/camera.h:155-173 (92 bytes) */
+typedef struct MiptImguiCamera {
+    float   eye[3], lookat[3], up[3];
+    uint8_t ortho, pad_[3];
+    float   fov, fd, aperture, speed;
+    float   u[3], v[3], w[3];
+} MiptImguiCamera;
+
+/* class LightVariant, imgui_test/light.h:10-51 (44 bytes): 40-byte union + tag.
+ *   tag 0 PointLight       (point_light.h):       a = position,  b = {lumi.xyz, dark.x}, c = dark.yz, -
+ *   tag 1 DirectionalLight (directional_light.h): a = direction, b = {lumi.xyz, jitter}, c = dark.xyz
+ *   tag 2 VolumetricLight  (volumetric_light.h):  a = position,  b = {radius, lumi.xyz}, c = dark.xyz */
+typedef struct MiptImguiLight {
+    float   a[3];
+    float   b[4];
+    float   c[3];
+    int32_t tag;
+} MiptImguiLight;
+
+/* struct Params, imgui_test/optixTriangle.h:42-108 (128 bytes); every pointer is a DEVICE pointer */
+typedef struct MiptImguiParams {
+    unsigned int        image_width, image_height, samples_per_frame;
+    const MiptImguiCamera* camera;
+    unsigned int        dt;
+    uint8_t             dirty;           /* bool: overwrite the film instead of adding to it */
+    void*               image;           /* uchar4 per pixel */
+    float*              film;            /* packed float3 per pixel */
+    float               tfactor;
+    unsigned long long  handle;
+    const float*        normals;         /* packed float3, 3 per primitive */
+    const float*        vertices;        /* packed float3, 3 per primitive */
+    const int*          mat_indices;
+    int                 nmat_indices;
+    const MiptImguiLight* lights;
+    int                 nlights;
+    const float*        materials;       /* DiffuseMaterial: one float3 colour each (diffuse.h:3-16) */
+    int                 nmaterials;
+} MiptImguiParams;
+
+/* replaces optixLaunch in TracerWindow::run (imgui_test/tracer_window.cpp:101); params is a HOST pointer */
+int  mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* params,
+                       unsigned int width, unsigned int height, unsigned int depth);
+/* Camera::set_fd / Camera::compute_uvw (camera.h:36, 110-123), host side */
+void mipt_imgui_camera_set_fd(MiptImguiCamera* camera, float new_fd);
+void mipt_imgui_camera_compute_uvw(MiptImguiCamera* camera);
+
+/* ---------------------------------------------------------------------------
  * glTF scenes   (replaces sutil::loadScene + the host data of sutil::Scene,
  * SDK/sutil/Scene.cpp:267-550, Scene.h:53-159; host only, no device needed).
  * Instances are flattened to world-space triangles instead of GAS/IAS builds.

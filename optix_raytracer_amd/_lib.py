@@ -56,6 +56,27 @@ class MiptMaterialData(C.Structure):
                 ("double_sided", C.c_int32), ("base_color_texture", C.c_int32)]
 
 
+class MiptImguiCamera(C.Structure):
+    """class Camera of SDK/imgui_test (camera.h:155-173), 92 bytes"""
+    _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("ortho", C.c_uint8),
+                ("pad_", C.c_uint8 * 3), ("fov", C.c_float), ("fd", C.c_float), ("aperture", C.c_float),
+                ("speed", C.c_float), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3)]
+
+
+class MiptImguiLight(C.Structure):
+    """class LightVariant (light.h:10-51), 44 bytes"""
+    _fields_ = [("a", C.c_float * 3), ("b", C.c_float * 4), ("c", C.c_float * 3), ("tag", C.c_int32)]
+
+
+class MiptImguiParams(C.Structure):
+    """struct Params of SDK/imgui_test (optixTriangle.h:42-108), 128 bytes"""
+    _fields_ = [("image_width", C.c_uint), ("image_height", C.c_uint), ("samples_per_frame", C.c_uint),
+                ("camera", C.c_void_p), ("dt", C.c_uint), ("dirty", C.c_uint8), ("image", C.c_void_p),
+                ("film", C.c_void_p), ("tfactor", C.c_float), ("handle", C.c_ulonglong), ("normals", C.c_void_p),
+                ("vertices", C.c_void_p), ("mat_indices", C.c_void_p), ("nmat_indices", C.c_int),
+                ("lights", C.c_void_p), ("nlights", C.c_int), ("materials", C.c_void_p), ("nmaterials", C.c_int)]
+
+
 class MiptLaunchStats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
@@ -104,6 +125,9 @@ SYMBOLS = [
     ("mipt_shard_pixel", C.c_int, [C.c_uint, C.c_uint, C.c_uint, C.c_uint, _u32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("mipt_launch_shard", C.c_int, [_vp, _vp, C.POINTER(MiptParams), C.c_uint, C.c_uint, C.c_uint, C.c_uint, _vp]),
     ("mipt_unpermute", C.c_int, [_vp, _vp, _vp, C.c_uint, C.c_uint, C.c_uint, _vp, _vp]),
+    ("mipt_imgui_launch", C.c_int, [_vp, _vp, C.POINTER(MiptImguiParams), C.c_uint, C.c_uint, C.c_uint]),
+    ("mipt_imgui_camera_set_fd", None, [C.POINTER(MiptImguiCamera), C.c_float]),
+    ("mipt_imgui_camera_compute_uvw", None, [C.POINTER(MiptImguiCamera)]),
     ("mipt_scene_load", C.c_int, [C.c_char_p, C.POINTER(_vp), C.c_char_p, C.c_size_t]),
     ("mipt_scene_destroy", C.c_int, [_vp]),
     ("mipt_scene_info", C.c_int, [_vp, C.POINTER(MiptSceneInfo)]),

@@ -73,6 +73,10 @@ struct MiptContext {
     int      count_visits = 0;
     int      blocks_per_cu = 0;
     int      persistent = 2;
+    // SDK/imgui_test launches: K = nlights + 1 occlusion rays per primary hit
+    ShadowQueue im_sq{};
+    uint32_t*   im_flags = nullptr;
+    size_t      im_cap = 0;
     int      refill_min = 8, steal_min = 32, drain_max = 0;   // drain_max: measured no gain next to stealing
     int      profile = 0;
     int      lds_stack = kLdsStackEntries;
@@ -394,6 +398,9 @@ int mipt_context_destroy(MiptContext* c)
     if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_spill) (void)hipFree(c->d_spill);
+    if (c->im_sq.ray_o) (void)hipFree(c->im_sq.ray_o);
+    if (c->im_sq.contrib) (void)hipFree(c->im_sq.contrib);
+    if (c->im_flags) (void)hipFree(c->im_flags);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     delete c;
@@ -751,6 +758,72 @@ int mipt_get_launch_timings(MiptContext* ctx, MiptLaunchTimings* out)
     }
     ctx->timed.clear(); ctx->events_used = 0;      // sums cover every launch since the previous call
     return MIPT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SDK/imgui_test
+// ------------------------------------------------------------------------------------------------
+static_assert(sizeof(MiptImguiCamera) == 92 && sizeof(MiptImguiLight) == 44 && sizeof(MiptImguiParams) == 128,
+              "imgui_test device-object layouts (camera.h:155-173, light.h:10-51, optixTriangle.h:42-108)");
+
+int mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* p, unsigned int width, unsigned int height, unsigned int depth)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!p) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "params is null");
+    if (depth != 1 || width == 0 || height == 0 || width != p->image_width || height != p->image_height)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "launch size %ux%ux%u does not match params %ux%u", width, height, depth, p->image_width, p->image_height);
+    if (p->samples_per_frame == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "samples_per_frame must be >= 1");
+    if (p->dt == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "dt is 0: call frame_step() before the launch (tracer_window.cpp:92)");
+    if (!p->camera || !p->film || !p->normals || !p->mat_indices || !p->materials || p->nmaterials <= 0)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "camera / film / normals / mat_indices / materials must be set");
+    if (p->nlights < 0 || p->nlights > 31 || (p->nlights > 0 && !p->lights)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0..31 lights supported");
+    Accel* acc = find_accel(ctx, p->handle);
+    if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
+    int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);
+    if (rc) return rc;
+    const size_t need = (size_t)n_paths * (size_t)(p->nlights + 1);
+    if (need > ctx->im_cap) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        if (ctx->im_sq.ray_o) (void)hipFree(ctx->im_sq.ray_o);
+        if (ctx->im_sq.contrib) (void)hipFree(ctx->im_sq.contrib);
+        if (ctx->im_flags) (void)hipFree(ctx->im_flags);
+        ctx->im_sq = ShadowQueue{}; ctx->im_flags = nullptr; ctx->im_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->im_sq.ray_o, need * 2 * sizeof(float4)));
+        ctx->im_sq.ray_d = ctx->im_sq.ray_o + need;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->im_sq.contrib, need * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc((void**)&ctx->im_flags, need * sizeof(uint32_t)));
+        ctx->im_cap = need;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ctx->last_stream = st;
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    imgui_run(st, *p, n_paths, device_bvh(acc), ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->rg_seed,
+              ctx->d_ctr, trace_opts(ctx));
+    ctx->last_bounces = p->samples_per_frame;
+    HIPCHK(ctx, hipGetLastError());
+    return MIPT_SUCCESS;
+}
+
+void mipt_imgui_camera_set_fd(MiptImguiCamera* c, float new_fd)
+{
+    const f3 d = mk3(c->lookat[0], c->lookat[1], c->lookat[2]) - mk3(c->eye[0], c->eye[1], c->eye[2]);
+    c->fd = new_fd / length(d);                                         // camera.h:36
+}
+
+void mipt_imgui_camera_compute_uvw(MiptImguiCamera* c)                 // camera.h:110-123
+{
+    f3 w = (mk3(c->lookat[0], c->lookat[1], c->lookat[2]) - mk3(c->eye[0], c->eye[1], c->eye[2])) * c->fd;
+    const float wlen = length(w);
+    f3 u = normalize(cross(w, mk3(c->up[0], c->up[1], c->up[2])));
+    f3 v = normalize(cross(u, w));
+    const float vlen = wlen * tanf(0.5f * c->fov * 3.14159265358979323846f / 180.0f);
+    v = v * vlen;
+    u = u * vlen;
+    c->u[0] = u.x; c->u[1] = u.y; c->u[2] = u.z;
+    c->v[0] = v.x; c->v[1] = v.y; c->v[2] = v.z;
+    c->w[0] = w.x; c->w[1] = w.y; c->w[2] = w.z;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -938,3 +938,132 @@ void orc_primary_rays(const OrcParams* p, uint32_t y0, uint32_t y1, float* rays8
             q[4] = d.x;   q[5] = d.y;   q[6] = d.z;   q[7] = 1e16f;
         }
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* SDK/imgui_test (the author's sample) -- optixTriangle.cu:103-268           */
+/* ------------------------------------------------------------------------- */
+void orc_imgui_camera_set_fd(OrcImguiCamera* c, float new_fd)
+{
+    c->fd = new_fd / v3_length(v3_sub(v3_ld(c->lookat), v3_ld(c->eye)));      /* camera.h:36 */
+}
+
+void orc_imgui_camera_compute_uvw(OrcImguiCamera* c)                           /* camera.h:110-123 */
+{
+    v3 w = v3_scale(v3_sub(v3_ld(c->lookat), v3_ld(c->eye)), c->fd);
+    float wlen = v3_length(w);
+    v3 u = v3_normalize(v3_cross(w, v3_ld(c->up)));
+    v3 v = v3_normalize(v3_cross(u, w));
+    float vlen = wlen * tanf(0.5f * c->fov * 3.14159265358979323846f / 180.0f);
+    v = v3_scale(v, vlen);
+    u = v3_scale(u, vlen);                                                     /* ulen = vlen: square pixels, no aspect */
+    c->u[0] = u.x; c->u[1] = u.y; c->u[2] = u.z;
+    c->v[0] = v.x; c->v[1] = v.y; c->v[2] = v.z;
+    c->w[0] = w.x; c->w[1] = w.y; c->w[2] = w.z;
+}
+
+/* Camera::compute_ray, camera.h:127-144.  The two aperture draws are written as arguments of one
+ * make_float2 call in the reference; evaluated left to right here (as nvcc/clang do). */
+static void imgui_compute_ray(const OrcImguiCamera* c, uint32_t ix, uint32_t iy, uint32_t dimx, uint32_t dimy,
+                              v3* origin, v3* direction, uint32_t* seed)
+{
+    float dx = 2.0f * ((float)ix / (float)dimx) - 1.0f;
+    float dy = 2.0f * ((float)iy / (float)dimy) - 1.0f;
+    v3 u = v3_ld(c->u), v = v3_ld(c->v), w = v3_ld(c->w), eye = v3_ld(c->eye);
+    if (c->ortho) {
+        *direction = v3_normalize(v3_add(v3_add(v3_scale(u, dx), v3_scale(v, dy)), w));
+        *origin    = v3_add(v3_add(eye, v3_scale(u, dx)), v3_scale(v, dy));
+    } else {
+        float ax = (orc_rnd(seed) - 0.5f) * c->aperture;
+        float ay = (orc_rnd(seed) - 0.5f) * c->aperture;
+        dx = dx - ax; dy = dy - ay;
+        *direction = v3_normalize(v3_add(v3_add(v3_scale(u, dx), v3_scale(v, dy)), w));
+        *origin    = v3_add(v3_add(eye, v3_scale(u, ax)), v3_scale(v, ay));
+    }
+}
+
+/* LightVariant::wi / lumi, light.h:19-40 (point_light.h:20-25, directional_light.h:19-24, volumetric_light.h:22-27) */
+static v3 imgui_light_wi(const OrcImguiLight* l, v3 p, uint32_t* seed)
+{
+    if (l->tag == 0) return v3_sub(v3_ld(l->a), p);
+    if (l->tag == 1) {
+        float j = l->b[3];
+        float jx = j * orc_rnd(seed), jy = j * orc_rnd(seed), jz = j * orc_rnd(seed);
+        return v3_add(v3_ld(l->a), v3_make(jx, jy, jz));
+    }
+    {
+        float r = l->b[0];
+        float jx = r * orc_rnd(seed), jy = r * orc_rnd(seed), jz = r * orc_rnd(seed);
+        return v3_sub(v3_add(v3_ld(l->a), v3_make(jx, jy, jz)), p);
+    }
+}
+static v3 imgui_light_lumi(const OrcImguiLight* l)
+{
+    if (l->tag == 2) return v3_make(l->b[1], l->b[2], l->b[3]);
+    return v3_make(l->b[0], l->b[1], l->b[2]);
+}
+
+/* __closesthit__ch, optixTriangle.cu:174-268 */
+static v3 imgui_closesthit(const OrcScene* s, int mode, const OrcImguiFrame* f, v3 ray_o, v3 ray_d, const HitRec* h,
+                           uint32_t ix, uint32_t iy, OrcStats* st)
+{
+    const float* nb = f->normals + (size_t)h->prim * 9;
+    v3 n0 = v3_ld(nb), n1 = v3_ld(nb + 3), n2 = v3_ld(nb + 6);
+    v3 normal = v3_add(v3_add(v3_scale(n1, h->u), v3_scale(n2, h->v)), v3_scale(n0, 1.0f - h->u - h->v));
+    v3 P = v3_add(v3_add(ray_o, v3_scale(ray_d, h->t)), v3_scale(normal, 0.0001f));
+    uint32_t seed = orc_tea4(ix + f->image_width * iy, f->dt);          /* re-seeded identically for every sample (:201) */
+    v3 result = v3_make(0.0f, 0.0f, 0.0f);
+    int mi = f->mat_indices[h->prim];
+    if (mi < 0 || mi >= f->nmaterials) mi = 0;
+    v3 color = v3_ld(f->materials + 3 * mi);
+    for (int li = 0; li < f->nlights; ++li) {
+        v3 wi = imgui_light_wi(&f->lights[li], P, &seed);
+        float ndotwi = v3_dot(normal, wi);
+        HitRec sh;
+        trace(s, mode, P, wi, 0.01f, 1.0f, 1, &sh, st);                   /* tmax 1.0 in units of the un-normalised wi */
+        if (!(sh.hit || ndotwi < 0.0f))
+            result = v3_add(result, v3_scale(v3_mul(color, imgui_light_lumi(&f->lights[li])), ndotwi));
+        else
+            result = v3_add(result, v3_make(0.0f, 0.0f, 0.0f));
+    }
+    float nrm[3] = { normal.x, normal.y, normal.z };
+    float u1 = orc_rnd(&seed), u2 = orc_rnd(&seed);
+    float out[3];
+    orc_cosine_sample_hemisphere(u1, u2, out);
+    orc_onb_inverse_transform(nrm, out);                                   /* Onb keeps the un-normalised normal as its z axis */
+    HitRec ao;
+    trace(s, mode, P, v3_ld(out), 0.01f, 1e16f, 1, &ao, st);               /* only hit / no hit is used (:243-267) */
+    v3 ambient = v3_make(0.01f, 0.01f, 0.01f);
+    result = v3_add(result, ao.hit ? ambient : v3_mul(ambient, color));
+    return result;
+}
+
+int orc_imgui_render_rows(const OrcScene* s, int mode, const OrcImguiFrame* f, uint32_t y0, uint32_t y1, OrcStats* st)
+{
+    if (mode == ORC_MODE_BVH && !s->nodes) return -1;
+    const uint32_t W = f->image_width, H = f->image_height;
+    for (uint32_t y = y0; y < y1 && y < H; ++y)
+        for (uint32_t x = 0; x < W; ++x) {
+            const size_t index = (size_t)y * W + x;
+            v3 result = v3_make(0.0f, 0.0f, 0.0f);
+            uint32_t seed = orc_tea4(x + W * y, f->dt);
+            for (uint32_t i = 0; i < f->samples_per_frame; ++i) {
+                v3 ro, rd;
+                imgui_compute_ray(f->camera, x, y, W, H, &ro, &rd, &seed);
+                HitRec h;
+                trace(s, mode, ro, rd, 0.0f, 1e16f, 0, &h, st);
+                v3 payload = h.hit ? imgui_closesthit(s, mode, f, ro, rd, &h, x, y, st)
+                                   : v3_add(v3_scale(rd, 0.5f), v3_make(0.5f, 0.5f, 0.5f));     /* __miss__ms :153-171 */
+                result = v3_add(result, payload);
+            }
+            float* film = f->film + index * 3;
+            v3 fl = f->dirty ? result : v3_add(v3_ld(film), result);
+            film[0] = fl.x; film[1] = fl.y; film[2] = fl.z;
+            if (f->image) {
+                float inv = 1.0f / (float)f->dt;
+                float c[3] = { fl.x * inv, fl.y * inv, fl.z * inv };
+                orc_make_color(c, f->image + index * 4);
+            }
+        }
+    return 0;
+}

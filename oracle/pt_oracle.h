@@ -107,6 +107,39 @@ int orc_render_pixels(const OrcScene*, int mode, const OrcParams* p, uint32_t ma
                       const uint32_t* pixel_index, uint32_t n, float* compact_accum4,
                       const float* compact_prev4, OrcStats* stats);
 
+/* ---- SDK/imgui_test programs (optixTriangle.cu:103-268), restated ----
+ * Object layouts are the reference's device objects: Camera 92 B (camera.h:155-173), LightVariant 44 B
+ * (light.h:10-51: 40-byte union + tag 0 Point / 1 Directional / 2 Volumetric), DiffuseMaterial 12 B. */
+typedef struct OrcImguiCamera {
+    float   eye[3], lookat[3], up[3];
+    uint8_t ortho, pad_[3];
+    float   fov, fd, aperture, speed;
+    float   u[3], v[3], w[3];
+} OrcImguiCamera;
+
+typedef struct OrcImguiLight {
+    float   a[3];        /* Point: position | Directional: direction | Volumetric: position */
+    float   b[4];        /* Point: lumi[3], dark.x | Directional: lumi[3], jitter | Volumetric: radius, lumi[3] */
+    float   c[3];        /* rest of the union */
+    int32_t tag;
+} OrcImguiLight;
+
+typedef struct OrcImguiFrame {
+    uint32_t image_width, image_height, samples_per_frame, dt;
+    int32_t  dirty;
+    const OrcImguiCamera* camera;
+    const OrcImguiLight*  lights;    int32_t nlights;
+    const float*          materials; int32_t nmaterials;   /* float3 colour each (diffuse.h:3-16) */
+    const int32_t*        mat_indices;                     /* per primitive */
+    const float*          normals;                         /* 3 packed float3 per primitive (triangle_gas.cpp:16-75) */
+    float*                film;                            /* width*height float3, in/out */
+    uint8_t*              image;                           /* width*height uchar4 */
+} OrcImguiFrame;
+
+void orc_imgui_camera_compute_uvw(OrcImguiCamera* cam);                       /* camera.h:110-123 */
+void orc_imgui_camera_set_fd(OrcImguiCamera* cam, float new_fd);              /* camera.h:36 */
+int  orc_imgui_render_rows(const OrcScene*, int mode, const OrcImguiFrame* f, uint32_t y0, uint32_t y1, OrcStats* stats);
+
 /* primary rays exactly as raygen emits them for sample 0 (for traversal tests) */
 void orc_primary_rays(const OrcParams* p, uint32_t y0, uint32_t y1, float* rays8);
 

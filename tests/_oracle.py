@@ -37,6 +37,24 @@ class OrcStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class OrcImguiCamera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("ortho", C.c_uint8),
+                ("pad_", C.c_uint8 * 3), ("fov", C.c_float), ("fd", C.c_float), ("aperture", C.c_float),
+                ("speed", C.c_float), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3)]
+
+
+class OrcImguiLight(C.Structure):
+    _fields_ = [("a", C.c_float * 3), ("b", C.c_float * 4), ("c", C.c_float * 3), ("tag", C.c_int32)]
+
+
+class OrcImguiFrame(C.Structure):
+    _fields_ = [("image_width", C.c_uint32), ("image_height", C.c_uint32), ("samples_per_frame", C.c_uint32),
+                ("dt", C.c_uint32), ("dirty", C.c_int32), ("camera", C.POINTER(OrcImguiCamera)),
+                ("lights", C.POINTER(OrcImguiLight)), ("nlights", C.c_int32), ("materials", C.POINTER(C.c_float)),
+                ("nmaterials", C.c_int32), ("mat_indices", C.POINTER(C.c_int32)), ("normals", C.POINTER(C.c_float)),
+                ("film", C.POINTER(C.c_float)), ("image", C.POINTER(C.c_uint8))]
+
+
 def _build():
     src = os.path.join(ORACLE_DIR, "pt_oracle.c")
     if os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
@@ -104,6 +122,13 @@ def lib():
     L.orc_render_pixels.restype = C.c_int
     L.orc_render_pixels.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcParams), C.c_uint32, C.c_void_p, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.POINTER(OrcStats)]
+    L.orc_imgui_camera_compute_uvw.restype = None
+    L.orc_imgui_camera_compute_uvw.argtypes = [C.POINTER(OrcImguiCamera)]
+    L.orc_imgui_camera_set_fd.restype = None
+    L.orc_imgui_camera_set_fd.argtypes = [C.POINTER(OrcImguiCamera), C.c_float]
+    L.orc_imgui_render_rows.restype = C.c_int
+    L.orc_imgui_render_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcImguiFrame), C.c_uint32, C.c_uint32,
+                                        C.POINTER(OrcStats)]
     L.orc_primary_rays.restype = None
     L.orc_primary_rays.argtypes = [C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_void_p]
     _lib = L
