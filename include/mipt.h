@@ -155,8 +155,8 @@ typedef enum MiptOption {
     MIPT_OPT_REFILL_MIN   = 7, /* streaming waves: idle lanes that trigger a swap-in/prefetch round (default 8) */
     MIPT_OPT_STEAL_MIN    = 8, /* streaming waves: once the ray range is exhausted, this many idle lanes trigger a
                                   round in which they take stack entries (subtrees) of busy rays (default 32, 65 = never) */
-    MIPT_OPT_DRAIN_MAX    = 9  /* streaming waves: with at most this many rays left (and no fresh ones), a wave finishes
-                                  them in tight per-lane loops without bookkeeping (0 = off) */
+    MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
+                                  (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;
 
 /* per-kernel device time (ms), summed over every kernel launched since the previous

@@ -67,7 +67,7 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
 
 struct TraceOpts {
     int  persistent;           // 2: streaming waves (default), 1: persistent while-while waves, 0: one thread per ray
-    int  refill_min, steal_min, drain_max; // k_trace_stream thresholds
+    int  refill_min, steal_min, burst_bulk, burst_dry; // k_trace_stream knobs
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
     int  lds_stack;            // kLdsStackEntries (default) or kStackEntries (all of the stack in LDS)

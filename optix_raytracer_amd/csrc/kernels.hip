@@ -163,7 +163,8 @@ struct TraceArgs {
     uint32_t*       spill;        // gridDim.x * (kStackEntries - LDS_N) * 64 words (stack overflow slabs)
     int             refill_min;   // k_trace_stream: idle lanes that trigger a swap-in / prefetch round
     int             steal_min;    // k_trace_stream: idle lanes that trigger a steal round once the ray range is exhausted
-    int             drain_max;    // k_trace_stream: with at most this many rays left, the wave runs them in tight loops
+    int             burst_bulk;   // k_trace_stream: traversal steps per bookkeeping round while fresh rays remain
+    int             burst_dry;    // ... and once the ray range is exhausted
 };
 
 template <int MODE>
@@ -411,147 +412,84 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
         }
         // any-hit: a participant stops as soon as another one has found an occluder
         if (STEAL && MODE != 0 && has_ray && shared && sh_prim[own] != 0xffffffffu) T.node = kSentinel;
-        // ------------------------------------------------------------ last rays of the wave: tight per-lane loops
-        // With a handful of rays left there is nothing to schedule any more; what counts is the latency of
-        // each step.  The loop below is the same step sequence without the per-iteration bookkeeping.
-        if (dry && 64 - n_idle <= a.drain_max && n_idle < 64 && __ballot(nxt_valid) == 0ull) {
-            while (has_ray && T.node != kSentinel) {
-                const bool in2 = T.node >= 0;
-                const uint32_t d2 = ~(uint32_t)T.node;
-                const uint32_t f2 = d2 >> 4, c2 = d2 & 15u;
-                const uint32_t off2 = in2 ? ((uint32_t)T.node << 6) : (a.bvh.tri_byte_off + f2 * 48u);
-                const float4 m0 = ld16(blob, off2), m1 = ld16(blob, off2 + 16u), m2 = ld16(blob, off2 + 32u), m3 = ld16(blob, off2 + 48u);
-                if (in2) {
-                    if (COUNT) ++n_visits;
-                    const float ax0 = __builtin_fmaf(m0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(m0.y, T.idir.x, T.nood.x);
-                    const float ay0 = __builtin_fmaf(m0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(m0.w, T.idir.y, T.nood.y);
-                    const float az0 = __builtin_fmaf(m2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(m2.y, T.idir.z, T.nood.z);
-                    const float bx0 = __builtin_fmaf(m1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(m1.y, T.idir.x, T.nood.x);
-                    const float by0 = __builtin_fmaf(m1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(m1.w, T.idir.y, T.nood.y);
-                    const float bz0 = __builtin_fmaf(m2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(m2.w, T.idir.z, T.nood.z);
-                    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                                      __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
-                    const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                                      __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
-                    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                                      __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
-                    const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                                      __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
-                    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                    const int c0 = (int)f2u(m3.x), c1 = (int)f2u(m3.y);
-                    if (h0 && h1) {
-                        const bool swp = tn1 < tn0;
-                        stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
-                        ++T.sp;
-                        T.node = swp ? c1 : c0;
-                    } else if (h0 || h1) {
-                        T.node = h0 ? c0 : c1;
-                    } else if (T.sp == sb) {
-                        T.node = kSentinel;
-                    } else {
-                        --T.sp;
-                        T.node = (int)stk[T.sp * 64 + lane];
-                    }
+        // ------------------------------------------------------------ a burst of traversal steps
+        // The bookkeeping above (ballots, refill, steal round) is amortised over `burst` steps; a lane that
+        // finishes inside a burst idles until its end.
+        const int burst = dry ? a.burst_dry : a.burst_bulk;
+        for (int bi = 0; bi < burst; ++bi) {
+            if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
+            // ------------------------------------------------------------ this iteration's load: 64 B per lane
+            const bool inner   = has_ray && T.node >= 0;
+            const bool at_leaf = has_ray && T.node < 0 && T.node != kSentinel;
+            const uint32_t ldesc = ~(uint32_t)T.node;
+            const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
+            uint32_t off = 0u;                                             // idle lanes re-read node 0 (a broadcast)
+            if (inner) off = (uint32_t)T.node << 6;
+            if (at_leaf && lcnt != 0u) off = a.bvh.tri_byte_off + lfirst * 48u;
+            const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
+            asm volatile("" ::: "memory");
+            // ------------------------------------------------------------ one inner-node step
+            if (inner) {
+                if (COUNT) ++n_visits;
+                const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
+                const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
+                const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
+                const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
+                const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
+                const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
+                const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
+                const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
+                const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                                  __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
+                const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                                  __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
+                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+                const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+                if (h0 && h1) {
+                    const bool swp = tn1 < tn0;
+                    stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
+                    ++T.sp;
+                    T.node = swp ? c1 : c0;
+                } else if (h0 || h1) {
+                    T.node = h0 ? c0 : c1;
+                } else if (T.sp == sb) {
+                    T.node = kSentinel;
                 } else {
-                    bool stop2 = false;
-                    if (c2 != 0u) {
-                        if (COUNT) ++n_tests;
-                        const f3 e1 = mk3(m1.x, m1.y, m1.z), e2 = mk3(m2.x, m2.y, m2.z);
-                        const f3 p = fcross(T.d, e2);
-                        const float det = fdot(e1, p);
-                        const float inv = 1.0f / det;
-                        const f3 tv = T.o - mk3(m0.x, m0.y, m0.z);
-                        const float u = fdot(tv, p) * inv;
-                        const f3 q = fcross(tv, e1);
-                        const float v = fdot(T.d, q) * inv;
-                        const float t = fdot(e2, q) * inv;
-                        const uint32_t prim = f2u(m0.w);
-                        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax;
-                        if (MODE != 0) {
-                            stop2 = ok;
-                            if (ok) { T.tbest = t; T.prim = prim; }
-                        } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
-                            T.tbest = t; T.prim = prim; T.u = u; T.v = v;
-                        }
+                    --T.sp;
+                    T.node = (int)stk[T.sp * 64 + lane];
+                }
+            }
+            // ------------------------------------------------------------ one triangle test (branch free)
+            if (at_leaf) {
+                bool stop = false;
+                if (lcnt != 0u) {
+                    if (COUNT) ++n_tests;
+                    const float4 ta = n0, tb = n1, tc = n2;
+                    const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
+                    const f3 p = fcross(T.d, e2);
+                    const float det = fdot(e1, p);
+                    const float inv = 1.0f / det;
+                    const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
+                    const float u = fdot(tv, p) * inv;
+                    const f3 q = fcross(tv, e1);
+                    const float v = fdot(T.d, q) * inv;
+                    const float t = fdot(e2, q) * inv;
+                    const uint32_t prim = f2u(ta.w);
+                    const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax;
+                    if (MODE != 0) {
+                        stop = ok;
+                        if (ok) { T.tbest = t; T.prim = prim; }
+                    } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
+                        T.tbest = t; T.prim = prim; T.u = u; T.v = v;
                     }
-                    if (stop2) T.node = kSentinel;
-                    else if (c2 > 1u) T.node = ~(int)(((f2 + 1u) << 4) | (c2 - 1u));
-                    else if (T.sp == sb) T.node = kSentinel;
-                    else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
                 }
+                if (stop) T.node = kSentinel;
+                else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
+                else if (T.sp == sb) T.node = kSentinel;
+                else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
             }
-        }
-        // ------------------------------------------------------------ this iteration's load: 64 B per lane
-        const bool inner   = has_ray && T.node >= 0;
-        const bool at_leaf = has_ray && T.node < 0 && T.node != kSentinel;
-        const uint32_t ldesc = ~(uint32_t)T.node;
-        const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
-        uint32_t off = 0u;                                             // idle lanes re-read node 0 (a broadcast)
-        if (inner) off = (uint32_t)T.node << 6;
-        if (at_leaf && lcnt != 0u) off = a.bvh.tri_byte_off + lfirst * 48u;
-        const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
-        asm volatile("" ::: "memory");
-        // ------------------------------------------------------------ one inner-node step
-        if (inner) {
-            if (COUNT) ++n_visits;
-            const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
-            const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
-            const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
-            const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
-            const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
-            const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
-            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                              __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
-            const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                              __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
-            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                              __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
-            const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                              __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
-            if (h0 && h1) {
-                const bool swp = tn1 < tn0;
-                stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
-                ++T.sp;
-                T.node = swp ? c1 : c0;
-            } else if (h0 || h1) {
-                T.node = h0 ? c0 : c1;
-            } else if (T.sp == sb) {
-                T.node = kSentinel;
-            } else {
-                --T.sp;
-                T.node = (int)stk[T.sp * 64 + lane];
-            }
-        }
-        // ------------------------------------------------------------ one triangle test (branch free)
-        if (at_leaf) {
-            bool stop = false;
-            if (lcnt != 0u) {
-                if (COUNT) ++n_tests;
-                const float4 ta = n0, tb = n1, tc = n2;
-                const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
-                const f3 p = fcross(T.d, e2);
-                const float det = fdot(e1, p);
-                const float inv = 1.0f / det;
-                const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
-                const float u = fdot(tv, p) * inv;
-                const f3 q = fcross(tv, e1);
-                const float v = fdot(T.d, q) * inv;
-                const float t = fdot(e2, q) * inv;
-                const uint32_t prim = f2u(ta.w);
-                const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax;
-                if (MODE != 0) {
-                    stop = ok;
-                    if (ok) { T.tbest = t; T.prim = prim; }
-                } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
-                    T.tbest = t; T.prim = prim; T.u = u; T.v = v;
-                }
-            }
-            if (stop) T.node = kSentinel;
-            else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
-            else if (T.sp == sb) T.node = kSentinel;
-            else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
         }
         // ------------------------------------------------------------ retire
         const bool done = has_ray && T.node == kSentinel;
@@ -940,7 +878,7 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
     TraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr; a.spill = o.spill;
-    a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.drain_max = o.drain_max;
+    a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
     launch_trace<0>(st, a, o);
 }
 
@@ -951,7 +889,7 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
     TraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.occluded = occluded; a.contrib = contrib; a.result = result; a.cursors = ctr->cursor_shadow; a.ctr = ctr;
-    a.spill = o.spill; a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.drain_max = o.drain_max;
+    a.spill = o.spill; a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
     if (occluded) launch_trace<1>(st, a, o);
     else          launch_trace<2>(st, a, o);
 }

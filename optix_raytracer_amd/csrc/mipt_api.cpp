@@ -77,7 +77,7 @@ struct MiptContext {
     ShadowQueue im_sq{};
     uint32_t*   im_flags = nullptr;
     size_t      im_cap = 0;
-    int      refill_min = 8, steal_min = 32, drain_max = 0;   // drain_max: measured no gain next to stealing
+    int      refill_min = 16, steal_min = 32, burst_bulk = 16, burst_dry = 8;   // tools/tune.py sweep, profiles/r01_tuning.txt
     int      profile = 0;
     int      lds_stack = kLdsStackEntries;
     uint32_t* d_spill = nullptr;
@@ -222,11 +222,11 @@ TraceOpts trace_opts(const MiptContext* c)
     TraceOpts o{};
     o.persistent = c->persistent;
     o.count_visits = c->count_visits;
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (c->persistent == 2 ? 20 : (c->lds_stack >= kStackEntries ? 20 : 32));
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (c->persistent == 2 ? 16 : (c->lds_stack >= kStackEntries ? 20 : 32));
     o.blocks = std::min(c->num_cus * per_cu, kMaxTraceBlocks);
     o.lds_stack = c->lds_stack;
     o.spill = c->d_spill;
-    o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.drain_max = c->drain_max;
+    o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.burst_bulk = c->burst_bulk; o.burst_dry = c->burst_dry;
     return o;
 }
 
@@ -424,9 +424,10 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
         c->refill_min = (int)value; return MIPT_SUCCESS;
-    case MIPT_OPT_DRAIN_MAX:
-        if (value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "drain threshold must be 0..64");
-        c->drain_max = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_BURST:
+        if ((value & 0xffu) < 1 || (value & 0xffu) > 64 || ((value >> 8) & 0xffu) < 1 || ((value >> 8) & 0xffu) > 64)
+            return c->fail(MIPT_ERROR_INVALID_VALUE, "burst lengths must be 1..64 (bulk | dry << 8)");
+        c->burst_bulk = (int)(value & 0xffu); c->burst_dry = (int)((value >> 8) & 0xffu); return MIPT_SUCCESS;
     case MIPT_OPT_STEAL_MIN:
         if (value < 1 || value > 65) return c->fail(MIPT_ERROR_INVALID_VALUE, "steal threshold must be 1..65 (65 = never)");
         c->steal_min = (int)value; return MIPT_SUCCESS;
@@ -453,7 +454,7 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_LDS_STACK: *value = (uint64_t)c->lds_stack; return MIPT_SUCCESS;
     case MIPT_OPT_REFILL_MIN: *value = (uint64_t)c->refill_min; return MIPT_SUCCESS;
     case MIPT_OPT_STEAL_MIN: *value = (uint64_t)c->steal_min; return MIPT_SUCCESS;
-    case MIPT_OPT_DRAIN_MAX: *value = (uint64_t)c->drain_max; return MIPT_SUCCESS;
+    case MIPT_OPT_BURST: *value = (uint64_t)c->burst_bulk | ((uint64_t)c->burst_dry << 8); return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;
     }
 }

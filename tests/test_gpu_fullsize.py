@@ -53,9 +53,10 @@ def test_headline_determinism_and_kernel_variants(big):
         a2, f2, s2 = _render(PT, st, ob)
         assert np.array_equal(a0.view(np.uint32), a2.view(np.uint32)) and np.array_equal(f0, f2), variant
     st.context.set_option(L.OPT_PERSISTENT, 2)
-    opts = (L.OPT_TRACE_GRID, L.OPT_REFILL_MIN, L.OPT_STEAL_MIN)
+    opts = (L.OPT_TRACE_GRID, L.OPT_REFILL_MIN, L.OPT_STEAL_MIN, L.OPT_BURST)
     defaults = [st.context.get_option(o) for o in opts]
-    for vals in ((4, 1, 1), (20, 32, 65), (32, 64, 16), (8, 8, 40)):     # incl. stealing on every idle lane / never
+    # incl. stealing on every idle lane / never, single-step and long bursts
+    for vals in ((4, 1, 1, 0x0101), (20, 32, 65, 0x4040), (32, 64, 16, 0x0120), (8, 8, 40, 0x1002)):
         for o, v in zip(opts, vals):
             st.context.set_option(o, v)
         a3, f3, _ = _render(PT, st, ob)

@@ -15,7 +15,7 @@ steals = [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['32
 drains = [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['0'])]
 for steal, drain, world in [(s_, d_, w_) for s_ in steals for d_ in drains for w_ in (1, 8)]:
     st.context.set_option(L.OPT_STEAL_MIN, steal)
-    st.context.set_option(L.OPT_DRAIN_MAX, drain)
+    st.context.set_option(L.OPT_BURST, (drain & 0xff) | ((drain >> 8) << 8))
     ns = api.shard_num_samples(W, H, world)
     compact = torch.zeros((ns, 4), dtype=torch.float32, device=st.device)
     gathered = torch.zeros((world * ns, 4), dtype=torch.float32, device=st.device)
@@ -34,5 +34,5 @@ for steal, drain, world in [(s_, d_, w_) for s_ in steals for d_ in drains for w
     dt = (time.perf_counter() - t0) / K * 1e3
     tm = st.context.launch_timings()
     st.context.set_option(L.OPT_PROFILE, 0)
-    print("steal %2d drain %2d world %d: rank-0 step %.3f ms (no all-gather) | closest %.3f any %.3f shade %.3f other %.3f" % (
+    print("steal %2d burst 0x%04x world %d: rank-0 step %.3f ms (no all-gather) | closest %.3f any %.3f shade %.3f other %.3f" % (
         steal, drain, world, dt, tm["ms_trace_closest"] / K, tm["ms_trace_any"] / K, tm["ms_shade"] / K, (tm["ms_raygen"] + tm["ms_resolve"]) / K), flush=True)

@@ -27,7 +27,8 @@ def main():
     ap.add_argument("--variants", type=str, default="2,1,0")
     ap.add_argument("--grids", type=str, default="24")
     ap.add_argument("--refill", type=str, default="8")
-    ap.add_argument("--steal", type=str, default="8")
+    ap.add_argument("--steal", type=str, default="32")
+    ap.add_argument("--burst", type=str, default="0x0808")
     a = ap.parse_args()
     ints = lambda s: [int(x) for x in s.split(",")]
     scene = scenes.random_soup(a.tris) if a.tris > 0 else scenes.cornell_box()
@@ -41,8 +42,10 @@ def main():
     print("counts:", st.context.launch_stats())
     st.context.set_option(L.OPT_COUNT_VISITS, 0)
     for variant in ints(a.variants):
-        combos = itertools.product(ints(a.grids), ints(a.refill), ints(a.steal)) if variant == 2 else [(ints(a.grids)[0], 8, 8)]
-        for grid, refill, steal in combos:
+        bursts = [int(x, 0) for x in a.burst.split(",")]
+        combos = itertools.product(ints(a.grids), ints(a.refill), ints(a.steal), bursts) if variant == 2 else [(ints(a.grids)[0], 8, 32, 0x0101)]
+        for grid, refill, steal, burst in combos:
+            st.context.set_option(L.OPT_BURST, burst)
             st.context.set_option(L.OPT_PERSISTENT, variant)
             st.context.set_option(L.OPT_TRACE_GRID, grid if variant else 0)
             st.context.set_option(L.OPT_REFILL_MIN, refill)
@@ -58,8 +61,8 @@ def main():
             dt = (time.perf_counter() - t0) / a.steps * 1e3
             tm = st.context.launch_timings()
             st.context.set_option(L.OPT_PROFILE, 0)
-            print("variant=%d grid/CU=%2d refill=%2d steal=%2d : frame %.3f ms | closest %.3f any %.3f shade %.3f other %.3f" % (
-                variant, grid, refill, steal, dt, tm["ms_trace_closest"] / a.steps, tm["ms_trace_any"] / a.steps,
+            print("variant=%d grid/CU=%2d refill=%2d steal=%2d burst=0x%04x : frame %.3f ms | closest %.3f any %.3f shade %.3f other %.3f" % (
+                variant, grid, refill, steal, burst, dt, tm["ms_trace_closest"] / a.steps, tm["ms_trace_any"] / a.steps,
                 tm["ms_shade"] / a.steps, (tm["ms_raygen"] + tm["ms_resolve"]) / a.steps), flush=True)
     PT.cleanupState(st)
 
