@@ -155,6 +155,9 @@ typedef enum MiptOption {
     MIPT_OPT_REFILL_MIN   = 7, /* streaming waves: idle lanes that trigger a swap-in/prefetch round (default 8) */
     MIPT_OPT_STEAL_MIN    = 8, /* streaming waves: once the ray range is exhausted, this many idle lanes trigger a
                                   round in which they take stack entries (subtrees) of busy rays (default 32, 65 = never) */
+    MIPT_OPT_BATCH_SAMPLES = 10, /* 0 (default): one wavefront pass per sample, contributions added in the reference's
+                                  order (bit-identical to the oracle); 1: all samples_per_launch samples of a launch are
+                                  paths of ONE pass with per-sample accumulators (same values to rounding, far fewer passes) */
     MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
                                   (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;

@@ -583,37 +583,49 @@ __global__ void k_advance(DeviceCounters* c)
 // frames, or by the StaticWorkDistribution map for a rank's shard.  The raygen-local seed advances
 // by the two jitter draws only (the path's own stream is discarded, :260-278), so it is kept per slot.
 // ------------------------------------------------------------------------------------------------
+// With fc.batch_spp != 0 every sample of the launch is a path of its own (path i -> sample i / paths_per_sample)
+// with its own accumulator slot `sample * n_slots + slot`; the raygen seed of sample s is reached by 2*s LCG
+// steps from the pixel's tea<4> seed, exactly the state the sequential loop would have.
 __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= fc.n_paths) return;
+    uint32_t i0 = i;
+    if (fc.batch_spp != 0u) { sample = i / fc.paths_per_sample; i0 = i - sample * fc.paths_per_sample; }
     int px, py; uint32_t slot; bool valid;
     if (fc.world == 0u) {
         const uint32_t tiles_x = (fc.width + 7u) >> 3;
-        const uint32_t tile = i >> 6, in = i & 63u;
+        const uint32_t tile = i0 >> 6, in = i0 & 63u;
         const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
         px = (int)(tx * 8u + (in & 7u));
         py = (int)(ty * 8u + (in >> 3));
         valid = (uint32_t)px < fc.width && (uint32_t)py < fc.height;
         slot = (uint32_t)py * fc.width + (uint32_t)px;
     } else {
-        shard_pixel(fc.width, fc.world, fc.rank, i, px, py);
+        shard_pixel(fc.width, fc.world, fc.rank, i0, px, py);
         valid = (uint32_t)px < fc.width && (uint32_t)py < fc.height;
-        slot = i;
+        slot = i0;
     }
+    if (fc.batch_spp != 0u) slot += sample * fc.n_slots;
     if (!valid) {
         // padding lane: a ray with an empty interval, killed by shade
         q.ray_o[i]   = make_float4(0.f, 0.f, 0.f, 1.0f);
         q.ray_d[i]   = make_float4(0.f, 0.f, 1.f, 0.0f);
         q.state_a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         q.state_b[i] = make_uint2(kInvalidSlot, 0u);
-        if (fc.world != 0u && sample == 0u) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fc.world != 0u && (sample == 0u || fc.batch_spp != 0u)) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    uint32_t seed = sample == 0u ? tea4((uint32_t)py * fc.width + (uint32_t)px, fc.subframe_index) : rg_seed[slot];
+    uint32_t seed;
+    if (fc.batch_spp != 0u) {
+        seed = tea4((uint32_t)py * fc.width + (uint32_t)px, fc.subframe_index);
+        for (uint32_t k = 0; k < 2u * sample; ++k) seed = 1664525u * seed + 1013904223u;
+    } else {
+        seed = sample == 0u ? tea4((uint32_t)py * fc.width + (uint32_t)px, fc.subframe_index) : rg_seed[slot];
+    }
     const float jx = rnd(seed);
     const float jy = rnd(seed);
-    rg_seed[slot] = seed;
+    if (fc.batch_spp == 0u) rg_seed[slot] = seed;
     const float dx = 2.0f * (((float)px + jx) / (float)fc.width) - 1.0f;
     const float dy = 2.0f * (((float)py + jy) / (float)fc.height) - 1.0f;
     const f3 U = mk3(fc.U[0], fc.U[1], fc.U[2]), V = mk3(fc.V[0], fc.V[1], fc.V[2]), W = mk3(fc.W[0], fc.W[1], fc.W[2]);
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample,
     q.ray_d[i]   = make_float4(dir.x, dir.y, dir.z, 1e16f);
     q.state_a[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
     q.state_b[i] = make_uint2(slot, 0u);
-    if (sample == 0u) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sample == 0u || fc.batch_spp != 0u) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -795,7 +807,13 @@ __global__ __launch_bounds__(256) void k_resolve(FrameConsts fc, const float4* r
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    const float4 r = result[i];
+    float4 r = result[i];
+    // batched samples: per-sample sums added in sample order (association differs from the sequential loop,
+    // values agree to rounding: within the 1e-5 tolerance, not bit for bit)
+    for (uint32_t s = 1; s < fc.batch_spp; ++s) {
+        const float4 t = result[(size_t)s * n_slots + i];
+        r.x += t.x; r.y += t.y; r.z += t.z;
+    }
     const float inv_spp = 1.0f / (float)fc.samples_per_launch;
     f3 c = mk3(r.x, r.y, r.z) * inv_spp;
     if (fc.subframe_index > 0u) {

@@ -72,6 +72,7 @@ struct MiptContext {
     uint32_t max_depth = 0;
     int      count_visits = 0;
     int      blocks_per_cu = 0;
+    int      batch_samples = 0;
     int      persistent = 2;
     // SDK/imgui_test launches: K = nlights + 1 occlusion rays per primary hit
     ShadowQueue im_sq{};
@@ -292,21 +293,31 @@ uint32_t shard_valid_pixels(uint32_t w, uint32_t h, uint32_t world, uint32_t ran
     return valid;
 }
 
-int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc, const Accel* acc, size_t n_slots,
+int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, const Accel* acc, size_t n_slots,
                   float4* accum_out, uint32_t* frame_out)
 {
+    FrameConsts fc = fc_in;
     const uint32_t n_valid = fc.world == 0u ? fc.width * fc.height : shard_valid_pixels(fc.width, fc.height, fc.world, fc.rank);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // batched samples: every sample is its own path with its own accumulator, one wavefront pass in all
+    const bool batch = ctx->batch_samples && fc.samples_per_launch > 1u &&
+                       (uint64_t)fc.n_paths * fc.samples_per_launch < (1ull << 31);
+    fc.paths_per_sample = fc.n_paths;
+    fc.n_slots = (uint32_t)n_slots;
+    fc.batch_spp = batch ? fc.samples_per_launch : 0u;
+    const uint32_t passes = batch ? 1u : fc.samples_per_launch;
+    const uint32_t pass_valid = batch ? n_valid * fc.samples_per_launch : n_valid;
+    if (batch) fc.n_paths *= fc.samples_per_launch;
     const uint32_t n_paths = fc.n_paths;
-    int rc = ensure_capacity(ctx, n_paths, n_slots);
+    int rc = ensure_capacity(ctx, n_paths, batch ? n_slots * fc.samples_per_launch : n_slots);
     if (rc) return rc;
     ctx->last_stream = st;
     const DeviceBvh bvh = device_bvh(acc);
     const TraceOpts opts = trace_opts(ctx);
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     uint32_t bounces_total = 0;
-    for (uint32_t s = 0; s < fc.samples_per_launch; ++s) {
-        launch_begin_sample(st, ctx->d_ctr, n_paths, n_valid);
+    for (uint32_t s = 0; s < passes; ++s) {
+        launch_begin_sample(st, ctx->d_ctr, n_paths, pass_valid);
         { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result); }
         int cur = 0;
         for (uint32_t bounce = 0;; ++bounce) {
@@ -424,6 +435,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
         c->refill_min = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_BATCH_SAMPLES: c->batch_samples = value ? 1 : 0; return MIPT_SUCCESS;
     case MIPT_OPT_BURST:
         if ((value & 0xffu) < 1 || (value & 0xffu) > 64 || ((value >> 8) & 0xffu) < 1 || ((value >> 8) & 0xffu) > 64)
             return c->fail(MIPT_ERROR_INVALID_VALUE, "burst lengths must be 1..64 (bulk | dry << 8)");
@@ -454,6 +466,7 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_LDS_STACK: *value = (uint64_t)c->lds_stack; return MIPT_SUCCESS;
     case MIPT_OPT_REFILL_MIN: *value = (uint64_t)c->refill_min; return MIPT_SUCCESS;
     case MIPT_OPT_STEAL_MIN: *value = (uint64_t)c->steal_min; return MIPT_SUCCESS;
+    case MIPT_OPT_BATCH_SAMPLES: *value = (uint64_t)c->batch_samples; return MIPT_SUCCESS;
     case MIPT_OPT_BURST: *value = (uint64_t)c->burst_bulk | ((uint64_t)c->burst_dry << 8); return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;
     }

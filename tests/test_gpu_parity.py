@@ -280,3 +280,33 @@ def test_indexed_strided_and_transformed_inputs():
         assert np.array_equal(hits[:, 1].view(np.uint32), prim) and np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
         assert (prim != 0xffffffff).sum() > 100
     ctx.destroy()
+
+
+def test_batched_samples_agree_within_tolerance():
+    """MIPT_OPT_BATCH_SAMPLES: all samples of a launch in one wavefront pass; per-sample sums are added in sample
+    order, so values agree with the sequential order to rounding (north_star tolerance 1e-5), ray counts exactly."""
+    _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import scenes
+    scene = scenes.cornell_box()
+    w, h, spp = 160, 96, 16
+    PT, st = _state(scene, w, h, spp, 0)
+    seq_acc, seq_frame, seq_stats = _render_gpu(PT, st)
+    st.context.set_option(L.OPT_BATCH_SAMPLES, 1)
+    acc, frame, stats = _render_gpu(PT, st)
+    st.context.set_option(L.OPT_BATCH_SAMPLES, 0)
+    osc = _oracle_scene(scene, st)
+    a, f, ost = osc.render(scenes.launch_desc(scene, w, h, spp), threads=4)
+    assert np.array_equal(seq_acc.view(np.uint32), a.view(np.uint32))                 # sequential order: bit exact
+    denom = np.maximum(np.abs(a), 1e-6)
+    assert (np.abs(acc - a) / denom).max() <= REL_TOL
+    assert np.abs(frame.astype(np.int32) - f.astype(np.int32)).max() <= 1
+    assert (frame != f).mean() < 1e-3
+    assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"]
+    assert stats["bounces"] < seq_stats["bounces"] / 4                                # far fewer wavefront iterations
+    # a second subframe in batch mode (progressive lerp on top of the batched result)
+    st.context.set_option(L.OPT_BATCH_SAMPLES, 1)
+    acc2, _, _ = _render_gpu(PT, st, 1)
+    a2, _, _ = osc.render(scenes.launch_desc(scene, w, h, spp, subframe=1), accum=a.copy(), threads=4)
+    assert (np.abs(acc2 - a2) / np.maximum(np.abs(a2), 1e-6)).max() <= REL_TOL
+    PT.cleanupState(st)

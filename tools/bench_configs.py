@@ -7,8 +7,9 @@ sys.path.insert(0, ROOT)
 import torch
 from optix_raytracer_amd import _lib as L, pathtracer as PT, scenes
 
-def run(name, scene, w, h, spp, max_depth, reps):
+def run(name, scene, w, h, spp, max_depth, reps, batch=0):
     st = PT.make_state(scene, w, h, spp, 0, max_depth=max_depth)
+    st.context.set_option(L.OPT_BATCH_SAMPLES, batch)
     ob = PT.OutputBuffer(w, h, st.device)
     PT.launchSubframe(ob, st)
     stats = st.context.launch_stats()
@@ -25,5 +26,6 @@ def run(name, scene, w, h, spp, max_depth, reps):
 
 run("C1 Cornell 512x512 spp1 (RR depth)", scenes.cornell_box(), 512, 512, 1, 0, 5)
 run("C2 Cornell 1920x1080 spp16 (RR depth)", scenes.cornell_box(), 1920, 1080, 16, 0, 2)
+run("C2 Cornell 1920x1080 spp16 (RR), batched samples", scenes.cornell_box(), 1920, 1080, 16, 0, 3, batch=1)
 run("C4 soup 1M 1920x1080 spp1 depth 1", scenes.random_soup(1_000_000), 1920, 1080, 1, 1, 10)
 run("C4 soup 1M 1920x1080 spp1 depth 8", scenes.random_soup(1_000_000), 1920, 1080, 1, 8, 5)
