@@ -250,6 +250,31 @@ int mipt_unpermute(MiptContext* ctx, void* stream, const void* gathered, unsigne
                    unsigned int width, unsigned int height, void* accum_buffer, void* frame_buffer);
 
 /* ---------------------------------------------------------------------------
+ * Layouts of the glTF launch path kept for its drop-in: whitted::LaunchParams
+ * (SDK/cuda/whitted.h:59-77, 128 bytes) and BufferView<T> (SDK/cuda/BufferView.h:33-49, 16 bytes).
+ * The Whitted/PBR programs that consume them (cuda/whitted.cu) are a later row;
+ * until then glTF scenes render through MiptParams with build-defined Lambert shading.
+ * ------------------------------------------------------------------------- */
+typedef struct MiptBufferView {
+    unsigned long long data;            /* CUdeviceptr */
+    unsigned int       count;
+    unsigned short     byte_stride;
+    unsigned short     elmt_byte_size;
+} MiptBufferView;
+
+typedef struct MiptWhittedLaunchParams {
+    unsigned int       width, height, subframe_index;
+    void*              accum_buffer;    /* float4* */
+    void*              frame_buffer;    /* uchar4* */
+    int                max_depth;
+    float              scene_epsilon;
+    float              eye[3], U[3], V[3], W[3];
+    MiptBufferView     lights;          /* BufferView<Light> */
+    float              miss_color[3];
+    unsigned long long handle;
+} MiptWhittedLaunchParams;
+
+/* ---------------------------------------------------------------------------
  * SDK/imgui_test (the fork author's interactive tracer): the same traversal kernels under its own
  * raygen / closest-hit / miss programs (imgui_test/optixTriangle.cu:103-268).  The structs keep the
  * layouts of the sample's device objects, so its host code can upload them unchanged.

@@ -34,6 +34,11 @@ static_assert(offsetof(MiptParams, light) == 84 && offsetof(MiptParams, handle) 
 static_assert(sizeof(MiptParallelogramLight) == 60, "ParallelogramLight layout");
 static_assert(sizeof(MiptHitGroupData) == 32, "HitGroupData layout");
 static_assert(sizeof(MiptBvhNode) == 64 && sizeof(MiptBvhTri) == 48, "BVH layout");
+// whitted::LaunchParams offsets probed from the reference build
+static_assert(sizeof(MiptWhittedLaunchParams) == 128 && sizeof(MiptBufferView) == 16, "whitted::LaunchParams layout");
+static_assert(offsetof(MiptWhittedLaunchParams, accum_buffer) == 16 && offsetof(MiptWhittedLaunchParams, max_depth) == 32, "whitted::LaunchParams layout");
+static_assert(offsetof(MiptWhittedLaunchParams, eye) == 40 && offsetof(MiptWhittedLaunchParams, lights) == 88, "whitted::LaunchParams layout");
+static_assert(offsetof(MiptWhittedLaunchParams, miss_color) == 104 && offsetof(MiptWhittedLaunchParams, handle) == 120, "whitted::LaunchParams layout");
 
 namespace {
 
