@@ -40,7 +40,6 @@ def parse():
     ap.add_argument("--grid", type=int, default=0, help="tuning: persistent workgroups per CU")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--steal-min", type=int, default=0)
-    ap.add_argument("--lds-stack", type=int, default=0, help="tuning: 16 or 32 LDS stack entries")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -161,8 +160,6 @@ def main():
         st.context.set_option(L.OPT_PERSISTENT, args.persistent)
     if args.grid:
         st.context.set_option(L.OPT_TRACE_GRID, args.grid)
-    if args.lds_stack:
-        st.context.set_option(L.OPT_LDS_STACK, args.lds_stack)
     if args.refill_min:
         st.context.set_option(L.OPT_REFILL_MIN, args.refill_min)
     if args.steal_min:
@@ -235,7 +232,7 @@ def main():
         tt_c = counts["tri_tests"] - counts["shadow_tri_tests"]
         bytes_closest = 64 * nv_c + 48 * tt_c + (32 + 16) * counts["closest_rays"]
         bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
-        variant = {2: "k_trace_stream", 1: "k_trace_persistent", 0: "k_trace_simple"}[int(st.context.get_option(L.OPT_PERSISTENT))]
+        variant = {2: "k_trace_stream", 0: "k_trace_simple"}[int(st.context.get_option(L.OPT_PERSISTENT))]
         if k_closest >= k_any:
             kname, kbytes, kms, klaunches = variant + "<0, false>", bytes_closest, k_closest, tm["n_trace_closest"]
         else:
@@ -256,7 +253,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather" % world,
                        "bvh_build_s": round(info["build_seconds"], 3), "setup_s": round(build_s, 3)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname) if world == 1 else None,
                          "algorithmic_bytes_per_launch": int(kbytes_launch),
                          "kernel_ms_avg": round(kms_avg, 4),
                          "per_frame_ms": {"trace_closest": round(k_closest, 4), "trace_any": round(k_any, 4),

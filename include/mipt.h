@@ -148,10 +148,9 @@ typedef enum MiptOption {
                                   k = at most k closest-hit queries per path (build extension) */
     MIPT_OPT_COUNT_VISITS = 2, /* 1 = traversal kernels count node visits / triangle tests */
     MIPT_OPT_TRACE_GRID   = 3, /* persistent-kernel workgroups per CU (0 = default) */
-    MIPT_OPT_PERSISTENT   = 4, /* traversal kernel: 2 (default) streaming waves, 1 persistent while-while waves,
-                                  0 one thread per ray.  All three visit the BVH in the same per-ray order. */
+    MIPT_OPT_PERSISTENT   = 4, /* traversal kernel: 2 (default) streaming persistent waves, 0 one thread per ray
+                                  (tight while-while loop; also the fallback for trees deeper than 24). */
     MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings) */
-    MIPT_OPT_LDS_STACK    = 6, /* traversal-stack entries kept in LDS: 16 (default, rest spills to global) or 32 */
     MIPT_OPT_REFILL_MIN   = 7, /* streaming waves: idle lanes that trigger a swap-in/prefetch round (default 8) */
     MIPT_OPT_STEAL_MIN    = 8, /* streaming waves: once the ray range is exhausted, this many idle lanes trigger a
                                   round in which they take stack entries (subtrees) of busy rays (default 32, 65 = never) */

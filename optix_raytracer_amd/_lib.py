@@ -91,7 +91,7 @@ class MiptLaunchTimings(C.Structure):
 
 LOG_CALLBACK = C.CFUNCTYPE(None, C.c_uint, C.c_char_p, C.c_char_p, C.c_void_p)
 
-OPT_MAX_DEPTH, OPT_COUNT_VISITS, OPT_TRACE_GRID, OPT_PERSISTENT, OPT_PROFILE, OPT_LDS_STACK = 1, 2, 3, 4, 5, 6
+OPT_MAX_DEPTH, OPT_COUNT_VISITS, OPT_TRACE_GRID, OPT_PERSISTENT, OPT_PROFILE = 1, 2, 3, 4, 5
 OPT_REFILL_MIN, OPT_STEAL_MIN, OPT_BURST, OPT_BATCH_SAMPLES = 7, 8, 9, 10
 
 # every symbol include/mipt.h declares: (name, restype, argtypes)

@@ -9,14 +9,11 @@
 namespace mipt {
 
 constexpr int      kStackEntries  = 32;     // traversal stack entries per lane == builder depth cap
-constexpr int      kLdsStackEntries = 16;   // of which in LDS (4 KB per wave -> 8 waves/SIMD); the rest spill to global
 constexpr int      kStreamStack = 24;       // k_trace_stream keeps its whole stack in LDS (6 KB per wave); deeper trees use the other kernels
-constexpr int      kMaxTraceBlocks = 256 * 32 * 2;
 constexpr uint32_t kInvalidSlot   = 0xffffffffu;
 constexpr int      kNumSegments   = 8;      // one ray-range segment per XCD
 constexpr int      kCursorStride  = 32;     // uint32 words between cursors (own 128-B line each)
-constexpr uint32_t kChunk         = 256;    // rays a wave takes from a segment cursor at a time (k_trace_persistent)
-constexpr uint32_t kStreamChunk   = 64;     // same, k_trace_stream
+constexpr uint32_t kStreamChunk   = 64;     // rays a wave takes from a segment cursor at a time (one 8x8 tile)
 constexpr uint32_t kShadeBlock    = 512;    // threads per shade workgroup == paths per queue-append atomic
 
 // device-resident queue counters + statistics (one per context)
@@ -70,12 +67,10 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
 };
 
 struct TraceOpts {
-    int  persistent;           // 2: streaming waves (default), 1: persistent while-while waves, 0: one thread per ray
+    int  persistent;           // 2: streaming waves (default), 0: one thread per ray
     int  refill_min, steal_min, burst_bulk, burst_dry; // k_trace_stream knobs
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
-    int  lds_stack;            // kLdsStackEntries (default) or kStackEntries (all of the stack in LDS)
-    uint32_t* spill;           // blocks * (kStackEntries - kLdsStackEntries) * 64 words
 };
 
 // ---- launches (all asynchronous on `st`) ----

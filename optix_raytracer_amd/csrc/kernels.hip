@@ -13,7 +13,8 @@
 //
 // Traversal is HBM/cache-latency bound pointer chasing (64-B nodes, 48-B triangles); MFMA is not used.
 // One ray per lane, per-lane traversal stack in LDS ([entry][lane] -> conflict free), persistent waves
-// that refill idle lanes from per-XCD ray-range cursors, wave-ballot compaction of the output queues.
+// that refill idle lanes from per-XCD ray-range cursors and share long rays in the drain phase,
+// wave-ballot compaction of the output queues.
 // Floating point: -ffp-contract=off, explicit fmaf only where the specification says so.
 #include "kernels.h"
 #include "detmath.h"
@@ -59,32 +60,22 @@ __device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd)
     T.sp = 0;
 }
 
-// Per-lane traversal stack: the first LDS_N entries live in LDS ([entry][lane]: bank = lane, conflict
-// free), deeper entries -- rare -- spill to a per-wave slab in global memory.  LDS_N = 16 keeps a wave at
-// 4 KB of LDS so that 8 waves per SIMD fit; the builder caps the tree depth at kStackEntries.
-template <int LDS_N>
+// Per-lane traversal stack in LDS, laid out [entry][lane]: bank = lane, conflict free.  The builder caps the
+// tree depth at kStackEntries, so it cannot overflow.
 struct Stack {
-    uint32_t* lds;       // LDS_N * 64 words
-    uint32_t* spill;     // (kStackEntries - LDS_N) * 64 words of global memory for this wave
+    uint32_t* lds;       // kStackEntries * 64 words
     int       lane;
-    __device__ __forceinline__ void push(int& sp, uint32_t v) const
-    {
-        if (LDS_N >= kStackEntries || sp < LDS_N) lds[sp * 64 + lane] = v;
-        else                                      spill[(sp - LDS_N) * 64 + lane] = v;
-        ++sp;
-    }
+    __device__ __forceinline__ void push(int& sp, uint32_t v) const { lds[sp * 64 + lane] = v; ++sp; }
     __device__ __forceinline__ int pop(int& sp) const
     {
         if (sp == 0) return kSentinel;
         --sp;
-        if (LDS_N >= kStackEntries || sp < LDS_N) return (int)lds[sp * 64 + lane];
-        return (int)spill[(sp - LDS_N) * 64 + lane];
+        return (int)lds[sp * 64 + lane];
     }
 };
 
 // one inner-node step: fetch 64 B, slab-test both children, descend into the nearer, push the other
-template <int LDS_N>
-__device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ nodes, const Stack<LDS_N>& stk)
+__device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ nodes, const Stack& stk)
 {
     const float4* np = nodes + (size_t)(uint32_t)T.node * 4u;
     const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
@@ -160,7 +151,6 @@ struct TraceArgs {
     float4*         result;       // MODE 2
     uint32_t*       cursors;      // kNumSegments cursors, kCursorStride apart
     DeviceCounters* ctr;
-    uint32_t*       spill;        // gridDim.x * (kStackEntries - LDS_N) * 64 words (stack overflow slabs)
     int             refill_min;   // k_trace_stream: idle lanes that trigger a swap-in / prefetch round
     int             steal_min;    // k_trace_stream: idle lanes that trigger a steal round once the ray range is exhausted
     int             burst_bulk;   // k_trace_stream: traversal steps per bookkeeping round while fresh rays remain
@@ -185,83 +175,6 @@ __device__ __forceinline__ void finish_ray(const TraceArgs& a, const Trav& T, ui
         }
     }
 }
-
-// ---- persistent waves: 64 lanes, each lane owns one ray; idle lanes are refilled from the ray range ----
-template <int MODE, bool COUNT, int LDS_N>
-__global__ __launch_bounds__(64) void k_trace_persistent(TraceArgs a)
-{
-    __shared__ uint32_t stk_lds[LDS_N * 64];
-    const int lane = (int)threadIdx.x;
-    const Stack<LDS_N> stk{ stk_lds, a.spill + (size_t)blockIdx.x * (size_t)((kStackEntries - LDS_N) * 64), lane };
-    uint32_t n = a.n_max;
-    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
-    // segment s covers [s*seg_len, min((s+1)*seg_len, n)); blocks with equal blockIdx%8 share an XCD (speed only)
-    const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
-    uint32_t seg = blockIdx.x & (kNumSegments - 1);
-    uint32_t tried = 0;
-    uint32_t pool_next = 0, pool_end = 0;
-    bool     active = false;
-    uint32_t ray = 0;
-    uint32_t n_visits = 0, n_tests = 0;
-    Trav T;
-    T.node = kSentinel; T.sp = 0;
-
-    for (;;) {
-        // ------------------------------------------------------------------ refill
-        const unsigned long long idle = __ballot(!active);
-        const int n_idle = __popcll(idle);
-        const bool exhausted = tried >= (uint32_t)kNumSegments && pool_next == pool_end;
-        if (n_idle == 64 || (n_idle >= 24 && !exhausted)) {
-            const uint32_t rank = lane_rank(idle);
-            uint32_t given = 0;
-            while (given < (uint32_t)n_idle) {
-                if (pool_next == pool_end) {
-                    if (tried >= (uint32_t)kNumSegments) break;
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(&a.cursors[seg * kCursorStride], kChunk);
-                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                    const uint32_t lo = seg * seg_len;
-                    uint32_t hi = lo + seg_len; hi = hi < n ? hi : n;
-                    if (lo >= hi || c >= hi - lo) { seg = (seg + 1u) & (kNumSegments - 1); ++tried; continue; }
-                    pool_next = lo + c;
-                    pool_end  = pool_next + kChunk < hi ? pool_next + kChunk : hi;
-                }
-                const uint32_t avail = pool_end - pool_next;
-                const uint32_t want  = (uint32_t)n_idle - given;
-                const uint32_t take  = avail < want ? avail : want;
-                if (!active && rank >= given && rank < given + take) {
-                    ray = pool_next + (rank - given);
-                    const float4 ro = a.ray_o[(size_t)ray * a.stride];
-                    const float4 rd = a.ray_d[(size_t)ray * a.stride];
-                    trav_init(T, ro, rd);
-                    active = true;
-                }
-                pool_next += take;
-                given += take;
-            }
-            if (__ballot(active) == 0ull) break;
-        }
-        // ------------------------------------------------------------------ traverse (while-while)
-        while (active && T.node >= 0) {
-            if (COUNT) ++n_visits;
-            visit_inner(T, a.bvh.nodes, stk);
-        }
-        if (active && T.node != kSentinel) {          // a leaf reference
-            const bool stop = visit_leaf<(MODE != 0)>(T, a.bvh.tris, n_tests);
-            if (stop) { finish_ray<MODE>(a, T, ray, true); active = false; T.node = kSentinel; }
-            else T.node = stk.pop(T.sp);
-        }
-        if (active && T.node == kSentinel) {
-            finish_ray<MODE>(a, T, ray, MODE == 0 ? (T.prim != 0xffffffffu) : false);
-            active = false;
-        }
-    }
-    if (COUNT) {
-        wave_add64(&a.ctr->node_visits[MODE != 0], n_visits);
-        wave_add64(&a.ctr->tri_tests[MODE != 0], n_tests);
-    }
-}
-
 
 // ---- streaming waves: the default traversal kernel -------------------------------------------
 // Every lane is a small state machine (at an inner node | at a leaf with k triangles left | idle) and
@@ -533,7 +446,7 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
 {
     __shared__ uint32_t stk_lds[kStackEntries * 64];
     const int lane = (int)threadIdx.x;
-    const Stack<kStackEntries> stk{ stk_lds, nullptr, lane };
+    const Stack stk{ stk_lds, lane };
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     uint32_t n_visits = 0, n_tests = 0;
@@ -876,15 +789,6 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
         const int blocks = o.blocks > 0 ? o.blocks : 4096;
         if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
         else                hipLaunchKernelGGL((k_trace_stream<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
-    } else if (o.persistent == 1) {
-        const int blocks = o.blocks > 0 ? o.blocks : 4096;
-        if (o.lds_stack >= kStackEntries) {
-            if (o.count_visits) hipLaunchKernelGGL((k_trace_persistent<MODE, true, kStackEntries>), dim3(blocks), dim3(64), 0, st, a);
-            else                hipLaunchKernelGGL((k_trace_persistent<MODE, false, kStackEntries>), dim3(blocks), dim3(64), 0, st, a);
-        } else {
-            if (o.count_visits) hipLaunchKernelGGL((k_trace_persistent<MODE, true, kLdsStackEntries>), dim3(blocks), dim3(64), 0, st, a);
-            else                hipLaunchKernelGGL((k_trace_persistent<MODE, false, kLdsStackEntries>), dim3(blocks), dim3(64), 0, st, a);
-        }
     } else {
         launch_simple<MODE>(st, a, o);
     }
@@ -895,7 +799,7 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
 {
     TraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
-    a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr; a.spill = o.spill;
+    a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr;
     a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
     launch_trace<0>(st, a, o);
 }
@@ -907,7 +811,7 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
     TraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.occluded = occluded; a.contrib = contrib; a.result = result; a.cursors = ctr->cursor_shadow; a.ctr = ctr;
-    a.spill = o.spill; a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
+    a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
     if (occluded) launch_trace<1>(st, a, o);
     else          launch_trace<2>(st, a, o);
 }

@@ -85,8 +85,6 @@ struct MiptContext {
     size_t      im_cap = 0;
     int      refill_min = 16, steal_min = 32, burst_bulk = 16, burst_dry = 8;   // tools/tune.py sweep, profiles/r01_tuning.txt
     int      profile = 0;
-    int      lds_stack = kLdsStackEntries;
-    uint32_t* d_spill = nullptr;
 
     // launch buffers
     size_t          cap_paths = 0, cap_slots = 0;
@@ -228,10 +226,7 @@ TraceOpts trace_opts(const MiptContext* c)
     TraceOpts o{};
     o.persistent = c->persistent;
     o.count_visits = c->count_visits;
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (c->persistent == 2 ? 16 : (c->lds_stack >= kStackEntries ? 20 : 32));
-    o.blocks = std::min(c->num_cus * per_cu, kMaxTraceBlocks);
-    o.lds_stack = c->lds_stack;
-    o.spill = c->d_spill;
+    o.blocks = c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 16);
     o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.burst_bulk = c->burst_bulk; o.burst_dry = c->burst_dry;
     return o;
 }
@@ -395,8 +390,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     }
     if (hipMalloc((void**)&c->d_ctr, sizeof(DeviceCounters)) != hipSuccess ||
         hipMemset(c->d_ctr, 0, sizeof(DeviceCounters)) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_pinned, 64) != hipSuccess ||
-        hipMalloc((void**)&c->d_spill, (size_t)kMaxTraceBlocks * (kStackEntries - kLdsStackEntries) * 64 * sizeof(uint32_t)) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_pinned, 64) != hipSuccess) {
         delete c;
         return MIPT_ERROR_OUT_OF_MEMORY;
     }
@@ -413,7 +407,6 @@ int mipt_context_destroy(MiptContext* c)
     free_launch_buffers(c);
     if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
-    if (c->d_spill) (void)hipFree(c->d_spill);
     if (c->im_sq.ray_o) (void)hipFree(c->im_sq.ray_o);
     if (c->im_sq.contrib) (void)hipFree(c->im_sq.contrib);
     if (c->im_flags) (void)hipFree(c->im_flags);
@@ -435,7 +428,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value > 32) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 32 single-wave workgroups fit a CU");
         c->blocks_per_cu = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PERSISTENT:
-        if (value > 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "traversal kernel variant must be 0, 1 or 2");
+        if (value != 0 && value != 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "traversal kernel variant must be 0 or 2");
         c->persistent = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
@@ -448,10 +441,6 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_STEAL_MIN:
         if (value < 1 || value > 65) return c->fail(MIPT_ERROR_INVALID_VALUE, "steal threshold must be 1..65 (65 = never)");
         c->steal_min = (int)value; return MIPT_SUCCESS;
-    case MIPT_OPT_LDS_STACK:
-        if (value != (uint64_t)kLdsStackEntries && value != (uint64_t)kStackEntries)
-            return c->fail(MIPT_ERROR_INVALID_VALUE, "LDS stack entries must be %d or %d", kLdsStackEntries, kStackEntries);
-        c->lds_stack = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PROFILE:
         if (c->last_stream || c->timed.size()) (void)hipStreamSynchronize(c->last_stream);
         c->profile = value ? 1 : 0; c->timed.clear(); c->events_used = 0; return MIPT_SUCCESS;
@@ -468,7 +457,6 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_TRACE_GRID: *value = (uint64_t)c->blocks_per_cu; return MIPT_SUCCESS;
     case MIPT_OPT_PERSISTENT: *value = (uint64_t)c->persistent; return MIPT_SUCCESS;
     case MIPT_OPT_PROFILE: *value = (uint64_t)c->profile; return MIPT_SUCCESS;
-    case MIPT_OPT_LDS_STACK: *value = (uint64_t)c->lds_stack; return MIPT_SUCCESS;
     case MIPT_OPT_REFILL_MIN: *value = (uint64_t)c->refill_min; return MIPT_SUCCESS;
     case MIPT_OPT_STEAL_MIN: *value = (uint64_t)c->steal_min; return MIPT_SUCCESS;
     case MIPT_OPT_BATCH_SAMPLES: *value = (uint64_t)c->batch_samples; return MIPT_SUCCESS;

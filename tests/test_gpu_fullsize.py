@@ -48,7 +48,7 @@ def test_headline_determinism_and_kernel_variants(big):
     a0, f0, s0 = _render(PT, st, ob)
     a1, f1, s1 = _render(PT, st, ob)
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and s0 == s1          # idempotent relaunch
-    for variant in (0, 1):                      # one-thread-per-ray and while-while kernels
+    for variant in (0,):                        # the one-thread-per-ray kernel
         st.context.set_option(L.OPT_PERSISTENT, variant)
         a2, f2, s2 = _render(PT, st, ob)
         assert np.array_equal(a0.view(np.uint32), a2.view(np.uint32)) and np.array_equal(f0, f2), variant

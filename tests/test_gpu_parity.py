@@ -61,7 +61,7 @@ def test_library_is_native_and_loaded():
     assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
 
 
-@pytest.mark.parametrize("persistent,steal", [(2, 8), (2, 1), (2, 65), (1, 8), (0, 8)])
+@pytest.mark.parametrize("persistent,steal", [(2, 32), (2, 1), (2, 65), (0, 32)])
 def test_traversal_records_bit_exact(persistent, steal):
     torch = _torch()
     from optix_raytracer_amd import _lib as L

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--variants", type=str, default="2,1,0")
+    ap.add_argument("--variants", type=str, default="2,0")
     ap.add_argument("--grids", type=str, default="24")
     ap.add_argument("--refill", type=str, default="8")
     ap.add_argument("--steal", type=str, default="32")
