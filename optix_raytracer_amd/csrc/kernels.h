@@ -9,7 +9,7 @@
 namespace mipt {
 
 constexpr int      kStackEntries  = 32;     // traversal stack entries per lane == builder depth cap
-constexpr int      kStreamStack = 24;       // k_trace_stream keeps its whole stack in LDS (6 KB per wave); deeper trees use the other kernels
+constexpr int      kStreamStack = 32;       // k_trace_stream: whole stack in LDS (8 KB + 2 KB merge slots per wave = 16 waves per CU)
 constexpr uint32_t kInvalidSlot   = 0xffffffffu;
 constexpr int      kNumSegments   = 8;      // one ray-range segment per XCD
 constexpr int      kCursorStride  = 32;     // uint32 words between cursors (own 128-B line each)
