@@ -251,8 +251,7 @@ int mipt_unpermute(MiptContext* ctx, void* stream, const void* gathered, unsigne
 /* ---------------------------------------------------------------------------
  * Layouts of the glTF launch path kept for its drop-in: whitted::LaunchParams
  * (SDK/cuda/whitted.h:59-77, 128 bytes) and BufferView<T> (SDK/cuda/BufferView.h:33-49, 16 bytes).
- * The Whitted/PBR programs that consume them (cuda/whitted.cu) are a later row;
- * until then glTF scenes render through MiptParams with build-defined Lambert shading.
+ * mipt_whitted_launch (below) runs the opaque, untextured subset of cuda/whitted.cu on them.
  * ------------------------------------------------------------------------- */
 typedef struct MiptBufferView {
     unsigned long long data;            /* CUdeviceptr */
@@ -272,6 +271,41 @@ typedef struct MiptWhittedLaunchParams {
     float              miss_color[3];
     unsigned long long handle;
 } MiptWhittedLaunchParams;
+
+/* the factors of MaterialData (SDK/cuda/MaterialData.h:33-130) that do not need texture objects */
+typedef struct MiptMaterialData {
+    float   base_color[4];
+    float   metallic, roughness;
+    float   emissive_factor[3];
+    float   alpha_cutoff;
+    int32_t alpha_mode;           /* 0 OPAQUE, 1 MASK, 2 BLEND */
+    int32_t double_sided;
+    int32_t base_color_texture;   /* glTF texture index or -1 (not decoded yet) */
+} MiptMaterialData;
+
+/* struct Light, SDK/cuda/Light.h:33-71 (36 bytes): type 0 POINT {color, intensity, position, falloff},
+ * type 1 AMBIENT {color} */
+typedef struct MiptLight {
+    int   type;
+    float color[3];
+    float intensity;
+    float position[3];
+    int   falloff;
+} MiptLight;
+
+/* The Whitted / glTF-PBR programs of cuda/whitted.cu (__raygen__pinhole :44-97, __miss__constant_radiance :139-142,
+ * __closesthit__radiance :149-289) as wavefront stages: pinhole raygen (pixel centre at subframe 0), GGX direct
+ * lighting from the point / ambient lights in params->lights with one occlusion ray per point light, progressive
+ * lerp + sRGB8.  Geometry comes as world-space triangles (mipt_scene_flatten / _flatten_normals): the SBT records of
+ * Scene::createSBT (Scene.cpp:1368-1470) become three device arrays and a material table.  Not yet: textures, vertex
+ * colours, alpha MASK / BLEND (cuda/whitted.cu:100-137, 268-286).
+ * d_vertices4 / d_normals4 (nullable): 3 float4 per triangle (device); d_material_index: per triangle (device);
+ * materials: host array. */
+int mipt_whitted_set_geometry(MiptContext* ctx, const void* d_vertices4, const void* d_normals4,
+                              const uint32_t* d_material_index, const MiptMaterialData* materials, uint32_t num_materials);
+/* replaces optixLaunch( scene.pipeline(), ... ) of optixMeshViewer.cpp:283-308; params is a HOST pointer */
+int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchParams* params,
+                        unsigned int width, unsigned int height, unsigned int depth);
 
 /* ---------------------------------------------------------------------------
  * SDK/imgui_test (the fork author's interactive tracer): the same traversal kernels under its own
@@ -338,17 +372,6 @@ typedef struct MiptSceneInfo {
     float    aabb_min[3], aabb_max[3];                                 /* union of the instances' world boxes */
 } MiptSceneInfo;
 
-/* the factors of MaterialData (SDK/cuda/MaterialData.h:33-130) that do not need texture objects */
-typedef struct MiptMaterialData {
-    float   base_color[4];
-    float   metallic, roughness;
-    float   emissive_factor[3];
-    float   alpha_cutoff;
-    int32_t alpha_mode;           /* 0 OPAQUE, 1 MASK, 2 BLEND */
-    int32_t double_sided;
-    int32_t base_color_texture;   /* glTF texture index or -1 (not decoded yet) */
-} MiptMaterialData;
-
 int mipt_scene_load(const char* filename, MiptScene** out, char* errbuf, size_t errlen);   /* .gltf (+ .bin / data: URIs) or .glb */
 int mipt_scene_destroy(MiptScene* scene);
 int mipt_scene_info(const MiptScene* scene, MiptSceneInfo* info);
@@ -357,6 +380,8 @@ int mipt_scene_camera(const MiptScene* scene, float eye[3], float lookat[3], flo
 int mipt_scene_material(const MiptScene* scene, uint32_t index, MiptMaterialData* out);
 /* vertices4_out: num_triangles*3 float4 {x,y,z,0}; material_index_out: num_triangles (0xffffffff = none) */
 int mipt_scene_flatten(const MiptScene* scene, float* vertices4_out, uint32_t* material_index_out);
+/* normals4_out: num_triangles*3 float4 {world-space normal (M^-T n, un-normalised), 1}; all 0 where a primitive has no NORMAL */
+int mipt_scene_flatten_normals(const MiptScene* scene, float* normals4_out);
 
 /* ---------------------------------------------------------------------------
  * Host helpers mirroring sutil (kept API: SDK/sutil/Camera.h:38-76)

@@ -56,6 +56,25 @@ class MiptMaterialData(C.Structure):
                 ("double_sided", C.c_int32), ("base_color_texture", C.c_int32)]
 
 
+class MiptBufferView(C.Structure):
+    """BufferView<T> (SDK/cuda/BufferView.h:33-49), 16 bytes"""
+    _fields_ = [("data", C.c_ulonglong), ("count", C.c_uint), ("byte_stride", C.c_ushort), ("elmt_byte_size", C.c_ushort)]
+
+
+class MiptWhittedLaunchParams(C.Structure):
+    """whitted::LaunchParams (SDK/cuda/whitted.h:59-77), 128 bytes"""
+    _fields_ = [("width", C.c_uint), ("height", C.c_uint), ("subframe_index", C.c_uint), ("accum_buffer", C.c_void_p),
+                ("frame_buffer", C.c_void_p), ("max_depth", C.c_int), ("scene_epsilon", C.c_float),
+                ("eye", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3),
+                ("lights", MiptBufferView), ("miss_color", C.c_float * 3), ("handle", C.c_ulonglong)]
+
+
+class MiptLight(C.Structure):
+    """struct Light (SDK/cuda/Light.h:33-71), 36 bytes: type 0 POINT, 1 AMBIENT"""
+    _fields_ = [("type", C.c_int), ("color", C.c_float * 3), ("intensity", C.c_float), ("position", C.c_float * 3),
+                ("falloff", C.c_int)]
+
+
 class MiptImguiCamera(C.Structure):
     """class Camera of SDK/imgui_test (camera.h:155-173), 92 bytes"""
     _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("ortho", C.c_uint8),
@@ -134,6 +153,9 @@ SYMBOLS = [
     ("mipt_scene_camera", C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp]),
     ("mipt_scene_material", C.c_int, [_vp, _u32, C.POINTER(MiptMaterialData)]),
     ("mipt_scene_flatten", C.c_int, [_vp, _vp, _vp]),
+    ("mipt_scene_flatten_normals", C.c_int, [_vp, _vp]),
+    ("mipt_whitted_set_geometry", C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(MiptMaterialData), _u32]),
+    ("mipt_whitted_launch", C.c_int, [_vp, _vp, C.POINTER(MiptWhittedLaunchParams), C.c_uint, C.c_uint, C.c_uint]),
     ("mipt_camera_uvw", None, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp]),
     ("mipt_scene_random_triangles", C.c_int, [_u32, _u32, C.c_float, _vp]),
 ]

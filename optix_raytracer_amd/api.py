@@ -127,6 +127,24 @@ class Scene:
             raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_flatten")
         return v[:n * 3], m[:n]
 
+    def flatten_normals(self):
+        """(n*3, 4) float32 {world-space normal, 1}; zero rows where a primitive has no NORMAL accessor"""
+        n = self.info()["num_triangles"]
+        v = np.zeros((max(n, 1) * 3, 4), np.float32)
+        rc = self._lib.mipt_scene_flatten_normals(self._h, v.ctypes.data)
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_flatten_normals")
+        return v[:n * 3]
+
+    def material_table(self):
+        """ctypes array of MiptMaterialData: the scene's materials + one all-zero record, which is what
+        Scene::createSBT gives a primitive without a material (`MaterialData()`, Scene.cpp:1423-1428)"""
+        n = self.info()["num_materials"]
+        tab = (L.MiptMaterialData * (n + 1))()
+        for k in range(n):
+            self._lib.mipt_scene_material(self._h, k, C.byref(tab[k]))
+        return tab
+
 
 class Context:
     """A device context (createContext, optixPathTracer.cpp:555-573)."""

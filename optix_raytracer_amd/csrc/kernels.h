@@ -90,6 +90,10 @@ void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result,
 // SDK/imgui_test pipeline (imgui_kernels.hip)
 void imgui_run(hipStream_t st, const MiptImguiParams& p, uint32_t n_paths, const DeviceBvh& bvh, PathQueue q, float4* hits,
                ShadowQueue sh, uint32_t* occluded, float4* result, uint32_t* rg_seed, DeviceCounters* ctr, const TraceOpts& opts);
+// SDK/cuda/whitted.cu pipeline (whitted_kernels.hip)
+void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_paths, const DeviceBvh& bvh, const float4* vertices4,
+                 const float4* normals4, const uint32_t* material_index, const MiptMaterialData* d_materials, uint32_t n_materials,
+                 PathQueue q, float4* hits, ShadowQueue sh, uint32_t* occluded, float4* result, DeviceCounters* ctr, const TraceOpts& opts);
 void launch_unpermute(hipStream_t st, const float4* gathered, uint32_t world, uint32_t width, uint32_t height,
                       float4* accum, uint32_t* frame);
 

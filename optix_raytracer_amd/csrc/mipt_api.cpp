@@ -79,7 +79,13 @@ struct MiptContext {
     int      blocks_per_cu = 0;
     int      batch_samples = 0;
     int      persistent = 2;
-    // SDK/imgui_test launches: K = nlights + 1 occlusion rays per primary hit
+    // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
+    const float4*     wh_vertices = nullptr;
+    const float4*     wh_normals = nullptr;
+    const uint32_t*   wh_material_index = nullptr;
+    MiptMaterialData* d_wh_materials = nullptr;
+    uint32_t          n_wh_materials = 0;
+    // SDK/imgui_test and whitted launches: K occlusion rays per primary hit
     ShadowQueue im_sq{};
     uint32_t*   im_flags = nullptr;
     size_t      im_cap = 0;
@@ -410,6 +416,7 @@ int mipt_context_destroy(MiptContext* c)
     if (c->im_sq.ray_o) (void)hipFree(c->im_sq.ray_o);
     if (c->im_sq.contrib) (void)hipFree(c->im_sq.contrib);
     if (c->im_flags) (void)hipFree(c->im_flags);
+    if (c->d_wh_materials) (void)hipFree(c->d_wh_materials);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     delete c;
@@ -773,6 +780,8 @@ int mipt_get_launch_timings(MiptContext* ctx, MiptLaunchTimings* out)
 static_assert(sizeof(MiptImguiCamera) == 92 && sizeof(MiptImguiLight) == 44 && sizeof(MiptImguiParams) == 128,
               "imgui_test device-object layouts (camera.h:155-173, light.h:10-51, optixTriangle.h:42-108)");
 
+static int ensure_group_capacity(MiptContext* ctx, size_t need);
+
 int mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* p, unsigned int width, unsigned int height, unsigned int depth)
 {
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
@@ -790,25 +799,79 @@ int mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* p, 
     const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
     int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);
     if (rc) return rc;
-    const size_t need = (size_t)n_paths * (size_t)(p->nlights + 1);
-    if (need > ctx->im_cap) {
-        HIPCHK(ctx, hipDeviceSynchronize());
-        if (ctx->im_sq.ray_o) (void)hipFree(ctx->im_sq.ray_o);
-        if (ctx->im_sq.contrib) (void)hipFree(ctx->im_sq.contrib);
-        if (ctx->im_flags) (void)hipFree(ctx->im_flags);
-        ctx->im_sq = ShadowQueue{}; ctx->im_flags = nullptr; ctx->im_cap = 0;
-        HIPCHK(ctx, hipMalloc((void**)&ctx->im_sq.ray_o, need * 2 * sizeof(float4)));
-        ctx->im_sq.ray_d = ctx->im_sq.ray_o + need;
-        HIPCHK(ctx, hipMalloc((void**)&ctx->im_sq.contrib, need * sizeof(float4)));
-        HIPCHK(ctx, hipMalloc((void**)&ctx->im_flags, need * sizeof(uint32_t)));
-        ctx->im_cap = need;
-    }
+    rc = ensure_group_capacity(ctx, (size_t)n_paths * (size_t)(p->nlights + 1));
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     imgui_run(st, *p, n_paths, device_bvh(acc), ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->rg_seed,
               ctx->d_ctr, trace_opts(ctx));
     ctx->last_bounces = p->samples_per_frame;
+    HIPCHK(ctx, hipGetLastError());
+    return MIPT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SDK/cuda/whitted.cu (optixMeshViewer's pipeline)
+// ------------------------------------------------------------------------------------------------
+static_assert(sizeof(MiptLight) == 36, "struct Light layout (cuda/Light.h:33-71)");
+
+static int ensure_group_capacity(MiptContext* ctx, size_t need)
+{
+    if (need <= ctx->im_cap) return MIPT_SUCCESS;
+    HIPCHK(ctx, hipDeviceSynchronize());
+    if (ctx->im_sq.ray_o) (void)hipFree(ctx->im_sq.ray_o);
+    if (ctx->im_sq.contrib) (void)hipFree(ctx->im_sq.contrib);
+    if (ctx->im_flags) (void)hipFree(ctx->im_flags);
+    ctx->im_sq = ShadowQueue{}; ctx->im_flags = nullptr; ctx->im_cap = 0;
+    HIPCHK(ctx, hipMalloc((void**)&ctx->im_sq.ray_o, need * 2 * sizeof(float4)));
+    ctx->im_sq.ray_d = ctx->im_sq.ray_o + need;
+    HIPCHK(ctx, hipMalloc((void**)&ctx->im_sq.contrib, need * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc((void**)&ctx->im_flags, need * sizeof(uint32_t)));
+    ctx->im_cap = need;
+    return MIPT_SUCCESS;
+}
+
+int mipt_whitted_set_geometry(MiptContext* ctx, const void* d_vertices4, const void* d_normals4, const uint32_t* d_material_index,
+                              const MiptMaterialData* materials, uint32_t num_materials)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!d_vertices4 || !materials || num_materials == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry: vertices and >= 1 material required");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    if (ctx->d_wh_materials) { (void)hipFree(ctx->d_wh_materials); ctx->d_wh_materials = nullptr; }
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_materials, (size_t)num_materials * sizeof(MiptMaterialData)));
+    HIPCHK(ctx, hipMemcpy(ctx->d_wh_materials, materials, (size_t)num_materials * sizeof(MiptMaterialData), hipMemcpyHostToDevice));
+    ctx->n_wh_materials = num_materials;
+    ctx->wh_vertices = (const float4*)d_vertices4; ctx->wh_normals = (const float4*)d_normals4; ctx->wh_material_index = d_material_index;
+    return MIPT_SUCCESS;
+}
+
+int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchParams* p, unsigned int width, unsigned int height, unsigned int depth)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!p) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "params is null");
+    if (depth != 1 || width == 0 || height == 0 || width != p->width || height != p->height)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "launch size %ux%ux%u does not match params %ux%u", width, height, depth, p->width, p->height);
+    if (!p->accum_buffer) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "params.accum_buffer is null");
+    if (p->lights.count > 31 || (p->lights.count && !p->lights.data)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0..31 lights supported");
+    if (p->lights.count && p->lights.byte_stride != 0 && p->lights.byte_stride != sizeof(MiptLight))
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "lights must be tightly packed (BufferView stride %u)", (unsigned)p->lights.byte_stride);
+    if (!ctx->wh_vertices || !ctx->d_wh_materials) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "mipt_whitted_set_geometry was not called");
+    Accel* acc = find_accel(ctx, p->handle);
+    if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
+    int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);
+    if (rc) return rc;
+    rc = ensure_group_capacity(ctx, (size_t)n_paths * (size_t)(p->lights.count + 1));
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ctx->last_stream = st;
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    whitted_run(st, *p, n_paths, device_bvh(acc), ctx->wh_vertices, ctx->wh_normals, ctx->wh_material_index, ctx->d_wh_materials,
+                ctx->n_wh_materials, ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->d_ctr, trace_opts(ctx));
+    ctx->last_bounces = 1;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
 }

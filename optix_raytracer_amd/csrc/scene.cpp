@@ -205,7 +205,7 @@ struct View {                     // cuda/BufferView.h:33-49 on host memory
     int buffer = -1; size_t offset = 0; uint32_t count = 0; uint16_t byte_stride = 0, elmt_byte_size = 0;
     bool valid() const { return buffer >= 0; }
 };
-struct Primitive { View indices, positions; int material = -1; };
+struct Primitive { View indices, positions, normals; int material = -1; };
 struct Mesh { std::string name; std::vector<Primitive> prims; Aabb object_aabb; };
 struct Instance { M4 transform; int mesh = -1; Aabb world_aabb; };
 struct Cam { float eye[3], lookat[3], up[3], fovY, aspect; };
@@ -371,6 +371,7 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
                     if (pos_idx < 0) throw std::runtime_error("glTF: primitive without POSITION");
                     p.positions = view_from_accessor(root, sc, pos_idx);
                     if (p.positions.elmt_byte_size != 4) throw std::runtime_error("glTF: POSITION must be float");
+                    p.normals = view_from_accessor(root, sc, attrs.integer("NORMAL", -1));           // Scene.cpp:490-498
                     const Json& pa = root.at("accessors").arr[(size_t)pos_idx];
                     const Json* mn = pa.find("min"); const Json* mx = pa.find("max");
                     if (mn && mx && mn->size() >= 3 && mx->size() >= 3) {
@@ -482,6 +483,48 @@ int mipt_scene_flatten(const MiptScene* sc, float* vertices4_out, uint32_t* mate
                 if (material_index_out) material_index_out[t_out] = p.material < 0 ? 0xffffffffu : (uint32_t)p.material;
             }
         }
+    return MIPT_SUCCESS;
+}
+
+// World-space shading normals for the Whitted programs (cuda/LocalGeometry.h:114-126): per triangle 3 float4
+// {n.xyz, 1} = (M^-T) * object normal, un-normalised; w = 0 and xyz = 0 where the primitive has no NORMAL
+// attribute (then the geometric normal is used).  The reference interpolates in object space and transforms
+// afterwards (optixTransformNormalFromObjectToWorldSpace); transforming the vertices first is linear-equivalent.
+int mipt_scene_flatten_normals(const MiptScene* sc, float* normals4_out)
+{
+    if (!sc || (!normals4_out && sc->num_triangles)) return MIPT_ERROR_INVALID_VALUE;
+    size_t t_out = 0;
+    for (const Instance& in : sc->instances) {
+        const float* m = in.transform.m;
+        // cofactors of the upper 3x3 (= det * inverse transpose), divided by det
+        const float c00 = m[5] * m[10] - m[6] * m[9], c01 = m[6] * m[8] - m[4] * m[10], c02 = m[4] * m[9] - m[5] * m[8];
+        const float c10 = m[2] * m[9] - m[1] * m[10], c11 = m[0] * m[10] - m[2] * m[8], c12 = m[1] * m[8] - m[0] * m[9];
+        const float c20 = m[1] * m[6] - m[2] * m[5], c21 = m[2] * m[4] - m[0] * m[6], c22 = m[0] * m[5] - m[1] * m[4];
+        const float det = (m[0] * c00 + m[1] * c01) + m[2] * c02;
+        const float inv = det != 0.0f ? 1.0f / det : 0.0f;
+        for (const Primitive& p : sc->meshes[(size_t)in.mesh].prims) {
+            const uint32_t n_tris = (p.indices.valid() ? p.indices.count : p.positions.count) / 3u;
+            for (uint32_t t = 0; t < n_tris; ++t, ++t_out) {
+                for (int c = 0; c < 3; ++c) {
+                    float* o = normals4_out + (t_out * 3 + (size_t)c) * 4;
+                    o[0] = o[1] = o[2] = o[3] = 0.0f;
+                    if (!p.normals.valid() || p.normals.elmt_byte_size != 4) continue;
+                    uint32_t vi = 3u * t + (uint32_t)c;
+                    if (p.indices.valid()) {
+                        const uint8_t* ip = sc->buffers[(size_t)p.indices.buffer].data() + p.indices.offset + (size_t)vi * p.indices.byte_stride;
+                        if (p.indices.elmt_byte_size == 2) { uint16_t v; std::memcpy(&v, ip, 2); vi = v; } else std::memcpy(&vi, ip, 4);
+                    }
+                    if (vi >= p.normals.count) return MIPT_ERROR_INVALID_VALUE;
+                    float n[3];
+                    std::memcpy(n, sc->buffers[(size_t)p.normals.buffer].data() + p.normals.offset + (size_t)vi * p.normals.byte_stride, 12);
+                    o[0] = ((c00 * n[0] + c01 * n[1]) + c02 * n[2]) * inv;
+                    o[1] = ((c10 * n[0] + c11 * n[1]) + c12 * n[2]) * inv;
+                    o[2] = ((c20 * n[0] + c21 * n[1]) + c22 * n[2]) * inv;
+                    o[3] = 1.0f;
+                }
+            }
+        }
+    }
     return MIPT_SUCCESS;
 }
 

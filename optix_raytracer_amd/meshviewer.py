@@ -1,0 +1,173 @@
+"""Host side of the glTF viewer above the C ABI, mirroring SDK/optixMeshViewer/optixMeshViewer.cpp
+(same function names and order of calls; failures raise, like OPTIX_CHECK / CUDA_CHECK):
+
+    sutil::loadScene + scene.finalize()  (main :445-447)      -> loadScene
+    initCameraState :326                                       -> initCameraState
+    initLaunchParams :190                                      -> initLaunchParams (two point lights, miss 0.1)
+    handleCameraUpdate :235 / updateState :274                 -> handleCameraUpdate / updateState
+    launchSubframe :284                                        -> launchSubframe
+
+Scene::finalize (Scene.cpp:803-815: createContext, buildMeshAccels, buildInstanceAccel, createPTXModule,
+createProgramGroups, createPipeline, createSBT) collapses to one accel build over the flattened instances plus
+mipt_whitted_set_geometry; the programs are fixed-function HIP kernels inside libmipt.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import api
+from .camera import Camera
+from .pathtracer import OutputBuffer  # noqa: F401  (the viewer uses the same CUDAOutputBuffer<uchar4>)
+
+LIGHT_POINT, LIGHT_AMBIENT = 0, 1          # Light::Type (cuda/Light.h:37-41)
+FALLOFF_NONE, FALLOFF_LINEAR, FALLOFF_QUADRATIC = 0, 1, 2
+
+
+class MeshViewerState:
+    def __init__(self):
+        self.context = None
+        self.scene = None            # api.Scene
+        self.handle = 0
+        self.d_vertices = None       # (n*3, 4) f32 world-space triangle soup
+        self.d_normals = None        # (n*3, 4) f32 or None
+        self.d_material_index = None
+        self.materials = None        # ctypes array, host
+        self.d_lights = None         # uint8 tensor holding MiptLight records
+        self.lights = None           # host copy (ctypes array)
+        self.params = L.MiptWhittedLaunchParams()
+        self.accum = None
+        self.camera = None
+        self.camera_changed = True
+        self.device = None
+        self.stream = None
+        self.width, self.height = 1024, 768       # optixMeshViewer.cpp:84-85
+
+
+def loadScene(state, filename, device_index=0, log=None, log_level=0):
+    """sutil::loadScene( infile, scene ); scene.finalize();"""
+    state.device = torch.device("cuda", device_index)
+    torch.cuda.set_device(state.device)
+    state.scene = api.Scene(filename)
+    state.context = api.Context(device_index, log=log, log_level=log_level)
+    verts, mat = state.scene.flatten()
+    if verts.shape[0] == 0:
+        raise api.MiptError(1, "MIPT_ERROR_INVALID_VALUE", "scene has no triangles")
+    normals = state.scene.flatten_normals()
+    state.d_vertices = torch.from_numpy(np.ascontiguousarray(verts)).to(state.device)
+    state.d_normals = torch.from_numpy(np.ascontiguousarray(normals)).to(state.device) if np.any(normals[:, 3] != 0) else None
+    state.d_material_index = torch.from_numpy(mat.astype(np.int32)).to(state.device)
+    state.handle = state.context.accel_build([{
+        "vertices": state.d_vertices.data_ptr(), "num_vertices": verts.shape[0], "stride": 16,
+    }])
+    state.materials = state.scene.material_table()
+    state.context._check(state.context._lib.mipt_whitted_set_geometry(
+        state.context._h, state.d_vertices.data_ptr(), state.d_normals.data_ptr() if state.d_normals is not None else None,
+        state.d_material_index.data_ptr(), state.materials, len(state.materials)))
+
+
+def initCameraState(state):
+    cam = state.scene.camera()
+    state.camera = Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], cam["aspect"])
+    state.camera_changed = True
+
+
+def make_lights(records):
+    """records: iterable of dicts(type, color, intensity, position, falloff) -> ctypes MiptLight array"""
+    records = list(records)
+    arr = (L.MiptLight * max(len(records), 1))()
+    for k, r in enumerate(records):
+        arr[k].type = int(r.get("type", LIGHT_POINT))
+        arr[k].color = (C.c_float * 3)(*[float(x) for x in r["color"]])
+        arr[k].intensity = float(r.get("intensity", 0.0))
+        arr[k].position = (C.c_float * 3)(*[float(x) for x in r.get("position", (0, 0, 0))])
+        arr[k].falloff = int(r.get("falloff", FALLOFF_QUADRATIC))
+    return arr, len(records)
+
+
+def default_lights(aabb_min, aabb_max):
+    """the two point lights of initLaunchParams (:199-211), fp32 arithmetic as written there"""
+    lo, hi = np.asarray(aabb_min, np.float32), np.asarray(aabb_max, np.float32)
+    ext = hi - lo
+    loffset = np.float32(ext[int(np.argmax(ext))])                    # Aabb::maxExtent
+    center = (lo + hi) * np.float32(0.5)                              # Aabb::center
+    return [
+        {"type": LIGHT_POINT, "color": (1.0, 1.0, 0.8), "intensity": 5.0,
+         "position": center + np.array([loffset] * 3, np.float32), "falloff": FALLOFF_QUADRATIC},
+        {"type": LIGHT_POINT, "color": (0.8, 0.8, 1.0), "intensity": 3.0,
+         "position": center + np.array([-loffset, np.float32(0.5) * loffset, np.float32(-0.5) * loffset], np.float32),
+         "falloff": FALLOFF_QUADRATIC},
+    ]
+
+
+def initLaunchParams(state, width=None, height=None, lights=None):
+    if width:
+        state.width, state.height = int(width), int(height)
+    p = state.params
+    p.width, p.height = state.width, state.height
+    state.accum = torch.zeros((state.height, state.width, 4), dtype=torch.float32, device=state.device)
+    p.accum_buffer = state.accum.data_ptr()
+    p.frame_buffer = None
+    p.subframe_index = 0
+    info = state.scene.info()
+    recs = default_lights(info["aabb_min"], info["aabb_max"]) if lights is None else lights
+    state.lights, n = make_lights(recs)
+    raw = np.frombuffer(bytes(state.lights), np.uint8).copy()
+    state.d_lights = torch.from_numpy(raw).to(state.device)
+    p.lights.data = state.d_lights.data_ptr()
+    p.lights.count = n
+    p.lights.byte_stride = 0
+    p.lights.elmt_byte_size = C.sizeof(L.MiptLight)
+    p.miss_color = (C.c_float * 3)(0.1, 0.1, 0.1)
+    p.handle = state.handle
+    state.stream = torch.cuda.Stream(device=state.device)
+
+
+def handleCameraUpdate(state):
+    if not state.camera_changed:
+        return
+    state.camera_changed = False
+    p = state.params
+    state.camera.setAspectRatio(np.float32(state.width) / np.float32(state.height))
+    p.eye = (C.c_float * 3)(*[float(x) for x in state.camera.eye()])
+    U, V, W = state.camera.UVWFrame()
+    p.U = (C.c_float * 3)(*U.tolist())
+    p.V = (C.c_float * 3)(*V.tolist())
+    p.W = (C.c_float * 3)(*W.tolist())
+
+
+def updateState(state):
+    if state.camera_changed:
+        state.params.subframe_index = 0
+    handleCameraUpdate(state)
+
+
+def launchSubframe(output_buffer, state):
+    state.params.frame_buffer = output_buffer.map()
+    output_buffer.setStream(state.stream)
+    state.context._check(state.context._lib.mipt_whitted_launch(
+        state.context._h, state.stream.cuda_stream, C.byref(state.params), state.width, state.height, 1))
+    output_buffer.unmap()
+    state.context.sync()
+
+
+def cleanup(state):
+    if state.context:
+        state.context.destroy()
+        state.context = None
+    state.d_vertices = state.d_normals = state.d_material_index = state.d_lights = state.accum = None
+
+
+def render(filename, width, height, subframes=1, lights=None, device_index=0):
+    """main() of the sample in file-output mode (:466-485): returns (state, uchar4 image as numpy)"""
+    st = MeshViewerState()
+    loadScene(st, filename, device_index)
+    initCameraState(st)
+    initLaunchParams(st, width, height, lights)
+    out = OutputBuffer(width, height, st.device)
+    for _ in range(subframes):
+        updateState(st)
+        launchSubframe(out, st)
+        st.params.subframe_index += 1
+    return st, out.getHostPointer()

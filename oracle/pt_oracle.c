@@ -1067,3 +1067,120 @@ int orc_imgui_render_rows(const OrcScene* s, int mode, const OrcImguiFrame* f, u
         }
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* SDK/cuda/whitted.cu -- glTF PBR direct lighting (opaque, untextured)       */
+/* ------------------------------------------------------------------------- */
+static inline float pow5(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }   /* powf(x, 5) as products (detmath) */
+
+/* whitted_cuda.h:48-72 */
+static v3 w_schlick(v3 spec, float VdH)
+{
+    float p = pow5(1.0f - VdH);
+    return v3_add(spec, v3_scale(v3_sub(v3_make(1.0f, 1.0f, 1.0f), spec), p));
+}
+static float w_vis(float NdL, float NdV, float alpha)
+{
+    float a2 = alpha * alpha;
+    float g0 = NdL * sqrtf(NdV * NdV * (1.0f - a2) + a2);
+    float g1 = NdV * sqrtf(NdL * NdL * (1.0f - a2) + a2);
+    return 2.0f * NdL * NdV / (g0 + g1);
+}
+static float w_ggx(float NdH, float alpha)
+{
+    float a2 = alpha * alpha;
+    float x = NdH * NdH * (a2 - 1.0f) + 1.0f;
+    return a2 / (3.14159265358979323846f * x * x);
+}
+
+/* __closesthit__radiance, cuda/whitted.cu:149-289, with getLocalGeometry (cuda/LocalGeometry.h:59-127) on
+ * world-space vertices */
+static v3 whitted_closesthit(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 ray_o, v3 ray_d, const HitRec* h, OrcStats* st)
+{
+    (void)ray_o;                                         /* geom.P is interpolated, not origin + t * direction */
+    const float* vb = s->verts + (size_t)h->prim * 12;
+    v3 P0 = v3_ld(vb), P1 = v3_ld(vb + 4), P2 = v3_ld(vb + 8);
+    float b0 = 1.0f - h->u - h->v;
+    v3 P = v3_add(v3_add(v3_scale(P0, b0), v3_scale(P1, h->u)), v3_scale(P2, h->v));
+    v3 Ng = v3_normalize(v3_cross(v3_sub(P1, P0), v3_sub(P2, P0)));
+    v3 N = Ng;
+    if (f->normals4) {
+        const float* nb = f->normals4 + (size_t)h->prim * 12;
+        if (nb[3] != 0.0f) {
+            v3 n = v3_add(v3_add(v3_scale(v3_ld(nb), b0), v3_scale(v3_ld(nb + 4), h->u)), v3_scale(v3_ld(nb + 8), h->v));
+            N = v3_normalize(n);
+        }
+    }
+    uint32_t mi = f->material_index ? f->material_index[h->prim] : 0u;
+    if (mi >= f->nmaterials) mi = f->nmaterials - 1u;
+    const OrcMaterialW* m = &f->materials[mi];
+    v3 base = v3_make(m->base_color[0], m->base_color[1], m->base_color[2]);      /* geom.color = 1: no COLOR_0 yet */
+    float metallic = m->metallic * 1.0f, roughness = m->roughness * 1.0f;       /* mr_tex = 1 */
+    const float F0 = 0.04f;
+    v3 diff_color = v3_scale(v3_scale(base, 1.0f - F0), 1.0f - metallic);
+    v3 f0v = v3_make(F0, F0, F0);
+    v3 spec_color = v3_add(f0v, v3_scale(v3_sub(base, f0v), metallic));           /* lerp, vec_math.h:500 */
+    float alpha = roughness * roughness;
+    v3 result = v3_make(0.0f, 0.0f, 0.0f);
+    result = v3_add(result, v3_mul(v3_ld(m->emissive_factor), v3_make(1.0f, 1.0f, 1.0f)));
+    if (v3_dot(N, ray_d) > 0.0f) N = v3_make(-N.x, -N.y, -N.z);
+    for (uint32_t i = 0; i < f->nlights; ++i) {
+        const OrcLightW* l = &f->lights[i];
+        if (l->type == 0) {
+            v3 toL = v3_sub(v3_ld(l->position), P);
+            float Ld = v3_length(toL);
+            float invd = 1.0f / Ld;
+            v3 L = v3_scale(toL, invd);
+            v3 nd = v3_normalize(ray_d);
+            v3 Vv = v3_make(-nd.x, -nd.y, -nd.z);
+            v3 H = v3_normalize(v3_add(L, Vv));
+            float NdL = v3_dot(N, L), NdV = v3_dot(N, Vv), NdH = v3_dot(N, H), VdH = v3_dot(Vv, H);
+            if (NdL > 0.0f && NdV > 0.0f) {
+                HitRec sh;
+                trace(s, mode, P, L, 0.001f, Ld - 0.001f, 1, &sh, st);
+                if (!sh.hit) {
+                    v3 F = w_schlick(spec_color, VdH);
+                    float G = w_vis(NdL, NdV, alpha);
+                    float D = w_ggx(NdH, alpha);
+                    v3 one = v3_make(1.0f, 1.0f, 1.0f);
+                    v3 diff = v3_scale(v3_mul(v3_sub(one, F), diff_color), 1.0f / 3.14159265358979323846f);
+                    v3 spec = v3_scale(v3_scale(F, G), D);
+                    v3 lc = v3_scale(v3_scale(v3_scale(v3_ld(l->color), 1.0f), l->intensity), NdL);
+                    result = v3_add(result, v3_mul(lc, v3_add(diff, spec)));
+                }
+            }
+        } else if (l->type == 1) {
+            result = v3_add(result, v3_mul(v3_ld(l->color), base));
+        }
+    }
+    return result;
+}
+
+int orc_whitted_render_rows(const OrcScene* s, int mode, const OrcWhittedFrame* f, uint32_t y0, uint32_t y1, OrcStats* st)
+{
+    if (mode == ORC_MODE_BVH && !s->nodes) return -1;
+    v3 eye = v3_ld(f->eye), U = v3_ld(f->U), V = v3_ld(f->V), W = v3_ld(f->W);
+    for (uint32_t y = y0; y < y1 && y < f->height; ++y)
+        for (uint32_t x = 0; x < f->width; ++x) {
+            size_t idx = (size_t)y * f->width + x;
+            uint32_t seed = orc_tea4(y * f->width + x, f->subframe_index);
+            float jx = 0.5f, jy = 0.5f;                                          /* pixel centre at subframe 0 (:60-61) */
+            if (f->subframe_index != 0) { jx = orc_rnd(&seed); jy = orc_rnd(&seed); }
+            float dx = 2.0f * (((float)x + jx) / (float)f->width) - 1.0f;
+            float dy = 2.0f * (((float)y + jy) / (float)f->height) - 1.0f;
+            v3 rd = v3_normalize(v3_add(v3_add(v3_scale(U, dx), v3_scale(V, dy)), W));
+            HitRec h;
+            trace(s, mode, eye, rd, 0.0f, 1e16f, 0, &h, st);
+            v3 c = h.hit ? whitted_closesthit(s, mode, f, eye, rd, &h, st) : v3_ld(f->miss_color);
+            float* acc = f->accum_buffer + idx * 4;
+            if (f->subframe_index > 0) {
+                float a = 1.0f / (float)(f->subframe_index + 1);
+                v3 pr = v3_ld(acc);
+                c = v3_add(pr, v3_scale(v3_sub(c, pr), a));
+            }
+            acc[0] = c.x; acc[1] = c.y; acc[2] = c.z; acc[3] = 1.0f;
+            if (f->frame_buffer) { float cc[3] = { c.x, c.y, c.z }; orc_make_color(cc, f->frame_buffer + idx * 4); }
+        }
+    return 0;
+}

@@ -140,6 +140,32 @@ void orc_imgui_camera_compute_uvw(OrcImguiCamera* cam);                       /*
 void orc_imgui_camera_set_fd(OrcImguiCamera* cam, float new_fd);              /* camera.h:36 */
 int  orc_imgui_render_rows(const OrcScene*, int mode, const OrcImguiFrame* f, uint32_t y0, uint32_t y1, OrcStats* stats);
 
+/* ---- SDK/cuda/whitted.cu programs (__raygen__pinhole :44-97, __miss__constant_radiance :139-142,
+ * __closesthit__radiance :149-289), opaque + untextured subset, on world-space triangles ---- */
+typedef struct OrcLightW {            /* struct Light, cuda/Light.h:33-71 (36 bytes) */
+    int32_t type;                     /* 0 POINT, 1 AMBIENT */
+    float   color[3], intensity, position[3];
+    int32_t falloff;
+} OrcLightW;
+
+typedef struct OrcMaterialW {         /* the MaterialData factors used (cuda/MaterialData.h) */
+    float base_color[4], metallic, roughness, emissive_factor[3];
+} OrcMaterialW;
+
+typedef struct OrcWhittedFrame {      /* whitted::LaunchParams (cuda/whitted.h:59-77) + the scene arrays */
+    uint32_t width, height, subframe_index;
+    float*   accum_buffer;            /* float4 */
+    uint8_t* frame_buffer;            /* uchar4 */
+    float    eye[3], U[3], V[3], W[3];
+    const OrcLightW* lights; uint32_t nlights;
+    float    miss_color[3];
+    const float*        normals4;     /* 3 float4 per triangle {world normal, has_normal} or NULL */
+    const uint32_t*     material_index;
+    const OrcMaterialW* materials; uint32_t nmaterials;
+} OrcWhittedFrame;
+
+int orc_whitted_render_rows(const OrcScene*, int mode, const OrcWhittedFrame* f, uint32_t y0, uint32_t y1, OrcStats* stats);
+
 /* primary rays exactly as raygen emits them for sample 0 (for traversal tests) */
 void orc_primary_rays(const OrcParams* p, uint32_t y0, uint32_t y1, float* rays8);
 

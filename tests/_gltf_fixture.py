@@ -66,7 +66,8 @@ def write(tmpdir, n_grid=6):
     pos0 = np.stack([xs.ravel(), 0.15 * rng.standard_normal(g * g), zs.ravel()], 1).astype(f32)
     inter = np.zeros((g * g, 6), f32)
     inter[:, :3] = pos0
-    inter[:, 3:] = (0, 1, 0)
+    nrm = np.random.default_rng(5).standard_normal((g * g, 3)) * 0.25 + (0, 1, 0)      # smooth-ish, not unit length
+    inter[:, 3:] = nrm.astype(f32)
     idx0 = []
     for j in range(g - 1):
         for i in range(g - 1):
@@ -115,6 +116,7 @@ def write(tmpdir, n_grid=6):
             {"bufferView": 3, "componentType": 5126, "count": 20, "type": "VEC3", "min": mm(pos2)[0], "max": mm(pos2)[1]},
             {"bufferView": 4, "componentType": 5125, "count": int(idx2.size), "type": "SCALAR"},
             {"bufferView": 5, "componentType": 5123, "count": 4, "type": "SCALAR"},
+            {"bufferView": 0, "byteOffset": 12, "componentType": 5126, "count": g * g, "type": "VEC3"},
         ],
         "materials": [
             {"name": "red", "pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.1, 0.1, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.5}},
@@ -122,7 +124,7 @@ def write(tmpdir, n_grid=6):
         ],
         "meshes": [
             {"name": "ground", "primitives": [
-                {"attributes": {"POSITION": 0}, "indices": 1, "material": 0, "mode": 4},
+                {"attributes": {"POSITION": 0, "NORMAL": 6}, "indices": 1, "material": 0, "mode": 4},
                 {"attributes": {"POSITION": 2}, "material": 1},
                 {"attributes": {"POSITION": 0}, "indices": 5, "mode": 1}]},
             {"name": "blob", "primitives": [{"attributes": {"POSITION": 3}, "indices": 4}]},
@@ -170,6 +172,12 @@ def write(tmpdir, n_grid=6):
     emit(x3, pos2, idx2, 0xFFFFFFFF)
     eye = m4_apply(x4, np.array([0, 0, 0, 1], f32))[:3]
     up = m4_apply(x4, np.array([0, 1, 0, 0], f32))[:3]
-    expect = {"vertices": np.asarray(tris, f32), "mat_index": np.asarray(mats, np.uint32), "eye": eye, "up": up,
+    # world-space normals of primitive 0 (the only one with a NORMAL accessor): M^-T n, float64 reference
+    it = np.linalg.inv(x1.astype(np.float64)[:3, :3]).T
+    n_grid_tris = idx0.size // 3
+    normals = np.zeros((len(tris), 4), np.float64)
+    normals[: n_grid_tris * 3, :3] = inter[idx0.reshape(-1), 3:].astype(np.float64) @ it.T
+    normals[: n_grid_tris * 3, 3] = 1.0
+    expect = {"normals": normals, "vertices": np.asarray(tris, f32), "mat_index": np.asarray(mats, np.uint32), "eye": eye, "up": up,
               "fovY": f32(f32(0.7) * f32(180.0) / f32(np.pi)), "aspect": f32(1.25), "n_instances": 3, "n_meshes": 2}
     return gltf, glb, expect

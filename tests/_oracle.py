@@ -37,6 +37,25 @@ class OrcStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class OrcLightW(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("intensity", C.c_float), ("position", C.c_float * 3),
+                ("falloff", C.c_int32)]
+
+
+class OrcMaterialW(C.Structure):
+    _fields_ = [("base_color", C.c_float * 4), ("metallic", C.c_float), ("roughness", C.c_float),
+                ("emissive_factor", C.c_float * 3)]
+
+
+class OrcWhittedFrame(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("subframe_index", C.c_uint32),
+                ("accum_buffer", C.c_void_p), ("frame_buffer", C.c_void_p),
+                ("eye", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3),
+                ("lights", C.POINTER(OrcLightW)), ("nlights", C.c_uint32), ("miss_color", C.c_float * 3),
+                ("normals4", C.c_void_p), ("material_index", C.c_void_p),
+                ("materials", C.POINTER(OrcMaterialW)), ("nmaterials", C.c_uint32)]
+
+
 class OrcImguiCamera(C.Structure):
     _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("ortho", C.c_uint8),
                 ("pad_", C.c_uint8 * 3), ("fov", C.c_float), ("fd", C.c_float), ("aperture", C.c_float),
@@ -129,6 +148,9 @@ def lib():
     L.orc_imgui_render_rows.restype = C.c_int
     L.orc_imgui_render_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcImguiFrame), C.c_uint32, C.c_uint32,
                                         C.POINTER(OrcStats)]
+    L.orc_whitted_render_rows.restype = C.c_int
+    L.orc_whitted_render_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcWhittedFrame), C.c_uint32, C.c_uint32,
+                                          C.POINTER(OrcStats)]
     L.orc_primary_rays.restype = None
     L.orc_primary_rays.argtypes = [C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_void_p]
     _lib = L
@@ -216,6 +238,45 @@ class Scene:
         lib().orc_trace_any(self._h, mode, rays.ctypes.data, n, occ.ctypes.data,
                             C.byref(stats) if stats is not None else None)
         return occ
+
+    def render_whitted(self, launch, lights, materials, material_index, normals4=None, accum=None, mode=MODE_BVH):
+        """SDK/cuda/whitted.cu restatement.  launch: dict(width,height,subframe,eye,U,V,W,miss_color);
+        lights: list of dict(type,color,intensity,position); materials: list of dict(base_color,metallic,roughness,
+        emissive_factor).  Returns (accum HxWx4 f32, frame HxWx4 u8, stats)."""
+        w, h = int(launch["width"]), int(launch["height"])
+        if accum is None:
+            accum = np.zeros((h, w, 4), np.float32)
+        frame = np.zeros((h, w, 4), np.uint8)
+        f = OrcWhittedFrame()
+        f.width, f.height, f.subframe_index = w, h, int(launch.get("subframe", 0))
+        f.accum_buffer, f.frame_buffer = accum.ctypes.data, frame.ctypes.data
+        for k in ("eye", "U", "V", "W"):
+            setattr(f, k, _f3(launch[k]))
+        f.miss_color = _f3(launch.get("miss_color", (0.1, 0.1, 0.1)))
+        la = (OrcLightW * max(len(lights), 1))()
+        for k, r in enumerate(lights):
+            la[k].type = int(r.get("type", 0))
+            la[k].color = _f3(r["color"])
+            la[k].intensity = float(r.get("intensity", 0.0))
+            la[k].position = _f3(r.get("position", (0, 0, 0)))
+            la[k].falloff = int(r.get("falloff", 2))
+        f.lights, f.nlights = la, len(lights)
+        ma = (OrcMaterialW * len(materials))()
+        for k, m in enumerate(materials):
+            ma[k].base_color = (C.c_float * 4)(*[float(x) for x in m["base_color"]])
+            ma[k].metallic, ma[k].roughness = float(m["metallic"]), float(m["roughness"])
+            ma[k].emissive_factor = _f3(m["emissive_factor"])
+        f.materials, f.nmaterials = ma, len(materials)
+        mi = np.ascontiguousarray(material_index, np.uint32)
+        f.material_index = mi.ctypes.data
+        if normals4 is not None:
+            normals4 = np.ascontiguousarray(normals4, np.float32)
+            f.normals4 = normals4.ctypes.data
+        st = OrcStats()
+        rc = lib().orc_whitted_render_rows(self._h, mode, C.byref(f), 0, h, C.byref(st))
+        if rc:
+            raise RuntimeError("orc_whitted_render_rows: %d" % rc)
+        return accum, frame, st.as_dict()
 
     def make_params(self, launch, accum=None, frame=None):
         """launch: dict with width,height,spp,subframe,eye,U,V,W,light{corner,v1,v2,normal,emission}"""

@@ -1,0 +1,214 @@
+"""The glTF / PBR programs of SDK/cuda/whitted.cu (opaque, untextured subset): oracle known answers on CPU,
+HIP kernels against the oracle on the GPU, through the optixMeshViewer host mirror."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _gltf_fixture as FX
+import _oracle as O
+
+f32 = np.float32
+
+
+def _quad(a, b, c, d):
+    return [a, b, c, a, c, d]
+
+
+def _plane_scene():
+    """floor (material 0) at y = 0, a small blocker (material 1) at y = 1 above x,z in [-0.25, 0.25]"""
+    v = _quad((-2, 0, -2), (-2, 0, 2), (2, 0, 2), (2, 0, -2)) + _quad((-.25, 1, -.25), (-.25, 1, .25), (.25, 1, .25), (.25, 1, -.25))
+    verts = np.zeros((12, 4), f32)
+    verts[:, :3] = np.asarray(v, f32)
+    mat = np.asarray([0, 0, 1, 1], np.uint32)
+    sc = O.Scene({"vertices": verts, "mat_index": mat, "emission": np.zeros((2, 3), f32), "diffuse": np.ones((2, 3), f32)})
+    sc.build_bvh()
+    return sc, verts, mat
+
+
+MATS = [{"base_color": (0.8, 0.5, 0.2, 1.0), "metallic": 0.25, "roughness": 0.6, "emissive_factor": (0.01, 0.02, 0.03)},
+        {"base_color": (0.1, 0.9, 0.1, 1.0), "metallic": 0.0, "roughness": 0.9, "emissive_factor": (0.0, 0.0, 0.0)}]
+
+
+def _ggx_reference(P, N, eye, light, m):
+    """double-precision restatement of whitted.cu:185-262 for one point light, unoccluded"""
+    base = np.asarray(m["base_color"][:3], np.float64)
+    F0 = 0.04
+    diff_color = base * (1 - F0) * (1 - m["metallic"])
+    spec_color = F0 + m["metallic"] * (base - F0)
+    alpha = m["roughness"] ** 2
+    L = np.asarray(light["position"], np.float64) - P
+    L /= np.linalg.norm(L)
+    V = eye - P
+    V /= np.linalg.norm(V)
+    H = (L + V) / np.linalg.norm(L + V)
+    NdL, NdV, NdH, VdH = N @ L, N @ V, N @ H, V @ H
+    F = spec_color + (1 - spec_color) * (1 - VdH) ** 5
+    a2 = alpha * alpha
+    G = 2 * NdL * NdV / (NdL * np.sqrt(NdV * NdV * (1 - a2) + a2) + NdV * np.sqrt(NdL * NdL * (1 - a2) + a2))
+    D = a2 / (np.pi * (NdH * NdH * (a2 - 1) + 1) ** 2)
+    return np.asarray(light["color"], np.float64) * light["intensity"] * NdL * ((1 - F) * diff_color / np.pi + F * G * D)
+
+
+def _launch(w, h, eye, lookat, up=(0, 0, -1), fov=60.0, subframe=0):
+    U, V, W = O.camera_uvw(eye, lookat, up, fov, w / h)
+    return {"width": w, "height": h, "subframe": subframe, "eye": np.asarray(eye, f32), "U": U, "V": V, "W": W,
+            "miss_color": (0.1, 0.2, 0.3)}
+
+
+def test_oracle_whitted_known_answers():
+    sc, verts, mat = _plane_scene()
+    w = h = 65
+    eye = np.asarray((0.0, 4.0, 0.0))
+    la = _launch(w, h, eye, (0, 0, 0), fov=90.0)
+    point = {"type": 0, "color": (1.0, 0.9, 0.8), "intensity": 4.0, "position": (0.0, 3.0, 0.0)}
+    ambient = {"type": 1, "color": (0.05, 0.05, 0.1)}
+    accum, frame, st = sc.render_whitted(la, [point, ambient], MATS, mat)
+    assert st["closest_rays"] == w * h
+    # corners leave the 4x4 floor at fov 90 from y = 4: miss colour, alpha 1
+    assert np.allclose(accum[0, 0], (0.1, 0.2, 0.3, 1.0), rtol=0, atol=1e-7)
+    # centre pixel hits the blocker (material 1), lit from straight above
+    c = accum[h // 2, w // 2, :3]
+    ref = _ggx_reference(np.array([0, 1.0, 0]), np.array([0, 1.0, 0]), eye, point, MATS[1]) + np.asarray(ambient["color"]) * MATS[1]["base_color"][:3]
+    assert np.allclose(c, ref, rtol=2e-5)
+    # a floor pixel right under the blocker's rim region is shadowed: emissive + ambient only
+    # (light at y=3 over a blocker of half-width .25 at y=1 shadows |x|,|z| < .375 on the floor; the camera at y=4 sees
+    #  the floor only outside |x| > 1/3 there, so x = 0.35 is visible and in shadow)
+    px = int(round((0.35 / 4.0 + 1) * 0.5 * w - 0.5))
+    shadowed = accum[h // 2, px, :3]
+    amb = np.asarray(ambient["color"]) * MATS[0]["base_color"][:3] + MATS[0]["emissive_factor"]
+    assert np.allclose(shadowed, amb, rtol=1e-6)
+    # a floor pixel well outside the shadow: full formula
+    px2 = int(round((1.5 / 4.0 + 1) * 0.5 * w - 0.5))
+    x_world = ((px2 + 0.5) / w * 2 - 1) * 4.0
+    lit = accum[h // 2, px2, :3]
+    ref2 = _ggx_reference(np.array([x_world, 0, 0]), np.array([0, 1.0, 0]), eye, point, MATS[0]) + amb
+    assert np.allclose(lit, ref2, rtol=5e-5)
+    assert st["shadow_rays"] > 0 and np.isfinite(accum).all()
+    assert frame[0, 0, 3] == 255
+
+
+def test_oracle_whitted_progressive_lerp_and_brute_force():
+    sc, verts, mat = _plane_scene()
+    w, h = 40, 30
+    lights = [{"type": 0, "color": (1, 1, 1), "intensity": 3.0, "position": (1.0, 2.5, 0.5)}]
+    a0, _, _ = sc.render_whitted(_launch(w, h, (0.5, 3, 0.2), (0, 0, 0)), lights, MATS, mat)
+    a0b, _, _ = sc.render_whitted(_launch(w, h, (0.5, 3, 0.2), (0, 0, 0)), lights, MATS, mat, mode=O.MODE_BRUTE)
+    assert np.array_equal(a0.view(np.uint32), a0b.view(np.uint32))
+    acc = a0.copy()
+    a1, _, _ = sc.render_whitted(_launch(w, h, (0.5, 3, 0.2), (0, 0, 0), subframe=1), lights, MATS, mat, accum=acc)
+    single, _, _ = sc.render_whitted(_launch(w, h, (0.5, 3, 0.2), (0, 0, 0), subframe=1), lights, MATS, mat,
+                                     accum=np.zeros_like(a0))
+    # lerp(prev, new, 1/2); `single` started from a zero accumulator so it holds new/2
+    assert np.allclose(a1[..., :3], 0.5 * a0[..., :3] + single[..., :3], rtol=1e-6, atol=1e-7)
+
+
+def test_shading_normals_flip_towards_the_viewer():
+    sc, verts, mat = _plane_scene()
+    w = h = 16
+    lights = [{"type": 0, "color": (1, 1, 1), "intensity": 3.0, "position": (0.5, 2.5, 1.0)}]
+    up_n = np.zeros((12, 4), f32); up_n[:, 1] = 1; up_n[:, 3] = 1
+    dn_n = up_n.copy(); dn_n[:, 1] = -2.5                         # un-normalised and pointing away: must be flipped
+    a, _, _ = sc.render_whitted(_launch(w, h, (0.0, 3, 0.0), (0, 0, 0)), lights, MATS, mat, normals4=up_n)
+    b, _, _ = sc.render_whitted(_launch(w, h, (0.0, 3, 0.0), (0, 0, 0)), lights, MATS, mat, normals4=dn_n)
+    c, _, _ = sc.render_whitted(_launch(w, h, (0.0, 3, 0.0), (0, 0, 0)), lights, MATS, mat, normals4=None)
+    assert np.array_equal(a, b)
+    assert np.allclose(a, c, rtol=1e-5, atol=1e-7)                # geometric normal of the planes is +-y as well
+
+
+def test_scene_flatten_normals(tmp_path):
+    from optix_raytracer_amd import api
+    gltf, glb, expect = FX.write(tmp_path)
+    for path in (gltf, glb):
+        sc = api.Scene(path)
+        n = sc.flatten_normals()
+        assert n.shape == expect["normals"].shape
+        assert np.array_equal(n[:, 3], expect["normals"][:, 3].astype(f32))
+        assert np.allclose(n[:, :3], expect["normals"][:, :3], rtol=2e-5, atol=2e-6)
+        tab = sc.material_table()
+        assert len(tab) == sc.info()["num_materials"] + 1
+        assert list(tab[len(tab) - 1].base_color) == [0.0] * 4 and tab[len(tab) - 1].roughness == 0.0
+
+
+def test_meshviewer_default_lights_follow_the_sample():
+    from optix_raytracer_amd import meshviewer as MV
+    l0, l1 = MV.default_lights((-1.0, 0.0, -2.0), (3.0, 1.0, 2.0))     # extent (4,1,4): longest axis x, maxExtent 4
+    assert np.allclose(l0["position"], (5.0, 4.5, 4.0)) and l0["intensity"] == 5.0 and l0["color"] == (1.0, 1.0, 0.8)
+    assert np.allclose(l1["position"], (-3.0, 2.5, -2.0)) and l1["intensity"] == 3.0
+    arr, n = MV.make_lights([l0, l1])
+    assert n == 2 and C.sizeof(arr) == 72 and arr[1].type == MV.LIGHT_POINT and arr[0].falloff == MV.FALLOFF_QUADRATIC
+
+
+def _oracle_for_state(st, nodes, tris):
+    verts = st.d_vertices.cpu().numpy()
+    mat = st.d_material_index.cpu().numpy().view(np.uint32)
+    sc = O.Scene({"vertices": verts, "mat_index": np.zeros(mat.shape[0], np.uint32), "emission": np.zeros((1, 3), f32),
+                  "diffuse": np.ones((1, 3), f32)})
+    sc.set_bvh(nodes, tris)
+    mats = [{"base_color": list(m.base_color), "metallic": m.metallic, "roughness": m.roughness,
+             "emissive_factor": list(m.emissive_factor)} for m in st.materials]
+    lights = [{"type": l.type, "color": list(l.color), "intensity": l.intensity, "position": list(l.position),
+               "falloff": l.falloff} for l in list(st.lights)[: st.params.lights.count]]
+    normals = st.d_normals.cpu().numpy() if st.d_normals is not None else None
+    return sc, mats, lights, mat, normals
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,subframes,custom", [(160, 120, 1, False), (97, 61, 3, True)])
+def test_whitted_programs_match_the_oracle(tmp_path, w, h, subframes, custom):
+    import torch
+    assert torch.cuda.is_available()
+    from optix_raytracer_amd import meshviewer as MV
+    gltf, _, _ = FX.write(tmp_path)
+    lights = None
+    if custom:
+        lights = [{"type": MV.LIGHT_AMBIENT, "color": (0.02, 0.03, 0.05)},
+                  {"type": MV.LIGHT_POINT, "color": (1.0, 0.7, 0.4), "intensity": 6.0, "position": (1.5, 3.0, 2.0)},
+                  {"type": MV.LIGHT_POINT, "color": (0.3, 0.5, 1.0), "intensity": 4.0, "position": (-2.0, 1.0, -1.0)},
+                  {"type": MV.LIGHT_POINT, "color": (1.0, 1.0, 1.0), "intensity": 2.0, "position": (0.0, -3.0, 0.5)}]
+    st = MV.MeshViewerState()
+    MV.loadScene(st, gltf)
+    MV.initCameraState(st)
+    MV.initLaunchParams(st, w, h, lights)
+    out = MV.OutputBuffer(w, h, st.device)
+    tot_c = tot_s = 0
+    for _ in range(subframes):
+        MV.updateState(st)
+        MV.launchSubframe(out, st)
+        s = st.context.launch_stats()
+        tot_c += s["closest_rays"]; tot_s += s["shadow_rays"]
+        st.params.subframe_index += 1
+    nodes, tris = st.context.accel_export(st.handle)
+    sc, mats, lts, mat, normals = _oracle_for_state(st, nodes, tris)
+    p = st.params
+    acc = np.zeros((h, w, 4), f32)
+    oc = osr = 0
+    for sf in range(subframes):
+        la = {"width": w, "height": h, "subframe": sf, "eye": list(p.eye), "U": list(p.U), "V": list(p.V), "W": list(p.W),
+              "miss_color": list(p.miss_color)}
+        acc, frame, ost = sc.render_whitted(la, lts, mats, mat, normals4=normals, accum=acc)
+        oc += ost["closest_rays"]; osr += ost["shadow_rays"]
+    got = st.accum.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(out.getHostPointer(), frame)
+    assert tot_c == oc == w * h * subframes and tot_s == osr > 0
+    hit = np.abs(acc[..., :3] - np.asarray(list(p.miss_color), f32)).sum(2) > 0
+    assert 0.08 < hit.mean() and np.isfinite(acc).all() and acc[..., :3].max() > 0.05
+    MV.cleanup(st)
+
+
+@pytest.mark.gpu
+def test_whitted_launch_errors():
+    import torch
+    assert torch.cuda.is_available()
+    from optix_raytracer_amd import _lib as L, api
+    ctx = api.Context(0)
+    p = L.MiptWhittedLaunchParams()
+    p.width, p.height = 8, 8
+    rc = ctx._lib.mipt_whitted_launch(ctx._h, None, C.byref(p), 8, 8, 1)
+    assert rc == 1 and b"accum_buffer" in ctx._lib.mipt_last_error_string(ctx._h)
+    acc = torch.zeros((8, 8, 4), device="cuda")
+    p.accum_buffer = acc.data_ptr()
+    assert ctx._lib.mipt_whitted_launch(ctx._h, None, C.byref(p), 8, 4, 1) == 1            # size mismatch
+    assert ctx._lib.mipt_whitted_launch(ctx._h, None, C.byref(p), 8, 8, 1) == 6            # geometry not set
+    ctx.destroy()
