@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--max-depth", type=int, default=MAX_DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", type=str, default="nccl", help="debug: 'gloo' lets several ranks share one GPU (functional check only)")
-    ap.add_argument("--persistent", type=int, default=-1, help="tuning: 1/0 forces the persistent / one-thread-per-ray traversal kernels")
+    ap.add_argument("--persistent", type=int, default=-1, help="tuning: traversal kernel variant (3 entry pool, 2 streaming waves, 0 one thread per ray)")
     ap.add_argument("--grid", type=int, default=0, help="tuning: persistent workgroups per CU")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--steal-min", type=int, default=0)
@@ -232,11 +232,12 @@ def main():
         tt_c = counts["tri_tests"] - counts["shadow_tri_tests"]
         bytes_closest = 64 * nv_c + 48 * tt_c + (32 + 16) * counts["closest_rays"]
         bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
-        variant = {2: "k_trace_stream", 0: "k_trace_simple"}[int(st.context.get_option(L.OPT_PERSISTENT))]
+        variant = {3: "k_trace_pool<%d>", 2: "k_trace_stream<%d, false>", 0: "k_trace_simple<%d, false>"}[
+            int(st.context.get_option(L.OPT_PERSISTENT))]
         if k_closest >= k_any:
-            kname, kbytes, kms, klaunches = variant + "<0, false>", bytes_closest, k_closest, tm["n_trace_closest"]
+            kname, kbytes, kms, klaunches = variant % 0, bytes_closest, k_closest, tm["n_trace_closest"]
         else:
-            kname, kbytes, kms, klaunches = variant + "<2, false>", bytes_any, k_any, tm["n_trace_any"]
+            kname, kbytes, kms, klaunches = variant % 2, bytes_any, k_any, tm["n_trace_any"]
         launches_per_step = max(klaunches // args.steps, 1)
         kms_avg = kms / launches_per_step          # average duration of one launch of that kernel
         kbytes_launch = kbytes / launches_per_step

@@ -36,6 +36,7 @@ struct DeviceBvh {
     uint32_t tri_byte_off;     // tris == (char*)nodes + tri_byte_off (one allocation); 0 if that offset needs > 32 bits
     uint32_t blob_bytes;       // size of that allocation (buffer-descriptor range)
     uint32_t depth;            // deepest leaf (stack entries a ray can need)
+    uint32_t pool_ok;          // fits k_trace_pool's packed entries: < 2^25 nodes, < 2^22 triangles, leaves of <= 7
 };
 
 // SoA path queues, capacity `cap` entries each
@@ -69,6 +70,7 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
 struct TraceOpts {
     int  persistent;           // 2: streaming waves (default), 0: one thread per ray
     int  refill_min, steal_min, burst_bulk, burst_dry; // k_trace_stream knobs
+    int  tail_pct, pool_low, pool_chunk;   // k_trace_pool knobs (0 = default)
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
 };

@@ -155,6 +155,9 @@ struct TraceArgs {
     int             steal_min;    // k_trace_stream: idle lanes that trigger a steal round once the ray range is exhausted
     int             burst_bulk;   // k_trace_stream: traversal steps per bookkeeping round while fresh rays remain
     int             burst_dry;    // ... and once the ray range is exhausted
+    uint32_t        tail_len;     // k_trace_pool: launches of at most this many rays run on the entry pool from the start
+    int             pool_low;     // k_trace_pool: pool size below which the next chunk of rays is prefetched
+    int             pool_chunk;   // k_trace_pool: rays per chunk in the tail phase
 };
 
 template <int MODE>
@@ -438,6 +441,450 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
         wave_add64(&a.ctr->node_visits[MODE != 0], n_visits);
         wave_add64(&a.ctr->tri_tests[MODE != 0], n_tests);
     }
+}
+
+// ---- streaming waves + entry pool: the default traversal kernel -------------------------------
+// Bulk phase: as k_trace_stream (one ray per lane, register-prefetched refill), while plenty of rays remain.
+// Tail phase: once fewer rays remain than `tail_len` (about one per lane of the grid: from then on the launch
+// time is the slowest wave's, not the throughput) and `steal_min` lanes are idle, the wave stops being "one
+// ray per lane".  Every pending traversal-stack entry of every lane is moved, in place, into ONE stack of
+// (entry, ray slot) pairs -- the wave's entry pool -- and each round pops up to 64 entries, whichever rays
+// they belong to; each lane processes one (an inner node: slab-test both children and push the survivors,
+// nearer last; a leaf reference: test its first triangle and push the rest of the leaf).  A ray with many
+// pending subtrees is traversed by many lanes at once instead of being a dependent-load chain of hundreds of
+// steps in one lane, and the wave now fetches new rays in small chunks whenever its pool runs low, so the
+// remaining rays spread over the waves by work, not by count.  A launch with fewer rays than lanes (shadow
+// rays, a shard of a multi-GPU frame) runs in the tail phase from the start.
+// The ray of slot s stays in the registers of lane s (read by the others with ds_bpermute); its running best
+// hit lives in LDS as one 64-bit word (order-preserving t bits << 32 | primitive) merged with ds_min_u64:
+// min t, tie -> lowest primitive, the conventions of the sequential traversal, which visits a subset of what
+// the pool visits -- same result, but visit counters differ, so COUNT launches use k_trace_stream.
+// Packed entry: bit 31 leaf | 25-bit payload | 6-bit slot; inner payload = node index, leaf payload =
+// first << 3 | count.  The launcher only selects this kernel for BVHs that fit (DeviceBvh::pool_ok).
+constexpr int kPoolCap   = kStreamStack * 64;
+constexpr int kPoolChunk = 16;            // rays fetched at a time in the tail phase
+
+__device__ __forceinline__ uint32_t pool_pack(int ref, uint32_t slot)
+{
+    if (ref >= 0) return ((uint32_t)ref << 6) | slot;
+    const uint32_t desc = ~(uint32_t)ref;
+    return 0x80000000u | ((desc >> 4) << 9) | ((desc & 7u) << 6) | slot;
+}
+__device__ __forceinline__ uint32_t ord_bits(float f) { const uint32_t b = f2u(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float    ord_float(uint32_t k) { return u2f(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+
+// The wave's private range of ray indices (all members wave-uniform).  Each per-XCD segment of the ray array is
+// split into a STATIC part -- one first chunk per wave of that XCD, taken without any atomic -- and a dynamic
+// part handed out by the segment's cursor.  Same-address atomics serialise in L2 at tens of ns each, so 4096
+// waves that all start (or all run dry) at the same moment must not queue on 8 cache lines: the first chunk
+// is implicit, and a wave whose segment has run out LOOKS at all 8 cursors with one 8-lane load instead of
+// probing them with 8 consecutive atomics.  (A load in front of EVERY grab, or a shared "exhausted" flag
+// word, were both measured slower: closest-hit kernel 0.63 -> 0.85 ms on the headline frame.)
+struct RayRange {
+    uint32_t seg, next, end, tried;
+    uint32_t stat;            // rays per segment covered by the static first chunks
+    bool     dry;             // every segment is exhausted
+};
+
+__device__ __forceinline__ void range_init(RayRange& r, uint32_t n, uint32_t seg_len, uint32_t first_chunk)
+{
+    r.seg = blockIdx.x & (kNumSegments - 1);
+    r.stat = (gridDim.x / kNumSegments) * first_chunk;            // the launcher makes gridDim.x a multiple of 8
+    const uint32_t lo = r.seg * seg_len;
+    uint32_t hi = lo + seg_len; hi = hi < n ? hi : n;
+    const uint32_t mine = lo + (blockIdx.x / kNumSegments) * first_chunk;
+    r.next = mine < hi ? mine : 0u;
+    r.end  = mine < hi ? (mine + first_chunk < hi ? mine + first_chunk : hi) : 0u;
+    r.dry  = false; r.tried = 0u;
+}
+
+// makes [next, end) non-empty by grabbing up to `chunk` rays; false when every segment is exhausted
+__device__ __forceinline__ bool range_grab(const TraceArgs& a, RayRange& r, uint32_t n, uint32_t seg_len, uint32_t chunk, int lane)
+{
+    while (r.next == r.end) {
+        if (r.dry) return false;
+        const uint32_t lo = r.seg * seg_len;
+        uint32_t hi = lo + seg_len; hi = hi < n ? hi : n;
+        const uint32_t len = hi > lo ? hi - lo : 0u;
+        uint32_t c = len;
+        if (len > r.stat) {
+            if (lane == 0) c = atomicAdd(&a.cursors[r.seg * kCursorStride], chunk);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        }
+        if (len > r.stat && c < len - r.stat) {
+            r.next = lo + r.stat + c;
+            r.end  = r.next + chunk < hi ? r.next + chunk : hi;
+            break;
+        }
+        r.seg = (r.seg + 1u) & (kNumSegments - 1);
+        if (++r.tried >= (uint32_t)kNumSegments) { r.dry = true; return false; }
+    }
+    return true;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_trace_pool(TraceArgs a)
+{
+    __shared__ uint32_t           stk[kPoolCap];         // bulk: [entry][lane] stacks; tail: the entry pool
+    __shared__ unsigned long long sh_best[64];           // per ray slot
+    __shared__ float              sh_u[64], sh_v[64];
+    __shared__ int                sh_pending[64];        // pool entries of the slot's ray
+    __shared__ uint32_t           sh_done[64];           // any-hit: an occluder was found
+    const int lane = (int)threadIdx.x;
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
+    RayRange rr;
+    range_init(rr, n, seg_len, n > a.tail_len ? (uint32_t)kStreamChunk : (uint32_t)a.pool_chunk);
+    const int refill_min = a.refill_min, steal_min = a.steal_min < 64 ? a.steal_min : 64;   // 64: switch when the wave is empty
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+
+    bool     has_ray = false, nxt_valid = false;
+    uint32_t ray = 0, nxt_idx = 0;
+    float4   nxt_o = make_float4(0.f, 0.f, 0.f, 0.f), nxt_d = nxt_o;
+    Trav T;
+    T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
+    bool dry = false;
+#ifdef MIPT_POOL_STATS
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long n_bulk_iter = 0, n_rounds = 0, n_popped = 0, n_live = 0, t_grab = 0, n_grab = 0;
+#endif
+
+    // ================================================================ bulk: one ray per lane
+    if (n > a.tail_len) {
+        for (;;) {
+            const unsigned long long idle = __ballot(!has_ray);
+            const int n_idle = __popcll(idle);
+            if (n_idle == 64 || n_idle >= refill_min) {
+                if (!has_ray && nxt_valid) {
+                    ray = nxt_idx;
+                    trav_init(T, nxt_o, nxt_d);
+                    has_ray = T.node != kSentinel;
+                    if (!has_ray) finish_ray<MODE>(a, T, ray, false);
+                    nxt_valid = false;
+                }
+                if (!dry) {
+                    const unsigned long long want = __ballot(!nxt_valid);
+                    const uint32_t n_want = (uint32_t)__popcll(want);
+                    const uint32_t rank = lane_rank(want);
+                    uint32_t given = 0;
+                    while (given < n_want) {
+#ifdef MIPT_POOL_STATS
+                        const unsigned long long tg0 = wall_clock64();
+                        const bool got_ = range_grab(a, rr, n, seg_len, kStreamChunk, lane);
+                        t_grab += wall_clock64() - tg0; ++n_grab;
+                        if (!got_) { dry = true; break; }
+#else
+                        if (!range_grab(a, rr, n, seg_len, kStreamChunk, lane)) { dry = true; break; }
+#endif
+                        const uint32_t avail = rr.end - rr.next;
+                        const uint32_t need  = n_want - given;
+                        const uint32_t take  = avail < need ? avail : need;
+                        if (!nxt_valid && rank >= given && rank < given + take) {
+                            nxt_idx = rr.next + (rank - given);
+                            nxt_o = a.ray_o[(size_t)nxt_idx * a.stride];      // lands while this lane keeps traversing
+                            nxt_d = a.ray_d[(size_t)nxt_idx * a.stride];
+                            nxt_valid = true;
+                        }
+                        rr.next += take;
+                        given += take;
+                    }
+                }
+            }
+            if (dry && __popcll(__ballot(!has_ray)) >= steal_min && __ballot(nxt_valid && !has_ray) == 0ull) break;
+            // ------------------------------------------------------------ a burst of traversal steps
+            const int burst = dry ? a.burst_dry : a.burst_bulk;
+            for (int bi = 0; bi < burst; ++bi) {
+                if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
+#ifdef MIPT_POOL_STATS
+                ++n_bulk_iter;
+#endif
+                const bool inner   = has_ray && T.node >= 0;
+                const bool at_leaf = has_ray && T.node < 0 && T.node != kSentinel;
+                const uint32_t ldesc = ~(uint32_t)T.node;
+                const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
+                uint32_t off = 0u;
+                if (inner) off = (uint32_t)T.node << 6;
+                if (at_leaf && lcnt != 0u) off = a.bvh.tri_byte_off + lfirst * 48u;
+                const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
+                asm volatile("" ::: "memory");
+                if (inner) {
+                    const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
+                    const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
+                    const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
+                    const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
+                    const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
+                    const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
+                    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                                      __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
+                    const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                                      __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
+                    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                                      __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
+                    const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                                      __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
+                    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+                    const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+                    if (h0 && h1) {
+                        const bool swp = tn1 < tn0;
+                        stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
+                        ++T.sp;
+                        T.node = swp ? c1 : c0;
+                    } else if (h0 || h1) {
+                        T.node = h0 ? c0 : c1;
+                    } else if (T.sp == 0) {
+                        T.node = kSentinel;
+                    } else {
+                        --T.sp;
+                        T.node = (int)stk[T.sp * 64 + lane];
+                    }
+                }
+                if (at_leaf) {
+                    bool stop = false;
+                    if (lcnt != 0u) {
+                        const float4 ta = n0, tb = n1, tc = n2;
+                        const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
+                        const f3 p = fcross(T.d, e2);
+                        const float det = fdot(e1, p);
+                        const float inv = 1.0f / det;
+                        const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
+                        const float u = fdot(tv, p) * inv;
+                        const f3 q = fcross(tv, e1);
+                        const float v = fdot(T.d, q) * inv;
+                        const float t = fdot(e2, q) * inv;
+                        const uint32_t prim = f2u(ta.w);
+                        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax;
+                        if (MODE != 0) {
+                            stop = ok;
+                            if (ok) { T.tbest = t; T.prim = prim; }
+                        } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
+                            T.tbest = t; T.prim = prim; T.u = u; T.v = v;
+                        }
+                    }
+                    if (stop) T.node = kSentinel;
+                    else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
+                    else if (T.sp == 0) T.node = kSentinel;
+                    else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
+                }
+            }
+            const bool done = has_ray && T.node == kSentinel;
+            if (done) { finish_ray<MODE>(a, T, ray, T.prim != 0xffffffffu); has_ray = false; }
+        }
+    }
+#ifdef MIPT_POOL_STATS
+    const unsigned long long t_bulk = wall_clock64();
+    if (MODE == 0 && lane == 0) {
+        atomicAdd(&a.ctr->dbg[0], t_bulk - t_start);
+        atomicAdd(&a.ctr->dbg[7], n_bulk_iter);
+    }
+#endif
+
+    // ================================================================ tail: one entry pool per wave
+    // open the merge slots with what each lane has found so far
+    sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
+    sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
+    // move the per-lane stacks into the pool, row by row and in place: row e is read before at most
+    // (entries so far) + 64 <= (e + 1) * 64 words are written
+    int psize = 0;
+    for (int e = 0; e < kStreamStack; ++e) {
+        const bool in = has_ray && T.sp > e;
+        const unsigned long long m = __ballot(in);
+        if (m == 0ull) break;
+        uint32_t v = 0u;
+        if (in) v = stk[e * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (in) stk[psize + (int)lane_rank(m)] = pool_pack((int)v, (uint32_t)lane);
+        psize += __popcll(m);
+    }
+    {
+        const unsigned long long m = __ballot(has_ray);           // the node each busy lane stands at
+        if (has_ray) stk[psize + (int)lane_rank(m)] = pool_pack(T.node, (uint32_t)lane);
+        psize += __popcll(m);
+    }
+    sh_pending[lane] = has_ray ? T.sp + 1 : 0;
+    bool occ = has_ray;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    for (;;) {
+        // ------------------------------------------------------------ retire finished rays, start prefetched ones
+        if (occ && sh_pending[lane] == 0) {
+            const unsigned long long key = sh_best[lane];
+            Trav R = T;
+            R.tbest = ord_float((uint32_t)(key >> 32)); R.prim = (uint32_t)key; R.u = sh_u[lane]; R.v = sh_v[lane];
+            finish_ray<MODE>(a, R, ray, MODE == 0 ? R.prim != 0xffffffffu : sh_done[lane] != 0u);
+            occ = false;
+        }
+        bool start = !occ && nxt_valid;
+        if (start) {
+            ray = nxt_idx;
+            trav_init(T, nxt_o, nxt_d);
+            nxt_valid = false;
+            if (T.node == kSentinel) { finish_ray<MODE>(a, T, ray, false); start = false; }
+            else {
+                occ = true;
+                sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
+                sh_done[lane] = 0u; sh_pending[lane] = 1;
+            }
+        }
+        {
+            const unsigned long long m = __ballot(start);
+            if (m != 0ull) {
+                if (start) stk[psize + (int)lane_rank(m)] = pool_pack(0, (uint32_t)lane);
+                psize += __popcll(m);
+            }
+        }
+        // ------------------------------------------------------------ pool running low: prefetch a small chunk of rays
+        if (!dry && psize < a.pool_low && __ballot(nxt_valid) == 0ull) {
+            const unsigned long long want = __ballot(!occ);
+            uint32_t n_want = (uint32_t)__popcll(want);
+            n_want = n_want < (uint32_t)a.pool_chunk ? n_want : (uint32_t)a.pool_chunk;
+            const uint32_t rank = lane_rank(want);
+            uint32_t given = 0;
+            while (given < n_want) {
+#ifdef MIPT_POOL_STATS
+                const unsigned long long tg0 = wall_clock64();
+                const bool got_ = range_grab(a, rr, n, seg_len, (uint32_t)a.pool_chunk, lane);
+                t_grab += wall_clock64() - tg0; ++n_grab;
+                if (!got_) { dry = true; break; }
+#else
+                if (!range_grab(a, rr, n, seg_len, (uint32_t)a.pool_chunk, lane)) { dry = true; break; }
+#endif
+                const uint32_t avail = rr.end - rr.next;
+                const uint32_t need  = n_want - given;
+                const uint32_t take  = avail < need ? avail : need;
+                if (!occ && rank >= given && rank < given + take) {
+                    nxt_idx = rr.next + (rank - given);
+                    nxt_o = a.ray_o[(size_t)nxt_idx * a.stride];
+                    nxt_d = a.ray_d[(size_t)nxt_idx * a.stride];
+                    nxt_valid = true;
+                }
+                rr.next += take;
+                given += take;
+            }
+        }
+        if (psize == 0) {
+            if (__ballot(nxt_valid) != 0ull) continue;            // rays on their way: start them next round
+            if (dry) break;
+            continue;                                             // (not reached: an empty pool with rays left prefetches above)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // ------------------------------------------------------------ pop up to 64 entries (each lane adds at most one net entry)
+        int k = psize < 64 ? psize : 64;
+        const int room = kPoolCap - 104 - psize;                  // 64 for ray starts, 40 for a single-lane descent
+        if (k > room) k = room > 1 ? room : 1;
+        const bool have = lane < k;
+        uint32_t ent = 0u;
+        if (have) ent = stk[psize - 1 - lane];
+        psize -= k;
+#ifdef MIPT_POOL_STATS
+        ++n_rounds; n_popped += (unsigned long long)k;
+#endif
+        const uint32_t slot = ent & 63u;
+        // the ray of that slot, from its owner's registers
+        const float ox = shfl_f(T.o.x, slot), oy = shfl_f(T.o.y, slot), oz = shfl_f(T.o.z, slot);
+        const float dx = shfl_f(T.d.x, slot), dy = shfl_f(T.d.y, slot), dz = shfl_f(T.d.z, slot);
+        const float ix = shfl_f(T.idir.x, slot), iy = shfl_f(T.idir.y, slot), iz = shfl_f(T.idir.z, slot);
+        const float nx = shfl_f(T.nood.x, slot), ny = shfl_f(T.nood.y, slot), nz = shfl_f(T.nood.z, slot);
+        const float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
+        float tcur = tmx;
+        bool live = have;
+        if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[slot] >> 32)); }
+        else           { if (have && sh_done[slot] != 0u) live = false; }
+        const bool leaf = (ent >> 31) != 0u;
+        const uint32_t payload = (ent >> 6) & 0x1ffffffu;
+        const uint32_t lfirst = payload >> 3, lcnt = payload & 7u;
+        const bool do_inner = live && !leaf;
+        const bool do_tri   = live && leaf && lcnt != 0u;
+#ifdef MIPT_POOL_STATS
+        n_live += (unsigned long long)__popcll(__ballot(do_inner || do_tri));
+#endif
+        uint32_t off = 0u;
+        if (do_inner) off = payload << 6;
+        if (do_tri)   off = a.bvh.tri_byte_off + lfirst * 48u;
+        const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
+        asm volatile("" ::: "memory");
+        uint32_t push0 = 0u, push1 = 0u;
+        int npush = 0;
+        if (do_inner) {
+            const float ax0 = __builtin_fmaf(n0.x, ix, nx), ax1 = __builtin_fmaf(n0.y, ix, nx);
+            const float ay0 = __builtin_fmaf(n0.z, iy, ny), ay1 = __builtin_fmaf(n0.w, iy, ny);
+            const float az0 = __builtin_fmaf(n2.x, iz, nz), az1 = __builtin_fmaf(n2.y, iz, nz);
+            const float bx0 = __builtin_fmaf(n1.x, ix, nx), bx1 = __builtin_fmaf(n1.y, ix, nx);
+            const float by0 = __builtin_fmaf(n1.z, iy, ny), by1 = __builtin_fmaf(n1.w, iy, ny);
+            const float bz0 = __builtin_fmaf(n2.z, iz, nz), bz1 = __builtin_fmaf(n2.w, iz, nz);
+            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                              __builtin_fmaxf(__builtin_fminf(az0, az1), tmn));
+            const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                              __builtin_fminf(__builtin_fmaxf(az0, az1), tcur));
+            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                              __builtin_fmaxf(__builtin_fminf(bz0, bz1), tmn));
+            const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                              __builtin_fminf(__builtin_fmaxf(bz0, bz1), tcur));
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+            if (h0 && h1) {
+                const bool swp = tn1 < tn0;
+                push0 = pool_pack(swp ? c0 : c1, slot);           // farther child below ...
+                push1 = pool_pack(swp ? c1 : c0, slot);           // ... the nearer one on top
+                npush = 2;
+            } else if (h0 || h1) {
+                push1 = pool_pack(h0 ? c0 : c1, slot);
+                npush = 1;
+            }
+        }
+        if (do_tri) {
+            const f3 rd = mk3(dx, dy, dz);
+            const f3 e1 = mk3(n1.x, n1.y, n1.z), e2 = mk3(n2.x, n2.y, n2.z);
+            const f3 p = fcross(rd, e2);
+            const float det = fdot(e1, p);
+            const float inv = 1.0f / det;
+            const f3 tv = mk3(ox, oy, oz) - mk3(n0.x, n0.y, n0.z);
+            const float u = fdot(tv, p) * inv;
+            const f3 q = fcross(tv, e1);
+            const float v = fdot(rd, q) * inv;
+            const float t = fdot(e2, q) * inv;
+            const uint32_t prim = f2u(n0.w);
+            const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmn && t < tmx;
+            bool stop = false;
+            if (MODE != 0) {
+                if (ok) { sh_done[slot] = 1u; stop = true; }
+            } else if (ok) {
+                const unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
+                atomicMin(&sh_best[slot], key);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; }
+            }
+            if (!stop && lcnt > 1u) {
+                push1 = 0x80000000u | ((lfirst + 1u) << 9) | ((lcnt - 1u) << 6) | slot;
+                npush = 1;
+            }
+        }
+        if (have && npush != 1) atomicAdd(&sh_pending[slot], npush - 1);
+        {
+            const unsigned long long m2 = __ballot(npush == 2);
+            if (m2 != 0ull) {
+                if (npush == 2) stk[psize + (int)lane_rank(m2)] = push0;
+                psize += __popcll(m2);
+            }
+            const unsigned long long m1 = __ballot(npush >= 1);
+            if (m1 != 0ull) {
+                if (npush >= 1) stk[psize + (int)lane_rank(m1)] = push1;
+                psize += __popcll(m1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+#ifdef MIPT_POOL_STATS
+    if (MODE == 0 && lane == 0) {
+        const unsigned long long t_end = wall_clock64();
+        atomicAdd(&a.ctr->dbg[1], t_end - t_bulk);
+        atomicAdd(&a.ctr->dbg[2], n_rounds);
+        atomicAdd(&a.ctr->dbg[3], t_grab);
+        atomicAdd(&a.ctr->dbg[6], n_popped);
+        atomicMax(&a.ctr->dbg[4], t_end - t_start);
+        atomicAdd(&a.ctr->dbg[5], n_grab);
+    }
+#endif
 }
 
 // ---- one thread per ray (no refill); same per-ray visiting order ----
@@ -785,9 +1232,15 @@ template <int MODE>
 static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
 {
     if (a.n_max == 0) return;
-    if (o.persistent == 2 && a.bvh.tri_byte_off != 0u && a.bvh.depth <= (uint32_t)kStreamStack) {
-        const int blocks = o.blocks > 0 ? o.blocks : 4096;
-        if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
+    if (o.persistent >= 2 && a.bvh.tri_byte_off != 0u && a.bvh.depth <= (uint32_t)kStreamStack) {
+        const int blocks = ((o.blocks > 0 ? o.blocks : 4096) + kNumSegments - 1) / kNumSegments * kNumSegments;
+        // launches with at most this many rays run on the entry pool from the start: one ray per lane of the grid
+        // for closest hit, 60 % of that for any hit (measured on shards of the headline frame, profiles/)
+        a.tail_len = (uint32_t)(((unsigned long long)blocks * 64ull * (unsigned long long)(o.tail_pct > 0 ? o.tail_pct : 200) * (MODE == 0 ? 100ull : 60ull)) / 10000ull);
+        a.pool_low = o.pool_low > 0 ? o.pool_low : 16;
+        a.pool_chunk = o.pool_chunk > 0 ? o.pool_chunk : kPoolChunk;
+        if (o.persistent == 3 && !o.count_visits && a.bvh.pool_ok) hipLaunchKernelGGL((k_trace_pool<MODE>), dim3(blocks), dim3(64), 0, st, a);
+        else if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
         else                hipLaunchKernelGGL((k_trace_stream<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
     } else {
         launch_simple<MODE>(st, a, o);

@@ -78,7 +78,8 @@ struct MiptContext {
     int      count_visits = 0;
     int      blocks_per_cu = 0;
     int      batch_samples = 0;
-    int      persistent = 2;
+    int      persistent = 3;
+    int      tail_pct = 200, pool_low = 16, pool_chunk = 16;
     // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
     const float4*     wh_vertices = nullptr;
     const float4*     wh_normals = nullptr;
@@ -234,6 +235,7 @@ TraceOpts trace_opts(const MiptContext* c)
     o.count_visits = c->count_visits;
     o.blocks = c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 16);
     o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.burst_bulk = c->burst_bulk; o.burst_dry = c->burst_dry;
+    o.tail_pct = c->tail_pct; o.pool_low = c->pool_low; o.pool_chunk = c->pool_chunk;
     return o;
 }
 
@@ -253,6 +255,7 @@ DeviceBvh device_bvh(const Accel* a)
 {
     DeviceBvh b{};
     b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes; b.depth = a->host.depth;
+    b.pool_ok = (a->host.nodes.size() < (1u << 25) && a->host.tris.size() < (1u << 22) && a->host.leaf_max <= 7u) ? 1u : 0u;
     return b;
 }
 
@@ -400,6 +403,12 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
         delete c;
         return MIPT_ERROR_OUT_OF_MEMORY;
     }
+    // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
+    if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
+    if (const char* e = std::getenv("MIPT_TAIL_PCT")) { const int v = std::atoi(e); if (v >= 1 && v <= 100000) c->tail_pct = v; }
+    if (const char* e = std::getenv("MIPT_POOL_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) c->pool_chunk = v; }
+    if (const char* e = std::getenv("MIPT_POOL_LOW")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) c->pool_low = v; }
+    if (const char* e = std::getenv("MIPT_STEAL_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) c->steal_min = v; }
     *out = c;
     return MIPT_SUCCESS;
 }
@@ -435,7 +444,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value > 32) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 32 single-wave workgroups fit a CU");
         c->blocks_per_cu = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PERSISTENT:
-        if (value != 0 && value != 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "traversal kernel variant must be 0 or 2");
+        if (value != 0 && value != 2 && value != 3) return c->fail(MIPT_ERROR_INVALID_VALUE, "traversal kernel variant must be 0, 2 or 3");
         c->persistent = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
@@ -747,8 +756,8 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     stats->shadow_node_visits = h.node_visits[1]; stats->shadow_tri_tests = h.tri_tests[1];
     stats->bounces = ctx->last_bounces; stats->reserved = 0;
     if (ctx->log_level >= 4)
-        ctx->log(4, "SCHED", "stream<closest>: iterations %llu, inner lanes %llu, leaf lanes %llu (tested %llu in %llu iterations), idle lanes %llu, refill rounds %llu",
-                 h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[5], h.dbg[4], h.dbg[6]);
+        ctx->log(4, "SCHED", "pool<closest>: bulk ticks %llu (iterations %llu), tail ticks %llu, rounds %llu, popped %llu, grab ticks %llu in %llu calls, max wave ticks %llu",
+                 h.dbg[0], h.dbg[7], h.dbg[1], h.dbg[2], h.dbg[6], h.dbg[3], h.dbg[5], h.dbg[4]);
     return MIPT_SUCCESS;
 }
 

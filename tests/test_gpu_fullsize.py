@@ -48,11 +48,11 @@ def test_headline_determinism_and_kernel_variants(big):
     a0, f0, s0 = _render(PT, st, ob)
     a1, f1, s1 = _render(PT, st, ob)
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and s0 == s1          # idempotent relaunch
-    for variant in (0,):                        # the one-thread-per-ray kernel
+    for variant in (0, 2):                      # the one-thread-per-ray kernel, streaming waves with subtree stealing
         st.context.set_option(L.OPT_PERSISTENT, variant)
         a2, f2, s2 = _render(PT, st, ob)
         assert np.array_equal(a0.view(np.uint32), a2.view(np.uint32)) and np.array_equal(f0, f2), variant
-    st.context.set_option(L.OPT_PERSISTENT, 2)
+    st.context.set_option(L.OPT_PERSISTENT, 3)
     opts = (L.OPT_TRACE_GRID, L.OPT_REFILL_MIN, L.OPT_STEAL_MIN, L.OPT_BURST)
     defaults = [st.context.get_option(o) for o in opts]
     # incl. stealing on every idle lane / never, single-step and long bursts

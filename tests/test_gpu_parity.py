@@ -61,7 +61,7 @@ def test_library_is_native_and_loaded():
     assert torch.cuda.get_device_properties(0).gcnArchName.startswith("gfx950")
 
 
-@pytest.mark.parametrize("persistent,steal", [(2, 32), (2, 1), (2, 65), (0, 32)])
+@pytest.mark.parametrize("persistent,steal", [(3, 32), (3, 1), (3, 65), (2, 32), (2, 1), (2, 65), (0, 32)])
 def test_traversal_records_bit_exact(persistent, steal):
     torch = _torch()
     from optix_raytracer_amd import _lib as L
@@ -117,6 +117,48 @@ def test_traversal_records_bit_exact(persistent, steal):
             st.context.trace_any(st.gas_handle, d_seg.data_ptr(), n, d_occ.data_ptr())
             assert np.array_equal(d_occ.cpu().numpy().astype(np.uint8), occ), counting
         PT.cleanupState(st)
+
+
+@pytest.mark.parametrize("grid,steal,n_rays", [(1, 32, 150_000), (1, 8, 40_000), (2, 64, 70_000), (16, 32, 300_000)])
+def test_entry_pool_kernel_all_phases(grid, steal, n_rays):
+    """variant 3 on launches that (a) start in the bulk phase and go over to the entry pool when the ray range runs
+    dry, (b) run on the pool from the start; hit records and flags equal the counting build's (= the oracle's order)"""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import scenes
+    scene = scenes.random_soup(30000)
+    PT, st = _state(scene, 64, 64)
+    st.context.set_option(L.OPT_PERSISTENT, 3)
+    st.context.set_option(L.OPT_TRACE_GRID, grid)
+    st.context.set_option(L.OPT_STEAL_MIN, steal)
+    rng = np.random.default_rng(grid * 1000 + steal)
+    rays = np.zeros((n_rays, 8), np.float32)
+    rays[:, :3] = rng.uniform(-0.2, 1.2, (n_rays, 3))
+    rays[:, 4:7] = rng.normal(size=(n_rays, 3))
+    rays[:, 3], rays[:, 7] = 0.001, 1e16
+    rays[::97, 7] = 0.0                                   # empty intervals sprinkled in
+    # a coherent block of long rays so that some waves are much heavier than others
+    rays[:4096, :3] = (0.5, 0.5, -0.5); rays[:4096, 4:7] = rng.normal((0, 0, 1), 0.02, (4096, 3))
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros((n_rays, 4), dtype=torch.float32, device="cuda")
+    d_occ = torch.zeros(n_rays, dtype=torch.int32, device="cuda")
+    out = {}
+    for counting in (0, 1):
+        st.context.set_option(L.OPT_COUNT_VISITS, counting)
+        d_hits.zero_(); d_occ.zero_()
+        st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), n_rays, d_hits.data_ptr())
+        st.context.trace_any(st.gas_handle, d_rays.data_ptr(), n_rays, d_occ.data_ptr())
+        st.context.sync()
+        out[counting] = (d_hits.cpu().numpy().copy(), d_occ.cpu().numpy().copy())
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1], out[1][1])
+    hit = out[0][0][:, 0] > 0
+    assert 0.05 < hit.mean() < 1.0 and np.array_equal(hit, out[0][1] != 0)
+    osc = _oracle_scene(scene, st)
+    t, prim, u, v = osc.trace_closest(rays[:20000], O.MODE_BVH)
+    assert np.array_equal(out[0][0][:20000, 0].view(np.uint32), t.view(np.uint32))
+    assert np.array_equal(out[0][0][:20000, 1].view(np.uint32), prim)
+    PT.cleanupState(st)
 
 
 def test_cornell_config1_512_spp1():

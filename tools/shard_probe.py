@@ -13,7 +13,7 @@ stream = torch.cuda.current_stream()
 frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=st.device)
 steals = [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['32'])]
 drains = [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['0'])]
-for steal, drain, world in [(s_, d_, w_) for s_ in steals for d_ in drains for w_ in (1, 8)]:
+for steal, drain, world in [(s_, d_, w_) for s_ in steals for d_ in drains for w_ in [int(x) for x in os.environ.get('PROBE_WORLDS', '1,8').split(',')]]:
     st.context.set_option(L.OPT_STEAL_MIN, steal)
     st.context.set_option(L.OPT_BURST, (drain & 0xff) | ((drain >> 8) << 8))
     ns = api.shard_num_samples(W, H, world)
