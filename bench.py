@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", type=str, default="nccl", help="debug: 'gloo' lets several ranks share one GPU (functional check only)")
     ap.add_argument("--persistent", type=int, default=-1, help="tuning: traversal kernel variant (3 entry pool, 2 streaming waves, 0 one thread per ray)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="N > 1: all-gather + scatter on the launch stream instead of overlapping the next frame's tracing")
+    ap.add_argument("--verify", action="store_true", help="debug: compare the gathered frame with a single-launch frame, bit for bit")
+    ap.add_argument("--force-shard-path", action="store_true", help="debug: run the N > 1 code path (shard, gather, scatter) on one GPU")
     ap.add_argument("--grid", type=int, default=0, help="tuning: persistent workgroups per CU")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--steal-min", type=int, default=0)
@@ -168,21 +172,39 @@ def main():
     frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=st.device)
     st.params.frame_buffer = frame.data_ptr()
     st.params.subframe_index = 0
-    if world > 1:
+    sharded = world > 1 or args.force_shard_path
+    if sharded:
+        # two compact / gathered buffers: the all-gather + scatter of frame k run on a second stream while the
+        # main stream already traces frame k+1 (a progressive renderer's steady state); every step's gather
+        # and scatter still complete inside the timed region (fence = barrier + device synchronize)
         ns = api.shard_num_samples(w, h, world)
-        compact = torch.zeros((ns, 4), dtype=torch.float32, device=st.device)
-        gathered = torch.zeros((world * ns, 4), dtype=torch.float32, device=st.device)
+        compact = [torch.zeros((ns, 4), dtype=torch.float32, device=st.device) for _ in range(2)]
+        gathered = [torch.zeros((world * ns, 4), dtype=torch.float32, device=st.device) for _ in range(2)]
+        xstream = torch.cuda.Stream(device=st.device) if args.overlap else stream
+        rendered = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+    state = {"k": 0}
 
     def step():
-        if world == 1:
+        if not sharded:
             st.context.launch(st.params, w, h, 1, stream=stream.cuda_stream)
-        else:
-            st.context.launch_shard(st.params, w, h, rank, world, compact.data_ptr(), stream=stream.cuda_stream)
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, compact)      # the path's one exchange (RCCL over xGMI)
+            return
+        b = state["k"] & 1
+        state["k"] += 1
+        if state["k"] > 2:
+            stream.wait_event(consumed[b])                      # frame k-2's gather has read compact[b]
+        st.context.launch_shard(st.params, w, h, rank, world, compact[b].data_ptr(), stream=stream.cuda_stream)
+        rendered[b].record(stream)
+        with torch.cuda.stream(xstream):
+            xstream.wait_event(rendered[b])
+            if world == 1:
+                gathered[b].copy_(compact[b])
+            elif args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered[b], compact[b])      # the path's one exchange (RCCL over xGMI)
             else:
-                gathered.copy_(D.all_gather_shards(compact.cpu(), world))   # debug backend: staged through the host
-            st.context.unpermute(gathered.data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=stream.cuda_stream)
+                gathered[b].copy_(D.all_gather_shards(compact[b].cpu(), world))   # debug backend: staged through the host
+            consumed[b].record(xstream)
+            st.context.unpermute(gathered[b].data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=xstream.cuda_stream)
 
     def fence():
         if world > 1:
@@ -198,9 +220,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # ---- timed region: exactly K steps between barrier + synchronize
-    st.context.set_option(L.OPT_PROFILE, 1)       # HIP events around each kernel, on the launch stream
-    k_closest = k_any = k_shade = k_other = 0.0
+    # ---- timed region: exactly K steps between barrier + synchronize.  HIP events bracket the two traversal
+    # kernels on the launch stream (4 records per frame; bracketing all kernels costs 3 % of the frame)
+    st.context.set_option(L.OPT_PROFILE, 2)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -208,9 +230,26 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tm = st.context.launch_timings()              # event sums over all K timed steps (read after the fence)
-    k_closest, k_any, k_shade = (tm[k] / args.steps for k in ("ms_trace_closest", "ms_trace_any", "ms_shade"))
-    k_other = (tm["ms_raygen"] + tm["ms_resolve"]) / args.steps
+    k_closest, k_any = (tm[k] / args.steps for k in ("ms_trace_closest", "ms_trace_any"))
+    # ---- per-kernel breakdown of the other kernels: a few more steps with every kernel bracketed, untimed
+    st.context.set_option(L.OPT_PROFILE, 1)
+    nb = min(args.steps, 5)
+    for _ in range(nb):
+        step()
+    fence()
+    tb = st.context.launch_timings()
+    k_shade = tb["ms_shade"] / nb
+    k_other = (tb["ms_raygen"] + tb["ms_resolve"]) / nb
     st.context.set_option(L.OPT_PROFILE, 0)
+
+    if args.verify and sharded:
+        got = st.accum.clone()
+        st.context.launch(st.params, w, h, 1, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(got.view(torch.int32), st.accum.view(torch.int32)))
+        print("verify: sharded + gathered frame %s the single-launch frame" % ("==" if same else "!="), file=sys.stderr)
+        if not same:
+            raise SystemExit("bench.py --verify: frames differ")
 
     rays_local = counts["closest_rays"] + counts["shadow_rays"]
     t_max = elapsed
@@ -251,7 +290,8 @@ def main():
                                    "(primary + NEE shadow ray), BVH2 %d nodes depth %d" % (
                                        args.tris, w, h, SPP, args.max_depth, info["num_nodes"], info["depth"]),
                        "rays_per_frame": rays_total, "closest_rays": counts["closest_rays"] if world == 1 else None,
-                       "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather" % world,
+                       "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather%s" % (
+                           world, " (frame k's gather overlaps frame k+1's tracing)" if args.overlap else ""),
                        "bvh_build_s": round(info["build_seconds"], 3), "setup_s": round(build_s, 3)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname) if world == 1 else None,

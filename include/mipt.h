@@ -153,7 +153,8 @@ typedef enum MiptOption {
                                   with subtree stealing (also used when a BVH does not fit the pool's packed entries:
                                   >= 2^25 nodes, >= 2^22 triangles or leaves of more than 7); 0 one thread per ray
                                   (tight while-while loop; also the fallback for trees deeper than 32). */
-    MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings) */
+    MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings),
+                                  2 = only the two traversal kernels (10 -> 4 event records per frame) */
     MIPT_OPT_REFILL_MIN   = 7, /* streaming waves: idle lanes that trigger a swap-in/prefetch round (default 8) */
     MIPT_OPT_STEAL_MIN    = 8, /* streaming waves: once the ray range is exhausted, this many idle lanes make the wave
                                   go over to its entry pool (variant 3) / trigger a round in which idle lanes take

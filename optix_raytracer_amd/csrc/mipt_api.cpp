@@ -147,14 +147,15 @@ struct MiptContext {
 namespace {
 
 struct TimedScope {
-    MiptContext* c; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr;
+    MiptContext* c; hipStream_t st; int kind; bool on = false; hipEvent_t a = nullptr, b = nullptr;
     TimedScope(MiptContext* c_, hipStream_t st_, int kind_) : c(c_), st(st_), kind(kind_)
     {
-        if (c->profile) { a = c->get_event(); b = c->get_event(); if (a) (void)hipEventRecord(a, st); }
+        on = c->profile == 1 || (c->profile == 2 && (kind_ == T_CLOSEST || kind_ == T_ANY));
+        if (on) { a = c->get_event(); b = c->get_event(); if (a) (void)hipEventRecord(a, st); }
     }
     ~TimedScope()
     {
-        if (c->profile && a && b) { (void)hipEventRecord(b, st); c->timed.push_back({ a, b, kind }); }
+        if (on && a && b) { (void)hipEventRecord(b, st); c->timed.push_back({ a, b, kind }); }
     }
 };
 
@@ -459,7 +460,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         c->steal_min = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PROFILE:
         if (c->last_stream || c->timed.size()) (void)hipStreamSynchronize(c->last_stream);
-        c->profile = value ? 1 : 0; c->timed.clear(); c->events_used = 0; return MIPT_SUCCESS;
+        c->profile = value == 2 ? 2 : (value ? 1 : 0); c->timed.clear(); c->events_used = 0; return MIPT_SUCCESS;
     default: return c->fail(MIPT_ERROR_INVALID_VALUE, "unknown option %d", option);
     }
 }
