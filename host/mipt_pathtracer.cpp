@@ -4,7 +4,7 @@
 // functions in the same order, the same command-line flags (--file/-f, --dim=WxH, --launch-samples/-s),
 // the same Params / ParallelogramLight / HitGroupData / MissData structs, a HIP version of the
 // CUDA_DEVICE mode of sutil::CUDAOutputBuffer<uchar4> (SDK/sutil/CUDAOutputBuffer.h:54-94), sutil::Camera
-// (SDK/sutil/Camera.h:38-76) and the PPM branch of sutil::saveImage (SDK/sutil/sutil.cpp:542-575: rows are
+// (SDK/sutil/Camera.h:38-76); the image is written by mipt_save_image (sutil::saveImage's rules, sutil.cpp:542-709: rows are
 // flipped on write, row 0 of the buffer is the bottom of the image).  createModule / createProgramGroups /
 // createPipeline (:686-826) have no counterpart.  Extra flags: --scene cornell|soup, --tris N,
 // --max-depth K (0 = Russian roulette only, the reference's behaviour), --subframes N.
@@ -228,19 +228,11 @@ void launchSubframe(HIPOutputBuffer<uchar4_>& output_buffer, PathTracerState& st
     MIPT_CHECK(mipt_sync(state.context));
 }
 
-void saveImagePPM(const char* fname, const uchar4_* data, int width, int height)          // sutil.cpp:542-575 + savePPM
+void saveImage(const char* fname, const uchar4_* data, int width, int height)             // sutil::saveImage, UNSIGNED_BYTE4
 {
-    std::vector<unsigned char> pix((size_t)width * height * 3);
-    for (int j = height - 1; j >= 0; --j)
-        for (int i = 0; i < width; ++i) {
-            const size_t dst = 3 * (size_t)width * (height - j - 1) + 3 * (size_t)i, src = (size_t)width * j + i;
-            pix[dst] = data[src].x; pix[dst + 1] = data[src].y; pix[dst + 2] = data[src].z;
-        }
-    FILE* f = std::fopen(fname, "wb");
-    if (!f) throw Exception(std::string("cannot open ") + fname);
-    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
-    std::fwrite(pix.data(), 1, pix.size(), f);
-    std::fclose(f);
+    char err[256] = { 0 };
+    if (mipt_save_image(fname, data, (uint32_t)width, (uint32_t)height, MIPT_IMAGE_UNSIGNED_BYTE4, 0, err, sizeof err) != MIPT_SUCCESS)
+        throw Exception(err);                                                               // .ppm or .png, as the reference
 }
 
 void cleanupState(PathTracerState& state)                                   // :901-918
@@ -303,7 +295,7 @@ int main(int argc, char* argv[])
         MIPT_CHECK(mipt_get_launch_stats(state.context, &st));
         std::cerr << "last launch: " << st.closest_rays << " closest + " << st.shadow_rays << " shadow rays, "
                   << st.bounces << " wavefront iterations\n";
-        saveImagePPM(outfile.c_str(), output_buffer.getHostPointer(), output_buffer.width(), output_buffer.height());
+        saveImage(outfile.c_str(), output_buffer.getHostPointer(), output_buffer.width(), output_buffer.height());
         cleanupState(state);
     } catch (std::exception& e) {                                          // :1089-1093
         std::cerr << "Caught exception: " << e.what() << "\n";

@@ -389,6 +389,22 @@ int mipt_scene_flatten(const MiptScene* scene, float* vertices4_out, uint32_t* m
 int mipt_scene_flatten_normals(const MiptScene* scene, float* normals4_out);
 
 /* ---------------------------------------------------------------------------
+ * Image output   (replaces sutil::saveImage, SDK/sutil/sutil.cpp:542-709; host only)
+ * ------------------------------------------------------------------------- */
+typedef enum MiptImageFormat {          /* sutil::BufferImageFormat, SDK/sutil/sutil.h:53-58 */
+    MIPT_IMAGE_UNSIGNED_BYTE4 = 0,
+    MIPT_IMAGE_FLOAT4         = 1,
+    MIPT_IMAGE_FLOAT3         = 2
+} MiptImageFormat;
+/* Chooses the container by the last three characters of `filename`, as the reference does:
+ *   ppm: any format; written top row first (buffer row 0 is the bottom row); float channels -> toSRGB unless
+ *        disable_srgb_conversion, then int(256 x) clamped to 0..255
+ *   png: UNSIGNED_BYTE4 only, RGBA8, flipped vertically;   exr: FLOAT3 / FLOAT4 only, half floats, buffer row order.
+ * Unsupported combinations fail with the reference's exception text in errbuf.  data is a HOST pointer. */
+int mipt_save_image(const char* filename, const void* data, uint32_t width, uint32_t height, int pixel_format,
+                    int disable_srgb_conversion, char* errbuf, size_t errlen);
+
+/* ---------------------------------------------------------------------------
  * Host helpers mirroring sutil (kept API: SDK/sutil/Camera.h:38-76)
  * ------------------------------------------------------------------------- */
 /* Camera::UVWFrame, SDK/sutil/Camera.cpp:34-46 (fod = m_fod, the fork's focal scale) */

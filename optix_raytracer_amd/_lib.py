@@ -110,6 +110,7 @@ class MiptLaunchTimings(C.Structure):
 
 LOG_CALLBACK = C.CFUNCTYPE(None, C.c_uint, C.c_char_p, C.c_char_p, C.c_void_p)
 
+IMAGE_UNSIGNED_BYTE4, IMAGE_FLOAT4, IMAGE_FLOAT3 = 0, 1, 2
 OPT_MAX_DEPTH, OPT_COUNT_VISITS, OPT_TRACE_GRID, OPT_PERSISTENT, OPT_PROFILE = 1, 2, 3, 4, 5
 OPT_REFILL_MIN, OPT_STEAL_MIN, OPT_BURST, OPT_BATCH_SAMPLES = 7, 8, 9, 10
 
@@ -154,6 +155,7 @@ SYMBOLS = [
     ("mipt_scene_material", C.c_int, [_vp, _u32, C.POINTER(MiptMaterialData)]),
     ("mipt_scene_flatten", C.c_int, [_vp, _vp, _vp]),
     ("mipt_scene_flatten_normals", C.c_int, [_vp, _vp]),
+    ("mipt_save_image", C.c_int, [C.c_char_p, _vp, _u32, _u32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     ("mipt_whitted_set_geometry", C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(MiptMaterialData), _u32]),
     ("mipt_whitted_launch", C.c_int, [_vp, _vp, C.POINTER(MiptWhittedLaunchParams), C.c_uint, C.c_uint, C.c_uint]),
     ("mipt_camera_uvw", None, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp]),

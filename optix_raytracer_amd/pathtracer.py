@@ -134,3 +134,46 @@ def make_state(scene, width, height, spp=1, device_index=0, max_depth=0, log=Non
     handleCameraUpdate(st, Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], 1.0))
     st.context.set_option(L.OPT_MAX_DEPTH, max_depth)
     return st
+
+
+def renderLoop(state, output_buffer, subframes, on_subframe=None, stats_every=0, stats_out=None):
+    """The do { } while loop of main() (optixPathTracer.cpp:1021-1045) without the window: updateState ->
+    launchSubframe -> (display callback) -> ++subframe_index, with the three timers of sutil::displayStats
+    (sutil.cpp:742-775) accumulated and reported as JSON lines instead of an ImGui overlay."""
+    import json
+    import time
+    state_update_time = render_time = display_time = 0.0
+    frames = 0
+    for k in range(int(subframes)):
+        t0 = time.perf_counter()
+        # updateState (:471-485): camera / resize changes would reset subframe_index here
+        t1 = time.perf_counter()
+        state_update_time += t1 - t0
+        t0 = t1
+        launchSubframe(output_buffer, state)
+        t1 = time.perf_counter()
+        render_time += t1 - t0
+        t0 = t1
+        if on_subframe is not None:
+            on_subframe(k, output_buffer)
+        t1 = time.perf_counter()
+        display_time += t1 - t0
+        frames += 1
+        if stats_every and frames % stats_every == 0:
+            line = {"subframe": int(state.params.subframe_index), "state_update_ms": 1e3 * state_update_time / frames,
+                    "render_ms": 1e3 * render_time / frames, "display_ms": 1e3 * display_time / frames}
+            (stats_out or print)(json.dumps(line))
+        state.params.subframe_index += 1
+    state.context.sync()
+    return {"state_update_s": state_update_time, "render_s": render_time, "display_s": display_time, "subframes": frames}
+
+
+def renderToFile(scene, outfile, width=768, height=768, samples_per_launch=16, subframes=1, device_index=0, max_depth=0):
+    """main() with --file (optixPathTracer.cpp:1051-1079; defaults 768x768, 16 spp :75, 930-931): renders and writes
+    the uchar4 frame with sutil::saveImage's rules (optix_raytracer_amd.image).  Returns the state."""
+    from . import image
+    st = make_state(scene, width, height, samples_per_launch, device_index, max_depth)
+    out = OutputBuffer(width, height, st.device)
+    renderLoop(st, out, subframes)
+    image.saveImage(outfile, out.getHostPointer(), False)
+    return st

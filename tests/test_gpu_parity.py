@@ -352,3 +352,30 @@ def test_batched_samples_agree_within_tolerance():
     a2, _, _ = osc.render(scenes.launch_desc(scene, w, h, spp, subframe=1), accum=a.copy(), threads=4)
     assert (np.abs(acc2 - a2) / np.maximum(np.abs(a2), 1e-6)).max() <= REL_TOL
     PT.cleanupState(st)
+
+
+def test_render_loop_and_file_output(tmp_path):
+    """main()'s --file branch + the progressive loop: 3 sub-frames of the Cornell box, PPM and PNG written with
+    sutil::saveImage's flip; the accumulated frame equals the oracle's after the same 3 sub-frames"""
+    _torch()
+    from optix_raytracer_amd import image, scenes
+    import test_image_io as TI
+    scene = scenes.cornell_box()
+    w, h, spp = 96, 64, 2
+    from optix_raytracer_amd import pathtracer as PTm
+    st = PTm.renderToFile(scene, tmp_path / "cornell.ppm", w, h, spp, subframes=3)
+    acc = st.accum.cpu().numpy()
+    osc = _oracle_scene(scene, st)
+    a = None
+    for sf in range(3):
+        a, f, _ = osc.render(scenes.launch_desc(scene, w, h, spp, subframe=sf), accum=a)
+    _assert_pixels(acc, a)
+    ppm = TI._read_ppm(tmp_path / "cornell.ppm")
+    assert np.array_equal(ppm, f[::-1, :, :3])
+    image.saveImage(tmp_path / "cornell.png", f)
+    assert np.array_equal(TI._read_png(tmp_path / "cornell.png"), f[::-1])
+    lines = []
+    out = PTm.OutputBuffer(w, h, st.device)
+    t = PTm.renderLoop(st, out, 4, stats_every=2, stats_out=lines.append)
+    assert t["subframes"] == 4 and len(lines) == 2 and st.params.subframe_index == 7 and '"render_ms"' in lines[0]
+    PTm.cleanupState(st)
