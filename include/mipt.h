@@ -277,7 +277,17 @@ typedef struct MiptWhittedLaunchParams {
     unsigned long long handle;
 } MiptWhittedLaunchParams;
 
-/* the factors of MaterialData (SDK/cuda/MaterialData.h:33-130) that do not need texture objects */
+/* MaterialData::Texture (SDK/cuda/MaterialData.h:60-72) with the CUDA texture object replaced by the index of the
+ * scene's texture; offset / rotation / scale come from KHR_texture_transform (Scene.cpp:214-265) */
+typedef struct MiptTextureInfo {
+    int32_t texture;              /* index for mipt_scene_texture, -1 = none */
+    int32_t texcoord;             /* TEXCOORD set, 0 or 1 */
+    float   offset[2];
+    float   rotation[2];          /* { sin, cos } */
+    float   scale[2];
+} MiptTextureInfo;
+
+/* MaterialData (SDK/cuda/MaterialData.h:33-130), the PBR branch */
 typedef struct MiptMaterialData {
     float   base_color[4];
     float   metallic, roughness;
@@ -285,8 +295,20 @@ typedef struct MiptMaterialData {
     float   alpha_cutoff;
     int32_t alpha_mode;           /* 0 OPAQUE, 1 MASK, 2 BLEND */
     int32_t double_sided;
-    int32_t base_color_texture;   /* glTF texture index or -1 (not decoded yet) */
+    MiptTextureInfo base_color_tex, metallic_roughness_tex, normal_tex, emissive_tex;
 } MiptMaterialData;
+
+/* one glTF texture = sampler state + decoded image (Scene::addImage / addSampler, Scene.cpp:576-652).
+ * texels: RGBA, 8 or 16 bits per component, row 0 = top row of the image; owned by the scene (host memory).
+ * An image the loader cannot decode (anything but non-interlaced PNG for now) yields width = height = 0 and
+ * texels = NULL: materials that use it render untextured. */
+typedef struct MiptTextureData {
+    uint32_t    width, height, bits;
+    uint32_t    address_s, address_t;     /* 0 wrap, 1 clamp, 2 mirror (cudaTextureAddressMode order) */
+    uint32_t    filter;                   /* 0 point, 1 linear */
+    int32_t     image;                    /* glTF image index */
+    const void* texels;
+} MiptTextureData;
 
 /* struct Light, SDK/cuda/Light.h:33-71 (36 bytes): type 0 POINT {color, intensity, position, falloff},
  * type 1 AMBIENT {color} */
@@ -387,6 +409,13 @@ int mipt_scene_material(const MiptScene* scene, uint32_t index, MiptMaterialData
 int mipt_scene_flatten(const MiptScene* scene, float* vertices4_out, uint32_t* material_index_out);
 /* normals4_out: num_triangles*3 float4 {world-space normal (M^-T n, un-normalised), 1}; all 0 where a primitive has no NORMAL */
 int mipt_scene_flatten_normals(const MiptScene* scene, float* normals4_out);
+/* texture i of the scene (glTF "textures"); the texel pointer stays valid until mipt_scene_destroy */
+int mipt_scene_texture(const MiptScene* scene, uint32_t index, MiptTextureData* out);
+/* TEXCOORD_<set> per corner: uv2_out = num_triangles*3 float2; present_out (nullable) = num_triangles bytes, 0 where
+ * the primitive has no such attribute (uv then 0).  Float VEC2 accessors only, as the reference reads them. */
+int mipt_scene_flatten_texcoords(const MiptScene* scene, uint32_t set, float* uv2_out, uint8_t* present_out);
+/* COLOR_0 per corner: rgba4_out = num_triangles*3 float4 (1,1,1,1 where absent); float VEC4 accessors only */
+int mipt_scene_flatten_colors(const MiptScene* scene, float* rgba4_out, uint8_t* present_out);
 
 /* ---------------------------------------------------------------------------
  * Image output   (replaces sutil::saveImage, SDK/sutil/sutil.cpp:542-709; host only)

@@ -50,10 +50,22 @@ class MiptSceneInfo(C.Structure):
                 ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3)]
 
 
+class MiptTextureInfo(C.Structure):
+    """MaterialData::Texture (cuda/MaterialData.h:60-72), 32 bytes"""
+    _fields_ = [("texture", C.c_int32), ("texcoord", C.c_int32), ("offset", C.c_float * 2), ("rotation", C.c_float * 2),
+                ("scale", C.c_float * 2)]
+
+
 class MiptMaterialData(C.Structure):
     _fields_ = [("base_color", C.c_float * 4), ("metallic", C.c_float), ("roughness", C.c_float),
                 ("emissive_factor", C.c_float * 3), ("alpha_cutoff", C.c_float), ("alpha_mode", C.c_int32),
-                ("double_sided", C.c_int32), ("base_color_texture", C.c_int32)]
+                ("double_sided", C.c_int32), ("base_color_tex", MiptTextureInfo), ("metallic_roughness_tex", MiptTextureInfo),
+                ("normal_tex", MiptTextureInfo), ("emissive_tex", MiptTextureInfo)]
+
+
+class MiptTextureData(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("bits", C.c_uint32), ("address_s", C.c_uint32),
+                ("address_t", C.c_uint32), ("filter", C.c_uint32), ("image", C.c_int32), ("texels", C.c_void_p)]
 
 
 class MiptBufferView(C.Structure):
@@ -155,6 +167,9 @@ SYMBOLS = [
     ("mipt_scene_material", C.c_int, [_vp, _u32, C.POINTER(MiptMaterialData)]),
     ("mipt_scene_flatten", C.c_int, [_vp, _vp, _vp]),
     ("mipt_scene_flatten_normals", C.c_int, [_vp, _vp]),
+    ("mipt_scene_texture", C.c_int, [_vp, _u32, C.POINTER(MiptTextureData)]),
+    ("mipt_scene_flatten_texcoords", C.c_int, [_vp, _u32, _vp, _vp]),
+    ("mipt_scene_flatten_colors", C.c_int, [_vp, _vp, _vp]),
     ("mipt_save_image", C.c_int, [C.c_char_p, _vp, _u32, _u32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     ("mipt_whitted_set_geometry", C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(MiptMaterialData), _u32]),
     ("mipt_whitted_launch", C.c_int, [_vp, _vp, C.POINTER(MiptWhittedLaunchParams), C.c_uint, C.c_uint, C.c_uint]),

@@ -70,6 +70,11 @@ def host_bvh(vertices4):
     return nodes, tris[:info.num_triangles], {k: getattr(info, k) for k, _ in info._fields_}
 
 
+def _texture_info(t):
+    return {"texture": t.texture, "texcoord": t.texcoord, "offset": tuple(t.offset), "rotation": tuple(t.rotation),
+            "scale": tuple(t.scale)}
+
+
 class Scene:
     """Host scene loaded from glTF: the data side of sutil::Scene (SDK/sutil/Scene.h:53-159) behind
     sutil::loadScene (Scene.cpp:267).  Raises MiptError on a malformed file, like the reference throws."""
@@ -114,7 +119,8 @@ class Scene:
             out.append({"base_color": np.array(m.base_color, np.float32), "metallic": m.metallic, "roughness": m.roughness,
                         "emissive_factor": np.array(m.emissive_factor, np.float32), "alpha_mode": m.alpha_mode,
                         "alpha_cutoff": m.alpha_cutoff, "double_sided": bool(m.double_sided),
-                        "base_color_texture": m.base_color_texture})
+                        "base_color_texture": m.base_color_tex.texture,
+                        **{k: _texture_info(getattr(m, k)) for k in ("base_color_tex", "metallic_roughness_tex", "normal_tex", "emissive_tex")}})
         return out
 
     def flatten(self):
@@ -135,6 +141,43 @@ class Scene:
         if rc:
             raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_flatten_normals")
         return v[:n * 3]
+
+    def textures(self):
+        """list of dicts: width, height, bits, address_s/t (0 wrap, 1 clamp, 2 mirror), filter (0 point, 1 linear), image,
+        texels = (h, w, 4) uint8 / uint16 array (a copy) or None when the image could not be decoded"""
+        out = []
+        for k in range(self.info()["num_textures"]):
+            t = L.MiptTextureData()
+            self._lib.mipt_scene_texture(self._h, k, C.byref(t))
+            d = {f: getattr(t, f) for f in ("width", "height", "bits", "address_s", "address_t", "filter", "image")}
+            d["texels"] = None
+            if t.texels and t.width:
+                dt = np.uint16 if t.bits == 16 else np.uint8
+                n = t.width * t.height * 4
+                buf = (C.c_uint16 * n if t.bits == 16 else C.c_uint8 * n).from_address(t.texels)
+                d["texels"] = np.frombuffer(buf, dt).reshape(t.height, t.width, 4).copy()
+            out.append(d)
+        return out
+
+    def flatten_texcoords(self, tex_set=0):
+        """(n*3, 2) float32 TEXCOORD_<set> per corner, (n,) uint8 presence per triangle"""
+        n = self.info()["num_triangles"]
+        uv = np.zeros((max(n, 1) * 3, 2), np.float32)
+        present = np.zeros(max(n, 1), np.uint8)
+        rc = self._lib.mipt_scene_flatten_texcoords(self._h, tex_set, uv.ctypes.data, present.ctypes.data)
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_flatten_texcoords")
+        return uv[:n * 3], present[:n]
+
+    def flatten_colors(self):
+        """(n*3, 4) float32 COLOR_0 per corner (1 where absent), (n,) uint8 presence per triangle"""
+        n = self.info()["num_triangles"]
+        col = np.ones((max(n, 1) * 3, 4), np.float32)
+        present = np.zeros(max(n, 1), np.uint8)
+        rc = self._lib.mipt_scene_flatten_colors(self._h, col.ctypes.data, present.ctypes.data)
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_flatten_colors")
+        return col[:n * 3], present[:n]
 
     def material_table(self):
         """ctypes array of MiptMaterialData: the scene's materials + one all-zero record, which is what

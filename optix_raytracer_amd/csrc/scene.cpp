@@ -8,8 +8,9 @@
 // meshes as lists of TRIANGLES primitives (indices, POSITION, material, object aabb from accessor
 // min/max), the node recursion `parent * matrix^T * T * R * S`, perspective camera nodes, instances with
 // world aabbs, scene aabb, first-camera lookat = aabb centre, default camera.  Textures/images/samplers
-// are counted but not decoded.  GAS/IAS building is replaced by flattening instances
+// (PNG images are decoded here, png_decode.cpp; sampler state and KHR_texture_transform are kept).  GAS/IAS building is replaced by flattening instances
 // to world-space triangles, which mipt_accel_build turns into one BVH.
+#include "png_decode.h"
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -205,7 +206,8 @@ struct View {                     // cuda/BufferView.h:33-49 on host memory
     int buffer = -1; size_t offset = 0; uint32_t count = 0; uint16_t byte_stride = 0, elmt_byte_size = 0;
     bool valid() const { return buffer >= 0; }
 };
-struct Primitive { View indices, positions, normals; int material = -1; };
+struct Primitive { View indices, positions, normals, texcoords[2], colors; int material = -1; };
+struct Texture { uint32_t address_s = 0, address_t = 0, filter = 1; int image = -1; };
 struct Mesh { std::string name; std::vector<Primitive> prims; Aabb object_aabb; };
 struct Instance { M4 transform; int mesh = -1; Aabb world_aabb; };
 struct Cam { float eye[3], lookat[3], up[3], fovY, aspect; };
@@ -219,6 +221,9 @@ struct MiptScene {
     std::vector<Instance> instances;
     std::vector<Cam> cameras;
     Aabb scene_aabb;
+    std::vector<mipt::DecodedImage> images;      // width 0: not decodable here
+    std::vector<std::string> image_errors;
+    std::vector<Texture> textures;
     uint32_t num_images = 0, num_textures = 0, num_triangles = 0;
 };
 
@@ -335,14 +340,76 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
             data.resize(want);
             sc.buffers.push_back(std::move(data));
         }
-    if (const Json* j = root.find("images")) sc.num_images = (uint32_t)j->size();
-    if (const Json* j = root.find("textures")) sc.num_textures = (uint32_t)j->size();
+    // Images -- all loaded up front (Scene.cpp:303-320).  Undecodable images are kept as empty slots.
+    if (const Json* imgs = root.find("images"))
+        for (const Json& gi : imgs->arr) {
+            std::vector<uint8_t> bytes;
+            std::string why;
+            try {
+                const std::string uri = gi.string("uri", "");
+                const int bv_idx = gi.integer("bufferView", -1);
+                if (!uri.empty()) {
+                    if (uri.compare(0, 5, "data:") == 0) {
+                        const size_t comma = uri.find(',');
+                        if (comma == std::string::npos) throw std::runtime_error("bad data URI");
+                        bytes = base64_decode(uri, comma + 1);
+                    } else bytes = read_file(dir + uri);
+                } else if (bv_idx >= 0 && (size_t)bv_idx < root.at("bufferViews").size()) {
+                    const Json& bv = root.at("bufferViews").arr[(size_t)bv_idx];
+                    const int b = bv.integer("buffer", -1);
+                    const size_t off = (size_t)bv.number("byteOffset", 0), len = (size_t)bv.number("byteLength", 0);
+                    if (b < 0 || (size_t)b >= sc.buffers.size() || off + len > sc.buffers[(size_t)b].size()) throw std::runtime_error("image bufferView out of range");
+                    bytes.assign(sc.buffers[(size_t)b].begin() + (long)off, sc.buffers[(size_t)b].begin() + (long)(off + len));
+                } else throw std::runtime_error("image without uri or bufferView");
+            } catch (const std::exception& e) { why = e.what(); }
+            mipt::DecodedImage img;
+            if (why.empty() && !mipt::decode_png(bytes.data(), bytes.size(), img, why)) img = mipt::DecodedImage();
+            sc.images.push_back(std::move(img));
+            sc.image_errors.push_back(why);
+        }
+    sc.num_images = (uint32_t)sc.images.size();
+    // Textures -- sampler state + image (Scene.cpp:325-348)
+    if (const Json* texs = root.find("textures"))
+        for (const Json& gt : texs->arr) {
+            Texture t;
+            t.image = gt.integer("source", -1);
+            const int si = gt.integer("sampler", -1);
+            const Json* samplers = root.find("samplers");
+            if (si >= 0 && samplers && (size_t)si < samplers->size()) {
+                const Json& gs = samplers->arr[(size_t)si];
+                const int ws = gs.integer("wrapS", 10497), wt = gs.integer("wrapT", 10497);
+                t.address_s = ws == 33071 ? 1u : ws == 33648 ? 2u : 0u;
+                t.address_t = wt == 33071 ? 1u : wt == 33648 ? 2u : 0u;
+                t.filter = gs.integer("minFilter", -1) == 9728 ? 0u : 1u;
+            }
+            sc.textures.push_back(t);
+        }
+    sc.num_textures = (uint32_t)sc.textures.size();
+    auto parse_texture_info = [&](const Json* ti, MiptTextureInfo& out) {                  // parseTextureInfo, Scene.cpp:214-265
+        out.texture = -1; out.texcoord = 0;
+        out.offset[0] = out.offset[1] = 0.0f; out.scale[0] = out.scale[1] = 1.0f; out.rotation[0] = 0.0f; out.rotation[1] = 1.0f;
+        if (!ti) return;
+        const int idx = ti->integer("index", -1);
+        if (idx < 0 || (size_t)idx >= sc.textures.size()) return;
+        out.texture = idx;
+        out.texcoord = ti->integer("texCoord", 0);
+        float rotation = 0.0f;
+        if (const Json* ext = ti->find("extensions")) if (const Json* tt = ext->find("KHR_texture_transform")) {
+            if (const Json* o = tt->find("offset")) if (o->size() >= 2) { out.offset[0] = (float)o->arr[0].num; out.offset[1] = (float)o->arr[1].num; }
+            if (tt->has("rotation")) rotation = (float)tt->number("rotation", 0.0);
+            if (const Json* sc2 = tt->find("scale")) if (sc2->size() >= 2) { out.scale[0] = (float)sc2->arr[0].num; out.scale[1] = (float)sc2->arr[1].num; }
+        }
+        out.rotation[0] = std::sin(rotation); out.rotation[1] = std::cos(rotation);
+        if (out.texcoord < 0 || out.texcoord >= 2) out.texcoord = 0;                       // "Maximum supported texcoords exceded"
+    };
 
     if (const Json* mats = root.find("materials"))
         for (const Json& gm : mats->arr) {
             MiptMaterialData m{};                                    // defaults of MaterialData() (cuda/MaterialData.h:44-51)
             m.base_color[0] = m.base_color[1] = m.base_color[2] = m.base_color[3] = 1.0f;
-            m.metallic = 1.0f; m.roughness = 1.0f; m.base_color_texture = -1;
+            m.metallic = 1.0f; m.roughness = 1.0f;
+            parse_texture_info(nullptr, m.base_color_tex); parse_texture_info(nullptr, m.metallic_roughness_tex);
+            parse_texture_info(gm.find("normalTexture"), m.normal_tex); parse_texture_info(gm.find("emissiveTexture"), m.emissive_tex);
             m.double_sided = gm.find("doubleSided") && gm.find("doubleSided")->b ? 1 : 0;
             const std::string am = gm.string("alphaMode", "OPAQUE");
             m.alpha_mode = am == "MASK" ? 1 : am == "BLEND" ? 2 : 0;
@@ -351,7 +418,8 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
                 if (const Json* c = pbr->find("baseColorFactor")) if (c->size() == 4) for (int k = 0; k < 4; ++k) m.base_color[k] = (float)c->arr[(size_t)k].num;
                 if (pbr->has("roughnessFactor")) m.roughness = (float)pbr->number("roughnessFactor", 1.0);
                 if (pbr->has("metallicFactor")) m.metallic = (float)pbr->number("metallicFactor", 1.0);
-                if (const Json* t = pbr->find("baseColorTexture")) m.base_color_texture = t->integer("index", -1);
+                parse_texture_info(pbr->find("baseColorTexture"), m.base_color_tex);
+                parse_texture_info(pbr->find("metallicRoughnessTexture"), m.metallic_roughness_tex);
             }
             if (const Json* e = gm.find("emissiveFactor")) if (e->size() == 3) for (int k = 0; k < 3; ++k) m.emissive_factor[k] = (float)e->arr[(size_t)k].num;
             sc.materials.push_back(m);
@@ -372,6 +440,16 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
                     p.positions = view_from_accessor(root, sc, pos_idx);
                     if (p.positions.elmt_byte_size != 4) throw std::runtime_error("glTF: POSITION must be float");
                     p.normals = view_from_accessor(root, sc, attrs.integer("NORMAL", -1));           // Scene.cpp:490-498
+                    auto float_view = [&](const char* name, const char* type) {                        // :502-531, float accessors only
+                        const int ai = attrs.integer(name, -1);
+                        if (ai < 0 || (size_t)ai >= root.at("accessors").size()) return View();
+                        const Json& acc = root.at("accessors").arr[(size_t)ai];
+                        if (acc.integer("componentType", 0) != 5126 || acc.string("type", "") != type) return View();
+                        return view_from_accessor(root, sc, ai);
+                    };
+                    p.texcoords[0] = float_view("TEXCOORD_0", "VEC2");
+                    p.texcoords[1] = float_view("TEXCOORD_1", "VEC2");
+                    p.colors = float_view("COLOR_0", "VEC4");
                     const Json& pa = root.at("accessors").arr[(size_t)pos_idx];
                     const Json* mn = pa.find("min"); const Json* mx = pa.find("max");
                     if (mn && mx && mn->size() >= 3 && mx->size() >= 3) {
@@ -398,6 +476,38 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
             sc.num_triangles += (p.indices.valid() ? p.indices.count : p.positions.count) / 3u;
 }
 
+}  // namespace
+
+namespace {
+// per-corner attribute of every flattened triangle, in mipt_scene_flatten's triangle order
+template <int N>
+int flatten_attribute(const MiptScene* sc, int which, float fill, float* out, uint8_t* present)
+{
+    if (!sc || (!out && sc->num_triangles)) return MIPT_ERROR_INVALID_VALUE;
+    size_t t_out = 0;
+    for (const Instance& in : sc->instances)
+        for (const Primitive& p : sc->meshes[(size_t)in.mesh].prims) {
+            const View& v = which < 2 ? p.texcoords[which] : p.colors;
+            const uint32_t n_tris = (p.indices.valid() ? p.indices.count : p.positions.count) / 3u;
+            for (uint32_t t = 0; t < n_tris; ++t) {
+                for (int c = 0; c < 3; ++c) {
+                    float* o = out + (t_out * 3 + (size_t)c) * N;
+                    for (int k = 0; k < N; ++k) o[k] = fill;
+                    if (!v.valid()) continue;
+                    uint32_t vi = 3u * t + (uint32_t)c;
+                    if (p.indices.valid()) {
+                        const uint8_t* ip = sc->buffers[(size_t)p.indices.buffer].data() + p.indices.offset + (size_t)vi * p.indices.byte_stride;
+                        if (p.indices.elmt_byte_size == 2) { uint16_t x; std::memcpy(&x, ip, 2); vi = x; } else { std::memcpy(&vi, ip, 4); }
+                    }
+                    if (vi >= v.count) return MIPT_ERROR_INVALID_VALUE;
+                    std::memcpy(o, sc->buffers[(size_t)v.buffer].data() + v.offset + (size_t)vi * v.byte_stride, sizeof(float) * N);
+                }
+                if (present) present[t_out] = v.valid() ? 1 : 0;
+                ++t_out;
+            }
+        }
+    return MIPT_SUCCESS;
+}
 }  // namespace
 
 extern "C" {
@@ -526,6 +636,30 @@ int mipt_scene_flatten_normals(const MiptScene* sc, float* normals4_out)
         }
     }
     return MIPT_SUCCESS;
+}
+
+int mipt_scene_texture(const MiptScene* sc, uint32_t index, MiptTextureData* out)
+{
+    if (!sc || !out || index >= sc->textures.size()) return MIPT_ERROR_INVALID_VALUE;
+    const Texture& t = sc->textures[index];
+    std::memset(out, 0, sizeof *out);
+    out->address_s = t.address_s; out->address_t = t.address_t; out->filter = t.filter; out->image = t.image;
+    if (t.image >= 0 && (size_t)t.image < sc->images.size() && sc->images[(size_t)t.image].width) {
+        const mipt::DecodedImage& im = sc->images[(size_t)t.image];
+        out->width = im.width; out->height = im.height; out->bits = im.bits; out->texels = im.rgba.data();
+    }
+    return MIPT_SUCCESS;
+}
+
+int mipt_scene_flatten_texcoords(const MiptScene* sc, uint32_t set, float* uv2_out, uint8_t* present_out)
+{
+    if (set >= 2) return MIPT_ERROR_INVALID_VALUE;
+    return flatten_attribute<2>(sc, (int)set, 0.0f, uv2_out, present_out);
+}
+
+int mipt_scene_flatten_colors(const MiptScene* sc, float* rgba4_out, uint8_t* present_out)
+{
+    return flatten_attribute<4>(sc, 2, 1.0f, rgba4_out, present_out);
 }
 
 }  // extern "C"
