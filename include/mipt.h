@@ -321,15 +321,29 @@ typedef struct MiptLight {
 } MiptLight;
 
 /* The Whitted / glTF-PBR programs of cuda/whitted.cu (__raygen__pinhole :44-97, __miss__constant_radiance :139-142,
- * __closesthit__radiance :149-289) as wavefront stages: pinhole raygen (pixel centre at subframe 0), GGX direct
- * lighting from the point / ambient lights in params->lights with one occlusion ray per point light, progressive
- * lerp + sRGB8.  Geometry comes as world-space triangles (mipt_scene_flatten / _flatten_normals): the SBT records of
- * Scene::createSBT (Scene.cpp:1368-1470) become three device arrays and a material table.  Not yet: textures, vertex
- * colours, alpha MASK / BLEND (cuda/whitted.cu:100-137, 268-286).
- * d_vertices4 / d_normals4 (nullable): 3 float4 per triangle (device); d_material_index: per triangle (device);
- * materials: host array. */
-int mipt_whitted_set_geometry(MiptContext* ctx, const void* d_vertices4, const void* d_normals4,
-                              const uint32_t* d_material_index, const MiptMaterialData* materials, uint32_t num_materials);
+ * __closesthit__radiance :149-289) as wavefront stages: pinhole raygen (pixel centre at subframe 0), LocalGeometry
+ * (cuda/LocalGeometry.h:59-176: interpolated position / normal / COLOR_0 / two texcoord sets with dpdu, dpdv),
+ * base-colour (linearised), metallic-roughness, emissive and normal textures with KHR_texture_transform
+ * (cuda/LocalShading.h:37-53), GGX direct lighting from the point / ambient lights in params->lights with one
+ * occlusion ray per point light, progressive lerp + sRGB8.  Geometry comes as world-space triangles
+ * (mipt_scene_flatten*): the SBT records of Scene::createSBT (Scene.cpp:1368-1470) become device arrays, a
+ * material table and a texture table.  Not yet: alpha MASK / BLEND (the any-hit programs and the BLEND
+ * continuation ray, cuda/whitted.cu:100-137, 268-286) -- every material renders opaque.
+ * Texture fetches use fp32 bilinear weights (the hardware's 8-bit weights are not modelled). */
+typedef struct MiptWhittedGeometry {
+    const void*     vertices4;            /* device: 3 float4 per triangle, world space */
+    const void*     normals4;             /* device, nullable: 3 float4 {normal, has_normal} per triangle */
+    const uint32_t* material_index;       /* device, nullable: per triangle; >= num_materials selects the last material */
+    const float*    texcoords[2];         /* device, nullable: 3 float2 per triangle (TEXCOORD_0 / _1) */
+    const uint8_t*  texcoord_present[2];  /* device, nullable: per triangle; NULL = present wherever texcoords is given */
+    const float*    colors4;              /* device, nullable: 3 float4 per triangle (COLOR_0) */
+    const uint8_t*  color_present;        /* device, nullable */
+} MiptWhittedGeometry;
+/* geometry arrays stay caller-owned (device); materials (host array) and textures (host array, host texels) are
+ * copied into the context.  textures may be NULL / 0. */
+int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geometry,
+                              const MiptMaterialData* materials, uint32_t num_materials,
+                              const MiptTextureData* textures, uint32_t num_textures);
 /* replaces optixLaunch( scene.pipeline(), ... ) of optixMeshViewer.cpp:283-308; params is a HOST pointer */
 int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchParams* params,
                         unsigned int width, unsigned int height, unsigned int depth);

@@ -87,6 +87,12 @@ class MiptLight(C.Structure):
                 ("falloff", C.c_int)]
 
 
+class MiptWhittedGeometry(C.Structure):
+    _fields_ = [("vertices4", C.c_void_p), ("normals4", C.c_void_p), ("material_index", C.c_void_p),
+                ("texcoords", C.c_void_p * 2), ("texcoord_present", C.c_void_p * 2), ("colors4", C.c_void_p),
+                ("color_present", C.c_void_p)]
+
+
 class MiptImguiCamera(C.Structure):
     """class Camera of SDK/imgui_test (camera.h:155-173), 92 bytes"""
     _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("ortho", C.c_uint8),
@@ -171,7 +177,8 @@ SYMBOLS = [
     ("mipt_scene_flatten_texcoords", C.c_int, [_vp, _u32, _vp, _vp]),
     ("mipt_scene_flatten_colors", C.c_int, [_vp, _vp, _vp]),
     ("mipt_save_image", C.c_int, [C.c_char_p, _vp, _u32, _u32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
-    ("mipt_whitted_set_geometry", C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(MiptMaterialData), _u32]),
+    ("mipt_whitted_set_geometry", C.c_int, [_vp, C.POINTER(MiptWhittedGeometry), C.POINTER(MiptMaterialData), _u32,
+                                            C.POINTER(MiptTextureData), _u32]),
     ("mipt_whitted_launch", C.c_int, [_vp, _vp, C.POINTER(MiptWhittedLaunchParams), C.c_uint, C.c_uint, C.c_uint]),
     ("mipt_camera_uvw", None, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp]),
     ("mipt_scene_random_triangles", C.c_int, [_u32, _u32, C.c_float, _vp]),

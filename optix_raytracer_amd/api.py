@@ -179,6 +179,14 @@ class Scene:
             raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_flatten_colors")
         return col[:n * 3], present[:n]
 
+    def texture_table(self):
+        """ctypes array of MiptTextureData whose texel pointers point into the scene (valid while it lives)"""
+        n = self.info()["num_textures"]
+        tab = (L.MiptTextureData * max(n, 1))()
+        for k in range(n):
+            self._lib.mipt_scene_texture(self._h, k, C.byref(tab[k]))
+        return tab, n
+
     def material_table(self):
         """ctypes array of MiptMaterialData: the scene's materials + one all-zero record, which is what
         Scene::createSBT gives a primitive without a material (`MaterialData()`, Scene.cpp:1423-1428)"""

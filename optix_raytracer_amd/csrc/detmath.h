@@ -41,9 +41,9 @@ MIPT_HD void det_sincos(float x, float& s, float& c)
     c = (q == 1 || q == 2) ? -b : b;
 }
 
-// x^(1/2.4), x a positive normal float.  log2 by the atanh series on the reduced mantissa,
+// x^k, x a positive normal float (k = 1/2.4 for sRGB encoding, 2.2 for whitted::linearize).  log2 by the atanh series on the reduced mantissa,
 // exp2 by a degree-7 polynomial on [-0.5, 0.5], exponent re-inserted with integer arithmetic.
-MIPT_HD float det_pow_inv24(float x)
+MIPT_HD float det_powk(float x, float k)
 {
     const uint32_t ix = f2u(x);
     int   e = (int)(ix >> 23) - 127;
@@ -59,7 +59,7 @@ MIPT_HD float det_pow_inv24(float x)
     const float hfsq = 0.5f * f * f;
     const float lnm  = f - (hfsq - s * (hfsq + R));
     const float lg2  = __builtin_fmaf(lnm, 1.44269502f, (float)e);
-    const float y    = lg2 * 0.416666657f;
+    const float y    = lg2 * k;
     const float n    = __builtin_rintf(y);
     const float g    = y - n;
     float p = __builtin_fmaf(1.52527338e-5f, g, 1.54035304e-4f);
@@ -71,6 +71,10 @@ MIPT_HD float det_pow_inv24(float x)
     p       = __builtin_fmaf(p, g, 1.0f);
     return u2f(f2u(p) + ((uint32_t)(int)n << 23));
 }
+
+MIPT_HD float det_pow_inv24(float x) { return det_powk(x, 0.416666657f); }
+// powf(c, 2.2f) of whitted::linearize (cuda/whitted_cuda.h:73-80) for texture values in [0, 1]
+MIPT_HD float det_pow22(float x) { return x < 1e-10f ? 0.0f : det_powk(x, 2.2f); }
 
 // ---- integer RNG, SDK/cuda/random.h:31-67 (tea<4>, lcg, rnd) ----
 MIPT_HD uint32_t tea4(uint32_t v0, uint32_t v1)

@@ -93,8 +93,17 @@ void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result,
 void imgui_run(hipStream_t st, const MiptImguiParams& p, uint32_t n_paths, const DeviceBvh& bvh, PathQueue q, float4* hits,
                ShadowQueue sh, uint32_t* occluded, float4* result, uint32_t* rg_seed, DeviceCounters* ctr, const TraceOpts& opts);
 // SDK/cuda/whitted.cu pipeline (whitted_kernels.hip)
-void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_paths, const DeviceBvh& bvh, const float4* vertices4,
-                 const float4* normals4, const uint32_t* material_index, const MiptMaterialData* d_materials, uint32_t n_materials,
+struct WhGeometry {                // MiptWhittedGeometry with typed pointers
+    const float4* vertices4; const float4* normals4; const uint32_t* material_index;
+    const float2* texcoords[2]; const uint8_t* texcoord_present[2];
+    const float4* colors4; const uint8_t* color_present;
+};
+struct WhTexture {                 // MiptTextureData with the texels in device memory
+    uint32_t width, height, bits, address_s, address_t, filter;
+    const void* texels;
+};
+void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_paths, const DeviceBvh& bvh, const WhGeometry& geo,
+                 const MiptMaterialData* d_materials, uint32_t n_materials, const WhTexture* d_textures, uint32_t n_textures,
                  PathQueue q, float4* hits, ShadowQueue sh, uint32_t* occluded, float4* result, DeviceCounters* ctr, const TraceOpts& opts);
 void launch_unpermute(hipStream_t st, const float4* gathered, uint32_t world, uint32_t width, uint32_t height,
                       float4* accum, uint32_t* frame);

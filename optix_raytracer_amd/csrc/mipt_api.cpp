@@ -81,11 +81,12 @@ struct MiptContext {
     int      persistent = 3;
     int      tail_pct = 200, pool_low = 16, pool_chunk = 16;
     // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
-    const float4*     wh_vertices = nullptr;
-    const float4*     wh_normals = nullptr;
-    const uint32_t*   wh_material_index = nullptr;
+    WhGeometry        wh_geo{};
     MiptMaterialData* d_wh_materials = nullptr;
     uint32_t          n_wh_materials = 0;
+    WhTexture*        d_wh_textures = nullptr;          // descriptor table on the device
+    std::vector<void*> wh_texels;                       // device copies of the texel arrays
+    uint32_t          n_wh_textures = 0;
     // SDK/imgui_test and whitted launches: K occlusion rays per primary hit
     ShadowQueue im_sq{};
     uint32_t*   im_flags = nullptr;
@@ -427,6 +428,8 @@ int mipt_context_destroy(MiptContext* c)
     if (c->im_sq.contrib) (void)hipFree(c->im_sq.contrib);
     if (c->im_flags) (void)hipFree(c->im_flags);
     if (c->d_wh_materials) (void)hipFree(c->d_wh_materials);
+    if (c->d_wh_textures) (void)hipFree(c->d_wh_textures);
+    for (void* t : c->wh_texels) if (t) (void)hipFree(t);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     delete c;
@@ -842,18 +845,50 @@ static int ensure_group_capacity(MiptContext* ctx, size_t need)
     return MIPT_SUCCESS;
 }
 
-int mipt_whitted_set_geometry(MiptContext* ctx, const void* d_vertices4, const void* d_normals4, const uint32_t* d_material_index,
-                              const MiptMaterialData* materials, uint32_t num_materials)
+int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geo, const MiptMaterialData* materials, uint32_t num_materials,
+                              const MiptTextureData* textures, uint32_t num_textures)
 {
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
-    if (!d_vertices4 || !materials || num_materials == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry: vertices and >= 1 material required");
+    if (!geo || !geo->vertices4 || !materials || num_materials == 0)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry: vertices and >= 1 material required");
+    if (num_textures && !textures) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry: num_textures without textures");
+    for (uint32_t i = 0; i < num_textures; ++i)
+        if (textures[i].texels && textures[i].width && textures[i].bits != 8 && textures[i].bits != 16)
+            return ctx->fail(MIPT_ERROR_INVALID_VALUE, "texture %u: %u bits per component (8 or 16 supported, Scene.cpp:587-600)", i, textures[i].bits);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());
     if (ctx->d_wh_materials) { (void)hipFree(ctx->d_wh_materials); ctx->d_wh_materials = nullptr; }
+    if (ctx->d_wh_textures) { (void)hipFree(ctx->d_wh_textures); ctx->d_wh_textures = nullptr; }
+    for (void* t : ctx->wh_texels) if (t) (void)hipFree(t);
+    ctx->wh_texels.clear(); ctx->n_wh_textures = 0;
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_materials, (size_t)num_materials * sizeof(MiptMaterialData)));
     HIPCHK(ctx, hipMemcpy(ctx->d_wh_materials, materials, (size_t)num_materials * sizeof(MiptMaterialData), hipMemcpyHostToDevice));
     ctx->n_wh_materials = num_materials;
-    ctx->wh_vertices = (const float4*)d_vertices4; ctx->wh_normals = (const float4*)d_normals4; ctx->wh_material_index = d_material_index;
+    if (num_textures) {
+        std::vector<WhTexture> table(num_textures);
+        for (uint32_t i = 0; i < num_textures; ++i) {
+            const MiptTextureData& t = textures[i];
+            WhTexture& d = table[i];
+            d = WhTexture{};
+            d.address_s = t.address_s; d.address_t = t.address_t; d.filter = t.filter;
+            void* dev = nullptr;
+            if (t.texels && t.width && t.height) {
+                const size_t bytes = (size_t)t.width * t.height * 4u * (t.bits / 8u);
+                HIPCHK(ctx, hipMalloc(&dev, bytes));
+                ctx->wh_texels.push_back(dev);
+                HIPCHK(ctx, hipMemcpy(dev, t.texels, bytes, hipMemcpyHostToDevice));
+                d.width = t.width; d.height = t.height; d.bits = t.bits; d.texels = dev;
+            }
+        }
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_textures, (size_t)num_textures * sizeof(WhTexture)));
+        HIPCHK(ctx, hipMemcpy(ctx->d_wh_textures, table.data(), (size_t)num_textures * sizeof(WhTexture), hipMemcpyHostToDevice));
+        ctx->n_wh_textures = num_textures;
+    }
+    WhGeometry g{};
+    g.vertices4 = (const float4*)geo->vertices4; g.normals4 = (const float4*)geo->normals4; g.material_index = geo->material_index;
+    for (int j = 0; j < 2; ++j) { g.texcoords[j] = (const float2*)geo->texcoords[j]; g.texcoord_present[j] = geo->texcoord_present[j]; }
+    g.colors4 = (const float4*)geo->colors4; g.color_present = geo->color_present;
+    ctx->wh_geo = g;
     return MIPT_SUCCESS;
 }
 
@@ -867,7 +902,7 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     if (p->lights.count > 31 || (p->lights.count && !p->lights.data)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0..31 lights supported");
     if (p->lights.count && p->lights.byte_stride != 0 && p->lights.byte_stride != sizeof(MiptLight))
         return ctx->fail(MIPT_ERROR_INVALID_VALUE, "lights must be tightly packed (BufferView stride %u)", (unsigned)p->lights.byte_stride);
-    if (!ctx->wh_vertices || !ctx->d_wh_materials) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "mipt_whitted_set_geometry was not called");
+    if (!ctx->wh_geo.vertices4 || !ctx->d_wh_materials) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "mipt_whitted_set_geometry was not called");
     Accel* acc = find_accel(ctx, p->handle);
     if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -879,8 +914,8 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
-    whitted_run(st, *p, n_paths, device_bvh(acc), ctx->wh_vertices, ctx->wh_normals, ctx->wh_material_index, ctx->d_wh_materials,
-                ctx->n_wh_materials, ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->d_ctr, trace_opts(ctx));
+    whitted_run(st, *p, n_paths, device_bvh(acc), ctx->wh_geo, ctx->d_wh_materials, ctx->n_wh_materials, ctx->d_wh_textures,
+                ctx->n_wh_textures, ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->d_ctr, trace_opts(ctx));
     ctx->last_bounces = 1;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;

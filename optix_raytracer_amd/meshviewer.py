@@ -33,6 +33,11 @@ class MeshViewerState:
         self.d_vertices = None       # (n*3, 4) f32 world-space triangle soup
         self.d_normals = None        # (n*3, 4) f32 or None
         self.d_material_index = None
+        self.d_texcoords = [None, None]   # (n*3, 2) f32 per TEXCOORD set
+        self.d_texcoord_present = [None, None]
+        self.d_colors = None         # (n*3, 4) f32 COLOR_0
+        self.d_color_present = None
+        self.textures = None         # (ctypes MiptTextureData array, count): texels live in the api.Scene
         self.materials = None        # ctypes array, host
         self.d_lights = None         # uint8 tensor holding MiptLight records
         self.lights = None           # host copy (ctypes array)
@@ -58,13 +63,28 @@ def loadScene(state, filename, device_index=0, log=None, log_level=0):
     state.d_vertices = torch.from_numpy(np.ascontiguousarray(verts)).to(state.device)
     state.d_normals = torch.from_numpy(np.ascontiguousarray(normals)).to(state.device) if np.any(normals[:, 3] != 0) else None
     state.d_material_index = torch.from_numpy(mat.astype(np.int32)).to(state.device)
+    for j in range(2):
+        uv, has = state.scene.flatten_texcoords(j)
+        if has.any():
+            state.d_texcoords[j] = torch.from_numpy(np.ascontiguousarray(uv)).to(state.device)
+            state.d_texcoord_present[j] = torch.from_numpy(np.ascontiguousarray(has)).to(state.device)
+    col, has = state.scene.flatten_colors()
+    if has.any():
+        state.d_colors = torch.from_numpy(np.ascontiguousarray(col)).to(state.device)
+        state.d_color_present = torch.from_numpy(np.ascontiguousarray(has)).to(state.device)
     state.handle = state.context.accel_build([{
         "vertices": state.d_vertices.data_ptr(), "num_vertices": verts.shape[0], "stride": 16,
     }])
     state.materials = state.scene.material_table()
+    state.textures = state.scene.texture_table()
+    ptr = lambda t: t.data_ptr() if t is not None else None            # noqa: E731
+    geo = L.MiptWhittedGeometry()
+    geo.vertices4, geo.normals4, geo.material_index = ptr(state.d_vertices), ptr(state.d_normals), ptr(state.d_material_index)
+    geo.texcoords = (C.c_void_p * 2)(ptr(state.d_texcoords[0]), ptr(state.d_texcoords[1]))
+    geo.texcoord_present = (C.c_void_p * 2)(ptr(state.d_texcoord_present[0]), ptr(state.d_texcoord_present[1]))
+    geo.colors4, geo.color_present = ptr(state.d_colors), ptr(state.d_color_present)
     state.context._check(state.context._lib.mipt_whitted_set_geometry(
-        state.context._h, state.d_vertices.data_ptr(), state.d_normals.data_ptr() if state.d_normals is not None else None,
-        state.d_material_index.data_ptr(), state.materials, len(state.materials)))
+        state.context._h, C.byref(geo), state.materials, len(state.materials), state.textures[0], state.textures[1]))
 
 
 def initCameraState(state):
@@ -157,6 +177,7 @@ def cleanup(state):
         state.context.destroy()
         state.context = None
     state.d_vertices = state.d_normals = state.d_material_index = state.d_lights = state.accum = None
+    state.d_texcoords = [None, None]; state.d_texcoord_present = [None, None]; state.d_colors = state.d_color_present = None
 
 
 def render(filename, width, height, subframes=1, lights=None, device_index=0):

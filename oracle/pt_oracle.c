@@ -126,9 +126,9 @@ void orc_det_sincos(float x, float* s_out, float* c_out)
     }
 }
 
-/* x^(1/2.4) for normal positive x <= ~2; log2 via fdlibm-style series, exp2 via
+/* x^k (k = 1/2.4, 2.2) for normal positive x <= ~2; log2 via fdlibm-style series, exp2 via
  * degree-7 polynomial.  ~2 ulp. */
-float orc_det_pow_inv24(float x)
+static float det_powk(float x, float k)
 {
     uint32_t ix = f2u(x);
     int      e  = (int)(ix >> 23) - 127;
@@ -144,7 +144,7 @@ float orc_det_pow_inv24(float x)
     float hfsq = 0.5f * f * f;
     float lnm  = f - (hfsq - s * (hfsq + R));
     float lg2  = fmaf(lnm, 1.44269502f, (float)e);
-    float y    = lg2 * 0.416666657f;
+    float y    = lg2 * k;
     float n    = rintf(y);
     float g    = y - n;
     float p    = fmaf(1.52527338e-5f, g, 1.54035304e-4f);
@@ -156,6 +156,10 @@ float orc_det_pow_inv24(float x)
     p          = fmaf(p, g, 1.0f);
     return u2f(f2u(p) + ((uint32_t)(int)n << 23));
 }
+
+float orc_det_pow_inv24(float x) { return det_powk(x, 0.416666657f); }
+/* powf(c, 2.2f) of whitted::linearize (cuda/whitted_cuda.h:73-80), texture values in [0, 1] */
+float orc_det_pow22(float x) { return x < 1e-10f ? 0.0f : det_powk(x, 2.2f); }
 
 /* ------------------------------------------------------------------------- */
 /* Camera -- SDK/sutil/Camera.cpp:34-46 (fod = author's m_fod, Camera.h:64,75) */
@@ -1094,37 +1098,144 @@ static float w_ggx(float NdH, float alpha)
     return a2 / (3.14159265358979323846f * x * x);
 }
 
-/* __closesthit__radiance, cuda/whitted.cu:149-289, with getLocalGeometry (cuda/LocalGeometry.h:59-127) on
- * world-space vertices */
-static v3 whitted_closesthit(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 ray_o, v3 ray_d, const HitRec* h, OrcStats* st)
+/* ---- texture fetch: what tex2D<float4> does for the objects of Scene::addSampler (Scene.cpp:624-652) ---- */
+static int wrap_index(int i, int n, uint32_t mode)
 {
-    (void)ray_o;                                         /* geom.P is interpolated, not origin + t * direction */
+    if (mode == 1u) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+    if (mode == 2u) { int p = i % (2 * n); if (p < 0) p += 2 * n; return p < n ? p : 2 * n - 1 - p; }
+    int p = i % n; return p < 0 ? p + n : p;
+}
+static void fetch_texel(const OrcTextureW* t, int x, int y, float o[4])
+{
+    size_t at = ((size_t)y * t->width + (size_t)x) * 4;
+    if (t->bits == 16) { const uint16_t* p = (const uint16_t*)t->texels + at; for (int k = 0; k < 4; ++k) o[k] = (float)p[k] / 65535.0f; }
+    else               { const uint8_t*  p = (const uint8_t*)t->texels + at;  for (int k = 0; k < 4; ++k) o[k] = (float)p[k] / 255.0f; }
+}
+void orc_sample_texture(const OrcTextureW* t, float u, float v, float out[4])
+{
+    const int W = (int)t->width, H = (int)t->height;
+    if (t->filter == 0u) {
+        int x = wrap_index((int)floorf(u * (float)W), W, t->address_s), y = wrap_index((int)floorf(v * (float)H), H, t->address_t);
+        fetch_texel(t, x, y, out);
+        return;
+    }
+    float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float a = fx - x0f, b = fy - y0f;
+    int x0 = wrap_index((int)x0f, W, t->address_s), x1 = wrap_index((int)x0f + 1, W, t->address_s);
+    int y0 = wrap_index((int)y0f, H, t->address_t), y1 = wrap_index((int)y0f + 1, H, t->address_t);
+    float t00[4], t10[4], t01[4], t11[4];
+    fetch_texel(t, x0, y0, t00); fetch_texel(t, x1, y0, t10); fetch_texel(t, x0, y1, t01); fetch_texel(t, x1, y1, t11);
+    for (int k = 0; k < 4; ++k) {
+        float top = t00[k] + a * (t10[k] - t00[k]);
+        float bot = t01[k] + a * (t11[k] - t01[k]);
+        out[k] = top + b * (bot - top);
+    }
+}
+
+typedef struct { float u, v; v3 dpdu, dpdv; } TexcoordW;
+typedef struct { v3 P, N, Ng; TexcoordW tc[2]; float color[4]; } LocalGeomW;
+
+/* getLocalGeometry (cuda/LocalGeometry.h:59-176) on world-space triangles.  dpdu / dpdv come from the world-space
+ * corners (the reference takes object-space ones even under an instance transform). */
+static void local_geometry(const OrcScene* s, const OrcWhittedFrame* f, const HitRec* h, LocalGeomW* g)
+{
     const float* vb = s->verts + (size_t)h->prim * 12;
     v3 P0 = v3_ld(vb), P1 = v3_ld(vb + 4), P2 = v3_ld(vb + 8);
     float b0 = 1.0f - h->u - h->v;
-    v3 P = v3_add(v3_add(v3_scale(P0, b0), v3_scale(P1, h->u)), v3_scale(P2, h->v));
-    v3 Ng = v3_normalize(v3_cross(v3_sub(P1, P0), v3_sub(P2, P0)));
-    v3 N = Ng;
+    g->P = v3_add(v3_add(v3_scale(P0, b0), v3_scale(P1, h->u)), v3_scale(P2, h->v));
+    for (int k = 0; k < 4; ++k) g->color[k] = 1.0f;
+    if (f->colors4 && (!f->color_present || f->color_present[h->prim])) {
+        const float* c = f->colors4 + (size_t)h->prim * 12;
+        for (int k = 0; k < 4; ++k) g->color[k] = (b0 * c[k] + h->u * c[4 + k]) + h->v * c[8 + k];
+    }
+    g->Ng = v3_normalize(v3_cross(v3_sub(P1, P0), v3_sub(P2, P0)));
+    g->N = g->Ng;
     if (f->normals4) {
         const float* nb = f->normals4 + (size_t)h->prim * 12;
         if (nb[3] != 0.0f) {
             v3 n = v3_add(v3_add(v3_scale(v3_ld(nb), b0), v3_scale(v3_ld(nb + 4), h->u)), v3_scale(v3_ld(nb + 8), h->v));
-            N = v3_normalize(n);
+            g->N = v3_normalize(n);
         }
     }
+    v3 dp1 = v3_sub(P0, P2), dp2 = v3_sub(P1, P2);
+    for (int j = 0; j < 2; ++j) {
+        TexcoordW* tc = &g->tc[j];
+        if (f->texcoords[j] && (!f->texcoord_present[j] || f->texcoord_present[j][h->prim])) {
+            const float* uv = f->texcoords[j] + (size_t)h->prim * 6;
+            tc->u = (b0 * uv[0] + h->u * uv[2]) + h->v * uv[4];
+            tc->v = (b0 * uv[1] + h->u * uv[3]) + h->v * uv[5];
+            float du1 = uv[0] - uv[4], du2 = uv[2] - uv[4], dv1 = uv[1] - uv[5], dv2 = uv[3] - uv[5];
+            float det = du1 * dv2 - dv1 * du2;
+            float invdet = 1.0f / det;
+            tc->dpdu = v3_scale(v3_sub(v3_scale(dp1, dv2), v3_scale(dp2, dv1)), invdet);
+            tc->dpdv = v3_scale(v3_add(v3_scale(dp1, -du2), v3_scale(dp2, du1)), invdet);
+        } else {
+            tc->u = h->u; tc->v = h->v;                                  /* UV = barys */
+            tc->dpdu = v3_make(-dp1.x, -dp1.y, -dp1.z);
+            tc->dpdv = v3_add(v3_make(-dp1.x, -dp1.y, -dp1.z), dp2);
+        }
+    }
+}
+
+/* sampleTexture<float4> (cuda/LocalShading.h:37-53); returns 0 when the material has no such texture (or its
+ * image could not be decoded), 1 + the sample otherwise */
+static int sample_material_texture(const OrcWhittedFrame* f, const OrcTexInfoW* ti, const LocalGeomW* g, float out[4])
+{
+    if (ti->texture < 0 || (uint32_t)ti->texture >= f->ntextures) return 0;
+    const OrcTextureW* t = &f->textures[ti->texture];
+    if (t->width == 0 || !t->texels) return 0;
+    const TexcoordW* tc = &g->tc[ti->texcoord == 1 ? 1 : 0];
+    float ux = tc->u * ti->scale[0], uy = tc->v * ti->scale[1];
+    float tu = (ux * ti->rotation[1] + uy * ti->rotation[0]) + ti->offset[0];
+    float tv = (ux * -ti->rotation[0] + uy * ti->rotation[1]) + ti->offset[1];
+    orc_sample_texture(t, tu, tv, out);
+    return 1;
+}
+
+/* __closesthit__radiance, cuda/whitted.cu:149-289 (alpha modes are not applied yet: every material is opaque) */
+static v3 whitted_closesthit(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 ray_o, v3 ray_d, const HitRec* h, OrcStats* st)
+{
+    (void)ray_o;                                         /* geom.P is interpolated, not origin + t * direction */
+    LocalGeomW g;
+    local_geometry(s, f, h, &g);
     uint32_t mi = f->material_index ? f->material_index[h->prim] : 0u;
     if (mi >= f->nmaterials) mi = f->nmaterials - 1u;
     const OrcMaterialW* m = &f->materials[mi];
-    v3 base = v3_make(m->base_color[0], m->base_color[1], m->base_color[2]);      /* geom.color = 1: no COLOR_0 yet */
-    float metallic = m->metallic * 1.0f, roughness = m->roughness * 1.0f;       /* mr_tex = 1 */
+    float bc[4];
+    for (int k = 0; k < 4; ++k) bc[k] = m->base_color[k] * g.color[k];
+    float tx[4];
+    if (sample_material_texture(f, &m->base_color_tex, &g, tx)) {
+        bc[0] *= orc_det_pow22(tx[0]); bc[1] *= orc_det_pow22(tx[1]); bc[2] *= orc_det_pow22(tx[2]);   /* linearize, not the alpha */
+        bc[3] *= tx[3];
+    }
+    v3 base = v3_make(bc[0], bc[1], bc[2]);
+    float metallic = m->metallic, roughness = m->roughness;
+    float mr[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+    sample_material_texture(f, &m->metallic_roughness_tex, &g, mr);          /* (occlusion, roughness, metallic) */
+    roughness *= mr[1];
+    metallic *= mr[2];
     const float F0 = 0.04f;
     v3 diff_color = v3_scale(v3_scale(base, 1.0f - F0), 1.0f - metallic);
     v3 f0v = v3_make(F0, F0, F0);
     v3 spec_color = v3_add(f0v, v3_scale(v3_sub(base, f0v), metallic));           /* lerp, vec_math.h:500 */
     float alpha = roughness * roughness;
     v3 result = v3_make(0.0f, 0.0f, 0.0f);
-    result = v3_add(result, v3_mul(v3_ld(m->emissive_factor), v3_make(1.0f, 1.0f, 1.0f)));
+    float em[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+    sample_material_texture(f, &m->emissive_tex, &g, em);
+    result = v3_add(result, v3_mul(v3_ld(m->emissive_factor), v3_make(em[0], em[1], em[2])));
+    v3 N = g.N;
+    float nt[4];
+    if (sample_material_texture(f, &m->normal_tex, &g, nt)) {
+        float nx = 2.0f * nt[0] - 1.0f, ny = 2.0f * nt[1] - 1.0f, nz = 2.0f * nt[2] - 1.0f;
+        const float* rot = m->normal_tex.rotation;
+        float tx_ = nx * rot[1] + ny * -rot[0];
+        float ty_ = nx * rot[0] + ny * rot[1];
+        const TexcoordW* tc = &g.tc[m->normal_tex.texcoord == 1 ? 1 : 0];
+        N = v3_normalize(v3_add(v3_add(v3_scale(v3_normalize(tc->dpdu), tx_), v3_scale(v3_normalize(tc->dpdv), ty_)), v3_scale(g.N, nz)));
+    }
     if (v3_dot(N, ray_d) > 0.0f) N = v3_make(-N.x, -N.y, -N.z);
+    const v3 P = g.P;
     for (uint32_t i = 0; i < f->nlights; ++i) {
         const OrcLightW* l = &f->lights[i];
         if (l->type == 0) {

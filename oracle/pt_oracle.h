@@ -69,6 +69,7 @@ void     orc_make_color(const float c[3], uint8_t out[4]);
 void     orc_vec_kat(const float a[3], const float b[3], float t, float out[17]);
 void     orc_det_sincos(float x, float* s, float* c);
 float    orc_det_pow_inv24(float x);
+float    orc_det_pow22(float x);
 void     orc_cosine_sample_hemisphere(float u1, float u2, float p[3]);
 void     orc_onb_inverse_transform(const float n[3], float p[3]);
 void     orc_work_pixel(int width, int height, int num_gpus, int gpu, int sample_idx, int* px, int* py);
@@ -148,9 +149,25 @@ typedef struct OrcLightW {            /* struct Light, cuda/Light.h:33-71 (36 by
     int32_t falloff;
 } OrcLightW;
 
-typedef struct OrcMaterialW {         /* the MaterialData factors used (cuda/MaterialData.h) */
-    float base_color[4], metallic, roughness, emissive_factor[3];
+typedef struct OrcTexInfoW {           /* MaterialData::Texture (cuda/MaterialData.h:60-72); texture < 0: none */
+    int32_t texture, texcoord;
+    float   offset[2], rotation[2] /* sin, cos */, scale[2];
+} OrcTexInfoW;
+
+typedef struct OrcMaterialW {         /* MaterialData, PBR branch (cuda/MaterialData.h) */
+    float   base_color[4], metallic, roughness, emissive_factor[3];
+    float   alpha_cutoff;
+    int32_t alpha_mode, double_sided;
+    OrcTexInfoW base_color_tex, metallic_roughness_tex, normal_tex, emissive_tex;
 } OrcMaterialW;
+
+typedef struct OrcTextureW {          /* cudaTextureObject state of Scene::addSampler (Scene.cpp:624-652) + texels */
+    uint32_t width, height, bits;     /* RGBA, 8 or 16 bits per component, row 0 = top; width 0: undecodable image */
+    uint32_t address_s, address_t;    /* 0 wrap, 1 clamp, 2 mirror */
+    uint32_t filter;                  /* 0 point, 1 linear */
+    int32_t  image;
+    const void* texels;
+} OrcTextureW;
 
 typedef struct OrcWhittedFrame {      /* whitted::LaunchParams (cuda/whitted.h:59-77) + the scene arrays */
     uint32_t width, height, subframe_index;
@@ -162,7 +179,16 @@ typedef struct OrcWhittedFrame {      /* whitted::LaunchParams (cuda/whitted.h:5
     const float*        normals4;     /* 3 float4 per triangle {world normal, has_normal} or NULL */
     const uint32_t*     material_index;
     const OrcMaterialW* materials; uint32_t nmaterials;
+    const float*        texcoords[2];        /* 3 float2 per triangle or NULL */
+    const uint8_t*      texcoord_present[2]; /* per triangle or NULL (= present wherever texcoords is given) */
+    const float*        colors4;             /* 3 float4 per triangle or NULL */
+    const uint8_t*      color_present;
+    const OrcTextureW*  textures; uint32_t ntextures;
 } OrcWhittedFrame;
+
+/* tex2D<float4> of a texture object created by Scene::addSampler: normalised coordinates, normalised-float read,
+ * point or bilinear filter (fp32 weights; the hardware's 8-bit weights are not modelled) */
+void orc_sample_texture(const OrcTextureW* t, float u, float v, float out[4]);
 
 int orc_whitted_render_rows(const OrcScene*, int mode, const OrcWhittedFrame* f, uint32_t y0, uint32_t y1, OrcStats* stats);
 

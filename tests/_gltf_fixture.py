@@ -181,3 +181,100 @@ def write(tmpdir, n_grid=6):
     expect = {"normals": normals, "vertices": np.asarray(tris, f32), "mat_index": np.asarray(mats, np.uint32), "eye": eye, "up": up,
               "fovY": f32(f32(0.7) * f32(180.0) / f32(np.pi)), "aspect": f32(1.25), "n_instances": 3, "n_meshes": 2}
     return gltf, glb, expect
+
+
+def write_textured(tmpdir, seed=3):
+    """A small scene that exercises the textured Whitted path: TEXCOORD_0/1, COLOR_0, base-colour / metallic-roughness /
+    normal / emissive textures, KHR_texture_transform, wrap / clamp / mirror / nearest samplers, an 8-bit RGBA, a palette
+    and a 16-bit PNG.  Returns the .gltf path."""
+    import _png_fixture as PF
+    rng = np.random.default_rng(seed)
+    # ---- images
+    yy, xx = np.mgrid[0:16, 0:16]
+    checker = np.zeros((16, 16, 4), int)
+    checker[..., 0] = np.where((xx // 4 + yy // 4) % 2, 230, 40)
+    checker[..., 1] = xx * 16
+    checker[..., 2] = yy * 16
+    checker[..., 3] = 255
+    png_rgba, _ = PF.encode(checker, 6, 8)
+    pal = rng.integers(30, 256, (8, 3))
+    png_pal, _ = PF.encode(rng.integers(0, 8, (5, 7, 1)), 3, 4, palette=pal)
+    nm = np.zeros((8, 8, 3), int)
+    nm[..., 0] = 32768 + (20000 * np.sin(xx[:8, :8] * 0.9)).astype(int)
+    nm[..., 1] = 32768 + (20000 * np.cos(yy[:8, :8] * 0.7)).astype(int)
+    nm[..., 2] = 60000
+    png_nm16, _ = PF.encode(nm, 2, 16)
+    mr = np.zeros((4, 4, 3), int)
+    mr[..., 1] = rng.integers(60, 256, (4, 4))
+    mr[..., 2] = rng.integers(0, 256, (4, 4))
+    png_mr, _ = PF.encode(mr, 2, 8)
+    (tmpdir / "nm16.png").write_bytes(png_nm16)
+    uri = lambda b: "data:image/png;base64," + base64.b64encode(b).decode()          # noqa: E731
+    # ---- geometry: a ground grid (uv0 + uv1), a tilted quad with vertex colours, a small emissive quad
+    g = 5
+    gx, gz = np.meshgrid(np.linspace(-2, 2, g), np.linspace(-2, 2, g))
+    pos0 = np.stack([gx.ravel(), 0.1 * np.sin(gx.ravel() * 2) * np.cos(gz.ravel()), gz.ravel()], 1).astype(f32)
+    uv0 = np.stack([(gx.ravel() + 2) / 4 * 2.5 - 0.3, (gz.ravel() + 2) / 4 * 1.7 + 0.2], 1).astype(f32)      # beyond [0,1]: wrap modes matter
+    uv1 = np.stack([(gz.ravel() + 2) / 4, (gx.ravel() + 2) / 4], 1).astype(f32)
+    nrm0 = np.tile(np.asarray([0, 1, 0], f32), (g * g, 1))
+    idx0 = []
+    for j in range(g - 1):
+        for i in range(g - 1):
+            a = j * g + i
+            idx0 += [a, a + g, a + 1, a + 1, a + g, a + g + 1]
+    idx0 = np.asarray(idx0, np.uint16)
+    pos1 = np.asarray([[-1, 0.3, -1], [-1, 1.6, -1.3], [0.6, 0.3, -1.2], [0.6, 0.3, -1.2], [-1, 1.6, -1.3], [0.6, 1.7, -1.5]], f32)
+    col1 = rng.uniform(0.2, 1.0, (6, 4)).astype(f32)
+    pos2 = np.asarray([[0.8, 0.5, 0.2], [1.6, 0.5, 0.2], [0.8, 1.3, 0.0], [1.6, 0.5, 0.2], [1.6, 1.3, 0.0], [0.8, 1.3, 0.0]], f32)
+    uv2 = np.asarray([[0, 1], [1, 1], [0, 0], [1, 1], [1, 0], [0, 0]], f32)
+    parts = [pos0, uv0, uv1, nrm0, idx0, pos1, col1, pos2, uv2]
+    offs, blob = [], b""
+    for p in parts:
+        blob += b"\0" * (-len(blob) % 4)
+        offs.append(len(blob))
+        blob += p.tobytes()
+    views = [{"buffer": 0, "byteOffset": o, "byteLength": p.nbytes} for o, p in zip(offs, parts)]
+
+    def mm(a):
+        return [float(x) for x in a.min(0)], [float(x) for x in a.max(0)]
+    acc = [
+        {"bufferView": 0, "componentType": 5126, "count": g * g, "type": "VEC3", "min": mm(pos0)[0], "max": mm(pos0)[1]},
+        {"bufferView": 1, "componentType": 5126, "count": g * g, "type": "VEC2"},
+        {"bufferView": 2, "componentType": 5126, "count": g * g, "type": "VEC2"},
+        {"bufferView": 3, "componentType": 5126, "count": g * g, "type": "VEC3"},
+        {"bufferView": 4, "componentType": 5123, "count": int(idx0.size), "type": "SCALAR"},
+        {"bufferView": 5, "componentType": 5126, "count": 6, "type": "VEC3", "min": mm(pos1)[0], "max": mm(pos1)[1]},
+        {"bufferView": 6, "componentType": 5126, "count": 6, "type": "VEC4"},
+        {"bufferView": 7, "componentType": 5126, "count": 6, "type": "VEC3", "min": mm(pos2)[0], "max": mm(pos2)[1]},
+        {"bufferView": 8, "componentType": 5126, "count": 6, "type": "VEC2"},
+    ]
+    doc = {
+        "asset": {"version": "2.0"},
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+        "bufferViews": views, "accessors": acc,
+        "images": [{"uri": uri(png_rgba)}, {"uri": uri(png_pal)}, {"uri": "nm16.png"}, {"uri": uri(png_mr)}],
+        "samplers": [{"wrapS": 10497, "wrapT": 33648}, {"wrapS": 33071, "wrapT": 33071, "minFilter": 9728}, {}],
+        "textures": [{"source": 0, "sampler": 0}, {"source": 1, "sampler": 1}, {"source": 2, "sampler": 2}, {"source": 3}, {"source": 0}],
+        "materials": [
+            {"name": "ground", "pbrMetallicRoughness": {
+                "baseColorFactor": [0.9, 0.8, 0.7, 1.0], "metallicFactor": 0.9, "roughnessFactor": 0.8,
+                "baseColorTexture": {"index": 0, "extensions": {"KHR_texture_transform": {"offset": [0.1, 0.05], "rotation": 0.4, "scale": [1.5, 0.75]}}},
+                "metallicRoughnessTexture": {"index": 3, "texCoord": 1}},
+             "normalTexture": {"index": 2, "texCoord": 1, "extensions": {"KHR_texture_transform": {"rotation": -0.7}}}},
+            {"name": "painted", "pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1], "metallicFactor": 0.1, "roughnessFactor": 0.6}},
+            {"name": "lamp", "pbrMetallicRoughness": {"baseColorTexture": {"index": 1}, "metallicFactor": 0.0, "roughnessFactor": 0.5},
+             "emissiveFactor": [0.6, 0.5, 0.4], "emissiveTexture": {"index": 4}},
+        ],
+        "meshes": [
+            {"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1, "TEXCOORD_1": 2, "NORMAL": 3}, "indices": 4, "material": 0}]},
+            {"primitives": [{"attributes": {"POSITION": 5, "COLOR_0": 6}, "material": 1},
+                            {"attributes": {"POSITION": 7, "TEXCOORD_0": 8}, "material": 2}]},
+        ],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 0.8, "aspectRatio": 1.5, "znear": 0.1}}],
+        "nodes": [{"mesh": 0}, {"mesh": 1, "rotation": [0.0, 0.2588190451, 0.0, 0.9659258263], "translation": [0.1, 0.0, 0.3]},
+                  {"camera": 0, "translation": [0.4, 2.2, 4.5], "rotation": [-0.1736481777, 0.0, 0.0, 0.984807753]}],
+        "scenes": [{"nodes": [0, 1, 2]}], "scene": 0,
+    }
+    path = tmpdir / "textured.gltf"
+    path.write_text(json.dumps(doc))
+    return path

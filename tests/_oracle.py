@@ -42,9 +42,21 @@ class OrcLightW(C.Structure):
                 ("falloff", C.c_int32)]
 
 
+class OrcTexInfoW(C.Structure):
+    _fields_ = [("texture", C.c_int32), ("texcoord", C.c_int32), ("offset", C.c_float * 2), ("rotation", C.c_float * 2),
+                ("scale", C.c_float * 2)]
+
+
 class OrcMaterialW(C.Structure):
     _fields_ = [("base_color", C.c_float * 4), ("metallic", C.c_float), ("roughness", C.c_float),
-                ("emissive_factor", C.c_float * 3)]
+                ("emissive_factor", C.c_float * 3), ("alpha_cutoff", C.c_float), ("alpha_mode", C.c_int32),
+                ("double_sided", C.c_int32), ("base_color_tex", OrcTexInfoW), ("metallic_roughness_tex", OrcTexInfoW),
+                ("normal_tex", OrcTexInfoW), ("emissive_tex", OrcTexInfoW)]
+
+
+class OrcTextureW(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("bits", C.c_uint32), ("address_s", C.c_uint32),
+                ("address_t", C.c_uint32), ("filter", C.c_uint32), ("image", C.c_int32), ("texels", C.c_void_p)]
 
 
 class OrcWhittedFrame(C.Structure):
@@ -53,7 +65,10 @@ class OrcWhittedFrame(C.Structure):
                 ("eye", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3),
                 ("lights", C.POINTER(OrcLightW)), ("nlights", C.c_uint32), ("miss_color", C.c_float * 3),
                 ("normals4", C.c_void_p), ("material_index", C.c_void_p),
-                ("materials", C.POINTER(OrcMaterialW)), ("nmaterials", C.c_uint32)]
+                ("materials", C.POINTER(OrcMaterialW)), ("nmaterials", C.c_uint32),
+                ("texcoords", C.c_void_p * 2), ("texcoord_present", C.c_void_p * 2),
+                ("colors4", C.c_void_p), ("color_present", C.c_void_p),
+                ("textures", C.POINTER(OrcTextureW)), ("ntextures", C.c_uint32)]
 
 
 class OrcImguiCamera(C.Structure):
@@ -151,6 +166,10 @@ def lib():
     L.orc_whitted_render_rows.restype = C.c_int
     L.orc_whitted_render_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcWhittedFrame), C.c_uint32, C.c_uint32,
                                           C.POINTER(OrcStats)]
+    L.orc_sample_texture.restype = None
+    L.orc_sample_texture.argtypes = [C.POINTER(OrcTextureW), C.c_float, C.c_float, C.POINTER(C.c_float * 4)]
+    L.orc_det_pow22.restype = C.c_float
+    L.orc_det_pow22.argtypes = [C.c_float]
     L.orc_primary_rays.restype = None
     L.orc_primary_rays.argtypes = [C.POINTER(OrcParams), C.c_uint32, C.c_uint32, C.c_void_p]
     _lib = L
@@ -239,10 +258,12 @@ class Scene:
                             C.byref(stats) if stats is not None else None)
         return occ
 
-    def render_whitted(self, launch, lights, materials, material_index, normals4=None, accum=None, mode=MODE_BVH):
+    def render_whitted(self, launch, lights, materials, material_index, normals4=None, accum=None, mode=MODE_BVH,
+                       texcoords=(None, None), texcoord_present=(None, None), colors4=None, color_present=None, textures=()):
         """SDK/cuda/whitted.cu restatement.  launch: dict(width,height,subframe,eye,U,V,W,miss_color);
         lights: list of dict(type,color,intensity,position); materials: list of dict(base_color,metallic,roughness,
-        emissive_factor).  Returns (accum HxWx4 f32, frame HxWx4 u8, stats)."""
+        emissive_factor[, <name>_tex: dict(texture,texcoord,offset,rotation,scale)]); textures: list of dict(texels
+        (h,w,4) uint8/uint16 or None, address_s, address_t, filter).  Returns (accum HxWx4 f32, frame HxWx4 u8, stats)."""
         w, h = int(launch["width"]), int(launch["height"])
         if accum is None:
             accum = np.zeros((h, w, 4), np.float32)
@@ -266,12 +287,46 @@ class Scene:
             ma[k].base_color = (C.c_float * 4)(*[float(x) for x in m["base_color"]])
             ma[k].metallic, ma[k].roughness = float(m["metallic"]), float(m["roughness"])
             ma[k].emissive_factor = _f3(m["emissive_factor"])
+            ma[k].alpha_cutoff = float(m.get("alpha_cutoff", 0.0))
+            ma[k].alpha_mode, ma[k].double_sided = int(m.get("alpha_mode", 0)), int(m.get("double_sided", 0))
+            for name in ("base_color_tex", "metallic_roughness_tex", "normal_tex", "emissive_tex"):
+                ti, src = getattr(ma[k], name), m.get(name)
+                ti.texture, ti.texcoord = -1, 0
+                ti.offset, ti.rotation, ti.scale = (C.c_float * 2)(0, 0), (C.c_float * 2)(0, 1), (C.c_float * 2)(1, 1)
+                if src is not None:
+                    ti.texture, ti.texcoord = int(src["texture"]), int(src.get("texcoord", 0))
+                    ti.offset = (C.c_float * 2)(*[float(x) for x in src.get("offset", (0, 0))])
+                    ti.rotation = (C.c_float * 2)(*[float(x) for x in src.get("rotation", (0, 1))])
+                    ti.scale = (C.c_float * 2)(*[float(x) for x in src.get("scale", (1, 1))])
         f.materials, f.nmaterials = ma, len(materials)
+        keep = []
         mi = np.ascontiguousarray(material_index, np.uint32)
         f.material_index = mi.ctypes.data
         if normals4 is not None:
             normals4 = np.ascontiguousarray(normals4, np.float32)
             f.normals4 = normals4.ctypes.data
+        for j in range(2):
+            if texcoords[j] is not None:
+                a = np.ascontiguousarray(texcoords[j], np.float32); keep.append(a)
+                f.texcoords[j] = a.ctypes.data
+                if texcoord_present[j] is not None:
+                    b = np.ascontiguousarray(texcoord_present[j], np.uint8); keep.append(b)
+                    f.texcoord_present[j] = b.ctypes.data
+        if colors4 is not None:
+            a = np.ascontiguousarray(colors4, np.float32); keep.append(a)
+            f.colors4 = a.ctypes.data
+            if color_present is not None:
+                b = np.ascontiguousarray(color_present, np.uint8); keep.append(b)
+                f.color_present = b.ctypes.data
+        ta = (OrcTextureW * max(len(textures), 1))()
+        for k, t in enumerate(textures):
+            ta[k].address_s, ta[k].address_t, ta[k].filter = int(t.get("address_s", 0)), int(t.get("address_t", 0)), int(t.get("filter", 1))
+            if t.get("texels") is not None:
+                tx = np.ascontiguousarray(t["texels"]); keep.append(tx)
+                ta[k].height, ta[k].width = tx.shape[0], tx.shape[1]
+                ta[k].bits = 16 if tx.dtype == np.uint16 else 8
+                ta[k].texels = tx.ctypes.data
+        f.textures, f.ntextures = ta, len(textures)
         st = OrcStats()
         rc = lib().orc_whitted_render_rows(self._h, mode, C.byref(f), 0, h, C.byref(st))
         if rc:

@@ -212,3 +212,176 @@ def test_whitted_launch_errors():
     assert ctx._lib.mipt_whitted_launch(ctx._h, None, C.byref(p), 8, 4, 1) == 1            # size mismatch
     assert ctx._lib.mipt_whitted_launch(ctx._h, None, C.byref(p), 8, 8, 1) == 6            # geometry not set
     ctx.destroy()
+
+
+# ------------------------------------------------------------------------------------------------ textures
+def _tex(texels, address_s=0, address_t=0, filter=1):
+    return {"texels": np.ascontiguousarray(texels), "address_s": address_s, "address_t": address_t, "filter": filter}
+
+
+def _sample(t, u, v):
+    d = O.OrcTextureW()
+    tx = t["texels"]
+    d.height, d.width, d.bits, d.texels = tx.shape[0], tx.shape[1], 16 if tx.dtype == np.uint16 else 8, tx.ctypes.data
+    d.address_s, d.address_t, d.filter = t["address_s"], t["address_t"], t["filter"]
+    out = (C.c_float * 4)()
+    O.lib().orc_sample_texture(C.byref(d), float(u), float(v), C.byref(out))
+    return np.array(out, np.float32)
+
+
+def test_texture_fetch_known_answers():
+    tx = np.zeros((2, 4, 4), np.uint8)
+    tx[0, :, 0] = (0, 51, 102, 255); tx[1, :, 0] = (255, 204, 153, 0)
+    tx[..., 3] = 255
+    lin = _tex(tx)
+    # texel centres return the texel, between two centres their mean, past the edge the wrapped neighbour
+    assert np.allclose(_sample(lin, 0.375, 0.25)[0], 51 / 255, atol=1e-7)
+    assert np.allclose(_sample(lin, 0.5, 0.25)[0], (51 + 102) / 510, atol=1e-7)
+    assert np.allclose(_sample(lin, 0.0, 0.25)[0], (0 + 255) / 510, atol=1e-7)          # wraps to texel 3
+    assert np.allclose(_sample(lin, 0.375, 0.5)[0], (51 + 204) / 510, atol=1e-7)
+    assert np.allclose(_sample(_tex(tx, address_s=1), 0.0, 0.25)[0], 0.0, atol=1e-7)       # clamp: texel 0 twice
+    assert np.allclose(_sample(_tex(tx, address_s=2), -0.125, 0.25)[0], 0.0, atol=1e-7)    # mirror: index -1 -> 0
+    assert np.allclose(_sample(_tex(tx, address_s=2), 1.125, 0.25)[0], 1.0, atol=1e-7)     # mirror: index 4 -> 3
+    pt = _tex(tx, filter=0)
+    assert _sample(pt, 0.49, 0.4)[0] == np.float32(51 / 255) and _sample(pt, 0.51, 0.6)[0] == np.float32(153 / 255)
+    assert _sample(pt, 1.26, 0.1)[0] == np.float32(51 / 255)                             # wraps
+    t16 = _tex((np.arange(8, dtype=np.uint16).reshape(1, 2, 4) * 8191))
+    assert np.allclose(_sample(t16, 0.25, 0.5), np.arange(4) * 8191 / 65535, atol=1e-7)
+
+
+def test_pow22_accuracy():
+    L = O.lib()
+    xs = np.concatenate([np.linspace(1 / 255, 1, 400), [1e-3, 1e-6, 0.5, 1.0]]).astype(np.float32)
+    got = np.array([L.orc_det_pow22(float(x)) for x in xs])
+    assert np.allclose(got, xs.astype(np.float64) ** 2.2, rtol=3e-6)
+    assert L.orc_det_pow22(0.0) == 0.0 and L.orc_det_pow22(1.0) == 1.0
+
+
+def test_oracle_textured_shading_known_answers():
+    """a unit quad seen from above under one ambient light: the pixel is ambient * base colour, so every texture
+    stage can be read off the image"""
+    verts = np.zeros((6, 4), f32)
+    verts[:, :3] = _quad((0, 0, 0), (0, 0, 1), (1, 0, 1), (1, 0, 0))
+    uv = np.asarray(_quad((0, 0), (0, 1), (1, 1), (1, 0)), f32)                          # u = x, v = z
+    sc = O.Scene({"vertices": verts, "mat_index": np.zeros(2, np.uint32), "emission": np.zeros((1, 3), f32), "diffuse": np.ones((1, 3), f32)})
+    sc.build_bvh()
+    w = h = 64
+    U, V, W = O.camera_uvw((0.5, 2.0, 0.5), (0.5, 0, 0.5), (0, 0, 1), 2 * np.degrees(np.arctan(0.25)), 1.0)     # sees exactly the quad
+    la = {"width": w, "height": h, "eye": (0.5, 2.0, 0.5), "U": U, "V": V, "W": W, "miss_color": (0, 0, 0)}
+    amb = [{"type": 1, "color": (0.5, 0.25, 1.0)}]
+    tx = np.zeros((2, 2, 4), np.uint8)
+    tx[0, 0] = (255, 128, 0, 255); tx[0, 1] = (0, 255, 128, 255); tx[1, 0] = (128, 0, 255, 255); tx[1, 1] = (64, 64, 64, 255)
+    mat = {"base_color": (0.8, 0.6, 0.4, 1.0), "metallic": 0.0, "roughness": 1.0, "emissive_factor": (0, 0, 0),
+           "base_color_tex": {"texture": 0}}
+    acc, _, _ = sc.render_whitted(la, amb, [mat], np.zeros(2, np.uint32), texcoords=(uv, None), textures=[_tex(tx, filter=0)])
+    px = lambda u, v: acc[int(v * h), int((1 - u) * w) if U[0] < 0 else int(u * w), :3]          # noqa: E731
+    # which image column shows world x: find it from the rendered quadrant colours instead of assuming the camera handedness
+    lin = lambda c: (np.asarray(c, np.float64) / 255) ** 2.2                                     # noqa: E731
+    want = {k: np.asarray(amb[0]["color"]) * np.asarray(mat["base_color"][:3]) * lin(tx[k][:3]) for k in ((0, 0), (0, 1), (1, 0), (1, 1))}
+    quads = {(0, 0): acc[h // 4, w // 4, :3], (0, 1): acc[h // 4, 3 * w // 4, :3], (1, 0): acc[3 * h // 4, w // 4, :3], (1, 1): acc[3 * h // 4, 3 * w // 4, :3]}
+    # every rendered quadrant equals exactly one texel's colour, and all four texels appear
+    used = set()
+    for q, val in quads.items():
+        match = [k for k, c in want.items() if np.allclose(val, c, rtol=2e-5, atol=1e-7)]
+        assert len(match) == 1, (q, val)
+        used.add(match[0])
+    assert len(used) == 4
+    # vertex colours multiply in; a 90-degree texture rotation permutes the quadrants; scale 2 with wrap repeats the image
+    col = np.tile(np.asarray([0.5, 1.0, 0.25, 1.0], f32), (6, 1))
+    acc2, _, _ = sc.render_whitted(la, amb, [mat], np.zeros(2, np.uint32), texcoords=(uv, None), colors4=col, textures=[_tex(tx, filter=0)])
+    assert np.allclose(acc2[h // 4, w // 4, :3], acc[h // 4, w // 4, :3] * (0.5, 1.0, 0.25), rtol=1e-6)
+    mat_s = dict(mat, base_color_tex={"texture": 0, "scale": (2.0, 2.0)})
+    acc3, _, _ = sc.render_whitted(la, amb, [mat_s], np.zeros(2, np.uint32), texcoords=(uv, None), textures=[_tex(tx, filter=0)])
+    assert np.allclose(acc3[h // 8, w // 8, :3], acc[h // 4, w // 4, :3], rtol=1e-6)
+    assert np.allclose(acc3[h // 8 + h // 2, w // 8 + w // 2, :3], acc[h // 4, w // 4, :3], rtol=1e-6)
+    # texcoord set 1 is used when the texture info says so; without texcoords UV = barycentrics (still textured)
+    mat_1 = dict(mat, base_color_tex={"texture": 0, "texcoord": 1})
+    acc4, _, _ = sc.render_whitted(la, amb, [mat_1], np.zeros(2, np.uint32), texcoords=(None, uv), textures=[_tex(tx, filter=0)])
+    assert np.array_equal(acc4, acc)
+    # emissive texture and factor
+    mat_e = dict(mat, emissive_factor=(0.5, 0.5, 0.5), emissive_tex={"texture": 0})
+    acc5, _, _ = sc.render_whitted(la, amb, [mat_e], np.zeros(2, np.uint32), texcoords=(uv, None), textures=[_tex(tx, filter=0)])
+    d = acc5[h // 4, w // 4, :3] - acc[h // 4, w // 4, :3]
+    assert any(np.allclose(d, 0.5 * tx[k][:3] / 255.0, atol=2e-6) for k in want)
+    # an undecodable texture (no texels) renders untextured
+    acc6, _, _ = sc.render_whitted(la, amb, [mat], np.zeros(2, np.uint32), texcoords=(uv, None), textures=[{"texels": None}])
+    assert np.allclose(acc6[h // 4, w // 4, :3], np.asarray(amb[0]["color"]) * mat["base_color"][:3], rtol=1e-6)
+
+
+def test_oracle_normal_map_and_metallic_roughness_texture():
+    verts = np.zeros((6, 4), f32)
+    verts[:, :3] = _quad((0, 0, 0), (0, 0, 1), (1, 0, 1), (1, 0, 0))
+    uv = np.asarray(_quad((0, 0), (0, 1), (1, 1), (1, 0)), f32)
+    sc = O.Scene({"vertices": verts, "mat_index": np.zeros(2, np.uint32), "emission": np.zeros((1, 3), f32), "diffuse": np.ones((1, 3), f32)})
+    sc.build_bvh()
+    w = h = 32
+    U, V, W = O.camera_uvw((0.5, 2.0, 0.5), (0.5, 0, 0.5), (0, 0, 1), 2 * np.degrees(np.arctan(0.25)), 1.0)
+    la = {"width": w, "height": h, "eye": (0.5, 2.0, 0.5), "U": U, "V": V, "W": W, "miss_color": (0, 0, 0)}
+    light = [{"type": 0, "color": (1, 1, 1), "intensity": 4.0, "position": (0.5, 3.0, 0.5)}]
+    mat = {"base_color": (0.8, 0.8, 0.8, 1.0), "metallic": 0.5, "roughness": 0.7, "emissive_factor": (0, 0, 0)}
+    flat, _, _ = sc.render_whitted(la, light, [mat], np.zeros(2, np.uint32), texcoords=(uv, None))
+    up = np.zeros((1, 1, 4), np.uint8); up[0, 0] = (128, 128, 255, 255)                   # (0, 0, 1) within 1/255
+    acc_up, _, _ = sc.render_whitted(la, light, [dict(mat, normal_tex={"texture": 0})], np.zeros(2, np.uint32), texcoords=(uv, None),
+                                     textures=[_tex(up)])
+    assert np.allclose(acc_up[..., :3], flat[..., :3], rtol=2e-2)                          # nearly the geometric normal
+    tilt = np.zeros((1, 1, 4), np.uint8); tilt[0, 0] = (255, 128, 128, 255)                # (1, 0, 0): along dpdu
+    acc_t, _, _ = sc.render_whitted(la, light, [dict(mat, normal_tex={"texture": 0})], np.zeros(2, np.uint32), texcoords=(uv, None),
+                                    textures=[_tex(tilt)])
+    assert acc_t[h // 2, w // 2, :3].sum() < 0.2 * flat[h // 2, w // 2, :3].sum()         # grazing normal: almost no light from above
+    # metallic-roughness texture scales the factors: (g, b) = (255, 0) -> roughness 0.7, metallic 0
+    mr = np.zeros((1, 1, 4), np.uint8); mr[0, 0] = (0, 255, 0, 255)
+    acc_mr, _, _ = sc.render_whitted(la, light, [dict(mat, metallic_roughness_tex={"texture": 0})], np.zeros(2, np.uint32),
+                                     texcoords=(uv, None), textures=[_tex(mr)])
+    ref, _, _ = sc.render_whitted(la, light, [dict(mat, metallic=0.0)], np.zeros(2, np.uint32), texcoords=(uv, None))
+    assert np.array_equal(acc_mr, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,subframes", [(150, 100, 1), (96, 64, 2)])
+def test_textured_whitted_programs_match_the_oracle(tmp_path, w, h, subframes):
+    import torch
+    assert torch.cuda.is_available()
+    from optix_raytracer_amd import meshviewer as MV
+    gltf = FX.write_textured(tmp_path)
+    lights = [{"type": MV.LIGHT_AMBIENT, "color": (0.05, 0.05, 0.06)},
+              {"type": MV.LIGHT_POINT, "color": (1.0, 0.95, 0.9), "intensity": 9.0, "position": (1.0, 4.0, 2.5)},
+              {"type": MV.LIGHT_POINT, "color": (0.4, 0.6, 1.0), "intensity": 5.0, "position": (-2.5, 1.5, 1.0)}]
+    st = MV.MeshViewerState()
+    MV.loadScene(st, gltf)
+    assert st.d_texcoords[0] is not None and st.d_texcoords[1] is not None and st.d_colors is not None and st.textures[1] == 5
+    MV.initCameraState(st)
+    MV.initLaunchParams(st, w, h, lights)
+    out = MV.OutputBuffer(w, h, st.device)
+    for _ in range(subframes):
+        MV.updateState(st)
+        MV.launchSubframe(out, st)
+        st.params.subframe_index += 1
+    nodes, tris = st.context.accel_export(st.handle)
+    sc, mats, lts, mat, normals = _oracle_for_state(st, nodes, tris)
+    smats = st.scene.materials()
+    for m, sm in zip(mats, smats):
+        for k in ("base_color_tex", "metallic_roughness_tex", "normal_tex", "emissive_tex"):
+            m[k] = sm[k]
+    textures = st.scene.textures()
+    assert all(t["texels"] is not None for t in textures) and textures[2]["bits"] == 16
+    uv = [st.scene.flatten_texcoords(j) for j in range(2)]
+    col = st.scene.flatten_colors()
+    p = st.params
+    acc = np.zeros((h, w, 4), f32)
+    for sf in range(subframes):
+        la = {"width": w, "height": h, "subframe": sf, "eye": list(p.eye), "U": list(p.U), "V": list(p.V), "W": list(p.W),
+              "miss_color": list(p.miss_color)}
+        acc, frame, ost = sc.render_whitted(la, lts, mats, mat, normals4=normals, accum=acc, texcoords=(uv[0][0], uv[1][0]),
+                                            texcoord_present=(uv[0][1], uv[1][1]), colors4=col[0], color_present=col[1], textures=textures)
+    got = st.accum.cpu().numpy()
+    bad = np.argwhere(got.view(np.uint32) != acc.view(np.uint32))
+    assert bad.size == 0, "first differing pixel %s: gpu %s cpu %s (%d differ)" % (bad[0], got[tuple(bad[0][:2])], acc[tuple(bad[0][:2])], len(bad))
+    assert np.array_equal(out.getHostPointer(), frame)
+    hit = np.abs(acc[..., :3] - np.asarray(list(p.miss_color), f32)).sum(2) > 0
+    assert hit.mean() > 0.3 and np.isfinite(acc).all()
+    # the textures matter: an untextured render of the same scene differs on most hit pixels
+    plain, _, _ = sc.render_whitted(dict(la, subframe=0), lts, [dict(m, base_color_tex=None, normal_tex=None, emissive_tex=None,
+                                                                    metallic_roughness_tex=None) for m in mats], mat, normals4=normals)
+    MV.cleanup(st)
+    if subframes == 1:
+        assert (np.abs(plain[..., :3] - acc[..., :3]).sum(2)[hit] > 1e-3).mean() > 0.5
