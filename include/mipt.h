@@ -105,7 +105,7 @@ typedef struct MiptBvhNode {
 /* triangle in leaf order: v0, e1 = v1 - v0, e2 = v2 - v0 (fp32), original index */
 typedef struct MiptBvhTri {
     float v0[3]; uint32_t prim;
-    float e1[3]; uint32_t pad1;
+    float e1[3]; uint32_t pad1;   /* MiptGeometryFlags of the triangle */
     float e2[3]; uint32_t pad2;
 } MiptBvhTri;
 
@@ -130,7 +130,22 @@ typedef struct MiptBuildInput {
     uint32_t        num_triangles;       /* indexed: number of triplets; else num_vertices/3 */
     const uint32_t* sbt_index_offsets;   /* per-triangle hit-group record index (host or device), NULL => 0 */
     const float*    transform3x4;        /* optional row-major 3x4 object->world (host), NULL => identity */
+    const uint32_t* flags;               /* OptixBuildInputTriangleArray::flags: one MiptGeometryFlags word per SBT record
+                                            (host), selected by sbt_index_offsets; NULL => MIPT_GEOMETRY_FLAG_NONE */
+    uint32_t        num_sbt_records;     /* length of flags */
 } MiptBuildInput;
+
+/* OptixGeometryFlags / OptixRayFlags values the samples use (optix_types.h); stored per triangle in MiptBvhTri::pad1 */
+typedef enum MiptGeometryFlags {
+    MIPT_GEOMETRY_FLAG_NONE                          = 0,
+    MIPT_GEOMETRY_FLAG_DISABLE_ANYHIT                = 1u << 0,
+    MIPT_GEOMETRY_FLAG_REQUIRE_SINGLE_ANYHIT_CALL    = 1u << 1,   /* always true here: a triangle sits in one leaf */
+    MIPT_GEOMETRY_FLAG_DISABLE_TRIANGLE_FACE_CULLING = 1u << 2
+} MiptGeometryFlags;
+typedef enum MiptRayFlags {
+    MIPT_RAY_FLAG_NONE                        = 0,
+    MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES  = 1u << 4    /* back = the ray sees the (v1-v0) x (v2-v0) side from behind */
+} MiptRayFlags;
 
 typedef struct MiptLaunchStats {
     uint64_t closest_rays;     /* primary + continuation rays traced by the last launch */
@@ -327,8 +342,11 @@ typedef struct MiptLight {
  * (cuda/LocalShading.h:37-53), GGX direct lighting from the point / ambient lights in params->lights with one
  * occlusion ray per point light, progressive lerp + sRGB8.  Geometry comes as world-space triangles
  * (mipt_scene_flatten*): the SBT records of Scene::createSBT (Scene.cpp:1368-1470) become device arrays, a
- * material table and a texture table.  Not yet: alpha MASK / BLEND (the any-hit programs and the BLEND
- * continuation ray, cuda/whitted.cu:100-137, 268-286) -- every material renders opaque.
+ * material table and a texture table.  Radiance rays cull back faces of single-sided materials
+ * (OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES, whitted_cuda.h:110; per-triangle geometry flags from MiptBuildInput::flags).
+ * When a material is MASK or BLEND the traversal runs the any-hit programs (cuda/whitted.cu:100-136: alpha test for
+ * radiance rays, accumulated attenuation for occlusion rays) and BLEND hits continue with a ray from the hit distance,
+ * composed back to front over at most MAX_TRACE_DEPTH = 8 levels (:268-286).
  * Texture fetches use fp32 bilinear weights (the hardware's 8-bit weights are not modelled). */
 typedef struct MiptWhittedGeometry {
     const void*     vertices4;            /* device: 3 float4 per triangle, world space */

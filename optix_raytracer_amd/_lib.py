@@ -40,7 +40,8 @@ class MiptAccelInfo(C.Structure):
 class MiptBuildInput(C.Structure):
     _fields_ = [("vertices", C.c_void_p), ("num_vertices", C.c_uint32), ("vertex_stride_bytes", C.c_uint32),
                 ("indices", C.c_void_p), ("index_format", C.c_uint32), ("index_stride_bytes", C.c_uint32),
-                ("num_triangles", C.c_uint32), ("sbt_index_offsets", C.c_void_p), ("transform3x4", C.c_void_p)]
+                ("num_triangles", C.c_uint32), ("sbt_index_offsets", C.c_void_p), ("transform3x4", C.c_void_p),
+                ("flags", C.c_void_p), ("num_sbt_records", C.c_uint32)]
 
 
 class MiptSceneInfo(C.Structure):
@@ -129,6 +130,9 @@ class MiptLaunchTimings(C.Structure):
 LOG_CALLBACK = C.CFUNCTYPE(None, C.c_uint, C.c_char_p, C.c_char_p, C.c_void_p)
 
 IMAGE_UNSIGNED_BYTE4, IMAGE_FLOAT4, IMAGE_FLOAT3 = 0, 1, 2
+GEOMETRY_FLAG_NONE, GEOMETRY_FLAG_DISABLE_ANYHIT, GEOMETRY_FLAG_REQUIRE_SINGLE_ANYHIT_CALL = 0, 1, 2
+GEOMETRY_FLAG_DISABLE_TRIANGLE_FACE_CULLING = 4
+RAY_FLAG_NONE, RAY_FLAG_CULL_BACK_FACING_TRIANGLES = 0, 16
 OPT_MAX_DEPTH, OPT_COUNT_VISITS, OPT_TRACE_GRID, OPT_PERSISTENT, OPT_PROFILE = 1, 2, 3, 4, 5
 OPT_REFILL_MIN, OPT_STEAL_MIN, OPT_BURST, OPT_BATCH_SAMPLES = 7, 8, 9, 10
 

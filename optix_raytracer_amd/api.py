@@ -242,7 +242,7 @@ class Context:
     # ---- accel
     def accel_build(self, inputs):
         """inputs: list of dicts {vertices(ptr|ndarray), num_vertices, stride, indices, index_format,
-        num_triangles, sbt_index_offsets, transform}"""
+        num_triangles, sbt_index_offsets, transform, flags (one MiptGeometryFlags word per SBT record)}"""
         arr = (L.MiptBuildInput * len(inputs))()
         keep = []
         for i, d in enumerate(inputs):
@@ -264,6 +264,11 @@ class Context:
             bi.index_stride_bytes = int(d.get("index_stride", 0))
             bi.num_triangles = int(d.get("num_triangles", 0))
             bi.sbt_index_offsets = ptr(d.get("sbt_index_offsets"))
+            fl = d.get("flags")
+            if fl is not None:
+                fl = np.ascontiguousarray(fl, dtype=np.uint32)
+                keep.append(fl)
+                bi.flags, bi.num_sbt_records = fl.ctypes.data, fl.shape[0]
             t = d.get("transform")
             if t is not None:
                 t = np.ascontiguousarray(t, dtype=np.float32).reshape(12)

@@ -80,7 +80,8 @@ void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, 
 void launch_advance(hipStream_t st, DeviceCounters* ctr);
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result);
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
-                          const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o);
+                          const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o,
+                          uint32_t ray_flags = 0u /* MiptRayFlags */);
 // mode 1: occluded flags (uint32 per ray); mode 2: accumulate contrib into result when unoccluded
 void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                       const uint32_t* n_ptr, uint32_t n_max, uint32_t* occluded, const float4* contrib, float4* result,
@@ -102,9 +103,21 @@ struct WhTexture {                 // MiptTextureData with the texels in device 
     uint32_t width, height, bits, address_s, address_t, filter;
     const void* texels;
 };
+struct WhBuffers {                 // launch storage owned by the context
+    PathQueue q[2];                // rays of the current / next level
+    float4* hits;
+    ShadowQueue sh;                // K entries per hit: occlusion ray + E0
+    float4* e1;
+    uint32_t* flags;               // occlusion result per entry: uint32 flag (fast kernels) or float attenuation (any-hit programs)
+    float4* group;
+    float4* levels;                // [max_levels][pixels]
+    uint32_t* n_levels;            // per pixel
+    uint32_t max_levels;           // 1 without BLEND materials, MAX_TRACE_DEPTH with
+    bool any_hit_programs;         // a MASK / BLEND material exists: traversal runs the any-hit programs
+};
 void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_paths, const DeviceBvh& bvh, const WhGeometry& geo,
                  const MiptMaterialData* d_materials, uint32_t n_materials, const WhTexture* d_textures, uint32_t n_textures,
-                 PathQueue q, float4* hits, ShadowQueue sh, uint32_t* occluded, float4* result, DeviceCounters* ctr, const TraceOpts& opts);
+                 const WhBuffers& B, DeviceCounters* ctr, const TraceOpts& opts);
 void launch_unpermute(hipStream_t st, const float4* gathered, uint32_t world, uint32_t width, uint32_t height,
                       float4* accum, uint32_t* frame);
 

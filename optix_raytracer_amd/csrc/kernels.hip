@@ -19,6 +19,7 @@
 #include "kernels.h"
 #include "detmath.h"
 #include "wave_util.h"
+#include "trav_core.h"
 
 namespace mipt {
 
@@ -27,91 +28,9 @@ namespace mipt {
 //   hit iff tmin < t < tmax; double sided; det == 0 rejected; u >= 0, v >= 0, u + v <= 1;
 //   closest-hit tie -> lowest original primitive index; near child first, tie -> child 0 first.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fdot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
-__device__ __forceinline__ f3    fcross(f3 a, f3 b)
-{
-    return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
-               __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
-}
-
-constexpr int kSentinel = (int)0x80000000;
-
-struct Trav {
-    f3       o, d, idir, nood;   // nood = -(o * idir)
-    float    tmin, tmax, tbest;
-    float    u, v;
-    uint32_t prim;
-    int      node, sp;
-};
-
-__device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd)
-{
-    T.o = mk3(ro.x, ro.y, ro.z);
-    T.d = mk3(rd.x, rd.y, rd.z);
-    T.tmin = ro.w; T.tmax = rd.w; T.tbest = rd.w;
-    const float eps = 8.27180613e-25f;   // 2^-80: keeps 1/d finite for axis-parallel rays
-    const float dx = __builtin_fabsf(T.d.x) > eps ? T.d.x : __builtin_copysignf(eps, T.d.x);
-    const float dy = __builtin_fabsf(T.d.y) > eps ? T.d.y : __builtin_copysignf(eps, T.d.y);
-    const float dz = __builtin_fabsf(T.d.z) > eps ? T.d.z : __builtin_copysignf(eps, T.d.z);
-    T.idir = mk3(1.0f / dx, 1.0f / dy, 1.0f / dz);
-    T.nood = mk3(-(T.o.x * T.idir.x), -(T.o.y * T.idir.y), -(T.o.z * T.idir.z));
-    T.u = 0.0f; T.v = 0.0f; T.prim = 0xffffffffu;
-    T.node = T.tmax > T.tmin ? 0 : kSentinel;   // empty interval: a miss without touching the BVH
-    T.sp = 0;
-}
-
-// Per-lane traversal stack in LDS, laid out [entry][lane]: bank = lane, conflict free.  The builder caps the
-// tree depth at kStackEntries, so it cannot overflow.
-struct Stack {
-    uint32_t* lds;       // kStackEntries * 64 words
-    int       lane;
-    __device__ __forceinline__ void push(int& sp, uint32_t v) const { lds[sp * 64 + lane] = v; ++sp; }
-    __device__ __forceinline__ int pop(int& sp) const
-    {
-        if (sp == 0) return kSentinel;
-        --sp;
-        return (int)lds[sp * 64 + lane];
-    }
-};
-
-// one inner-node step: fetch 64 B, slab-test both children, descend into the nearer, push the other
-__device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ nodes, const Stack& stk)
-{
-    const float4* np = nodes + (size_t)(uint32_t)T.node * 4u;
-    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-    const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
-    const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
-    const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
-    const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
-    const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
-    const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
-    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                      __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
-    const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                      __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
-    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                      __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
-    const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                      __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
-    const bool h0 = tn0 <= tf0;
-    const bool h1 = tn1 <= tf1;
-    int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
-    if (!h0 && !h1) {
-        T.node = stk.pop(T.sp);
-    } else if (h0 && h1) {
-        const bool swp = tn1 < tn0;
-        const int nearc = swp ? c1 : c0;
-        const int farc  = swp ? c0 : c1;
-        stk.push(T.sp, (uint32_t)farc);
-        T.node = nearc;
-    } else {
-        T.node = h0 ? c0 : c1;
-    }
-}
-
 // leaf step: Moeller-Trumbore on (v0, e1, e2); returns true when ANY mode may terminate
 template <bool ANY>
-__device__ __forceinline__ bool visit_leaf(Trav& T, const float4* __restrict__ tris, uint32_t& n_tests)
+__device__ __forceinline__ bool visit_leaf(Trav& T, const float4* __restrict__ tris, uint32_t& n_tests, bool cull_back)
 {
     const uint32_t desc = ~(uint32_t)T.node;
     const uint32_t first = desc >> 4, cnt = desc & 15u;
@@ -123,6 +42,7 @@ __device__ __forceinline__ bool visit_leaf(Trav& T, const float4* __restrict__ t
         const f3 p  = fcross(T.d, e2);
         const float det = fdot(e1, p);
         if (det == 0.0f) continue;
+        if (cull_back && det < 0.0f && (f2u(b.w) & 4u) == 0u) continue;       // back face of a single-sided triangle
         const float inv = 1.0f / det;
         const f3 tv = T.o - mk3(a.x, a.y, a.z);
         const float u = fdot(tv, p) * inv;
@@ -155,6 +75,7 @@ struct TraceArgs {
     int             steal_min;    // k_trace_stream: idle lanes that trigger a steal round once the ray range is exhausted
     int             burst_bulk;   // k_trace_stream: traversal steps per bookkeeping round while fresh rays remain
     int             burst_dry;    // ... and once the ray range is exhausted
+    uint32_t        ray_flags;    // MiptRayFlags of every ray of the launch (closest hit: back-face culling)
     uint32_t        tail_len;     // k_trace_pool: launches of at most this many rays run on the entry pool from the start
     int             pool_low;     // k_trace_pool: pool size below which the next chunk of rays is prefetched
     int             pool_chunk;   // k_trace_pool: rays per chunk in the tail phase
@@ -221,6 +142,7 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
     __shared__ int      sh_pending[64];
     __shared__ uint32_t sh_src[64], sh_node[64];         // steal round: donor lane / donated reference per pair
     const int lane = (int)threadIdx.x;
+    const bool cull_back = MODE == 0 && (a.ray_flags & 16u) != 0u;   // MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES: det < 0 is a back face
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
@@ -393,7 +315,8 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
                     const float v = fdot(T.d, q) * inv;
                     const float t = fdot(e2, q) * inv;
                     const uint32_t prim = f2u(ta.w);
-                    const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax;
+                    const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax &&
+                                    (!cull_back || det > 0.0f || (f2u(tb.w) & 4u) != 0u);
                     if (MODE != 0) {
                         stop = ok;
                         if (ok) { T.tbest = t; T.prim = prim; }
@@ -531,6 +454,7 @@ __global__ __launch_bounds__(64) void k_trace_pool(TraceArgs a)
     __shared__ int                sh_pending[64];        // pool entries of the slot's ray
     __shared__ uint32_t           sh_done[64];           // any-hit: an occluder was found
     const int lane = (int)threadIdx.x;
+    const bool cull_back = MODE == 0 && (a.ray_flags & 16u) != 0u;   // MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES: det < 0 is a back face
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
@@ -653,7 +577,8 @@ __global__ __launch_bounds__(64) void k_trace_pool(TraceArgs a)
                         const float v = fdot(T.d, q) * inv;
                         const float t = fdot(e2, q) * inv;
                         const uint32_t prim = f2u(ta.w);
-                        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax;
+                        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax &&
+                                        (!cull_back || det > 0.0f || (f2u(tb.w) & 4u) != 0u);
                         if (MODE != 0) {
                             stop = ok;
                             if (ok) { T.tbest = t; T.prim = prim; }
@@ -844,7 +769,8 @@ __global__ __launch_bounds__(64) void k_trace_pool(TraceArgs a)
             const float v = fdot(rd, q) * inv;
             const float t = fdot(e2, q) * inv;
             const uint32_t prim = f2u(n0.w);
-            const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmn && t < tmx;
+            const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmn && t < tmx &&
+                            (!cull_back || det > 0.0f || (f2u(n1.w) & 4u) != 0u);
             bool stop = false;
             if (MODE != 0) {
                 if (ok) { sh_done[slot] = 1u; stop = true; }
@@ -908,7 +834,7 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
                 visit_inner(T, a.bvh.nodes, stk);
             }
             if (T.node != kSentinel) {
-                if (visit_leaf<(MODE != 0)>(T, a.bvh.tris, n_tests)) { hit = true; break; }
+                if (visit_leaf<(MODE != 0)>(T, a.bvh.tris, n_tests, MODE == 0 && (a.ray_flags & 16u) != 0u)) { hit = true; break; }
                 T.node = stk.pop(T.sp);
             }
         }
@@ -1248,9 +1174,10 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
 }
 
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
-                          const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o)
+                          const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o, uint32_t ray_flags)
 {
     TraceArgs a{};
+    a.ray_flags = ray_flags;
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr;
     a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;

@@ -87,6 +87,12 @@ struct MiptContext {
     WhTexture*        d_wh_textures = nullptr;          // descriptor table on the device
     std::vector<void*> wh_texels;                       // device copies of the texel arrays
     uint32_t          n_wh_textures = 0;
+    bool              wh_any_hit = false, wh_blend = false;   // a MASK / BLEND material exists
+    float4*           wh_e1 = nullptr;                  // second float4 per occlusion entry (capacity im_cap)
+    float4*           wh_group = nullptr;               // per hit (capacity wh_group_cap)
+    size_t            wh_group_cap = 0;
+    float4*           wh_levels = nullptr;              // [MAX_TRACE_DEPTH][pixels] when BLEND materials exist
+    size_t            wh_levels_cap = 0;
     // SDK/imgui_test and whitted launches: K occlusion rays per primary hit
     ShadowQueue im_sq{};
     uint32_t*   im_flags = nullptr;
@@ -429,6 +435,9 @@ int mipt_context_destroy(MiptContext* c)
     if (c->im_flags) (void)hipFree(c->im_flags);
     if (c->d_wh_materials) (void)hipFree(c->d_wh_materials);
     if (c->d_wh_textures) (void)hipFree(c->d_wh_textures);
+    if (c->wh_e1) (void)hipFree(c->wh_e1);
+    if (c->wh_group) (void)hipFree(c->wh_group);
+    if (c->wh_levels) (void)hipFree(c->wh_levels);
     for (void* t : c->wh_texels) if (t) (void)hipFree(t);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -492,7 +501,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     if (!inputs || num_inputs == 0 || !handle_out) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_build: null argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<float>    world;     // 9 floats per triangle
-    std::vector<uint32_t> mats;
+    std::vector<uint32_t> mats, gflags;
     for (uint32_t k = 0; k < num_inputs; ++k) {
         const MiptBuildInput& in = inputs[k];
         const uint32_t stride = in.vertex_stride_bytes ? in.vertex_stride_bytes : 12u;
@@ -515,6 +524,8 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         const size_t base = world.size() / 9;
         world.resize((base + n_tris) * 9);
         mats.resize(base + n_tris);
+        gflags.resize(base + n_tris, 0u);
+        if (in.flags && in.num_sbt_records == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: flags without num_sbt_records", k);
         for (uint32_t t = 0; t < n_tris; ++t) {
             uint32_t vi[3];
             if (indexed) {
@@ -541,6 +552,10 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
             uint32_t m = 0;
             if (in.sbt_index_offsets) std::memcpy(&m, mbuf.data() + (size_t)t * 4, 4);
             mats[base + t] = m;
+            if (in.flags) {
+                if (m >= in.num_sbt_records) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: SBT index %u of triangle %u >= num_sbt_records %u", k, m, t, in.num_sbt_records);
+                gflags[base + t] = in.flags[m];
+            }
         }
     }
     const uint32_t n_tris = (uint32_t)(world.size() / 9);
@@ -550,6 +565,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         delete a;
         return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "BVH over %u triangles does not fit a %d-entry traversal stack", n_tris, kStackEntries);
     }
+    for (MiptBvhTri& t : a->host.tris) t.pad1 = gflags[t.prim];
     const size_t nb = a->host.nodes.size() * sizeof(MiptBvhNode);
     const size_t tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
     const size_t mb = std::max<size_t>(n_tris, 1) * sizeof(uint32_t);
@@ -836,11 +852,13 @@ static int ensure_group_capacity(MiptContext* ctx, size_t need)
     if (ctx->im_sq.ray_o) (void)hipFree(ctx->im_sq.ray_o);
     if (ctx->im_sq.contrib) (void)hipFree(ctx->im_sq.contrib);
     if (ctx->im_flags) (void)hipFree(ctx->im_flags);
-    ctx->im_sq = ShadowQueue{}; ctx->im_flags = nullptr; ctx->im_cap = 0;
+    if (ctx->wh_e1) (void)hipFree(ctx->wh_e1);
+    ctx->im_sq = ShadowQueue{}; ctx->im_flags = nullptr; ctx->wh_e1 = nullptr; ctx->im_cap = 0;
     HIPCHK(ctx, hipMalloc((void**)&ctx->im_sq.ray_o, need * 2 * sizeof(float4)));
     ctx->im_sq.ray_d = ctx->im_sq.ray_o + need;
     HIPCHK(ctx, hipMalloc((void**)&ctx->im_sq.contrib, need * sizeof(float4)));
     HIPCHK(ctx, hipMalloc((void**)&ctx->im_flags, need * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc((void**)&ctx->wh_e1, need * sizeof(float4)));
     ctx->im_cap = need;
     return MIPT_SUCCESS;
 }
@@ -864,6 +882,11 @@ int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geo, 
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_materials, (size_t)num_materials * sizeof(MiptMaterialData)));
     HIPCHK(ctx, hipMemcpy(ctx->d_wh_materials, materials, (size_t)num_materials * sizeof(MiptMaterialData), hipMemcpyHostToDevice));
     ctx->n_wh_materials = num_materials;
+    ctx->wh_any_hit = ctx->wh_blend = false;
+    for (uint32_t i = 0; i < num_materials; ++i) {
+        if (materials[i].alpha_mode != 0) ctx->wh_any_hit = true;
+        if (materials[i].alpha_mode == 2) ctx->wh_blend = true;
+    }
     if (num_textures) {
         std::vector<WhTexture> table(num_textures);
         for (uint32_t i = 0; i < num_textures; ++i) {
@@ -911,12 +934,33 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     if (rc) return rc;
     rc = ensure_group_capacity(ctx, (size_t)n_paths * (size_t)(p->lights.count + 1));
     if (rc) return rc;
+    if (ctx->wh_group_cap < n_paths) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        if (ctx->wh_group) (void)hipFree(ctx->wh_group);
+        ctx->wh_group = nullptr; ctx->wh_group_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->wh_group, (size_t)n_paths * sizeof(float4)));
+        ctx->wh_group_cap = n_paths;
+    }
+    const size_t level_words = (size_t)width * height * 8u;
+    if (ctx->wh_blend && ctx->wh_levels_cap < level_words) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        if (ctx->wh_levels) (void)hipFree(ctx->wh_levels);
+        ctx->wh_levels = nullptr; ctx->wh_levels_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->wh_levels, level_words * sizeof(float4)));
+        ctx->wh_levels_cap = level_words;
+    }
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    WhBuffers B{};
+    B.q[0] = ctx->q[0]; B.q[1] = ctx->q[1]; B.hits = ctx->hits; B.sh = ctx->im_sq; B.e1 = ctx->wh_e1; B.flags = ctx->im_flags;
+    B.group = ctx->wh_group; B.n_levels = ctx->rg_seed;
+    B.max_levels = ctx->wh_blend ? 8u : 1u;                     // whitted::MAX_TRACE_DEPTH
+    B.levels = ctx->wh_blend ? ctx->wh_levels : ctx->result;
+    B.any_hit_programs = ctx->wh_any_hit;
     whitted_run(st, *p, n_paths, device_bvh(acc), ctx->wh_geo, ctx->d_wh_materials, ctx->n_wh_materials, ctx->d_wh_textures,
-                ctx->n_wh_textures, ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->d_ctr, trace_opts(ctx));
-    ctx->last_bounces = 1;
+                ctx->n_wh_textures, B, ctx->d_ctr, trace_opts(ctx));
+    ctx->last_bounces = B.max_levels;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
 }

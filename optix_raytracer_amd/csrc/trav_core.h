@@ -1,0 +1,94 @@
+// trav_core.h -- the pieces of the BVH2 traversal shared by every traversal kernel (kernels.hip, whitted_kernels.hip):
+// ray set-up, the per-lane LDS stack, one inner-node step.  Build-defined conventions, identical sequence in
+// oracle/pt_oracle.c:
+//   hit iff tmin < t < tmax; double sided unless a launch culls back faces; det == 0 rejected; u >= 0, v >= 0,
+//   u + v <= 1; closest-hit tie -> lowest original primitive index; near child first, tie -> child 0 first.
+#pragma once
+#include "kernels.h"
+#include "detmath.h"
+
+namespace mipt {
+
+__device__ __forceinline__ float fdot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3    fcross(f3 a, f3 b)
+{
+    return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+               __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+constexpr int kSentinel = (int)0x80000000;
+
+struct Trav {
+    f3       o, d, idir, nood;   // nood = -(o * idir)
+    float    tmin, tmax, tbest;
+    float    u, v;
+    uint32_t prim;
+    int      node, sp;
+};
+
+__device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd)
+{
+    T.o = mk3(ro.x, ro.y, ro.z);
+    T.d = mk3(rd.x, rd.y, rd.z);
+    T.tmin = ro.w; T.tmax = rd.w; T.tbest = rd.w;
+    const float eps = 8.27180613e-25f;   // 2^-80: keeps 1/d finite for axis-parallel rays
+    const float dx = __builtin_fabsf(T.d.x) > eps ? T.d.x : __builtin_copysignf(eps, T.d.x);
+    const float dy = __builtin_fabsf(T.d.y) > eps ? T.d.y : __builtin_copysignf(eps, T.d.y);
+    const float dz = __builtin_fabsf(T.d.z) > eps ? T.d.z : __builtin_copysignf(eps, T.d.z);
+    T.idir = mk3(1.0f / dx, 1.0f / dy, 1.0f / dz);
+    T.nood = mk3(-(T.o.x * T.idir.x), -(T.o.y * T.idir.y), -(T.o.z * T.idir.z));
+    T.u = 0.0f; T.v = 0.0f; T.prim = 0xffffffffu;
+    T.node = T.tmax > T.tmin ? 0 : kSentinel;   // empty interval: a miss without touching the BVH
+    T.sp = 0;
+}
+
+// Per-lane traversal stack in LDS, laid out [entry][lane]: bank = lane, conflict free.  The builder caps the
+// tree depth at kStackEntries, so it cannot overflow.
+struct Stack {
+    uint32_t* lds;       // kStackEntries * 64 words
+    int       lane;
+    __device__ __forceinline__ void push(int& sp, uint32_t v) const { lds[sp * 64 + lane] = v; ++sp; }
+    __device__ __forceinline__ int pop(int& sp) const
+    {
+        if (sp == 0) return kSentinel;
+        --sp;
+        return (int)lds[sp * 64 + lane];
+    }
+};
+
+// one inner-node step: fetch 64 B, slab-test both children, descend into the nearer, push the other
+__device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ nodes, const Stack& stk)
+{
+    const float4* np = nodes + (size_t)(uint32_t)T.node * 4u;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
+    const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
+    const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
+    const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
+    const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
+    const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
+    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                      __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
+    const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                      __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
+    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                      __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
+    const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                      __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
+    const bool h0 = tn0 <= tf0;
+    const bool h1 = tn1 <= tf1;
+    int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+    if (!h0 && !h1) {
+        T.node = stk.pop(T.sp);
+    } else if (h0 && h1) {
+        const bool swp = tn1 < tn0;
+        const int nearc = swp ? c1 : c0;
+        const int farc  = swp ? c0 : c1;
+        stk.push(T.sp, (uint32_t)farc);
+        T.node = nearc;
+    } else {
+        T.node = h0 ? c0 : c1;
+    }
+}
+
+}  // namespace mipt

@@ -4,11 +4,14 @@
 //                   getLocalGeometry              (cuda/LocalGeometry.h:59-127) on world-space triangles
 //   k_wh_gather  <- the `result +=` lines once the occlusion flags are known, in light order
 //   k_wh_resolve <- progressive lerp + make_color (:82-96)
-// Subset: opaque, untextured materials (base colour / metallic / roughness / emissive factors), point and
-// ambient lights.  schlick's powf(x, 5) is x^2 * x^2 * x (detmath: no libm transcendentals).
+//   k_wh_trace   <- optixTrace with the any-hit programs (:100-136) when the scene has MASK / BLEND materials
+// Point and ambient lights; the BLEND continuation ray (:268-286) makes the pipeline a loop over up to
+// MAX_TRACE_DEPTH levels whose results are composed back to front, like the recursion.
+// schlick's powf(x, 5) is x^2 * x^2 * x (detmath: no libm transcendentals).
 #include "kernels.h"
 #include "detmath.h"
 #include "wave_util.h"
+#include "trav_core.h"
 
 namespace mipt {
 
@@ -75,6 +78,8 @@ __device__ float4 sample_texture(const WhTexture& t, float u, float v)
 struct WhTexcoord { float u, v; f3 dpdu, dpdv; };
 struct WhLocalGeom { f3 P, N; WhTexcoord tc[2]; float4 color; };
 
+constexpr uint32_t kWhMaxTraceDepth = 8u;                // whitted::MAX_TRACE_DEPTH, cuda/whitted.h:42
+
 // sampleTexture<float4> (cuda/LocalShading.h:37-53): false when the material has no such (decodable) texture
 __device__ __forceinline__ bool sample_material_texture(const WhConsts& c, const MiptTextureInfo& ti, const WhLocalGeom& g, float4& out)
 {
@@ -89,58 +94,12 @@ __device__ __forceinline__ bool sample_material_texture(const WhConsts& c, const
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_wh_raygen(WhConsts c, PathQueue q)
+// getLocalGeometry (cuda/LocalGeometry.h:59-176) on world-space corners
+__device__ __forceinline__ void local_geometry(const WhConsts& c, uint32_t prim, float bu, float bv, WhLocalGeom& g)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.n_paths) return;
-    const uint32_t tiles_x = (c.width + 7u) >> 3;
-    const uint32_t tile = i >> 6, in = i & 63u;
-    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const uint32_t px = tx * 8u + (in & 7u), py = ty * 8u + (in >> 3);
-    if (px >= c.width || py >= c.height) {
-        q.ray_o[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
-        q.ray_d[i] = make_float4(0.f, 0.f, 1.f, 0.0f);
-        q.state_b[i] = make_uint2(kInvalidSlot, 0u);
-        return;
-    }
-    uint32_t seed = tea4(py * c.width + px, c.subframe_index);
-    float jx = 0.5f, jy = 0.5f;
-    if (c.subframe_index != 0u) { jx = rnd(seed); jy = rnd(seed); }
-    const float dx = 2.0f * (((float)px + jx) / (float)c.width) - 1.0f;
-    const float dy = 2.0f * (((float)py + jy) / (float)c.height) - 1.0f;
-    const f3 dir = normalize(dx * ld3w(c.U) + dy * ld3w(c.V) + ld3w(c.W));
-    q.ray_o[i] = make_float4(c.eye[0], c.eye[1], c.eye[2], 0.0f);
-    q.ray_d[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
-    q.state_b[i] = make_uint2(py * c.width + px, 0u);
-}
-
-// per primary hit one group of K = nlights + 1 entries: entry 0 = emission (no ray), entry 1 + i = light i
-__global__ __launch_bounds__(256) void k_wh_shade(WhConsts c, PathQueue cur, const float4* hits, ShadowQueue sh, float4* result,
-                                                  DeviceCounters* ctr)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool is_hit = false;
-    uint32_t slot = kInvalidSlot;
-    float4 hit = make_float4(-1.f, 0.f, 0.f, 0.f);
-    if (i < c.n_paths) {
-        slot = cur.state_b[i].x;
-        if (slot != kInvalidSlot) {
-            hit = hits[i];
-            if (hit.x < 0.0f) result[slot] = make_float4(c.miss_color[0], c.miss_color[1], c.miss_color[2], 0.f);
-            else is_hit = true;
-        }
-    }
-    const uint32_t j = wave_append(is_hit, &ctr->n_next);
-    if (!is_hit) return;
-    const uint32_t K = c.nlights + 1u;
-    const uint32_t prim = f2u(hit.y);
-    const float4 rd4 = cur.ray_d[i];
-    const f3 ray_d = mk3(rd4.x, rd4.y, rd4.z);
-    // ---- getLocalGeometry (cuda/LocalGeometry.h:59-176) on world-space corners
-    WhLocalGeom g;
     const float4 a0 = c.geo.vertices4[(size_t)prim * 3u], a1 = c.geo.vertices4[(size_t)prim * 3u + 1u], a2 = c.geo.vertices4[(size_t)prim * 3u + 2u];
     const f3 P0 = mk3(a0.x, a0.y, a0.z), P1 = mk3(a1.x, a1.y, a1.z), P2 = mk3(a2.x, a2.y, a2.z);
-    const float bu = hit.z, bv = hit.w, b0 = 1.0f - hit.z - hit.w;
+    const float b0 = 1.0f - bu - bv;
     g.P = b0 * P0 + bu * P1 + bv * P2;
     g.color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     if (c.geo.colors4 && (!c.geo.color_present || c.geo.color_present[prim])) {
@@ -174,107 +133,308 @@ __global__ __launch_bounds__(256) void k_wh_shade(WhConsts c, PathQueue cur, con
             tc.dpdv = -dp1 + dp2;
         }
     }
-    // ---- material (cuda/whitted.cu:155-215)
-    uint32_t mi = c.geo.material_index ? c.geo.material_index[prim] : 0u;
-    if (mi >= c.nmaterials) mi = c.nmaterials - 1u;
-    const MiptMaterialData m = c.materials[mi];
-    float4 bc = make_float4(m.base_color[0] * g.color.x, m.base_color[1] * g.color.y, m.base_color[2] * g.color.z, m.base_color[3] * g.color.w);
+}
+
+__device__ __forceinline__ uint32_t prim_material(const WhConsts& c, uint32_t prim)
+{
+    const uint32_t mi = c.geo.material_index ? c.geo.material_index[prim] : 0u;
+    return mi >= c.nmaterials ? c.nmaterials - 1u : mi;
+}
+
+// ---- optixTrace with the any-hit programs of cuda/whitted.cu:100-136 ------------------------------------
+// One ray per thread, the sequential visiting order (= the oracle's), so that the product of the BLEND
+// attenuations is taken in a defined order.  Used instead of the fast kernels when a scene has MASK / BLEND
+// materials.  MODE 0: traceRadiance (closest hit, back-face culling, __anyhit__radiance) -> hit records;
+// MODE 1: traceOcclusion (__anyhit__occlusion, terminate on first accepted hit) -> attenuation per ray.
+__device__ __forceinline__ bool candidate_alpha(const WhConsts& c, uint32_t prim, float u, float v, uint32_t& mi, float& alpha)
+{
+    mi = prim_material(c, prim);
+    const MiptTextureInfo ti = c.materials[mi].base_color_tex;
+    if (ti.texture < 0 || (uint32_t)ti.texture >= c.ntextures) return false;
+    WhLocalGeom g;
+    local_geometry(c, prim, u, v, g);
     float4 tx;
-    if (sample_material_texture(c, m.base_color_tex, g, tx)) {
-        bc.x *= det_pow22(tx.x); bc.y *= det_pow22(tx.y); bc.z *= det_pow22(tx.z);      // linearize; not the alpha channel
-        bc.w *= tx.w;
-    }
-    const f3 base = mk3(bc.x, bc.y, bc.z);
-    float metallic = m.metallic, roughness = m.roughness;
-    float4 mr = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    sample_material_texture(c, m.metallic_roughness_tex, g, mr);                        // (occlusion, roughness, metallic)
-    roughness *= mr.y;
-    metallic *= mr.z;
-    const float F0 = 0.04f;
-    const f3 diff_color = (base * (1.0f - F0)) * (1.0f - metallic);
-    const f3 f0v = mk3(F0, F0, F0);
-    const f3 spec_color = f0v + metallic * (base - f0v);
-    const float alpha = roughness * roughness;
-    float4 emt = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    sample_material_texture(c, m.emissive_tex, g, emt);
-    const f3 em = ld3w(m.emissive_factor) * mk3(emt.x, emt.y, emt.z);
-    f3 N = g.N;
-    float4 nt;
-    if (sample_material_texture(c, m.normal_tex, g, nt)) {
-        const float nx = 2.0f * nt.x - 1.0f, ny = 2.0f * nt.y - 1.0f, nz = 2.0f * nt.z - 1.0f;
-        const float tx_ = nx * m.normal_tex.rotation[1] + ny * -m.normal_tex.rotation[0];
-        const float ty_ = nx * m.normal_tex.rotation[0] + ny * m.normal_tex.rotation[1];
-        const WhTexcoord& tc = g.tc[m.normal_tex.texcoord == 1 ? 1 : 0];
-        N = normalize((tx_ * normalize(tc.dpdu) + ty_ * normalize(tc.dpdv)) + nz * g.N);
-    }
-    const f3 P = g.P;
-    if (dot(N, ray_d) > 0.0f) N = -N;
-    const size_t base_i = (size_t)j * K;
-    sh.ray_o[base_i] = make_float4(0.f, 0.f, 0.f, 1.0f);                 // empty interval: never occluded
-    sh.ray_d[base_i] = make_float4(0.f, 0.f, 1.f, 0.0f);
-    sh.contrib[base_i] = make_float4(em.x, em.y, em.z, u2f(slot));
-    for (uint32_t li = 0; li < c.nlights; ++li) {
-        const MiptLight l = c.lights[li];
-        f3 contrib = mk3(0.0f, 0.0f, 0.0f);
-        float4 ro = make_float4(0.f, 0.f, 0.f, 1.0f), rd = make_float4(0.f, 0.f, 1.f, 0.0f);
-        if (l.type == 0) {
-            const f3 toL = ld3w(l.position) - P;
-            const float Ld = length(toL);
-            const float invd = 1.0f / Ld;
-            const f3 L = toL * invd;
-            const f3 V = -normalize(ray_d);
-            const f3 H = normalize(L + V);
-            const float NdL = dot(N, L), NdV = dot(N, V), NdH = dot(N, H), VdH = dot(V, H);
-            if (NdL > 0.0f && NdV > 0.0f) {
-                const f3 F = w_schlick(spec_color, VdH);
-                const float G = w_vis(NdL, NdV, alpha);
-                const float D = w_ggx(NdH, alpha);
-                const f3 diff = ((mk3(1.0f, 1.0f, 1.0f) - F) * diff_color) * (1.0f / 3.14159265358979323846f);
-                const f3 spec = (F * G) * D;
-                const f3 lc = ((ld3w(l.color) * 1.0f) * l.intensity) * NdL;
-                contrib = lc * (diff + spec);
-                ro = make_float4(P.x, P.y, P.z, 0.001f);
-                rd = make_float4(L.x, L.y, L.z, Ld - 0.001f);
+    if (!sample_material_texture(c, ti, g, tx)) return false;
+    alpha = tx.w;
+    return true;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wh_trace(WhConsts c, DeviceBvh bvh, const float4* ray_o, const float4* ray_d, const uint32_t* n_ptr,
+                                                 uint32_t n_max, float4* hits, float* attenuation, DeviceCounters* ctr)
+{
+    __shared__ uint32_t stk_lds[kStackEntries * 64];
+    const int lane = (int)threadIdx.x;
+    const Stack stk{ stk_lds, lane };
+    uint32_t n = n_max;
+    if (n_ptr) { const uint32_t m = *n_ptr; n = m < n ? m : n; }
+    for (uint32_t ray = blockIdx.x * 64u + threadIdx.x; ray < n; ray += gridDim.x * 64u) {
+        Trav T;
+        trav_init(T, ray_o[ray], ray_d[ray]);
+        float occlusion = 1.0f;
+        bool terminated = false;
+        while (T.node != kSentinel) {
+            while (T.node >= 0) visit_inner(T, bvh.nodes, stk);
+            if (T.node == kSentinel) break;
+            const uint32_t desc = ~(uint32_t)T.node;
+            const uint32_t first = desc >> 4, cnt = desc & 15u;
+            for (uint32_t i = 0; i < cnt && !terminated; ++i) {
+                const float4* tp = bvh.tris + (size_t)(first + i) * 3u;
+                const float4 a = tp[0], b = tp[1], cc = tp[2];
+                const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(cc.x, cc.y, cc.z);
+                const f3 p = fcross(T.d, e2);
+                const float det = fdot(e1, p);
+                if (det == 0.0f) continue;
+                const float inv = 1.0f / det;
+                const f3 tv = T.o - mk3(a.x, a.y, a.z);
+                const float u = fdot(tv, p) * inv;
+                const f3 q = fcross(tv, e1);
+                const float v = fdot(T.d, q) * inv;
+                const float t = fdot(e2, q) * inv;
+                if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) continue;
+                if (!(t > T.tmin && t < T.tmax)) continue;
+                const uint32_t prim = f2u(a.w), gflags = f2u(b.w);
+                if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;            // back face of a single-sided triangle
+                if ((gflags & 1u) == 0u) {                                               // any-hit program enabled
+                    uint32_t mi; float alpha;
+                    if (candidate_alpha(c, prim, u, v, mi, alpha)) {
+                        const MiptMaterialData& m = c.materials[mi];
+                        if (MODE == 0) {
+                            if (alpha < m.alpha_cutoff) continue;                        // optixIgnoreIntersection
+                        } else if (m.alpha_mode != 0) {
+                            if (m.alpha_mode == 1 && alpha < m.alpha_cutoff) continue;
+                            const float att = occlusion * (1.0f - alpha);
+                            if (att > 0.0f) { occlusion = att; continue; }
+                        }
+                    }
+                }
+                if (MODE != 0) { terminated = true; }
+                else if (t < T.tbest || (t == T.tbest && prim < T.prim)) { T.tbest = t; T.prim = prim; T.u = u; T.v = v; }
             }
-        } else if (l.type == 1) {
-            contrib = ld3w(l.color) * base;
+            if (terminated) break;
+            T.node = stk.pop(T.sp);
         }
-        sh.ray_o[base_i + 1u + li] = ro;
-        sh.ray_d[base_i + 1u + li] = rd;
-        sh.contrib[base_i + 1u + li] = make_float4(contrib.x, contrib.y, contrib.z, u2f(slot));
+        if (MODE == 0) hits[ray] = T.prim != 0xffffffffu ? make_float4(T.tbest, u2f(T.prim), T.u, T.v) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        else           attenuation[ray] = terminated ? 0.0f : occlusion;
+    }
+}
+
+// ---- raygen ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wh_raygen(WhConsts c, PathQueue q, uint32_t* n_levels)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_paths) return;
+    const uint32_t tiles_x = (c.width + 7u) >> 3;
+    const uint32_t tile = i >> 6, in = i & 63u;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t px = tx * 8u + (in & 7u), py = ty * 8u + (in >> 3);
+    if (px >= c.width || py >= c.height) {
+        q.ray_o[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
+        q.ray_d[i] = make_float4(0.f, 0.f, 1.f, 0.0f);
+        q.state_b[i] = make_uint2(kInvalidSlot, 0u);
+        return;
+    }
+    uint32_t seed = tea4(py * c.width + px, c.subframe_index);
+    float jx = 0.5f, jy = 0.5f;
+    if (c.subframe_index != 0u) { jx = rnd(seed); jy = rnd(seed); }
+    const float dx = 2.0f * (((float)px + jx) / (float)c.width) - 1.0f;
+    const float dy = 2.0f * (((float)py + jy) / (float)c.height) - 1.0f;
+    const f3 dir = normalize(dx * ld3w(c.U) + dy * ld3w(c.V) + ld3w(c.W));
+    q.ray_o[i] = make_float4(c.eye[0], c.eye[1], c.eye[2], 0.0f);
+    q.ray_d[i] = make_float4(dir.x, dir.y, dir.z, 1e16f);
+    q.state_b[i] = make_uint2(py * c.width + px, 0u);                            // payload depth 0
+    n_levels[py * c.width + px] = 0u;
+}
+
+// ---- closest-hit shading of one level ---------------------------------------------------------------------
+// Per hit one group of K = nlights + 1 entries (entry 0 = emission, entry 1 + i = light i): E0 = {colour, intensity
+// or a tag}, E1 = {diffuse + specular term, N.L} and the occlusion ray of a point light; the gather kernel multiplies
+// them with the attenuation in the reference's order.  tags in E0.w: -1 skip, -2 add E1.xyz as it is.
+struct WhLevel {
+    PathQueue cur, next;
+    const float4* hits;
+    ShadowQueue sh;              // occlusion rays + E0 in .contrib
+    float4* e1;
+    float4* group;               // per hit: {base alpha, is BLEND, slot bits, -}
+    float4* levels;              // [level][n_pixels]: {radiance of the level, 1 - alpha of a BLEND hit}
+    uint32_t* n_levels;          // per pixel: levels written so far
+    uint32_t level;              // = payload depth of the rays of this level
+    uint32_t n_pixels;
+    uint32_t bound;              // capacity of the queues
+};
+
+__global__ __launch_bounds__(256) void k_wh_shade(WhConsts c, WhLevel L, DeviceCounters* ctr)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_cur = ctr->n_cur < L.bound ? ctr->n_cur : L.bound;
+    bool is_hit = false;
+    uint32_t slot = kInvalidSlot;
+    float4 hit = make_float4(-1.f, 0.f, 0.f, 0.f);
+    if (i < n_cur) {
+        slot = L.cur.state_b[i].x;
+        if (slot != kInvalidSlot) {
+            hit = L.hits[i];
+            if (hit.x < 0.0f) {                                                  // __miss__constant_radiance
+                L.levels[(size_t)L.level * L.n_pixels + slot] = make_float4(c.miss_color[0], c.miss_color[1], c.miss_color[2], 0.f);
+                L.n_levels[slot] = L.level + 1u;
+            } else is_hit = true;
+        }
+    }
+    const uint32_t j = wave_append(is_hit, &ctr->n_shadow);                      // group index (scaled to rays by k_wh_scale)
+    // ---- surface
+    bool spawn = false;
+    float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4;
+    if (is_hit) {
+        const uint32_t K = c.nlights + 1u;
+        const uint32_t prim = f2u(hit.y);
+        ro4 = L.cur.ray_o[i]; rd4 = L.cur.ray_d[i];
+        const f3 ray_d = mk3(rd4.x, rd4.y, rd4.z);
+        WhLocalGeom g;
+        local_geometry(c, prim, hit.z, hit.w, g);
+        const MiptMaterialData m = c.materials[prim_material(c, prim)];
+        float4 bc = make_float4(m.base_color[0] * g.color.x, m.base_color[1] * g.color.y, m.base_color[2] * g.color.z, m.base_color[3] * g.color.w);
+        float4 tx;
+        if (sample_material_texture(c, m.base_color_tex, g, tx)) {
+            bc.x *= det_pow22(tx.x); bc.y *= det_pow22(tx.y); bc.z *= det_pow22(tx.z);      // linearize; not the alpha channel
+            bc.w *= tx.w;
+        }
+        const f3 base = mk3(bc.x, bc.y, bc.z);
+        float metallic = m.metallic, roughness = m.roughness;
+        float4 mr = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        sample_material_texture(c, m.metallic_roughness_tex, g, mr);                        // (occlusion, roughness, metallic)
+        roughness *= mr.y;
+        metallic *= mr.z;
+        const float F0 = 0.04f;
+        const f3 diff_color = (base * (1.0f - F0)) * (1.0f - metallic);
+        const f3 f0v = mk3(F0, F0, F0);
+        const f3 spec_color = f0v + metallic * (base - f0v);
+        const float alpha = roughness * roughness;
+        float4 emt = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        sample_material_texture(c, m.emissive_tex, g, emt);
+        const f3 em = ld3w(m.emissive_factor) * mk3(emt.x, emt.y, emt.z);
+        f3 N = g.N;
+        float4 nt;
+        if (sample_material_texture(c, m.normal_tex, g, nt)) {
+            const float nx = 2.0f * nt.x - 1.0f, ny = 2.0f * nt.y - 1.0f, nz = 2.0f * nt.z - 1.0f;
+            const float tx_ = nx * m.normal_tex.rotation[1] + ny * -m.normal_tex.rotation[0];
+            const float ty_ = nx * m.normal_tex.rotation[0] + ny * m.normal_tex.rotation[1];
+            const WhTexcoord& tc = g.tc[m.normal_tex.texcoord == 1 ? 1 : 0];
+            N = normalize((tx_ * normalize(tc.dpdu) + ty_ * normalize(tc.dpdv)) + nz * g.N);
+        }
+        const f3 P = g.P;
+        if (dot(N, ray_d) > 0.0f) N = -N;
+        const uint32_t depth = L.level + 1u;
+        const size_t base_i = (size_t)j * K;
+        const float4 no_ray_o = make_float4(0.f, 0.f, 0.f, 1.0f), no_ray_d = make_float4(0.f, 0.f, 1.f, 0.0f);   // empty interval
+        L.sh.ray_o[base_i] = no_ray_o; L.sh.ray_d[base_i] = no_ray_d;
+        L.sh.contrib[base_i] = make_float4(0.f, 0.f, 0.f, -2.0f);
+        L.e1[base_i] = make_float4(em.x, em.y, em.z, 0.f);
+        for (uint32_t li = 0; li < c.nlights; ++li) {
+            const MiptLight l = c.lights[li];
+            float4 e0 = make_float4(0.f, 0.f, 0.f, -1.0f), e1v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 ro = no_ray_o, rd = no_ray_d;
+            if (l.type == 0) {
+                if (depth < kWhMaxTraceDepth) {
+                    const f3 toL = ld3w(l.position) - P;
+                    const float Ld = length(toL);
+                    const float invd = 1.0f / Ld;
+                    const f3 Lv = toL * invd;
+                    const f3 V = -normalize(ray_d);
+                    const f3 H = normalize(Lv + V);
+                    const float NdL = dot(N, Lv), NdV = dot(N, V), NdH = dot(N, H), VdH = dot(V, H);
+                    if (NdL > 0.0f && NdV > 0.0f) {
+                        const f3 F = w_schlick(spec_color, VdH);
+                        const float G = w_vis(NdL, NdV, alpha);
+                        const float D = w_ggx(NdH, alpha);
+                        const f3 diff = ((mk3(1.0f, 1.0f, 1.0f) - F) * diff_color) * (1.0f / 3.14159265358979323846f);
+                        const f3 spec = (F * G) * D;
+                        const f3 ds = diff + spec;
+                        e0 = make_float4(l.color[0], l.color[1], l.color[2], l.intensity);
+                        e1v = make_float4(ds.x, ds.y, ds.z, NdL);
+                        if (!(l.intensity >= 0.0f)) e0.w = -1.0f;                        // negative / NaN intensities would collide with the tags
+                        ro = make_float4(P.x, P.y, P.z, 0.001f);
+                        rd = make_float4(Lv.x, Lv.y, Lv.z, Ld - 0.001f);
+                    }
+                }
+            } else if (l.type == 1) {
+                const f3 amb = ld3w(l.color) * base;
+                e0.w = -2.0f;
+                e1v = make_float4(amb.x, amb.y, amb.z, 0.f);
+            }
+            L.sh.ray_o[base_i + 1u + li] = ro;
+            L.sh.ray_d[base_i + 1u + li] = rd;
+            L.sh.contrib[base_i + 1u + li] = e0;
+            L.e1[base_i + 1u + li] = e1v;
+        }
+        const bool blend = m.alpha_mode == 2;
+        L.group[j] = make_float4(bc.w, blend ? 1.0f : 0.0f, u2f(slot), 0.f);
+        L.n_levels[slot] = L.level + 1u;
+        spawn = blend && depth < kWhMaxTraceDepth;                                          // continuation ray, whitted.cu:272-283
+    }
+    const uint32_t jn = wave_append(spawn, &ctr->n_next);
+    if (spawn) {
+        L.next.ray_o[jn] = make_float4(ro4.x, ro4.y, ro4.z, hit.x);                         // tmin = optixGetRayTmax() = the hit distance
+        L.next.ray_d[jn] = make_float4(rd4.x, rd4.y, rd4.z, 1e16f);
+        L.next.state_b[jn] = make_uint2(slot, L.level + 1u);
     }
 }
 
 __global__ void k_wh_scale(DeviceCounters* ctr, uint32_t K)
 {
-    if (threadIdx.x == 0) ctr->n_shadow = ctr->n_next * K;
+    if (threadIdx.x == 0) { ctr->bounce = ctr->n_shadow; ctr->n_shadow = ctr->n_shadow * K; }   // bounce := number of groups
 }
 
-__global__ __launch_bounds__(256) void k_wh_gather(uint32_t K, const float4* ray_d, const float4* contrib, const uint32_t* occluded,
-                                                   float4* result, DeviceCounters* ctr)
+// adds the entries of a group in the reference's order: result = 0 + emission, then the lights
+__global__ __launch_bounds__(256) void k_wh_gather(uint32_t K, WhLevel L, const uint32_t* occluded, const float* attenuation, DeviceCounters* ctr)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ctr->n_next) return;
+    if (j >= ctr->bounce) return;
     const size_t base = (size_t)j * K;
     f3 r = mk3(0.0f, 0.0f, 0.0f);
-    uint32_t slot = 0;
     uint32_t traced = 0;
     for (uint32_t k = 0; k < K; ++k) {
-        const float4 cc = contrib[base + k];
-        slot = f2u(cc.w);
-        if (!occluded[base + k]) r = r + mk3(cc.x, cc.y, cc.z);
-        traced += ray_d[base + k].w > 0.0f ? 1u : 0u;
+        const float4 e0 = L.sh.contrib[base + k], e1 = L.e1[base + k];
+        if (e0.w == -1.0f) continue;
+        if (e0.w == -2.0f) { r = r + mk3(e1.x, e1.y, e1.z); continue; }
+        ++traced;
+        const float att = attenuation ? attenuation[base + k] : (occluded[base + k] ? 0.0f : 1.0f);
+        if (att > 0.0f) {
+            const f3 lc = ((mk3(e0.x, e0.y, e0.z) * att) * e0.w) * e1.w;
+            r = r + lc * mk3(e1.x, e1.y, e1.z);
+        }
     }
-    result[slot] = make_float4(r.x, r.y, r.z, 0.f);
-    if (traced) atomicAdd(&ctr->shadow_rays, (unsigned long long)traced);     // occlusion rays really cast
+    const float4 gh = L.group[j];
+    const uint32_t slot = f2u(gh.z);
+    float w = 0.0f;
+    if (gh.y != 0.0f) { r = r * gh.x; w = 1.0f - gh.x; }                                    // ALPHA_MODE_BLEND: result *= base_color.w
+    L.levels[(size_t)L.level * L.n_pixels + slot] = make_float4(r.x, r.y, r.z, w);
+    if (traced) atomicAdd(&ctr->shadow_rays, (unsigned long long)traced);                   // occlusion rays really cast
 }
 
-__global__ __launch_bounds__(256) void k_wh_resolve(WhConsts c, const float4* result, float4* accum, uint32_t* frame)
+__global__ void k_wh_advance(DeviceCounters* c)
+{
+    const uint32_t i = threadIdx.x;
+    if (i == 0) { c->closest_rays += c->n_next; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; }
+    if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
+}
+
+// composes the levels back to front (result += alpha_payload.result * (1 - base_color.w), whitted.cu:285), then the
+// progressive lerp + sRGB8 of the raygen program (:82-96)
+__global__ __launch_bounds__(256) void k_wh_resolve(WhConsts c, const float4* levels, const uint32_t* n_levels, float4* accum, uint32_t* frame)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.width * c.height) return;
-    const float4 r = result[i];
-    f3 col = mk3(r.x, r.y, r.z);
+    const uint32_t n_pixels = c.width * c.height;
+    if (i >= n_pixels) return;
+    const uint32_t n = n_levels[i];
+    f3 col = mk3(0.0f, 0.0f, 0.0f);
+    if (n != 0u) {
+        const float4 last = levels[(size_t)(n - 1u) * n_pixels + i];
+        col = mk3(last.x, last.y, last.z);
+        for (uint32_t l = n - 1u; l-- > 0u;) {
+            const float4 a = levels[(size_t)l * n_pixels + i];
+            col = mk3(a.x, a.y, a.z) + col * mk3(a.w, a.w, a.w);
+        }
+    }
     if (c.subframe_index > 0u) {
         const float a = 1.0f / (float)(c.subframe_index + 1u);
         const float4 p = accum[i];
@@ -286,7 +446,7 @@ __global__ __launch_bounds__(256) void k_wh_resolve(WhConsts c, const float4* re
 
 void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_paths, const DeviceBvh& bvh, const WhGeometry& geo,
                  const MiptMaterialData* d_materials, uint32_t n_materials, const WhTexture* d_textures, uint32_t n_textures,
-                 PathQueue q, float4* hits, ShadowQueue sh, uint32_t* occluded, float4* result, DeviceCounters* ctr, const TraceOpts& opts)
+                 const WhBuffers& B, DeviceCounters* ctr, const TraceOpts& opts)
 {
     WhConsts c{};
     c.width = p.width; c.height = p.height; c.subframe_index = p.subframe_index; c.n_paths = n_paths;
@@ -295,15 +455,34 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
     c.geo = geo; c.materials = d_materials; c.nmaterials = n_materials; c.textures = d_textures; c.ntextures = n_textures;
     const uint32_t K = c.nlights + 1u;
     const uint32_t blocks = (n_paths + 255u) / 256u;
-    launch_begin_sample(st, ctr, n_paths, p.width * p.height);
-    hipLaunchKernelGGL(k_wh_raygen, dim3(blocks), dim3(256), 0, st, c, q);
-    launch_trace_closest(st, bvh, q.ray_o, q.ray_d, 1, &ctr->n_cur, n_paths, hits, ctr, opts);
-    hipLaunchKernelGGL(k_wh_shade, dim3(blocks), dim3(256), 0, st, c, q, hits, sh, result, ctr);
-    hipLaunchKernelGGL(k_wh_scale, dim3(1), dim3(64), 0, st, ctr, K);
-    launch_trace_any(st, bvh, sh.ray_o, sh.ray_d, 1, &ctr->n_shadow, n_paths * K, occluded, nullptr, nullptr, ctr, opts);
-    hipLaunchKernelGGL(k_wh_gather, dim3(blocks), dim3(256), 0, st, K, sh.ray_d, sh.contrib, occluded, result, ctr);
-    const uint32_t pb = (p.width * p.height + 255u) / 256u;
-    hipLaunchKernelGGL(k_wh_resolve, dim3(pb), dim3(256), 0, st, c, result, (float4*)p.accum_buffer, (uint32_t*)p.frame_buffer);
+    const uint32_t n_pixels = p.width * p.height;
+    launch_begin_sample(st, ctr, n_paths, n_pixels);
+    hipLaunchKernelGGL(k_wh_raygen, dim3(blocks), dim3(256), 0, st, c, B.q[0], B.n_levels);
+    const int tblocks = opts.blocks > 0 ? opts.blocks : 4096;
+    for (uint32_t level = 0; level < B.max_levels; ++level) {
+        const PathQueue cur = B.q[level & 1u], next = B.q[(level & 1u) ^ 1u];
+        if (B.any_hit_programs)
+            hipLaunchKernelGGL((k_wh_trace<0>), dim3(tblocks), dim3(64), 0, st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, (float*)nullptr, ctr);
+        else
+            launch_trace_closest(st, bvh, cur.ray_o, cur.ray_d, 1, &ctr->n_cur, n_paths, B.hits, ctr, opts,
+                                 MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES);          // traceRadiance, whitted_cuda.h:110
+        WhLevel L{};
+        L.cur = cur; L.next = next; L.hits = B.hits; L.sh = B.sh; L.e1 = B.e1; L.group = B.group; L.levels = B.levels; L.n_levels = B.n_levels;
+        L.level = level; L.n_pixels = n_pixels; L.bound = n_paths;
+        hipLaunchKernelGGL(k_wh_shade, dim3(blocks), dim3(256), 0, st, c, L, ctr);
+        hipLaunchKernelGGL(k_wh_scale, dim3(1), dim3(64), 0, st, ctr, K);
+        if (B.any_hit_programs)
+            hipLaunchKernelGGL((k_wh_trace<1>), dim3(tblocks), dim3(64), 0, st, c, bvh, B.sh.ray_o, B.sh.ray_d, &ctr->n_shadow, n_paths * K, (float4*)nullptr,
+                               (float*)B.flags, ctr);
+        else
+            launch_trace_any(st, bvh, B.sh.ray_o, B.sh.ray_d, 1, &ctr->n_shadow, n_paths * K, B.flags, nullptr, nullptr, ctr, opts);
+        hipLaunchKernelGGL(k_wh_gather, dim3(blocks), dim3(256), 0, st, K, L, (const uint32_t*)B.flags,
+                           B.any_hit_programs ? (const float*)B.flags : (const float*)nullptr, ctr);
+        hipLaunchKernelGGL(k_wh_advance, dim3(1), dim3(64), 0, st, ctr);
+    }
+    const uint32_t pb = (n_pixels + 255u) / 256u;
+    hipLaunchKernelGGL(k_wh_resolve, dim3(pb), dim3(256), 0, st, c, (const float4*)B.levels, (const uint32_t*)B.n_levels, (float4*)p.accum_buffer,
+                       (uint32_t*)p.frame_buffer);
 }
 
 }  // namespace mipt

@@ -72,10 +72,11 @@ def loadScene(state, filename, device_index=0, log=None, log_level=0):
     if has.any():
         state.d_colors = torch.from_numpy(np.ascontiguousarray(col)).to(state.device)
         state.d_color_present = torch.from_numpy(np.ascontiguousarray(has)).to(state.device)
+    state.materials = state.scene.material_table()
     state.handle = state.context.accel_build([{
         "vertices": state.d_vertices.data_ptr(), "num_vertices": verts.shape[0], "stride": 16,
+        "sbt_index_offsets": np.minimum(mat, len(state.materials) - 1).astype(np.uint32), "flags": geometry_flags(state.materials),
     }])
-    state.materials = state.scene.material_table()
     state.textures = state.scene.texture_table()
     ptr = lambda t: t.data_ptr() if t is not None else None            # noqa: E731
     geo = L.MiptWhittedGeometry()
@@ -85,6 +86,17 @@ def loadScene(state, filename, device_index=0, log=None, log_level=0):
     geo.colors4, geo.color_present = ptr(state.d_colors), ptr(state.d_color_present)
     state.context._check(state.context._lib.mipt_whitted_set_geometry(
         state.context._h, C.byref(geo), state.materials, len(state.materials), state.textures[0], state.textures[1]))
+
+
+def geometry_flags(materials):
+    """OptixGeometryFlags per material as Scene::buildMeshAccels picks them (Scene.cpp:904-966): opaque -> DISABLE_ANYHIT,
+    mask -> NONE, blend -> REQUIRE_SINGLE_ANYHIT_CALL, each | DISABLE_TRIANGLE_FACE_CULLING when doubleSided; the last
+    table entry (primitives without a material) is opaque and single sided"""
+    out = []
+    for m in materials:
+        base = {0: L.GEOMETRY_FLAG_DISABLE_ANYHIT, 1: L.GEOMETRY_FLAG_NONE, 2: L.GEOMETRY_FLAG_REQUIRE_SINGLE_ANYHIT_CALL}[int(m.alpha_mode)]
+        out.append(base | (L.GEOMETRY_FLAG_DISABLE_TRIANGLE_FACE_CULLING if m.double_sided else 0))
+    return np.asarray(out, np.uint32)
 
 
 def initCameraState(state):

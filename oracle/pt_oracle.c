@@ -284,6 +284,7 @@ struct OrcScene {
     Node64*   nodes; uint32_t n_nodes;
     Tri48*    tris;  uint32_t n_leaf_tris;
     int       depth;
+    uint32_t* prim_flags;  /* OptixGeometryFlags per ORIGINAL primitive (NULL = none): 1 DISABLE_ANYHIT, 4 DISABLE_TRIANGLE_FACE_CULLING */
 };
 
 #define LEAF_REF(first, count) (~(int32_t)(((uint32_t)(first) << 4) | (uint32_t)(count)))
@@ -327,7 +328,16 @@ void orc_scene_destroy(OrcScene* s)
 {
     if (!s) return;
     free(s->verts); free(s->mat); free(s->emission); free(s->diffuse);
-    free(s->brute); free(s->nodes); free(s->tris); free(s);
+    free(s->brute); free(s->nodes); free(s->tris); free(s->prim_flags); free(s);
+}
+
+/* OptixGeometryFlags per original primitive (copied); NULL clears them */
+void orc_scene_set_prim_flags(OrcScene* s, const uint32_t* flags)
+{
+    free(s->prim_flags); s->prim_flags = NULL;
+    if (!flags) return;
+    s->prim_flags = (uint32_t*)malloc((size_t)(s->n_tris ? s->n_tris : 1) * sizeof(uint32_t));
+    memcpy(s->prim_flags, flags, (size_t)s->n_tris * sizeof(uint32_t));
 }
 
 uint32_t orc_scene_num_nodes(const OrcScene* s) { return s->n_nodes; }
@@ -596,7 +606,7 @@ static inline void ray_prepare(Ray* r)
 }
 
 /* returns 1 and writes t,u,v when the triangle is hit inside (tmin, tmax) */
-static inline int tri_test(const Tri48* T, const Ray* r, float tmax, float* t_out, float* u_out, float* v_out)
+static inline int tri_test_det(const Tri48* T, const Ray* r, float tmax, float* t_out, float* u_out, float* v_out, float* det_out)
 {
     v3    e1 = v3_ld(T->e1), e2 = v3_ld(T->e2);
     v3    p   = fcross(r->d, e2);
@@ -610,8 +620,13 @@ static inline int tri_test(const Tri48* T, const Ray* r, float tmax, float* t_ou
     float t   = fdot(e2, q) * inv;
     if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) return 0;
     if (!(t > r->tmin && t < tmax)) return 0;
-    *t_out = t; *u_out = u; *v_out = v;
+    *t_out = t; *u_out = u; *v_out = v; *det_out = det;
     return 1;
+}
+static inline int tri_test(const Tri48* T, const Ray* r, float tmax, float* t_out, float* u_out, float* v_out)
+{
+    float det;
+    return tri_test_det(T, r, tmax, t_out, u_out, v_out, &det);
 }
 
 /* slab test of one child box; returns entry distance, hit flag through *hit */
@@ -628,6 +643,23 @@ static inline float box_test(const float x[2], const float y[2], const float z[2
 
 typedef struct { int hit; float t, u, v; uint32_t prim; } HitRec;
 
+/* what optixTrace's ray flags and the any-hit programs add to a plain traversal (NULL = nothing) */
+typedef struct TraceFilter {
+    uint32_t ray_flags;                                   /* 16 = OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES */
+    int    (*anyhit)(void* ctx, uint32_t prim, float t, float u, float v);   /* 0 = optixIgnoreIntersection() */
+    void*    ctx;
+} TraceFilter;
+
+/* back = the ray sees (v1-v0) x (v2-v0) from behind: det = e1 . (d x e2) = -d . Ng < 0 */
+static inline int filter_rejects(const OrcScene* s, const TraceFilter* f, uint32_t prim, float det, float t, float u, float v)
+{
+    if (!f) return 0;
+    uint32_t gf = s->prim_flags ? s->prim_flags[prim] : 0u;
+    if ((f->ray_flags & 16u) && !(gf & 4u) && det < 0.0f) return 1;
+    if (f->anyhit && !(gf & 1u) && !f->anyhit(f->ctx, prim, t, u, v)) return 1;
+    return 0;
+}
+
 static inline void consider(HitRec* h, float t, float u, float v, uint32_t prim)
 {
     if (!h->hit || t < h->t || (t == h->t && prim < h->prim)) {
@@ -635,13 +667,14 @@ static inline void consider(HitRec* h, float t, float u, float v, uint32_t prim)
     }
 }
 
-static void brute_force(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats* st)
+static void brute_force(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats* st, const TraceFilter* flt)
 {
     h->hit = 0; h->t = r->tmax; h->prim = 0xffffffffu; h->u = h->v = 0.0f;
     for (uint32_t i = 0; i < s->n_tris; ++i) {
-        float t, u, v;
+        float t, u, v, det;
         if (st) { st->tri_tests++; if (any) st->shadow_tri_tests++; }
-        if (tri_test(&s->brute[i], r, r->tmax, &t, &u, &v)) {
+        if (tri_test_det(&s->brute[i], r, r->tmax, &t, &u, &v, &det)) {
+            if (filter_rejects(s, flt, i, det, t, u, v)) continue;
             if (any) { h->hit = 1; h->t = t; h->prim = i; return; }
             consider(h, t, u, v, i);
         }
@@ -649,7 +682,7 @@ static void brute_force(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats*
 }
 
 /* per-ray stack traversal, near child first; identical visiting order to the HIP kernel */
-static void bvh_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats* st)
+static void bvh_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats* st, const TraceFilter* flt)
 {
     int32_t stack[STACK_MAX];
     int     sp = 0;
@@ -678,9 +711,10 @@ static void bvh_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats
         } else {
             uint32_t d = (uint32_t)~node, first = d >> 4, cnt = d & 15u;
             for (uint32_t i = first; i < first + cnt; ++i) {
-                float t, u, v;
+                float t, u, v, det;
                 if (st) { st->tri_tests++; if (any) st->shadow_tri_tests++; }
-                if (tri_test(&s->tris[i], r, r->tmax, &t, &u, &v)) {
+                if (tri_test_det(&s->tris[i], r, r->tmax, &t, &u, &v, &det)) {
+                    if (filter_rejects(s, flt, s->tris[i].prim, det, t, u, v)) continue;
                     if (any) { h->hit = 1; h->t = t; h->prim = s->tris[i].prim; return; }
                     consider(h, t, u, v, s->tris[i].prim);
                 }
@@ -690,14 +724,19 @@ static void bvh_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats
     }
 }
 
-static inline void trace(const OrcScene* s, int mode, v3 o, v3 d, float tmin, float tmax, int any,
-                         HitRec* h, OrcStats* st)
+static inline void trace_ex(const OrcScene* s, int mode, v3 o, v3 d, float tmin, float tmax, int any,
+                            HitRec* h, OrcStats* st, const TraceFilter* flt)
 {
     Ray r; r.o = o; r.d = d; r.tmin = tmin; r.tmax = tmax;
     ray_prepare(&r);
     if (st) { if (any) st->shadow_rays++; else st->closest_rays++; }
-    if (mode == ORC_MODE_BVH) bvh_traverse(s, &r, any, h, st);
-    else                      brute_force(s, &r, any, h, st);
+    if (mode == ORC_MODE_BVH) bvh_traverse(s, &r, any, h, st, flt);
+    else                      brute_force(s, &r, any, h, st, flt);
+}
+static inline void trace(const OrcScene* s, int mode, v3 o, v3 d, float tmin, float tmax, int any,
+                         HitRec* h, OrcStats* st)
+{
+    trace_ex(s, mode, o, d, tmin, tmax, any, h, st, NULL);
 }
 
 void orc_trace_closest(const OrcScene* s, int mode, const float* rays, uint32_t n,
@@ -1193,15 +1232,84 @@ static int sample_material_texture(const OrcWhittedFrame* f, const OrcTexInfoW* 
     return 1;
 }
 
-/* __closesthit__radiance, cuda/whitted.cu:149-289 (alpha modes are not applied yet: every material is opaque) */
-static v3 whitted_closesthit(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 ray_o, v3 ray_d, const HitRec* h, OrcStats* st)
+#define WH_MAX_TRACE_DEPTH 8u                     /* whitted::MAX_TRACE_DEPTH, cuda/whitted.h:42 */
+
+typedef struct { const OrcScene* s; const OrcWhittedFrame* f; float occlusion; } AnyhitCtx;
+
+static const OrcMaterialW* prim_material(const OrcWhittedFrame* f, uint32_t prim)
 {
-    (void)ray_o;                                         /* geom.P is interpolated, not origin + t * direction */
+    uint32_t mi = f->material_index ? f->material_index[prim] : 0u;
+    if (mi >= f->nmaterials) mi = f->nmaterials - 1u;
+    return &f->materials[mi];
+}
+
+/* alpha of the base-colour texture at a candidate hit; 0 = the material has no (decodable) base-colour texture */
+static int candidate_alpha(const AnyhitCtx* c, uint32_t prim, float t, float u, float v, const OrcMaterialW** m_out, float* alpha)
+{
+    const OrcMaterialW* m = prim_material(c->f, prim);
+    *m_out = m;
+    HitRec h; h.hit = 1; h.t = t; h.u = u; h.v = v; h.prim = prim;
+    LocalGeomW g;
+    local_geometry(c->s, c->f, &h, &g);
+    float tx[4];
+    if (!sample_material_texture(c->f, &m->base_color_tex, &g, tx)) return 0;
+    *alpha = tx[3];
+    return 1;
+}
+
+/* __anyhit__radiance, cuda/whitted.cu:100-111: "force mask mode, even for blend mode" */
+static int anyhit_radiance(void* ctx, uint32_t prim, float t, float u, float v)
+{
+    const AnyhitCtx* c = (const AnyhitCtx*)ctx;
+    const OrcMaterialW* m; float alpha;
+    if (candidate_alpha(c, prim, t, u, v, &m, &alpha) && alpha < m->alpha_cutoff) return 0;
+    return 1;
+}
+
+/* __anyhit__occlusion, cuda/whitted.cu:113-136 */
+static int anyhit_occlusion(void* ctx, uint32_t prim, float t, float u, float v)
+{
+    AnyhitCtx* c = (AnyhitCtx*)ctx;
+    const OrcMaterialW* m; float alpha;
+    if (candidate_alpha(c, prim, t, u, v, &m, &alpha) && m->alpha_mode != 0) {
+        if (m->alpha_mode == 1 && alpha < m->alpha_cutoff) return 0;
+        float attenuation = c->occlusion * (1.0f - alpha);
+        if (attenuation > 0.0f) { c->occlusion = attenuation; return 0; }
+    }
+    return 1;
+}
+
+/* whitted::traceOcclusion, cuda/whitted_cuda.h:127-160: pending attenuation, committed by the miss program only */
+static float whitted_trace_occlusion(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 o, v3 d, float tmin, float tmax, OrcStats* st)
+{
+    AnyhitCtx c = { s, f, 1.0f };
+    TraceFilter flt = { 0u, anyhit_occlusion, &c };
+    HitRec sh;
+    trace_ex(s, mode, o, d, tmin, tmax, 1, &sh, st, &flt);
+    return sh.hit ? 0.0f : c.occlusion;
+}
+
+static v3 whitted_closesthit(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 ray_o, v3 ray_d, const HitRec* h,
+                             uint32_t payload_depth, OrcStats* st);
+
+/* whitted::traceRadiance, cuda/whitted_cuda.h:88-119 (OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) + the miss program */
+static v3 whitted_trace_radiance(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 o, v3 d, float tmin, float tmax,
+                                 uint32_t payload_depth, OrcStats* st)
+{
+    AnyhitCtx c = { s, f, 1.0f };
+    TraceFilter flt = { 16u, anyhit_radiance, &c };
+    HitRec h;
+    trace_ex(s, mode, o, d, tmin, tmax, 0, &h, st, &flt);
+    return h.hit ? whitted_closesthit(s, mode, f, o, d, &h, payload_depth, st) : v3_ld(f->miss_color);
+}
+
+/* __closesthit__radiance, cuda/whitted.cu:149-289 */
+static v3 whitted_closesthit(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 ray_o, v3 ray_d, const HitRec* h,
+                             uint32_t payload_depth, OrcStats* st)
+{
     LocalGeomW g;
     local_geometry(s, f, h, &g);
-    uint32_t mi = f->material_index ? f->material_index[h->prim] : 0u;
-    if (mi >= f->nmaterials) mi = f->nmaterials - 1u;
-    const OrcMaterialW* m = &f->materials[mi];
+    const OrcMaterialW* m = prim_material(f, h->prim);
     float bc[4];
     for (int k = 0; k < 4; ++k) bc[k] = m->base_color[k] * g.color[k];
     float tx[4];
@@ -1235,34 +1343,44 @@ static v3 whitted_closesthit(const OrcScene* s, int mode, const OrcWhittedFrame*
         N = v3_normalize(v3_add(v3_add(v3_scale(v3_normalize(tc->dpdu), tx_), v3_scale(v3_normalize(tc->dpdv), ty_)), v3_scale(g.N, nz)));
     }
     if (v3_dot(N, ray_d) > 0.0f) N = v3_make(-N.x, -N.y, -N.z);
+    const uint32_t depth = payload_depth + 1u;
     const v3 P = g.P;
     for (uint32_t i = 0; i < f->nlights; ++i) {
         const OrcLightW* l = &f->lights[i];
         if (l->type == 0) {
-            v3 toL = v3_sub(v3_ld(l->position), P);
-            float Ld = v3_length(toL);
-            float invd = 1.0f / Ld;
-            v3 L = v3_scale(toL, invd);
-            v3 nd = v3_normalize(ray_d);
-            v3 Vv = v3_make(-nd.x, -nd.y, -nd.z);
-            v3 H = v3_normalize(v3_add(L, Vv));
-            float NdL = v3_dot(N, L), NdV = v3_dot(N, Vv), NdH = v3_dot(N, H), VdH = v3_dot(Vv, H);
-            if (NdL > 0.0f && NdV > 0.0f) {
-                HitRec sh;
-                trace(s, mode, P, L, 0.001f, Ld - 0.001f, 1, &sh, st);
-                if (!sh.hit) {
-                    v3 F = w_schlick(spec_color, VdH);
-                    float G = w_vis(NdL, NdV, alpha);
-                    float D = w_ggx(NdH, alpha);
-                    v3 one = v3_make(1.0f, 1.0f, 1.0f);
-                    v3 diff = v3_scale(v3_mul(v3_sub(one, F), diff_color), 1.0f / 3.14159265358979323846f);
-                    v3 spec = v3_scale(v3_scale(F, G), D);
-                    v3 lc = v3_scale(v3_scale(v3_scale(v3_ld(l->color), 1.0f), l->intensity), NdL);
-                    result = v3_add(result, v3_mul(lc, v3_add(diff, spec)));
+            if (depth < WH_MAX_TRACE_DEPTH) {
+                v3 toL = v3_sub(v3_ld(l->position), P);
+                float Ld = v3_length(toL);
+                float invd = 1.0f / Ld;
+                v3 L = v3_scale(toL, invd);
+                v3 nd = v3_normalize(ray_d);
+                v3 Vv = v3_make(-nd.x, -nd.y, -nd.z);
+                v3 H = v3_normalize(v3_add(L, Vv));
+                float NdL = v3_dot(N, L), NdV = v3_dot(N, Vv), NdH = v3_dot(N, H), VdH = v3_dot(Vv, H);
+                if (NdL > 0.0f && NdV > 0.0f) {
+                    float attenuation = whitted_trace_occlusion(s, mode, f, P, L, 0.001f, Ld - 0.001f, st);
+                    if (attenuation > 0.0f) {
+                        v3 F = w_schlick(spec_color, VdH);
+                        float G = w_vis(NdL, NdV, alpha);
+                        float D = w_ggx(NdH, alpha);
+                        v3 one = v3_make(1.0f, 1.0f, 1.0f);
+                        v3 diff = v3_scale(v3_mul(v3_sub(one, F), diff_color), 1.0f / 3.14159265358979323846f);
+                        v3 spec = v3_scale(v3_scale(F, G), D);
+                        v3 lc = v3_scale(v3_scale(v3_scale(v3_ld(l->color), attenuation), l->intensity), NdL);
+                        result = v3_add(result, v3_mul(lc, v3_add(diff, spec)));
+                    }
                 }
             }
         } else if (l->type == 1) {
             result = v3_add(result, v3_mul(v3_ld(l->color), base));
+        }
+    }
+    if (m->alpha_mode == 2) {                                                    /* ALPHA_MODE_BLEND, :268-286 */
+        result = v3_scale(result, bc[3]);
+        if (depth < WH_MAX_TRACE_DEPTH) {
+            v3 next = whitted_trace_radiance(s, mode, f, ray_o, ray_d, h->t, 1e16f, depth, st);
+            float w = 1.0f - bc[3];
+            result = v3_add(result, v3_mul(next, v3_make(w, w, w)));
         }
     }
     return result;
@@ -1281,9 +1399,7 @@ int orc_whitted_render_rows(const OrcScene* s, int mode, const OrcWhittedFrame* 
             float dx = 2.0f * (((float)x + jx) / (float)f->width) - 1.0f;
             float dy = 2.0f * (((float)y + jy) / (float)f->height) - 1.0f;
             v3 rd = v3_normalize(v3_add(v3_add(v3_scale(U, dx), v3_scale(V, dy)), W));
-            HitRec h;
-            trace(s, mode, eye, rd, 0.0f, 1e16f, 0, &h, st);
-            v3 c = h.hit ? whitted_closesthit(s, mode, f, eye, rd, &h, st) : v3_ld(f->miss_color);
+            v3 c = whitted_trace_radiance(s, mode, f, eye, rd, 0.0f, 1e16f, 0u, st);
             float* acc = f->accum_buffer + idx * 4;
             if (f->subframe_index > 0) {
                 float a = 1.0f / (float)(f->subframe_index + 1);

@@ -81,6 +81,7 @@ OrcScene* orc_scene_create(const float* vertices4 /* n_tris*3 float4 */, uint32_
                            const float* emission3, const float* diffuse3, uint32_t n_mat,
                            const float bg[4]);
 void      orc_scene_destroy(OrcScene*);
+void      orc_scene_set_prim_flags(OrcScene*, const uint32_t* flags_per_prim);   /* OptixGeometryFlags; NULL clears */
 /* own binned-SAH builder */
 int       orc_scene_build_bvh(OrcScene*, int leaf_max, int max_depth);
 /* adopt a BVH in the layout of include/mipt.h (MiptBvhNode / MiptBvhTri) */

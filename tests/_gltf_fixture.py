@@ -278,3 +278,71 @@ def write_textured(tmpdir, seed=3):
     path = tmpdir / "textured.gltf"
     path.write_text(json.dumps(doc))
     return path
+
+
+def write_alpha(tmpdir, seed=4):
+    """Alpha MASK / BLEND materials, single- and double-sided: a ground, a masked fence, two stacked blend panes (textured
+    alpha), an untextured blend pane, and two opaque panes seen from behind (one single sided -> culled for camera rays)."""
+    import _png_fixture as PF
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:8, 0:8]
+    fence = np.zeros((8, 8, 4), int)
+    fence[..., :3] = rng.integers(80, 256, (8, 8, 3))
+    fence[..., 3] = np.where((xx + yy) % 3 == 0, 0, np.where((xx * yy) % 5 == 0, 100, 255))
+    glass = np.zeros((4, 4, 4), int)
+    glass[..., :3] = rng.integers(0, 256, (4, 4, 3))
+    glass[..., 3] = rng.integers(60, 220, (4, 4))
+    uri = lambda b: "data:image/png;base64," + base64.b64encode(b).decode()          # noqa: E731
+    quad_uv = np.asarray([[0, 0], [1, 0], [1, 1], [0, 0], [1, 1], [0, 1]], f32)
+
+    def quad(p0, du, dv):
+        p0, du, dv = [np.asarray(x, f32) for x in (p0, du, dv)]
+        return np.stack([p0, p0 + du, p0 + du + dv, p0, p0 + du + dv, p0 + dv]).astype(f32)
+    quads = [
+        quad((-3, 0, 3), (6, 0, 0), (0, 0, -6)),            # 0 ground (+y)
+        quad((-1.5, 0, 0.5), (1.4, 0, 0), (0, 1.6, 0)),     # 1 fence, faces +z
+        quad((0.2, 0.1, 0.9), (1.3, 0, 0), (0, 1.4, 0)),    # 2 pane A (blend, textured)
+        quad((0.4, 0.2, 0.3), (1.3, 0, 0), (0, 1.4, 0)),    # 3 pane B behind A
+        quad((-0.6, 0.9, 1.4), (0.9, 0, 0), (0, 0.8, 0)),   # 4 untextured blend pane
+        quad((-2.6, 0.1, -0.5), (0, 0, 1.0), (0, 1.2, 0)),  # 5 opaque single sided, winding faces -x: seen from behind
+        quad((1.9, 0.1, -0.5), (0, 1.2, 0), (0, 0, 1.0)),   # 6 opaque double sided, faces -x as well from the camera? (+x normal flipped)
+    ]
+    mats_of = [0, 1, 2, 2, 3, 4, 5]
+    parts, views, accs, prims = [], [], [], []
+    blob = b""
+    for k, qv in enumerate(quads):
+        for arr, typ in ((qv, "VEC3"), (quad_uv, "VEC2")):
+            blob += b"\0" * (-len(blob) % 4)
+            views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": arr.nbytes})
+            a = {"bufferView": len(views) - 1, "componentType": 5126, "count": 6, "type": typ}
+            if typ == "VEC3":
+                a["min"] = [float(x) for x in arr.min(0)]; a["max"] = [float(x) for x in arr.max(0)]
+            accs.append(a)
+            blob += arr.tobytes()
+        prims.append({"attributes": {"POSITION": 2 * k, "TEXCOORD_0": 2 * k + 1}, "material": mats_of[k]})
+    doc = {
+        "asset": {"version": "2.0"},
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+        "bufferViews": views, "accessors": accs,
+        "images": [{"uri": uri(PF.encode(fence, 6, 8)[0])}, {"uri": uri(PF.encode(glass, 6, 8)[0])}],
+        "samplers": [{"minFilter": 9728}, {}],
+        "textures": [{"source": 0, "sampler": 0}, {"source": 1, "sampler": 1}],
+        "materials": [
+            {"name": "ground", "pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.8, 0.75, 1], "metallicFactor": 0.0, "roughnessFactor": 0.9}},
+            {"name": "fence", "alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True,
+             "pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicFactor": 0.0, "roughnessFactor": 0.7}},
+            {"name": "glass", "alphaMode": "BLEND", "doubleSided": True,
+             "pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 0.9], "baseColorTexture": {"index": 1}, "metallicFactor": 0.2, "roughnessFactor": 0.4}},
+            {"name": "film", "alphaMode": "BLEND", "doubleSided": True,
+             "pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.3, 0.2, 0.5], "metallicFactor": 0.0, "roughnessFactor": 0.8}},
+            {"name": "wall1", "pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.7, 0.3, 1], "metallicFactor": 0.0, "roughnessFactor": 0.8}},
+            {"name": "wall2", "doubleSided": True, "pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.3, 0.8, 1], "metallicFactor": 0.0, "roughnessFactor": 0.8}},
+        ],
+        "meshes": [{"primitives": prims}],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 0.9, "aspectRatio": 1.5, "znear": 0.1}}],
+        "nodes": [{"mesh": 0}, {"camera": 0, "translation": [0.0, 1.6, 5.0], "rotation": [-0.1305261922, 0.0, 0.0, 0.9914448614]}],
+        "scenes": [{"nodes": [0, 1]}], "scene": 0,
+    }
+    path = tmpdir / "alpha.gltf"
+    path.write_text(json.dumps(doc))
+    return path

@@ -135,6 +135,8 @@ def lib():
     L.orc_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.orc_scene_destroy.restype = None
     L.orc_scene_destroy.argtypes = [C.c_void_p]
+    L.orc_scene_set_prim_flags.restype = None
+    L.orc_scene_set_prim_flags.argtypes = [C.c_void_p, C.c_void_p]
     L.orc_scene_build_bvh.restype = C.c_int
     L.orc_scene_build_bvh.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_scene_set_bvh.restype = C.c_int
@@ -209,6 +211,16 @@ class Scene:
                 self._h = None
         except Exception:
             pass
+
+    def set_prim_flags(self, flags):
+        """OptixGeometryFlags per primitive (None clears): 1 DISABLE_ANYHIT, 4 DISABLE_TRIANGLE_FACE_CULLING"""
+        if flags is None:
+            lib().orc_scene_set_prim_flags(self._h, None)
+        else:
+            f = np.ascontiguousarray(flags, np.uint32)
+            assert f.shape[0] == self.n_tris
+            lib().orc_scene_set_prim_flags(self._h, f.ctypes.data)
+        return self
 
     def build_bvh(self, leaf_max=4, max_depth=48):
         rc = lib().orc_scene_build_bvh(self._h, leaf_max, max_depth)
