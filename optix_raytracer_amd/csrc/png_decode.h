@@ -1,4 +1,4 @@
-// png_decode.h -- PNG -> RGBA8 / RGBA16 for glTF images (host only).
+// png_decode.h -- PNG -> RGBA8 / RGBA16 and JPEG -> RGBA8 for glTF images (host only).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -15,6 +15,9 @@ struct DecodedImage {
 
 // false + `why` when the bytes are not a PNG this decoder handles (Adam7 interlacing is not supported)
 bool decode_png(const uint8_t* data, size_t size, DecodedImage& out, std::string& why);
+
+// baseline / extended sequential JPEG (8 bit, Huffman, 1 or 3 components) -> RGBA8 (jpeg_decode.cpp)
+bool decode_jpeg(const uint8_t* data, size_t size, DecodedImage& out, std::string& why);
 
 // raw DEFLATE (RFC 1951); false on a malformed stream
 bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out);

@@ -363,7 +363,11 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
                 } else throw std::runtime_error("image without uri or bufferView");
             } catch (const std::exception& e) { why = e.what(); }
             mipt::DecodedImage img;
-            if (why.empty() && !mipt::decode_png(bytes.data(), bytes.size(), img, why)) img = mipt::DecodedImage();
+            if (why.empty()) {
+                const bool jpeg = bytes.size() >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8;
+                const bool ok = jpeg ? mipt::decode_jpeg(bytes.data(), bytes.size(), img, why) : mipt::decode_png(bytes.data(), bytes.size(), img, why);
+                if (!ok) img = mipt::DecodedImage();
+            }
             sc.images.push_back(std::move(img));
             sc.image_errors.push_back(why);
         }

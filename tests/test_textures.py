@@ -133,3 +133,26 @@ def test_samplers_transforms_and_attributes(tmp_path):
     assert hasb.tolist() == [1, 1, 0] and np.array_equal(uvb[:6], uv1[idx])
     c, hasc = sc.flatten_colors()
     assert hasc.tolist() == [0, 0, 1] and np.array_equal(c[6:], col) and (c[:6] == 1).all()
+
+
+def test_jpeg_decoder_baseline(tmp_path):
+    import _jpeg_fixture as JF
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:37, 0:53]
+    smooth = np.stack([(xx * 4 + yy) % 256, (yy * 6) % 256, (xx * yy) % 256], 2).astype(np.uint8)
+    noisy = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    cases = [(smooth, (1, 1), 1.0, 0), (smooth, (2, 2), 1.0, 0), (smooth, (2, 1), 0.5, 3), (noisy, (2, 2), 0.3, 2), (noisy, (1, 1), 2.0, 0),
+             (smooth[..., 0], (1, 1), 1.0, 0), (noisy[..., 1], (1, 1), 0.25, 5)]
+    jpgs, wants = zip(*[JF.encode(img, s, qs, rst) for img, s, qs, rst in cases])
+    prog, _ = JF.encode(smooth, progressive_marker=True)
+    sc = api.Scene(_gltf_with_images(tmp_path, list(jpgs) + [prog], external=(1,)))
+    tex = sc.textures()
+    for k, (t, want) in enumerate(zip(tex, wants)):
+        assert t["texels"] is not None and t["bits"] == 8, k
+        assert t["texels"].shape == want.shape, k
+        diff = np.abs(t["texels"].astype(int) - want.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (k, diff.max(), (diff > 0).mean())       # float32 vs float64 rounding ties
+        assert (t["texels"][..., 3] == 255).all()
+    assert tex[-1]["texels"] is None                                                                   # progressive: refused, untextured
+    # the decode is close to the source picture at a fine quantisation (sanity of the whole chain)
+    assert np.abs(tex[0]["texels"][..., :3].astype(int) - cases[0][0].astype(int)).mean() < 15
