@@ -43,7 +43,7 @@ def main():
     st.context.set_option(L.OPT_COUNT_VISITS, 0)
     for variant in ints(a.variants):
         bursts = [int(x, 0) for x in a.burst.split(",")]
-        combos = itertools.product(ints(a.grids), ints(a.refill), ints(a.steal), bursts) if variant == 2 else [(ints(a.grids)[0], 8, 32, 0x0101)]
+        combos = itertools.product(ints(a.grids), ints(a.refill), ints(a.steal), bursts) if variant >= 2 else [(ints(a.grids)[0], 8, 32, 0x0101)]
         for grid, refill, steal, burst in combos:
             st.context.set_option(L.OPT_BURST, burst)
             st.context.set_option(L.OPT_PERSISTENT, variant)
