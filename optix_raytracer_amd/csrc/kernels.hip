@@ -132,6 +132,88 @@ __device__ __forceinline__ float4 ld16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byt
 __device__ __forceinline__ float shfl_f(float v, uint32_t src) { return __shfl(v, (int)src, 64); }
 __device__ __forceinline__ uint32_t shfl_u(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
 
+// One step of the lane state machine (see k_trace_stream): every lane loads 64 bytes -- its node, or its next
+// triangle -- then inner lanes do a slab step and leaf lanes one branch-free triangle test.  `sb` is the bottom of
+// the lane's stack (entries below it were given away); shared by k_trace_stream and the bulk phase of k_trace_pool.
+template <int MODE, bool COUNT>
+__device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_buffer_rsrc_t blob, uint32_t* stk, int lane, bool has_ray, Trav& T,
+                                            int sb, bool cull_back, uint32_t& n_visits, uint32_t& n_tests)
+{
+    // ------------------------------------------------------------ this iteration's load: 64 B per lane
+    const bool inner   = has_ray && T.node >= 0;
+    const bool at_leaf = has_ray && T.node < 0 && T.node != kSentinel;
+    const uint32_t ldesc = ~(uint32_t)T.node;
+    const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
+    uint32_t off = 0u;                                             // idle lanes re-read node 0 (a broadcast)
+    if (inner) off = (uint32_t)T.node << 6;
+    if (at_leaf && lcnt != 0u) off = a.bvh.tri_byte_off + lfirst * 48u;
+    const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
+    asm volatile("" ::: "memory");
+    // ------------------------------------------------------------ one inner-node step
+    if (inner) {
+        if (COUNT) ++n_visits;
+        const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
+        const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
+        const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
+        const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
+        const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
+        const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
+        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                          __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
+        const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                          __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
+        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                          __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
+        const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                          __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
+        const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+        const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+        if (h0 && h1) {
+            const bool swp = tn1 < tn0;
+            stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
+            ++T.sp;
+            T.node = swp ? c1 : c0;
+        } else if (h0 || h1) {
+            T.node = h0 ? c0 : c1;
+        } else if (T.sp == sb) {
+            T.node = kSentinel;
+        } else {
+            --T.sp;
+            T.node = (int)stk[T.sp * 64 + lane];
+        }
+    }
+    // ------------------------------------------------------------ one triangle test (branch free)
+    if (at_leaf) {
+        bool stop = false;
+        if (lcnt != 0u) {
+            if (COUNT) ++n_tests;
+            const float4 ta = n0, tb = n1, tc = n2;
+            const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
+            const f3 p = fcross(T.d, e2);
+            const float det = fdot(e1, p);
+            const float inv = 1.0f / det;
+            const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
+            const float u = fdot(tv, p) * inv;
+            const f3 q = fcross(tv, e1);
+            const float v = fdot(T.d, q) * inv;
+            const float t = fdot(e2, q) * inv;
+            const uint32_t prim = f2u(ta.w);
+            const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax &&
+                            (!cull_back || det > 0.0f || (f2u(tb.w) & 4u) != 0u);
+            if (MODE != 0) {
+                stop = ok;
+                if (ok) { T.tbest = t; T.prim = prim; }
+            } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
+                T.tbest = t; T.prim = prim; T.u = u; T.v = v;
+            }
+        }
+        if (stop) T.node = kSentinel;
+        else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
+        else if (T.sp == sb) T.node = kSentinel;
+        else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
+    }
+}
+
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
 {
@@ -256,79 +338,7 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
         const int burst = dry ? a.burst_dry : a.burst_bulk;
         for (int bi = 0; bi < burst; ++bi) {
             if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
-            // ------------------------------------------------------------ this iteration's load: 64 B per lane
-            const bool inner   = has_ray && T.node >= 0;
-            const bool at_leaf = has_ray && T.node < 0 && T.node != kSentinel;
-            const uint32_t ldesc = ~(uint32_t)T.node;
-            const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
-            uint32_t off = 0u;                                             // idle lanes re-read node 0 (a broadcast)
-            if (inner) off = (uint32_t)T.node << 6;
-            if (at_leaf && lcnt != 0u) off = a.bvh.tri_byte_off + lfirst * 48u;
-            const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
-            asm volatile("" ::: "memory");
-            // ------------------------------------------------------------ one inner-node step
-            if (inner) {
-                if (COUNT) ++n_visits;
-                const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
-                const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
-                const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
-                const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
-                const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
-                const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
-                const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                                  __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
-                const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                                  __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
-                const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                                  __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
-                const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                                  __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
-                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
-                if (h0 && h1) {
-                    const bool swp = tn1 < tn0;
-                    stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
-                    ++T.sp;
-                    T.node = swp ? c1 : c0;
-                } else if (h0 || h1) {
-                    T.node = h0 ? c0 : c1;
-                } else if (T.sp == sb) {
-                    T.node = kSentinel;
-                } else {
-                    --T.sp;
-                    T.node = (int)stk[T.sp * 64 + lane];
-                }
-            }
-            // ------------------------------------------------------------ one triangle test (branch free)
-            if (at_leaf) {
-                bool stop = false;
-                if (lcnt != 0u) {
-                    if (COUNT) ++n_tests;
-                    const float4 ta = n0, tb = n1, tc = n2;
-                    const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
-                    const f3 p = fcross(T.d, e2);
-                    const float det = fdot(e1, p);
-                    const float inv = 1.0f / det;
-                    const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
-                    const float u = fdot(tv, p) * inv;
-                    const f3 q = fcross(tv, e1);
-                    const float v = fdot(T.d, q) * inv;
-                    const float t = fdot(e2, q) * inv;
-                    const uint32_t prim = f2u(ta.w);
-                    const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax &&
-                                    (!cull_back || det > 0.0f || (f2u(tb.w) & 4u) != 0u);
-                    if (MODE != 0) {
-                        stop = ok;
-                        if (ok) { T.tbest = t; T.prim = prim; }
-                    } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
-                        T.tbest = t; T.prim = prim; T.u = u; T.v = v;
-                    }
-                }
-                if (stop) T.node = kSentinel;
-                else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
-                else if (T.sp == sb) T.node = kSentinel;
-                else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
-            }
+            stream_step<MODE, COUNT>(a, blob, stk, lane, has_ray, T, sb, cull_back, n_visits, n_tests);
         }
         // ------------------------------------------------------------ retire
         const bool done = has_ray && T.node == kSentinel;
@@ -523,74 +533,8 @@ __global__ __launch_bounds__(64) void k_trace_pool(TraceArgs a)
 #ifdef MIPT_POOL_STATS
                 ++n_bulk_iter;
 #endif
-                const bool inner   = has_ray && T.node >= 0;
-                const bool at_leaf = has_ray && T.node < 0 && T.node != kSentinel;
-                const uint32_t ldesc = ~(uint32_t)T.node;
-                const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
-                uint32_t off = 0u;
-                if (inner) off = (uint32_t)T.node << 6;
-                if (at_leaf && lcnt != 0u) off = a.bvh.tri_byte_off + lfirst * 48u;
-                const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
-                asm volatile("" ::: "memory");
-                if (inner) {
-                    const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
-                    const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
-                    const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
-                    const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
-                    const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
-                    const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
-                    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                                      __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
-                    const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                                      __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
-                    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                                      __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
-                    const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                                      __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
-                    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                    const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
-                    if (h0 && h1) {
-                        const bool swp = tn1 < tn0;
-                        stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
-                        ++T.sp;
-                        T.node = swp ? c1 : c0;
-                    } else if (h0 || h1) {
-                        T.node = h0 ? c0 : c1;
-                    } else if (T.sp == 0) {
-                        T.node = kSentinel;
-                    } else {
-                        --T.sp;
-                        T.node = (int)stk[T.sp * 64 + lane];
-                    }
-                }
-                if (at_leaf) {
-                    bool stop = false;
-                    if (lcnt != 0u) {
-                        const float4 ta = n0, tb = n1, tc = n2;
-                        const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
-                        const f3 p = fcross(T.d, e2);
-                        const float det = fdot(e1, p);
-                        const float inv = 1.0f / det;
-                        const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
-                        const float u = fdot(tv, p) * inv;
-                        const f3 q = fcross(tv, e1);
-                        const float v = fdot(T.d, q) * inv;
-                        const float t = fdot(e2, q) * inv;
-                        const uint32_t prim = f2u(ta.w);
-                        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax &&
-                                        (!cull_back || det > 0.0f || (f2u(tb.w) & 4u) != 0u);
-                        if (MODE != 0) {
-                            stop = ok;
-                            if (ok) { T.tbest = t; T.prim = prim; }
-                        } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
-                            T.tbest = t; T.prim = prim; T.u = u; T.v = v;
-                        }
-                    }
-                    if (stop) T.node = kSentinel;
-                    else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
-                    else if (T.sp == 0) T.node = kSentinel;
-                    else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
-                }
+                uint32_t nv_ = 0u, nt_ = 0u;
+                stream_step<MODE, false>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_);
             }
             const bool done = has_ray && T.node == kSentinel;
             if (done) { finish_ray<MODE>(a, T, ray, T.prim != 0xffffffffu); has_ray = false; }
