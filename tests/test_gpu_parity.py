@@ -379,3 +379,49 @@ def test_render_loop_and_file_output(tmp_path):
     t = PTm.renderLoop(st, out, 4, stats_every=2, stats_out=lines.append)
     assert t["subframes"] == 4 and len(lines) == 2 and st.params.subframe_index == 7 and '"render_ms"' in lines[0]
     PTm.cleanupState(st)
+
+
+def test_deep_tree_fills_the_traversal_stacks():
+    """triangles in geometric progression make the SAH builder peel them off one by one: a tree at the depth cap, rays
+    that walk it with full stacks; the entry-pool kernel (stack -> pool conversion near capacity), the streaming kernel
+    and the one-thread-per-ray kernel agree with the oracle"""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import scenes
+    n = 6000
+    rng = np.random.default_rng(21)
+    k = np.arange(n)
+    scale = (0.5 ** (k / 60.0)).astype(np.float32)                      # 100 octaves of sizes, shrinking towards the origin
+    centre = np.stack([scale, 0.3 * scale * np.sin(k * 0.37), 0.3 * scale * np.cos(k * 0.23)], 1).astype(np.float32)
+    verts = np.zeros((n * 3, 4), np.float32)
+    for c in range(3):
+        verts[c::3, :3] = centre + rng.normal(0, 1, (n, 3)).astype(np.float32) * scale[:, None] * 0.2
+    scene = {"name": "spiral", "vertices": verts, "mat_index": np.zeros(n, np.uint32), "emission": np.zeros((1, 3), np.float32),
+             "diffuse": np.ones((1, 3), np.float32), "bg": np.zeros(4, np.float32),
+             "light": scenes.cornell_box()["light"], "camera": {"eye": (2, 0, 0), "lookat": (0, 0, 0), "up": (0, 1, 0), "fovY": 40.0}}
+    PT, st = _state(scene, 64, 64)
+    info = st.context.accel_info(st.gas_handle)
+    assert info["depth"] == 32, info                                      # the builder's depth cap
+    osc = _oracle_scene(scene, st)
+    n_rays = 60000
+    rays = np.zeros((n_rays, 8), np.float32)
+    rays[:, :3] = rng.uniform((1.5, -0.3, -0.3), (2.0, 0.3, 0.3), (n_rays, 3))
+    zoom = (0.5 ** rng.uniform(0, 30, n_rays))[:, None]                    # aim at every scale of the spiral
+    target = np.stack([np.ones(n_rays), rng.uniform(-0.3, 0.3, n_rays), rng.uniform(-0.3, 0.3, n_rays)], 1) * zoom
+    rays[:, 4:7] = target - rays[:, :3]
+    rays[:, 3], rays[:, 7] = 0.0, 1e16
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros((n_rays, 4), dtype=torch.float32, device="cuda")
+    t, prim, u, v = osc.trace_closest(rays, O.MODE_BVH)
+    assert (prim != 0xffffffff).mean() > 0.3
+    for variant, grid, steal in ((3, 16, 32), (3, 1, 1), (3, 2, 64), (2, 1, 1), (0, 0, 32)):
+        st.context.set_option(L.OPT_PERSISTENT, variant)
+        st.context.set_option(L.OPT_TRACE_GRID, grid)
+        st.context.set_option(L.OPT_STEAL_MIN, steal)
+        d_hits.zero_()
+        st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), n_rays, d_hits.data_ptr())
+        st.context.sync()
+        hits = d_hits.cpu().numpy()
+        assert np.array_equal(hits[:, 1].view(np.uint32), prim), (variant, grid, steal)
+        assert np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32)), (variant, grid, steal)
+    PT.cleanupState(st)
