@@ -124,3 +124,58 @@ def from_gltf(filename):
         "camera": {"eye": cam["eye"], "lookat": cam["lookat"], "up": cam["up"], "fovY": cam["fovY"]},
         "info": info,
     }
+
+
+def write_rooms_gltf(path, n_boxes=20_000, seed=5):
+    """BASELINE config 5 asks for a Sponza-class glTF (~250 k triangles); the tree holds none, so this writes a
+    deterministic stand-in that still goes through the glTF loader: a hall of 4 x 1.5 x 4 units with
+    `n_boxes` axis-aligned boxes of random size on a jittered lattice (12 triangles each, u32 indices, one mesh,
+    six materials), a floor, and a perspective camera node looking down the hall.  Returns the path."""
+    import base64
+    import json
+    rng = np.random.default_rng(seed)
+    g = int(np.ceil(n_boxes ** (1.0 / 3.0)))
+    ijk = np.stack(np.meshgrid(np.arange(g), np.arange(g), np.arange(g), indexing="ij"), -1).reshape(-1, 3)[:n_boxes]
+    cell = np.asarray([4.0, 1.5, 4.0]) / g
+    centre = (ijk + 0.5 + rng.uniform(-0.3, 0.3, ijk.shape)) * cell
+    half = rng.uniform(0.08, 0.3, ijk.shape) * cell
+    corners = np.asarray([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float64)
+    pos = (centre[:, None, :] + corners[None] * half[:, None, :]).reshape(-1, 3).astype(np.float32)
+    faces = np.asarray([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]],
+                       np.uint32)
+    floor = np.asarray([[0, -0.01, 0], [4, -0.01, 0], [4, -0.01, 4], [0, -0.01, 4]], np.float32)
+    prims, blob = [], b""
+    views, accs = [], []
+
+    def add(arr, target_type, comp):
+        nonlocal blob
+        blob += b"\0" * (-len(blob) % 4)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": arr.nbytes})
+        a = {"bufferView": len(views) - 1, "componentType": comp, "count": int(arr.shape[0] if arr.ndim > 1 else arr.size), "type": target_type}
+        if target_type == "VEC3":
+            a["min"] = [float(x) for x in arr.min(0)]; a["max"] = [float(x) for x in arr.max(0)]
+        accs.append(a)
+        blob += arr.tobytes()
+        return len(accs) - 1
+    n_mat = 6
+    owner = rng.integers(0, n_mat, n_boxes)
+    for m in range(n_mat):
+        sel = np.nonzero(owner == m)[0]
+        if sel.size == 0:
+            continue
+        idx = (faces[None] + (sel[:, None, None] * 8).astype(np.uint32)).reshape(-1)
+        prims.append({"attributes": {"POSITION": None}, "indices": add(idx.astype(np.uint32), "SCALAR", 5125), "material": m})
+    p_acc = add(pos, "VEC3", 5126)
+    for p in prims:
+        p["attributes"]["POSITION"] = p_acc
+    prims.append({"attributes": {"POSITION": add(floor, "VEC3", 5126)}, "indices": add(np.asarray([0, 2, 1, 0, 3, 2], np.uint32), "SCALAR", 5125), "material": 0})
+    (path.parent / (path.stem + ".bin")).write_bytes(blob)
+    doc = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob), "uri": path.stem + ".bin"}], "bufferViews": views, "accessors": accs,
+           "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [float(x) for x in rng.uniform(0.3, 0.9, 3)] + [1.0], "metallicFactor": 0.0}}
+                         for _ in range(n_mat)],
+           "meshes": [{"primitives": prims}],
+           "cameras": [{"type": "perspective", "perspective": {"yfov": 0.8, "aspectRatio": 16 / 9, "znear": 0.05}}],
+           "nodes": [{"mesh": 0}, {"camera": 0, "translation": [2.0, 0.75, 5.2]}],
+           "scenes": [{"nodes": [0, 1]}], "scene": 0}
+    path.write_text(json.dumps(doc))
+    return path

@@ -29,3 +29,13 @@ run("C2 Cornell 1920x1080 spp16 (RR depth)", scenes.cornell_box(), 1920, 1080, 1
 run("C2 Cornell 1920x1080 spp16 (RR), batched samples", scenes.cornell_box(), 1920, 1080, 16, 0, 3, batch=1)
 run("C4 soup 1M 1920x1080 spp1 depth 1", scenes.random_soup(1_000_000), 1920, 1080, 1, 1, 10)
 run("C4 soup 1M 1920x1080 spp1 depth 8", scenes.random_soup(1_000_000), 1920, 1080, 1, 8, 5)
+
+# glTF configurations: the tree's Duck.gltf does not travel to the GPU box and there is no Sponza-class asset, so both
+# use the generated stand-in of scenes.write_rooms_gltf (same loader path); shading is the build-defined
+# Lambert over sutil::Scene materials
+import pathlib, tempfile
+tmp = pathlib.Path(tempfile.mkdtemp())
+small = scenes.from_gltf(scenes.write_rooms_gltf(tmp / "c3.gltf", n_boxes=350))
+run("C3-like glTF 4.2k tris 1920x1080 spp64 depth 8, batched", small, 1920, 1080, 64, 8, 1, batch=1)
+big = scenes.from_gltf(scenes.write_rooms_gltf(tmp / "c5.gltf", n_boxes=20_000))
+run("C5-like glTF 240k tris 3840x2160 spp4 depth 16, batched (1 GPU)", big, 3840, 2160, 4, 16, 1, batch=1)
