@@ -140,3 +140,25 @@ def test_product_bvh_is_deterministic():
     a = api.host_bvh(sc["vertices"])
     b = api.host_bvh(sc["vertices"])
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def test_header_is_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/mipt.h compiles as C99 without warnings, and the layouts the reference's
+    structs must keep have the sizes SURVEY.md 8a lists"""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "mipt.h"\n'
+                   '#define SA(x) typedef char sa_##__LINE__[(x) ? 1 : -1]\n'
+                   'typedef char a1[sizeof(MiptParams) == 152 ? 1 : -1];\n'
+                   'typedef char a2[sizeof(MiptWhittedLaunchParams) == 128 ? 1 : -1];\n'
+                   'typedef char a3[sizeof(MiptLight) == 36 ? 1 : -1];\n'
+                   'typedef char a4[sizeof(MiptImguiParams) == 128 ? 1 : -1];\n'
+                   'typedef char a5[sizeof(MiptImguiCamera) == 92 ? 1 : -1];\n'
+                   'typedef char a6[sizeof(MiptImguiLight) == 44 ? 1 : -1];\n'
+                   'typedef char a7[sizeof(MiptHitGroupData) == 32 ? 1 : -1];\n'
+                   'typedef char a8[sizeof(MiptBvhNode) == 64 && sizeof(MiptBvhTri) == 48 ? 1 : -1];\n'
+                   'int main(void) { return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
