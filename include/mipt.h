@@ -177,6 +177,9 @@ typedef enum MiptOption {
     MIPT_OPT_BATCH_SAMPLES = 10, /* 0 (default): one wavefront pass per sample, contributions added in the reference's
                                   order (bit-identical to the oracle); 1: all samples_per_launch samples of a launch are
                                   paths of ONE pass with per-sample accumulators (same values to rounding, far fewer passes) */
+    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build: 0 (default) binned SAH on the host cores, 1 linear BVH built on the
+                                  device (Morton codes + radix sort + Karras' radix tree; ~ PREFER_FAST_BUILD: a few ms per
+                                  million triangles, slower to traverse); falls back to 0 when that tree is too deep */
     MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
                                   (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;

@@ -93,6 +93,10 @@ void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result,
 // SDK/imgui_test pipeline (imgui_kernels.hip)
 void imgui_run(hipStream_t st, const MiptImguiParams& p, uint32_t n_paths, const DeviceBvh& bvh, PathQueue q, float4* hits,
                ShadowQueue sh, uint32_t* occluded, float4* result, uint32_t* rg_seed, DeviceCounters* ctr, const TraceOpts& opts);
+// device-side BVH build (lbvh_build.hip); *ok = false when the tree is deeper than depth_cap
+hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
+                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok);
+
 // SDK/cuda/whitted.cu pipeline (whitted_kernels.hip)
 struct WhGeometry {                // MiptWhittedGeometry with typed pointers
     const float4* vertices4; const float4* normals4; const uint32_t* material_index;

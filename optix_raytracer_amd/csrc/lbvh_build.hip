@@ -1,0 +1,265 @@
+// lbvh_build.hip -- device-side BVH2 build (the counterpart of OPTIX_BUILD_FLAG_PREFER_FAST_BUILD).
+// Linear BVH: 63-bit Morton codes of the triangle centroids, radix sort (rocPRIM through hipCUB), the binary radix
+// tree of Karras 2012 built fully in parallel, bottom-up box fitting, then subtrees of <= leaf_max triangles are
+// folded into leaves and the surviving inner nodes are renumbered (scan) and written in the 64-byte two-child layout
+// the traversal kernels read.  Same node / triangle layout as the host's binned-SAH builder (bvh_build.cpp), lower
+// tree quality, a few milliseconds instead of ~0.2 s per million triangles.  Results of a render do not depend on
+// which builder made the tree (closest hit: min t, tie -> lowest primitive).
+#include <hipcub/hipcub.hpp>
+
+#include "kernels.h"
+#include "detmath.h"
+
+namespace mipt {
+
+namespace {
+
+__device__ __forceinline__ uint32_t f_ord(float f) { const uint32_t b = f2u(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float    f_unord(uint32_t k) { return u2f(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+
+struct Box6 { float lo[3], hi[3]; };
+
+__global__ __launch_bounds__(256) void k_lbvh_prims(const float* __restrict__ world, uint32_t n, Box6* boxes, uint32_t* scene /* 6 ordered words */)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* v = world + (size_t)i * 9;
+    Box6 b;
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
+        b.hi[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+    }
+    boxes[i] = b;
+    for (int k = 0; k < 3; ++k) {                       // centroid bounds are enough for the Morton grid
+        const float c = 0.5f * (b.lo[k] + b.hi[k]);
+        atomicMin(&scene[k], f_ord(c));
+        atomicMax(&scene[3 + k], f_ord(c));
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long x)
+{
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_morton(const Box6* boxes, uint32_t n, const uint32_t* scene, unsigned long long* keys, uint32_t* vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long code = 0;
+    for (int k = 0; k < 3; ++k) {
+        const float lo = f_unord(scene[k]), hi = f_unord(scene[3 + k]);
+        const float c = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]);
+        const float ext = hi - lo;
+        float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        const unsigned long long q = (unsigned long long)fminf(t * 2097152.0f, 2097151.0f);
+        code |= spread21(q) << (2 - k);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+// length of the common prefix of the keys at sorted positions i and j; duplicates are told apart by their position
+__device__ __forceinline__ int delta(const unsigned long long* keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned int)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+// Karras 2012, Algorithm "Construct binary radix tree": internal node i covers sorted range [lo, hi]
+__global__ __launch_bounds__(256) void k_lbvh_hierarchy(const unsigned long long* keys, int n, int* left, int* right, int* parent_inner, int* parent_leaf,
+                                                       int* range_lo, int* range_hi)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    // children: a leaf (encoded ~position) when the sub-range is one element
+    const int lc = lo == gamma ? ~gamma : gamma;
+    const int rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+    left[i] = lc; right[i] = rc; range_lo[i] = lo; range_hi[i] = hi;
+    if (lc >= 0) parent_inner[lc] = i; else parent_leaf[~lc] = i;
+    if (rc >= 0) parent_inner[rc] = i; else parent_leaf[~rc] = i;
+    if (i == 0) parent_inner[0] = -1;
+}
+
+__device__ __forceinline__ Box6 box_union(const Box6& a, const Box6& b)
+{
+    Box6 r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = fminf(a.lo[k], b.lo[k]); r.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+    return r;
+}
+
+// bottom-up: the second thread to arrive at a node computes its box (its children's are final by then)
+__global__ __launch_bounds__(256) void k_lbvh_fit(const Box6* prim_boxes, const uint32_t* sorted_prims, int n, const int* left, const int* right,
+                                                 const int* parent_inner, const int* parent_leaf, Box6* node_boxes, uint32_t* arrived)
+{
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k >= n) return;
+    int node = parent_leaf[k];
+    while (node >= 0) {
+        __threadfence();
+        if (atomicAdd(&arrived[node], 1u) == 0u) return;
+        const int lc = left[node], rc = right[node];
+        // the sibling's box was written before its __threadfence + atomicAdd: read it past the L1 (agent-scope loads)
+        Box6 a, b;
+        for (int c = 0; c < 2; ++c) {
+            const int ch = c == 0 ? lc : rc;
+            Box6& dst = c == 0 ? a : b;
+            if (ch >= 0) {
+                const float* src = &node_boxes[ch].lo[0];
+                for (int k = 0; k < 6; ++k) (&dst.lo[0])[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else dst = prim_boxes[sorted_prims[~ch]];
+        }
+        node_boxes[node] = box_union(a, b);
+        node = parent_inner[node];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_flags(const int* range_lo, const int* range_hi, int n_inner, int leaf_max, uint32_t* emit)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner) return;
+    emit[i] = (i == 0 || range_hi[i] - range_lo[i] + 1 > leaf_max) ? 1u : 0u;
+}
+
+__device__ __forceinline__ void put_child(MiptBvhNode& nd, int c, const Box6& b, int ref)
+{
+    if (c == 0) { nd.c0x[0] = b.lo[0]; nd.c0x[1] = b.hi[0]; nd.c0y[0] = b.lo[1]; nd.c0y[1] = b.hi[1]; nd.c0z[0] = b.lo[2]; nd.c0z[1] = b.hi[2]; nd.c0 = ref; }
+    else        { nd.c1x[0] = b.lo[0]; nd.c1x[1] = b.hi[0]; nd.c1y[0] = b.lo[1]; nd.c1y[1] = b.hi[1]; nd.c1z[0] = b.lo[2]; nd.c1z[1] = b.hi[2]; nd.c1 = ref; }
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_emit(const int* left, const int* right, const int* range_lo, const int* range_hi, int n_inner, int leaf_max,
+                                                  const uint32_t* emit, const uint32_t* new_index, const Box6* prim_boxes, const uint32_t* sorted_prims,
+                                                  const Box6* node_boxes, MiptBvhNode* out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner || !emit[i]) return;
+    MiptBvhNode nd;
+    nd.pad0 = 0u; nd.pad1 = 0u;
+    for (int c = 0; c < 2; ++c) {
+        const int ch = c == 0 ? left[i] : right[i];
+        if (ch < 0) {                                                           // a single triangle
+            put_child(nd, c, prim_boxes[sorted_prims[~ch]], ~(int)(((uint32_t)(~ch) << 4) | 1u));
+        } else if (!emit[ch]) {                                                 // a subtree folded into one leaf
+            const int lo = range_lo[ch], cnt = range_hi[ch] - lo + 1;
+            put_child(nd, c, node_boxes[ch], ~(int)(((uint32_t)lo << 4) | (uint32_t)cnt));
+        } else {
+            put_child(nd, c, node_boxes[ch], (int)new_index[ch]);
+        }
+    }
+    out[new_index[i]] = nd;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_tris(const float* __restrict__ world, const uint32_t* sorted_prims, const uint32_t* gflags, uint32_t n, MiptBvhTri* out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t p = sorted_prims[k];
+    const float* v = world + (size_t)p * 9;
+    MiptBvhTri t;
+    for (int c = 0; c < 3; ++c) { t.v0[c] = v[c]; t.e1[c] = v[3 + c] - v[c]; t.e2[c] = v[6 + c] - v[c]; }
+    t.prim = p; t.pad1 = gflags ? gflags[p] : 0u; t.pad2 = 0u;
+    out[k] = t;
+}
+
+// inner nodes on the path from the root to each triangle's leaf (= traversal stack entries a ray can need)
+__global__ __launch_bounds__(256) void k_lbvh_depth(const int* parent_inner, const int* parent_leaf, const uint32_t* emit, int n, uint32_t* depth)
+{
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k >= n) return;
+    uint32_t d = 0;
+    for (int node = parent_leaf[k]; node >= 0; node = parent_inner[node]) d += emit[node];
+    atomicMax(depth, d);
+}
+
+}  // namespace
+
+// d_world: 9 floats per triangle (device); d_gflags: per triangle or null.  On success *d_blob is ONE allocation
+// nodes | triangles | 64 B pad (as mipt_accel_build makes for the host builder).  Returns hipSuccess and ok = false
+// when the tree is deeper than depth_cap (the caller falls back to the host builder).
+hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
+                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok)
+{
+    *ok = false; *d_blob = nullptr;
+    const int n_inner = (int)n - 1;
+    const uint32_t blocks = (n + 255u) / 256u;
+    char* tmp = nullptr;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_boxes = carve(sizeof(Box6) * n), o_nboxes = carve(sizeof(Box6) * n), o_keys = carve(8ull * n), o_keys2 = carve(8ull * n),
+                 o_vals = carve(4ull * n), o_vals2 = carve(4ull * n), o_left = carve(4ull * n), o_right = carve(4ull * n), o_pin = carve(4ull * n),
+                 o_plf = carve(4ull * n), o_lo = carve(4ull * n), o_hi = carve(4ull * n), o_arr = carve(4ull * n), o_emit = carve(4ull * n),
+                 o_idx = carve(4ull * n), o_misc = carve(256);
+    size_t sort_bytes = 0, scan_bytes = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                      (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, st);
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, n_inner, st);
+    if (e != hipSuccess) return e;
+    const size_t o_cub = carve(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+    e = hipMalloc((void**)&tmp, off);
+    if (e != hipSuccess) return e;
+    Box6* boxes = (Box6*)(tmp + o_boxes); Box6* nboxes = (Box6*)(tmp + o_nboxes);
+    unsigned long long* keys = (unsigned long long*)(tmp + o_keys); unsigned long long* keys2 = (unsigned long long*)(tmp + o_keys2);
+    uint32_t* vals = (uint32_t*)(tmp + o_vals); uint32_t* vals2 = (uint32_t*)(tmp + o_vals2);
+    int* left = (int*)(tmp + o_left); int* right = (int*)(tmp + o_right); int* pin = (int*)(tmp + o_pin); int* plf = (int*)(tmp + o_plf);
+    int* rlo = (int*)(tmp + o_lo); int* rhi = (int*)(tmp + o_hi);
+    uint32_t* arrived = (uint32_t*)(tmp + o_arr); uint32_t* emit = (uint32_t*)(tmp + o_emit); uint32_t* idx = (uint32_t*)(tmp + o_idx);
+    uint32_t* misc = (uint32_t*)(tmp + o_misc);          // [0..5] scene bounds (ordered), [8] depth
+    const uint32_t init[9] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u };
+    auto fail = [&](hipError_t err) { (void)hipFree(tmp); return err; };
+    if ((e = hipMemcpyAsync(misc, init, sizeof init, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
+    if ((e = hipMemsetAsync(arrived, 0, 4ull * n, st)) != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(k_lbvh_prims, dim3(blocks), dim3(256), 0, st, d_world, n, boxes, misc);
+    hipLaunchKernelGGL(k_lbvh_morton, dim3(blocks), dim3(256), 0, st, boxes, n, misc, keys, vals);
+    if ((e = hipcub::DeviceRadixSort::SortPairs(tmp + o_cub, sort_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, st)) != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocks), dim3(256), 0, st, keys2, (int)n, left, right, pin, plf, rlo, rhi);
+    hipLaunchKernelGGL(k_lbvh_fit, dim3(blocks), dim3(256), 0, st, boxes, vals2, (int)n, left, right, pin, plf, nboxes, arrived);
+    hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit);
+    if ((e = hipcub::DeviceScan::ExclusiveSum(tmp + o_cub, scan_bytes, emit, idx, n_inner, st)) != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(k_lbvh_depth, dim3(blocks), dim3(256), 0, st, pin, plf, emit, (int)n, misc + 8);
+    uint32_t last[2] = { 0, 0 }, dep = 0;
+    if ((e = hipMemcpyAsync(&last[0], idx + (n_inner - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(&last[1], emit + (n_inner - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(&dep, misc + 8, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
+    const uint32_t nn = last[0] + last[1];
+    *num_nodes = nn; *depth = dep;
+    if ((int)dep > depth_cap) { (void)hipFree(tmp); return hipSuccess; }                 // ok stays false
+    const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
+    float4* blob = nullptr;
+    if ((e = hipMalloc((void**)&blob, nb + tb + 64)) != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks), dim3(256), 0, st, left, right, rlo, rhi, n_inner, leaf_max, emit, idx, boxes, vals2, nboxes, (MiptBvhNode*)blob);
+    hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb));
+    if ((e = hipMemsetAsync((char*)blob + nb + tb, 0, 64, st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }
+    (void)hipFree(tmp);
+    *d_blob = blob; *ok = true;
+    return hipSuccess;
+}
+
+}  // namespace mipt

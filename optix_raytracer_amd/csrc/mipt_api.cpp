@@ -43,7 +43,10 @@ static_assert(offsetof(MiptWhittedLaunchParams, miss_color) == 104 && offsetof(M
 namespace {
 
 struct Accel {
-    HostBvh   host;
+    HostBvh   host;                // scratch of the host builder (emptied after the upload)
+    uint32_t  num_nodes = 0, num_tris = 0, depth = 0, leaf_max = 0;
+    double    seconds = 0.0;
+    int       builder = 0;         // 0 host binned SAH, 1 device LBVH
     float4*   d_nodes = nullptr;   // one allocation: nodes | triangles | 64 B pad
     float4*   d_tris  = nullptr;   // = d_nodes + num_nodes * 4
     uint32_t  tri_byte_off = 0;    // 0 when the blob does not fit 32-bit offsets (then no streaming kernel)
@@ -79,6 +82,7 @@ struct MiptContext {
     int      blocks_per_cu = 0;
     int      batch_samples = 0;
     int      persistent = 3;
+    int      build_mode = 0;              // MIPT_OPT_BUILD: 0 host binned SAH, 1 device LBVH
     int      tail_pct = 200, pool_low = 16, pool_chunk = 16;
     // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
     WhGeometry        wh_geo{};
@@ -262,8 +266,8 @@ Accel* find_accel(const MiptContext* c, unsigned long long h)
 DeviceBvh device_bvh(const Accel* a)
 {
     DeviceBvh b{};
-    b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes; b.depth = a->host.depth;
-    b.pool_ok = (a->host.nodes.size() < (1u << 25) && a->host.tris.size() < (1u << 22) && a->host.leaf_max <= 7u) ? 1u : 0u;
+    b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes; b.depth = a->depth;
+    b.pool_ok = (a->num_nodes < (1u << 25) && a->num_tris < (1u << 22) && a->leaf_max <= 7u) ? 1u : 0u;
     return b;
 }
 
@@ -463,6 +467,9 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
         c->refill_min = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_BATCH_SAMPLES: c->batch_samples = value ? 1 : 0; return MIPT_SUCCESS;
+    case MIPT_OPT_BUILD:
+        if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH) or 1 (device LBVH)");
+        c->build_mode = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_BURST:
         if ((value & 0xffu) < 1 || (value & 0xffu) > 64 || ((value >> 8) & 0xffu) < 1 || ((value >> 8) & 0xffu) > 64)
             return c->fail(MIPT_ERROR_INVALID_VALUE, "burst lengths must be 1..64 (bulk | dry << 8)");
@@ -489,6 +496,7 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_REFILL_MIN: *value = (uint64_t)c->refill_min; return MIPT_SUCCESS;
     case MIPT_OPT_STEAL_MIN: *value = (uint64_t)c->steal_min; return MIPT_SUCCESS;
     case MIPT_OPT_BATCH_SAMPLES: *value = (uint64_t)c->batch_samples; return MIPT_SUCCESS;
+    case MIPT_OPT_BUILD: *value = (uint64_t)c->build_mode; return MIPT_SUCCESS;
     case MIPT_OPT_BURST: *value = (uint64_t)c->burst_bulk | ((uint64_t)c->burst_dry << 8); return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;
     }
@@ -561,24 +569,57 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     const uint32_t n_tris = (uint32_t)(world.size() / 9);
     Accel* a = new Accel();
     a->n_prims = n_tris;
-    if (!build_bvh(world.data(), n_tris, 4, kStackEntries, default_build_threads(), a->host)) {
-        delete a;
-        return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "BVH over %u triangles does not fit a %d-entry traversal stack", n_tris, kStackEntries);
-    }
-    for (MiptBvhTri& t : a->host.tris) t.pad1 = gflags[t.prim];
-    const size_t nb = a->host.nodes.size() * sizeof(MiptBvhNode);
-    const size_t tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
     const size_t mb = std::max<size_t>(n_tris, 1) * sizeof(uint32_t);
-    hipError_t e = hipMalloc((void**)&a->d_nodes, nb + tb + 64);
+    size_t nb = 0, tb = 0;
+    hipError_t e = hipSuccess;
+    bool built = false;
+    if (ctx->build_mode == 1 && n_tris > 4u && (uint64_t)n_tris * 9u * 4u < (1ull << 31)) {
+        // device build (lbvh_build.hip); a tree deeper than the traversal stack falls back to the host builder
+        const auto t0 = std::chrono::steady_clock::now();
+        float* d_world = nullptr; uint32_t* d_gf = nullptr; float4* blob = nullptr;
+        e = hipMalloc((void**)&d_world, world.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d_world, world.data(), world.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_gf, (size_t)n_tris * 4u);
+        if (e == hipSuccess) e = hipMemcpy(d_gf, gflags.data(), (size_t)n_tris * 4u, hipMemcpyHostToDevice);
+        uint32_t nn = 0, dep = 0; bool ok = false;
+        if (e == hipSuccess) e = lbvh_build(nullptr, d_world, d_gf, n_tris, 4, kStackEntries, &blob, &nn, &dep, &ok);
+        if (d_world) (void)hipFree(d_world);
+        if (d_gf) (void)hipFree(d_gf);
+        if (e != hipSuccess) { delete a; return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e)); }
+        if (ok) {
+            nb = (size_t)nn * sizeof(MiptBvhNode); tb = (size_t)n_tris * sizeof(MiptBvhTri);
+            a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4);
+            a->num_nodes = nn; a->num_tris = n_tris; a->depth = dep; a->leaf_max = 4; a->builder = 1;
+            a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            built = true;
+        } else {
+            ctx->log(3, "ACCEL", "device LBVH is %u deep (stack holds %d): falling back to the host builder", dep, kStackEntries);
+        }
+    }
+    if (!built) {
+        if (!build_bvh(world.data(), n_tris, 4, kStackEntries, default_build_threads(), a->host)) {
+            delete a;
+            return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "BVH over %u triangles does not fit a %d-entry traversal stack", n_tris, kStackEntries);
+        }
+        for (MiptBvhTri& t : a->host.tris) t.pad1 = gflags[t.prim];
+        nb = a->host.nodes.size() * sizeof(MiptBvhNode);
+        tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
+        e = hipMalloc((void**)&a->d_nodes, nb + tb + 64);
+        if (e == hipSuccess) {
+            a->d_tris = a->d_nodes + nb / sizeof(float4);
+            e = hipMemset((char*)a->d_nodes + nb + tb, 0, 64);
+        }
+        if (e == hipSuccess) e = hipMemcpy(a->d_nodes, a->host.nodes.data(), nb, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !a->host.tris.empty()) e = hipMemcpy(a->d_tris, a->host.tris.data(), a->host.tris.size() * sizeof(MiptBvhTri), hipMemcpyHostToDevice);
+        a->num_nodes = (uint32_t)a->host.nodes.size(); a->num_tris = (uint32_t)a->host.tris.size();
+        a->depth = a->host.depth; a->leaf_max = a->host.leaf_max; a->seconds = a->host.seconds;
+        a->host = HostBvh();                                   // the device copy is the one that is used from here on
+    }
     if (e == hipSuccess) {
-        a->d_tris = a->d_nodes + nb / sizeof(float4);
         a->tri_byte_off = (nb + tb + 64 < (1ull << 31)) ? (uint32_t)nb : 0u;
         a->blob_bytes = a->tri_byte_off ? (uint32_t)(nb + tb + 64) : 0u;
-        e = hipMemset((char*)a->d_nodes + nb + tb, 0, 64);
+        e = hipMalloc((void**)&a->d_mat, mb);
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&a->d_mat, mb);
-    if (e == hipSuccess) e = hipMemcpy(a->d_nodes, a->host.nodes.data(), nb, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !a->host.tris.empty()) e = hipMemcpy(a->d_tris, a->host.tris.data(), a->host.tris.size() * sizeof(MiptBvhTri), hipMemcpyHostToDevice);
     if (e == hipSuccess && n_tris) e = hipMemcpy(a->d_mat, mats.data(), (size_t)n_tris * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         free_accel(a);
@@ -588,8 +629,8 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
     *handle_out = h;
-    ctx->log(4, "ACCEL", "built BVH2: %u tris, %zu nodes, depth %u, %.1f MB, %.3f s", n_tris, a->host.nodes.size(), a->host.depth,
-             (double)a->bytes / 1e6, a->host.seconds);
+    ctx->log(4, "ACCEL", "built BVH2 (%s): %u tris, %u nodes, depth %u, %.1f MB, %.3f s", a->builder ? "device LBVH" : "host SAH", n_tris,
+             a->num_nodes, a->depth, (double)a->bytes / 1e6, a->seconds);
     return MIPT_SUCCESS;
 }
 
@@ -610,12 +651,12 @@ int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccel
     if (!ctx || !info) return MIPT_ERROR_INVALID_VALUE;
     const Accel* a = find_accel(ctx, handle);
     if (!a) return MIPT_ERROR_INVALID_HANDLE;
-    info->num_nodes = (uint32_t)a->host.nodes.size();
-    info->num_triangles = (uint32_t)a->host.tris.size();
-    info->depth = a->host.depth;
-    info->leaf_max = a->host.leaf_max;
+    info->num_nodes = a->num_nodes;
+    info->num_triangles = a->num_tris;
+    info->depth = a->depth;
+    info->leaf_max = a->leaf_max;
     info->device_bytes = a->bytes;
-    info->build_seconds = a->host.seconds;
+    info->build_seconds = a->seconds;
     return MIPT_SUCCESS;
 }
 
@@ -626,9 +667,9 @@ int mipt_accel_export(const MiptContext* ctx, unsigned long long handle, MiptBvh
     if (!a) return MIPT_ERROR_INVALID_HANDLE;
     // exported from DEVICE memory, so the checker sees what the kernels read
     (void)hipSetDevice(ctx->device);
-    if (nodes_out && hipMemcpy(nodes_out, a->d_nodes, a->host.nodes.size() * sizeof(MiptBvhNode), hipMemcpyDeviceToHost) != hipSuccess) return MIPT_ERROR_HIP;
-    if (tris_out && !a->host.tris.empty() &&
-        hipMemcpy(tris_out, a->d_tris, a->host.tris.size() * sizeof(MiptBvhTri), hipMemcpyDeviceToHost) != hipSuccess) return MIPT_ERROR_HIP;
+    if (nodes_out && hipMemcpy(nodes_out, a->d_nodes, (size_t)a->num_nodes * sizeof(MiptBvhNode), hipMemcpyDeviceToHost) != hipSuccess) return MIPT_ERROR_HIP;
+    if (tris_out && a->num_tris &&
+        hipMemcpy(tris_out, a->d_tris, (size_t)a->num_tris * sizeof(MiptBvhTri), hipMemcpyDeviceToHost) != hipSuccess) return MIPT_ERROR_HIP;
     return MIPT_SUCCESS;
 }
 

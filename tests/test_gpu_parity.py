@@ -425,3 +425,46 @@ def test_deep_tree_fills_the_traversal_stacks():
         assert np.array_equal(hits[:, 1].view(np.uint32), prim), (variant, grid, steal)
         assert np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32)), (variant, grid, steal)
     PT.cleanupState(st)
+
+
+@pytest.mark.parametrize("name,n", [("cornell", 0), ("soup", 40000), ("soup", 7)])
+def test_device_lbvh_build_gives_the_same_pictures(name, n):
+    """MIPT_OPT_BUILD = 1: the linear BVH built on the device is a sound BVH over the same triangles (oracle validation),
+    traversal over it agrees with the oracle walking the same tree, and frames are bit-identical to those over the
+    host's SAH tree -- hit records do not depend on the tree"""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    scene = scenes.cornell_box() if name == "cornell" else scenes.random_soup(n)
+    w, h = 128, 96
+    frames, infos = [], []
+    for mode in (0, 1):
+        st = PT.PathTracerState()
+        PT.createContext(st, 0)
+        st.context.set_option(L.OPT_BUILD, mode)
+        PT.buildMeshAccel(st, scene)
+        PT.createSBT(st)
+        PT.initLaunchParams(st, w, h, 2)
+        cam = scene["camera"]
+        PT.handleCameraUpdate(st, PT.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], 1.0))
+        st.context.set_option(L.OPT_MAX_DEPTH, 3)
+        acc, frame, stats = _render_gpu(PT, st)
+        info = st.context.accel_info(st.gas_handle)
+        nodes, tris = st.context.accel_export(st.gas_handle)
+        osc = O.Scene(scene).set_bvh(nodes, tris)                       # raises if the tree is not a sound BVH of the scene
+        if mode == 1:
+            rays = osc.primary_rays(scenes.launch_desc(scene, w, h))[::7]
+            d_rays = torch.from_numpy(np.ascontiguousarray(rays)).cuda()
+            d_hits = torch.zeros((rays.shape[0], 4), dtype=torch.float32, device="cuda")
+            st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), rays.shape[0], d_hits.data_ptr())
+            st.context.sync()
+            t, prim, u, v = osc.trace_closest(rays, O.MODE_BVH)
+            hits = d_hits.cpu().numpy()
+            assert np.array_equal(hits[:, 1].view(np.uint32), prim) and np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
+        frames.append((acc, frame, stats)); infos.append(info)
+        PT.cleanupState(st)
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+    assert np.array_equal(frames[0][1], frames[1][1])
+    assert frames[0][2]["closest_rays"] == frames[1][2]["closest_rays"] and frames[0][2]["shadow_rays"] == frames[1][2]["shadow_rays"]
+    assert infos[0]["num_triangles"] == infos[1]["num_triangles"] and infos[1]["depth"] <= 32 and infos[1]["leaf_max"] <= 4
