@@ -93,7 +93,15 @@ void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result,
 // SDK/imgui_test pipeline (imgui_kernels.hip)
 void imgui_run(hipStream_t st, const MiptImguiParams& p, uint32_t n_paths, const DeviceBvh& bvh, PathQueue q, float4* hits,
                ShadowQueue sh, uint32_t* occluded, float4* result, uint32_t* rg_seed, DeviceCounters* ctr, const TraceOpts& opts);
-// device-side BVH build (lbvh_build.hip); *ok = false when the tree is deeper than depth_cap
+// device-side build-input assembly + BVH build (lbvh_build.hip); every pointer of GatherInput is a DEVICE pointer
+struct GatherInput {
+    const void* vertices; uint32_t num_vertices, vertex_stride;
+    const void* indices; uint32_t index_format, index_stride, num_triangles;
+    const uint32_t* sbt_index_offsets; const uint32_t* flags; uint32_t num_sbt_records;
+    uint32_t has_transform; float m[12];
+};
+void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, uint32_t* mats, uint32_t* gflags, uint32_t base, uint32_t* error);
+// *ok = false when the tree is deeper than depth_cap
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok);
 

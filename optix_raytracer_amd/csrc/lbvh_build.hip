@@ -196,7 +196,42 @@ __global__ __launch_bounds__(256) void k_lbvh_depth(const int* parent_inner, con
     atomicMax(depth, d);
 }
 
+// build-input assembly on the device: one OptixBuildInputTriangleArray-like input -> world-space triangles, SBT index
+// and geometry flags per triangle, appended at `base`
+__global__ __launch_bounds__(256) void k_gather_input(GatherInput in, float* world, uint32_t* mats, uint32_t* gflags, uint32_t base, uint32_t* error)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= in.num_triangles) return;
+    uint32_t vi[3];
+    if (in.index_format == 2u) {
+        const unsigned short* ip = (const unsigned short*)((const char*)in.indices + (size_t)t * in.index_stride);
+        vi[0] = ip[0]; vi[1] = ip[1]; vi[2] = ip[2];
+    } else if (in.index_format == 4u) {
+        const uint32_t* ip = (const uint32_t*)((const char*)in.indices + (size_t)t * in.index_stride);
+        vi[0] = ip[0]; vi[1] = ip[1]; vi[2] = ip[2];
+    } else { vi[0] = 3u * t; vi[1] = 3u * t + 1u; vi[2] = 3u * t + 2u; }
+    float* w = world + (size_t)(base + t) * 9;
+    for (int c = 0; c < 3; ++c) {
+        if (vi[c] >= in.num_vertices) { atomicMax(error, 1u); vi[c] = 0u; }
+        const float* v = (const float*)((const char*)in.vertices + (size_t)vi[c] * in.vertex_stride);
+        const float x = v[0], y = v[1], z = v[2];
+        if (in.has_transform) {
+            for (int r = 0; r < 3; ++r) w[3 * c + r] = ((in.m[4 * r] * x + in.m[4 * r + 1] * y) + in.m[4 * r + 2] * z) + in.m[4 * r + 3];
+        } else { w[3 * c] = x; w[3 * c + 1] = y; w[3 * c + 2] = z; }
+    }
+    uint32_t m = in.sbt_index_offsets ? in.sbt_index_offsets[t] : 0u;
+    uint32_t gf = 0u;
+    if (in.flags) { if (m >= in.num_sbt_records) { atomicMax(error, 2u); m = 0u; } gf = in.flags[m]; }
+    mats[base + t] = m; gflags[base + t] = gf;
+}
+
 }  // namespace
+
+void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, uint32_t* mats, uint32_t* gflags, uint32_t base, uint32_t* error)
+{
+    if (in.num_triangles == 0u) return;
+    hipLaunchKernelGGL(k_gather_input, dim3((in.num_triangles + 255u) / 256u), dim3(256), 0, st, in, world, mats, gflags, base, error);
+}
 
 // d_world: 9 floats per triangle (device); d_gflags: per triangle or null.  On success *d_blob is ONE allocation
 // nodes | triangles | 64 B pad (as mipt_accel_build makes for the host builder).  Returns hipSuccess and ok = false

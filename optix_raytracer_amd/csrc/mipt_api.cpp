@@ -503,11 +503,110 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
 }
 
 // ------------------------------------------------------------------------------------------------
+// MIPT_OPT_BUILD = 1: the whole build on the device -- inputs that live in host memory are uploaded as they are, a
+// gather kernel makes world-space triangles / SBT indices / geometry flags, lbvh_build.hip builds the tree.
+// Returns MIPT_SUCCESS with *handle_out = 0 when the caller should use the host builder instead (tiny scenes, a
+// tree deeper than the traversal stack).
+static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs, unsigned long long* handle_out)
+{
+    *handle_out = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint32_t> counts(num_inputs);
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < num_inputs; ++k) {
+        const MiptBuildInput& in = inputs[k];
+        const uint32_t stride = in.vertex_stride_bytes ? in.vertex_stride_bytes : 12u;
+        if (stride < 12u || (stride & 3u)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: vertex stride %u", k, stride);
+        if (in.num_vertices && !in.vertices) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: null vertices", k);
+        uint32_t n_tris = in.num_triangles;
+        if (!in.indices || in.index_format == 0) {
+            if (n_tris == 0) n_tris = in.num_vertices / 3u;
+            if ((uint64_t)n_tris * 3u > in.num_vertices) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: %u triangles need %u vertices, got %u", k, n_tris, n_tris * 3u, in.num_vertices);
+        } else if (in.index_format != 2u && in.index_format != 4u) {
+            return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: index format %u (expected 0, 2 or 4)", k, in.index_format);
+        }
+        if (in.flags && in.num_sbt_records == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "input %u: flags without num_sbt_records", k);
+        counts[k] = n_tris; total += n_tris;
+    }
+    if (total <= 4u || total * 36u >= (1ull << 31)) return MIPT_SUCCESS;
+    const uint32_t n = (uint32_t)total;
+    std::vector<void*> temps;
+    auto cleanup = [&]() { for (void* p : temps) if (p) (void)hipFree(p); };
+    auto dev_alloc = [&](size_t bytes, void** out) { hipError_t e = hipMalloc(out, bytes ? bytes : 4); if (e == hipSuccess) temps.push_back(*out); return e; };
+    auto on_device = [&](const void* p, size_t bytes, const void** out) {          // device copy of a host array, or the pointer itself
+        if (!p || bytes == 0) { *out = p; return hipSuccess; }
+        if (is_device_pointer(p)) { *out = p; return hipSuccess; }
+        void* d = nullptr;
+        hipError_t e = dev_alloc(bytes, &d);
+        if (e == hipSuccess) e = hipMemcpy(d, p, bytes, hipMemcpyHostToDevice);
+        *out = d;
+        return e;
+    };
+    float* d_world = nullptr; uint32_t* d_mats = nullptr; uint32_t* d_gf = nullptr; uint32_t* d_err = nullptr;
+    hipError_t e = dev_alloc((size_t)n * 36u, (void**)&d_world);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_mats, (size_t)n * 4u);
+    if (e == hipSuccess) e = dev_alloc((size_t)n * 4u, (void**)&d_gf);
+    if (e == hipSuccess) e = dev_alloc(4, (void**)&d_err);
+    if (e == hipSuccess) e = hipMemset(d_err, 0, 4);
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < num_inputs && e == hipSuccess; ++k) {
+        const MiptBuildInput& in = inputs[k];
+        GatherInput g{};
+        const uint32_t stride = in.vertex_stride_bytes ? in.vertex_stride_bytes : 12u;
+        const bool indexed = in.indices && in.index_format != 0;
+        g.num_vertices = in.num_vertices; g.vertex_stride = stride; g.num_triangles = counts[k];
+        g.index_format = indexed ? in.index_format : 0u;
+        g.index_stride = indexed ? (in.index_stride_bytes ? in.index_stride_bytes : 3u * in.index_format) : 0u;
+        e = on_device(in.vertices, in.num_vertices ? (size_t)(in.num_vertices - 1) * stride + 12u : 0u, &g.vertices);
+        if (e == hipSuccess && indexed) e = on_device(in.indices, counts[k] ? (size_t)(counts[k] - 1) * g.index_stride + 3u * in.index_format : 0u, &g.indices);
+        const void* p = nullptr;
+        if (e == hipSuccess) { e = on_device(in.sbt_index_offsets, (size_t)counts[k] * 4u, &p); g.sbt_index_offsets = (const uint32_t*)p; }
+        if (e == hipSuccess && in.flags) {                                          // the flags array is host memory by contract
+            void* d = nullptr;
+            e = dev_alloc((size_t)in.num_sbt_records * 4u, &d);
+            if (e == hipSuccess) e = hipMemcpy(d, in.flags, (size_t)in.num_sbt_records * 4u, hipMemcpyHostToDevice);
+            g.flags = (const uint32_t*)d; g.num_sbt_records = in.num_sbt_records;
+        }
+        if (in.transform3x4) { g.has_transform = 1u; std::memcpy(g.m, in.transform3x4, 48); }
+        if (e == hipSuccess) launch_gather_input(nullptr, g, d_world, d_mats, d_gf, base, d_err);
+        base += counts[k];
+    }
+    uint32_t err = 0;
+    if (e == hipSuccess) e = hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost);
+    float4* blob = nullptr; uint32_t nn = 0, dep = 0; bool ok = false;
+    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, 4, kStackEntries, &blob, &nn, &dep, &ok);
+    cleanup();
+    if (e != hipSuccess) { if (d_mats) (void)hipFree(d_mats); return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e)); }
+    if (err != 0u) { (void)hipFree(d_mats); return ctx->fail(MIPT_ERROR_INVALID_VALUE, err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records"); }
+    if (!ok) {
+        (void)hipFree(d_mats);
+        ctx->log(3, "ACCEL", "device LBVH is %u deep (stack holds %d): falling back to the host builder", dep, kStackEntries);
+        return MIPT_SUCCESS;
+    }
+    Accel* a = new Accel();
+    const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
+    a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
+    a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = 1;
+    a->tri_byte_off = (nb + tb + 64 < (1ull << 31)) ? (uint32_t)nb : 0u;
+    a->blob_bytes = a->tri_byte_off ? (uint32_t)(nb + tb + 64) : 0u;
+    a->bytes = nb + tb + (size_t)n * 4u;
+    a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const unsigned long long h = ++ctx->next_handle;
+    ctx->accels[h] = a;
+    *handle_out = h;
+    ctx->log(4, "ACCEL", "built BVH2 (device LBVH): %u tris, %u nodes, depth %u, %.1f MB, %.4f s", n, nn, dep, (double)a->bytes / 1e6, a->seconds);
+    return MIPT_SUCCESS;
+}
+
 int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs, unsigned long long* handle_out)
 {
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     if (!inputs || num_inputs == 0 || !handle_out) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_build: null argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->build_mode == 1) {
+        const int rc = accel_build_device(ctx, inputs, num_inputs, handle_out);
+        if (rc != MIPT_SUCCESS || *handle_out != 0ull) return rc;
+    }
     std::vector<float>    world;     // 9 floats per triangle
     std::vector<uint32_t> mats, gflags;
     for (uint32_t k = 0; k < num_inputs; ++k) {
@@ -572,31 +671,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     const size_t mb = std::max<size_t>(n_tris, 1) * sizeof(uint32_t);
     size_t nb = 0, tb = 0;
     hipError_t e = hipSuccess;
-    bool built = false;
-    if (ctx->build_mode == 1 && n_tris > 4u && (uint64_t)n_tris * 9u * 4u < (1ull << 31)) {
-        // device build (lbvh_build.hip); a tree deeper than the traversal stack falls back to the host builder
-        const auto t0 = std::chrono::steady_clock::now();
-        float* d_world = nullptr; uint32_t* d_gf = nullptr; float4* blob = nullptr;
-        e = hipMalloc((void**)&d_world, world.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(d_world, world.data(), world.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_gf, (size_t)n_tris * 4u);
-        if (e == hipSuccess) e = hipMemcpy(d_gf, gflags.data(), (size_t)n_tris * 4u, hipMemcpyHostToDevice);
-        uint32_t nn = 0, dep = 0; bool ok = false;
-        if (e == hipSuccess) e = lbvh_build(nullptr, d_world, d_gf, n_tris, 4, kStackEntries, &blob, &nn, &dep, &ok);
-        if (d_world) (void)hipFree(d_world);
-        if (d_gf) (void)hipFree(d_gf);
-        if (e != hipSuccess) { delete a; return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e)); }
-        if (ok) {
-            nb = (size_t)nn * sizeof(MiptBvhNode); tb = (size_t)n_tris * sizeof(MiptBvhTri);
-            a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4);
-            a->num_nodes = nn; a->num_tris = n_tris; a->depth = dep; a->leaf_max = 4; a->builder = 1;
-            a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            built = true;
-        } else {
-            ctx->log(3, "ACCEL", "device LBVH is %u deep (stack holds %d): falling back to the host builder", dep, kStackEntries);
-        }
-    }
-    if (!built) {
+    {
         if (!build_bvh(world.data(), n_tris, 4, kStackEntries, default_build_threads(), a->host)) {
             delete a;
             return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "BVH over %u triangles does not fit a %d-entry traversal stack", n_tris, kStackEntries);

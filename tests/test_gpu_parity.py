@@ -468,3 +468,49 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n):
     assert np.array_equal(frames[0][1], frames[1][1])
     assert frames[0][2]["closest_rays"] == frames[1][2]["closest_rays"] and frames[0][2]["shadow_rays"] == frames[1][2]["shadow_rays"]
     assert infos[0]["num_triangles"] == infos[1]["num_triangles"] and infos[1]["depth"] <= 32 and infos[1]["leaf_max"] <= 4
+
+
+def test_device_build_reads_every_input_form():
+    """indexed u16 / u32 / non-indexed inputs, strided vertices, a 3x4 transform, SBT offsets + geometry flags, host and
+    device pointers: the device-side input assembly makes the same triangles as the host builder's"""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L, api
+    rng = np.random.default_rng(3)
+    nv = 300
+    verts = np.zeros((nv, 6), np.float32)                       # stride 24: positions + junk
+    verts[:, :3] = rng.uniform(-1, 1, (nv, 3))
+    idx16 = rng.integers(0, nv, (150, 3)).astype(np.uint16)
+    idx32 = rng.integers(0, nv, (90, 3)).astype(np.uint32)
+    soup = rng.uniform(-2, 2, (60 * 3, 3)).astype(np.float32)
+    xf = np.asarray([[0.5, 0.1, 0, 1.0], [-0.1, 0.7, 0.2, -2.0], [0.0, 0.3, 0.9, 0.5]], np.float32)
+    sbt = rng.integers(0, 3, 150).astype(np.uint32)
+    flags = np.asarray([1, 0, 6], np.uint32)
+    d_verts = torch.from_numpy(verts).cuda()
+    d_idx32 = torch.from_numpy(idx32.astype(np.int32)).cuda()
+    inputs = [
+        {"vertices": d_verts.data_ptr(), "num_vertices": nv, "stride": 24, "indices": idx16, "index_format": 2, "num_triangles": 150,
+         "sbt_index_offsets": sbt, "flags": flags},
+        {"vertices": verts, "num_vertices": nv, "stride": 24, "indices": d_idx32.data_ptr(), "index_format": 4, "num_triangles": 90, "transform": xf},
+        {"vertices": soup, "num_vertices": 180, "stride": 12},
+    ]
+    out = []
+    for mode in (0, 1):
+        ctx = api.Context(0)
+        ctx.set_option(L.OPT_BUILD, mode)
+        h = ctx.accel_build(inputs)
+        info = ctx.accel_info(h)
+        assert info["num_triangles"] == 300
+        nodes, tris = ctx.accel_export(h)
+        t = np.frombuffer(tris.tobytes(), np.uint32).reshape(-1, 12)
+        out.append(t[np.argsort(t[:, 3])])                       # by original primitive index
+        ctx.destroy()
+    assert np.array_equal(out[0], out[1])
+    assert set(out[1][:150, 7]) <= {1, 0, 6} and (out[1][150:, 7] == 0).all()
+    # an index past the vertex array is an error on both paths
+    bad = dict(inputs[0], indices=np.full((150, 3), 999, np.uint16))
+    for mode in (0, 1):
+        ctx = api.Context(0)
+        ctx.set_option(L.OPT_BUILD, mode)
+        with pytest.raises(api.MiptError, match="out of range"):
+            ctx.accel_build([bad])
+        ctx.destroy()
