@@ -536,3 +536,20 @@ def test_alpha_modes_and_culling_match_the_oracle(tmp_path, w, h, subframes):
     assert np.array_equal(out.getHostPointer(), frame)
     assert tot_c == oc > w * h * subframes and tot_s == osr > 0                      # continuation rays were traced
     MV.cleanup(st)
+
+
+@pytest.mark.parametrize("name", ["textured", "alpha"])
+def test_oracle_whitted_golden_fixtures(tmp_path, name):
+    """the oracle's Whitted restatement on the generated glTF fixtures equals the committed golden images
+    (tests/golden/make_oracle_golden.py): a change of the oracle cannot go unnoticed"""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_oracle_golden", os.path.join(here, "golden", "make_oracle_golden.py"))
+    gold = np.load(os.path.join(here, "golden", "oracle_whitted_%s_48x32.npz" % name))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    acc, frame, st = mod.whitted_fixture({"textured": FX.write_textured, "alpha": FX.write_alpha}[name](tmp_path), 48, 32)
+    assert np.array_equal(acc.view(np.uint32), gold["accum"].view(np.uint32))
+    assert np.array_equal(frame, gold["frame"])
+    assert st["closest_rays"] == int(gold["closest_rays"]) and st["shadow_rays"] == int(gold["shadow_rays"])
