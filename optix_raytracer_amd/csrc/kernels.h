@@ -73,6 +73,7 @@ struct TraceOpts {
     int  tail_pct, pool_low, pool_chunk;   // k_trace_pool knobs (0 = default)
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
+    int  blocks_user, num_cus; // the grid was set with MIPT_OPT_TRACE_GRID; CUs of the device
 };
 
 // ---- launches (all asynchronous on `st`) ----

@@ -246,6 +246,7 @@ TraceOpts trace_opts(const MiptContext* c)
     o.persistent = c->persistent;
     o.count_visits = c->count_visits;
     o.blocks = c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 16);
+    o.blocks_user = c->blocks_per_cu > 0 ? 1 : 0; o.num_cus = c->num_cus;
     o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.burst_bulk = c->burst_bulk; o.burst_dry = c->burst_dry;
     o.tail_pct = c->tail_pct; o.pool_low = c->pool_low; o.pool_chunk = c->pool_chunk;
     return o;

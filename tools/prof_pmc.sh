@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes over the headline bench (run ON the GPU box through gpurun).  Counters are collected in
 # their own runs with --kernel-trace only (no --stats / sys-trace: MI355X_MICROARCH.md, gpurun rules).
+# (TA_* / TD_* counter sets abort rocprofv3 on this pool -- signal 6 -- and are left out.)
 # usage: tools/prof_pmc.sh <out-subdir-under-gpurun_out> [extra bench.py args]
 set -u
 OUT="$GRAFT_REPO_ROOT/gpurun_out/$1"; shift
@@ -19,10 +20,9 @@ SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_L
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 FETCH_SIZE
 WRITE_SIZE
-TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum
-TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum GRBM_GUI_ACTIVE
+GRBM_GUI_ACTIVE
 SETS
 python3 "$GRAFT_REPO_ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
