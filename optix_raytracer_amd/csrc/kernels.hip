@@ -1115,9 +1115,10 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
         a.pool_chunk = o.pool_chunk > 0 ? o.pool_chunk : kPoolChunk;
         if (pool) {
             const bool rows24 = a.bvh.depth <= 24u;
-            // default grid: 16 waves per CU; a big closest-hit launch over a shallow tree (20 waves fit a CU) runs faster on
-            // twice as many, smaller work items (headline frame: 0.67 -> 0.61 ms); any-hit launches do not (0.31 -> 0.34 ms)
-            if (!o.blocks_user && MODE == 0 && rows24 && a.n_max > a.tail_len) blocks *= 2;
+            // default grid: 16 waves per CU; a big launch over a shallow tree (20 waves fit a CU) runs faster on twice as
+            // many, smaller work items (headline frame: closest hit 0.67 -> 0.61 ms, any hit 0.31 -> 0.27 ms; a wave's static
+            // first range of more than one 64-ray chunk is slower: 1.04 / 1.12 / 1.31 ms per frame with 2 / 3 / 4 chunks)
+            if (!o.blocks_user && rows24 && a.n_max > a.tail_len) blocks *= 2;
             if (rows24) hipLaunchKernelGGL((k_trace_pool<MODE, 24>), dim3(blocks), dim3(64), 0, st, a);
             else        hipLaunchKernelGGL((k_trace_pool<MODE, 32>), dim3(blocks), dim3(64), 0, st, a);
         }

@@ -459,7 +459,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_MAX_DEPTH: c->max_depth = (uint32_t)value; return MIPT_SUCCESS;
     case MIPT_OPT_COUNT_VISITS: c->count_visits = value ? 1 : 0; return MIPT_SUCCESS;
     case MIPT_OPT_TRACE_GRID:
-        if (value > 32) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 32 single-wave workgroups fit a CU");
+        if (value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 64 single-wave workgroups per CU");
         c->blocks_per_cu = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PERSISTENT:
         if (value != 0 && value != 2 && value != 3) return c->fail(MIPT_ERROR_INVALID_VALUE, "traversal kernel variant must be 0, 2 or 3");
