@@ -376,18 +376,23 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
     }
 }
 
-// ---- streaming waves + entry pool: the default traversal kernel -------------------------------
-// Bulk phase: as k_trace_stream (one ray per lane, register-prefetched refill), while plenty of rays remain.
-// Tail phase: once fewer rays remain than `tail_len` (about one per lane of the grid: from then on the launch
-// time is the slowest wave's, not the throughput) and `steal_min` lanes are idle, the wave stops being "one
-// ray per lane".  Every pending traversal-stack entry of every lane is moved, in place, into ONE stack of
-// (entry, ray slot) pairs -- the wave's entry pool -- and each round pops up to 64 entries, whichever rays
-// they belong to; each lane processes one (an inner node: slab-test both children and push the survivors,
-// nearer last; a leaf reference: test its first triangle and push the rest of the leaf).  A ray with many
-// pending subtrees is traversed by many lanes at once instead of being a dependent-load chain of hundreds of
-// steps in one lane, and the wave now fetches new rays in small chunks whenever its pool runs low, so the
-// remaining rays spread over the waves by work, not by count.  A launch with fewer rays than lanes (shadow
-// rays, a shard of a multi-GPU frame) runs in the tail phase from the start.
+// ---- tiles + entry pool: the default traversal kernel -------------------------------------------------------
+// Bulk phase: the launch's rays are cut into tiles of 64 consecutive rays (one 8x8 pixel tile for primary rays);
+// a wave takes tile after tile (statically: wave w of XCD x takes tiles w, w + W, ... of the x-th eighth -- no
+// cursor, no atomic; with the default grid of one wave per tile up to 128 per CU the hardware's workgroup
+// dispatcher is the load balancer) and walks its 64 rays with the lane state machine of stream_step.
+// Tail phase: when `steal_min` lanes of the tile are finished the wave stops being "one ray per lane".  Every
+// pending traversal-stack entry of every lane is moved, in place, into ONE stack of (entry, ray slot) pairs --
+// the wave's entry pool -- and each round pops up to 64 entries, whichever rays they belong to; each lane
+// processes one (an inner node: slab-test both children and push the survivors, nearer last; a leaf reference:
+// test its first triangle and push the rest of the leaf).  A ray with many pending subtrees is traversed by
+// many lanes at once instead of being a dependent-load chain of hundreds of steps in one lane.
+// A launch with few rays (shadow rays of a small frame, a shard of a multi-GPU frame) runs on the pool from the
+// start: waves fetch rays 16 at a time from per-XCD cursors whenever their pool runs low, so 64 lanes serve
+// 16-32 rays and the rays spread over the waves by work.
+// (Measured and dropped: persistent waves that refill finished lanes from ray-range cursors with register
+//  prefetch -- the design of k_trace_stream -- in the bulk phase: 0.60 ms against 0.55 ms for the closest-hit
+//  kernel of the headline frame, and slower still on 1/2 and 1/4 frames.)
 // The ray of slot s stays in the registers of lane s (read by the others with ds_bpermute); its running best
 // hit lives in LDS as one 64-bit word (order-preserving t bits << 32 | primitive) merged with ds_min_u64:
 // min t, tie -> lowest primitive, the conventions of the sequential traversal, which visits a subset of what
@@ -456,7 +461,7 @@ __device__ __forceinline__ bool range_grab(const TraceArgs& a, RayRange& r, uint
 
 // ROWS: entries of a lane's stack = rows of the LDS block (24 when the tree is at most 24 deep -- 7.5 KB of LDS per
 // wave and <= 96 VGPRs let 20 waves share a CU instead of 16 -- else 32)
-template <int MODE, int ROWS>
+template <int MODE, int ROWS, bool TILED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? 5 : 4, ROWS == 24 ? 5 : 4))) void k_trace_pool(TraceArgs a)
 {
     constexpr int kPoolCap = ROWS * 64;
@@ -470,85 +475,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
-    RayRange rr;
-    range_init(rr, n, seg_len, n > a.tail_len ? (uint32_t)kStreamChunk : (uint32_t)a.pool_chunk);
-    const int refill_min = a.refill_min, steal_min = a.steal_min < 64 ? a.steal_min : 64;   // 64: switch when the wave is empty
+    const int steal_min = a.steal_min < 64 ? a.steal_min : 64;       // 64: switch when the wave is empty
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+    // a launch with many rays is cut into tiles of 64 consecutive rays, dealt out to the waves without any atomic;
+    // one with few rays runs on the entry pool from the start and fetches rays 16 at a time
+    constexpr bool tiled = TILED;                        // the host decides by the capacity of the launch (n_max)
+    const uint32_t tiles = (n + 63u) >> 6, tiles_seg = (tiles + kNumSegments - 1) / kNumSegments;
+    const uint32_t xcd = blockIdx.x & (kNumSegments - 1), waves_seg = gridDim.x / kNumSegments;   // gridDim.x is a multiple of 8
+    RayRange rr;
+    range_init(rr, n, seg_len, (uint32_t)a.pool_chunk);
 
     bool     has_ray = false, nxt_valid = false;
     uint32_t ray = 0, nxt_idx = 0;
     float4   nxt_o = make_float4(0.f, 0.f, 0.f, 0.f), nxt_d = nxt_o;
     Trav T;
     T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
-    bool dry = false;
-#ifdef MIPT_POOL_STATS
-    const unsigned long long t_start = wall_clock64();
-    unsigned long long n_bulk_iter = 0, n_rounds = 0, n_popped = 0, n_live = 0, t_grab = 0, n_grab = 0;
-#endif
+    bool dry = tiled;                                    // tiled: the tail phase never fetches
 
-    // ================================================================ bulk: one ray per lane
-    if (n > a.tail_len) {
-        for (;;) {
-            const unsigned long long idle = __ballot(!has_ray);
-            const int n_idle = __popcll(idle);
-            if (n_idle == 64 || n_idle >= refill_min) {
-                if (!has_ray && nxt_valid) {
-                    ray = nxt_idx;
-                    trav_init(T, nxt_o, nxt_d);
-                    has_ray = T.node != kSentinel;
-                    if (!has_ray) finish_ray<MODE>(a, T, ray, false);
-                    nxt_valid = false;
-                }
-                if (!dry) {
-                    const unsigned long long want = __ballot(!nxt_valid);
-                    const uint32_t n_want = (uint32_t)__popcll(want);
-                    const uint32_t rank = lane_rank(want);
-                    uint32_t given = 0;
-                    while (given < n_want) {
-#ifdef MIPT_POOL_STATS
-                        const unsigned long long tg0 = wall_clock64();
-                        const bool got_ = range_grab(a, rr, n, seg_len, kStreamChunk, lane);
-                        t_grab += wall_clock64() - tg0; ++n_grab;
-                        if (!got_) { dry = true; break; }
-#else
-                        if (!range_grab(a, rr, n, seg_len, kStreamChunk, lane)) { dry = true; break; }
-#endif
-                        const uint32_t avail = rr.end - rr.next;
-                        const uint32_t need  = n_want - given;
-                        const uint32_t take  = avail < need ? avail : need;
-                        if (!nxt_valid && rank >= given && rank < given + take) {
-                            nxt_idx = rr.next + (rank - given);
-                            nxt_o = a.ray_o[(size_t)nxt_idx * a.stride];      // lands while this lane keeps traversing
-                            nxt_d = a.ray_d[(size_t)nxt_idx * a.stride];
-                            nxt_valid = true;
-                        }
-                        rr.next += take;
-                        given += take;
-                    }
-                }
-            }
-            if (dry && __popcll(__ballot(!has_ray)) >= steal_min && __ballot(nxt_valid && !has_ray) == 0ull) break;
-            // ------------------------------------------------------------ a burst of traversal steps
-            const int burst = dry ? a.burst_dry : a.burst_bulk;
-            for (int bi = 0; bi < burst; ++bi) {
+    for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
+    if (tiled) {
+        // ============================================================ bulk: one ray per lane, one tile at a time
+        // XCD x (= blockIdx % 8) works through the x-th eighth of the tiles: a contiguous band of the image per L2
+        const uint32_t tile = xcd * tiles_seg + k;
+        if (k >= tiles_seg || tile >= tiles) break;
+        ray = tile * 64u + (uint32_t)lane;
+        has_ray = false;
+        if (ray < n) {
+            trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+            has_ray = T.node != kSentinel;
+            if (!has_ray) finish_ray<MODE>(a, T, ray, false);      // empty interval: a miss, no BVH access
+        }
+        while (__popcll(__ballot(!has_ray)) < steal_min) {
+            for (int bi = 0; bi < a.burst_bulk; ++bi) {
                 if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
-#ifdef MIPT_POOL_STATS
-                ++n_bulk_iter;
-#endif
                 uint32_t nv_ = 0u, nt_ = 0u;
                 stream_step<MODE, false>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_);
             }
             const bool done = has_ray && T.node == kSentinel;
             if (done) { finish_ray<MODE>(a, T, ray, T.prim != 0xffffffffu); has_ray = false; }
         }
+        if (__ballot(has_ray) == 0ull) continue;                     // the whole tile is finished
     }
-#ifdef MIPT_POOL_STATS
-    const unsigned long long t_bulk = wall_clock64();
-    if (MODE == 0 && lane == 0) {
-        atomicAdd(&a.ctr->dbg[0], t_bulk - t_start);
-        atomicAdd(&a.ctr->dbg[7], n_bulk_iter);
-    }
-#endif
 
     // ================================================================ tail: one entry pool per wave
     // open the merge slots with what each lane has found so far
@@ -585,7 +552,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
             finish_ray<MODE>(a, R, ray, MODE == 0 ? R.prim != 0xffffffffu : sh_done[lane] != 0u);
             occ = false;
         }
-        bool start = !occ && nxt_valid;
+        bool start = !tiled && !occ && nxt_valid;
         if (start) {
             ray = nxt_idx;
             trav_init(T, nxt_o, nxt_d);
@@ -605,21 +572,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
             }
         }
         // ------------------------------------------------------------ pool running low: prefetch a small chunk of rays
-        if (!dry && psize < a.pool_low && __ballot(nxt_valid) == 0ull) {
+        if (!tiled && !dry && psize < a.pool_low && __ballot(nxt_valid) == 0ull) {
             const unsigned long long want = __ballot(!occ);
             uint32_t n_want = (uint32_t)__popcll(want);
             n_want = n_want < (uint32_t)a.pool_chunk ? n_want : (uint32_t)a.pool_chunk;
             const uint32_t rank = lane_rank(want);
             uint32_t given = 0;
             while (given < n_want) {
-#ifdef MIPT_POOL_STATS
-                const unsigned long long tg0 = wall_clock64();
-                const bool got_ = range_grab(a, rr, n, seg_len, (uint32_t)a.pool_chunk, lane);
-                t_grab += wall_clock64() - tg0; ++n_grab;
-                if (!got_) { dry = true; break; }
-#else
                 if (!range_grab(a, rr, n, seg_len, (uint32_t)a.pool_chunk, lane)) { dry = true; break; }
-#endif
                 const uint32_t avail = rr.end - rr.next;
                 const uint32_t need  = n_want - given;
                 const uint32_t take  = avail < need ? avail : need;
@@ -634,7 +594,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
             }
         }
         if (psize == 0) {
-            if (__ballot(nxt_valid) != 0ull) continue;            // rays on their way: start them next round
+            if (!tiled && __ballot(nxt_valid) != 0ull) continue;  // rays on their way: start them next round
             if (dry) break;
             continue;                                             // (not reached: an empty pool with rays left prefetches above)
         }
@@ -647,9 +607,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
         uint32_t ent = 0u;
         if (have) ent = stk[psize - 1 - lane];
         psize -= k;
-#ifdef MIPT_POOL_STATS
-        ++n_rounds; n_popped += (unsigned long long)k;
-#endif
         const uint32_t slot = ent & 63u;
         // the ray of that slot, from its owner's registers
         const float ox = shfl_f(T.o.x, slot), oy = shfl_f(T.o.y, slot), oz = shfl_f(T.o.z, slot);
@@ -666,9 +623,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
         const uint32_t lfirst = payload >> 3, lcnt = payload & 7u;
         const bool do_inner = live && !leaf;
         const bool do_tri   = live && leaf && lcnt != 0u;
-#ifdef MIPT_POOL_STATS
-        n_live += (unsigned long long)__popcll(__ballot(do_inner || do_tri));
-#endif
         uint32_t off = 0u;
         if (do_inner) off = payload << 6;
         if (do_tri)   off = a.bvh.tri_byte_off + lfirst * 48u;
@@ -746,17 +700,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
-#ifdef MIPT_POOL_STATS
-    if (MODE == 0 && lane == 0) {
-        const unsigned long long t_end = wall_clock64();
-        atomicAdd(&a.ctr->dbg[1], t_end - t_bulk);
-        atomicAdd(&a.ctr->dbg[2], n_rounds);
-        atomicAdd(&a.ctr->dbg[3], t_grab);
-        atomicAdd(&a.ctr->dbg[6], n_popped);
-        atomicMax(&a.ctr->dbg[4], t_end - t_start);
-        atomicAdd(&a.ctr->dbg[5], n_grab);
+    if (!tiled) break;
     }
-#endif
 }
 
 // ---- one thread per ray (no refill); same per-ray visiting order ----
@@ -1107,20 +1052,31 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
     if (o.persistent >= 2 && a.bvh.tri_byte_off != 0u && a.bvh.depth <= (uint32_t)kStreamStack) {
         int blocks = ((o.blocks > 0 ? o.blocks : 4096) + kNumSegments - 1) / kNumSegments * kNumSegments;
         const bool pool = o.persistent == 3 && !o.count_visits && a.bvh.pool_ok;
-        // launches with at most this many rays run on the entry pool from the start: two rays per lane of a 16-waves-per-CU
-        // grid for closest hit, 60 % of that for any hit (measured on shards of the headline frame, profiles/)
+        // launches with at most this many rays run on the entry pool from the start: 1.25 rays per lane of a 16-waves-per-CU
+        // grid for closest hit, 0.4 for any hit (crossovers measured on shards of the headline frame, profiles/)
         const unsigned long long lanes16 = (unsigned long long)(o.num_cus > 0 ? o.num_cus : 256) * 16ull * 64ull;
-        a.tail_len = (uint32_t)((lanes16 * (unsigned long long)(o.tail_pct > 0 ? o.tail_pct : 200) * (MODE == 0 ? 100ull : 60ull)) / 10000ull);
+        a.tail_len = (uint32_t)((lanes16 * (unsigned long long)(o.tail_pct > 0 ? o.tail_pct : 100) * (MODE == 0 ? 125ull : 40ull)) / 10000ull);
         a.pool_low = o.pool_low > 0 ? o.pool_low : 16;
         a.pool_chunk = o.pool_chunk > 0 ? o.pool_chunk : kPoolChunk;
         if (pool) {
-            const bool rows24 = a.bvh.depth <= 24u;
-            // default grid: 16 waves per CU; a big launch over a shallow tree (20 waves fit a CU) runs faster on twice as
-            // many, smaller work items (headline frame: closest hit 0.67 -> 0.61 ms, any hit 0.31 -> 0.27 ms; a wave's static
-            // first range of more than one 64-ray chunk is slower: 1.04 / 1.12 / 1.31 ms per frame with 2 / 3 / 4 chunks)
-            if (!o.blocks_user && rows24 && a.n_max > a.tail_len) blocks *= 2;
-            if (rows24) hipLaunchKernelGGL((k_trace_pool<MODE, 24>), dim3(blocks), dim3(64), 0, st, a);
-            else        hipLaunchKernelGGL((k_trace_pool<MODE, 32>), dim3(blocks), dim3(64), 0, st, a);
+            // default grid: one wave per tile of 64 rays, between 16 and 128 waves per CU (beyond that a wave takes several
+            // tiles); the ray count may be smaller on the device (n_ptr), surplus waves leave at once
+            if (!o.blocks_user) {
+                const unsigned long long cus = (unsigned long long)(o.num_cus > 0 ? o.num_cus : 256);
+                unsigned long long want = ((unsigned long long)a.n_max + 63ull) / 64ull;
+                want = want < cus * 16ull ? cus * 16ull : (want > cus * 128ull ? cus * 128ull : want);
+                blocks = (int)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
+            }
+            // the host only knows the capacity of a launch; the shadow-ray queue is sized for one ray per path and typically
+            // holds a fifth to a quarter of that
+            const bool tiled = (MODE == 0 ? a.n_max : a.n_max / 4u) > a.tail_len;
+            if (a.bvh.depth <= 24u) {
+                if (tiled) hipLaunchKernelGGL((k_trace_pool<MODE, 24, true>), dim3(blocks), dim3(64), 0, st, a);
+                else       hipLaunchKernelGGL((k_trace_pool<MODE, 24, false>), dim3(blocks), dim3(64), 0, st, a);
+            } else {
+                if (tiled) hipLaunchKernelGGL((k_trace_pool<MODE, 32, true>), dim3(blocks), dim3(64), 0, st, a);
+                else       hipLaunchKernelGGL((k_trace_pool<MODE, 32, false>), dim3(blocks), dim3(64), 0, st, a);
+            }
         }
         else if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
         else                hipLaunchKernelGGL((k_trace_stream<MODE, false>), dim3(blocks), dim3(64), 0, st, a);

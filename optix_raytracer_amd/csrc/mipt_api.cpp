@@ -83,7 +83,7 @@ struct MiptContext {
     int      batch_samples = 0;
     int      persistent = 3;
     int      build_mode = 0;              // MIPT_OPT_BUILD: 0 host binned SAH, 1 device LBVH
-    int      tail_pct = 200, pool_low = 16, pool_chunk = 16;
+    int      tail_pct = 100, pool_low = 16, pool_chunk = 16;
     // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
     WhGeometry        wh_geo{};
     MiptMaterialData* d_wh_materials = nullptr;
@@ -459,7 +459,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_MAX_DEPTH: c->max_depth = (uint32_t)value; return MIPT_SUCCESS;
     case MIPT_OPT_COUNT_VISITS: c->count_visits = value ? 1 : 0; return MIPT_SUCCESS;
     case MIPT_OPT_TRACE_GRID:
-        if (value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 64 single-wave workgroups per CU");
+        if (value > 256) return c->fail(MIPT_ERROR_INVALID_VALUE, "at most 256 single-wave workgroups per CU");
         c->blocks_per_cu = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PERSISTENT:
         if (value != 0 && value != 2 && value != 3) return c->fail(MIPT_ERROR_INVALID_VALUE, "traversal kernel variant must be 0, 2 or 3");
@@ -892,9 +892,6 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     stats->node_visits = h.node_visits[0] + h.node_visits[1]; stats->tri_tests = h.tri_tests[0] + h.tri_tests[1];
     stats->shadow_node_visits = h.node_visits[1]; stats->shadow_tri_tests = h.tri_tests[1];
     stats->bounces = ctx->last_bounces; stats->reserved = 0;
-    if (ctx->log_level >= 4)
-        ctx->log(4, "SCHED", "pool<closest>: bulk ticks %llu (iterations %llu), tail ticks %llu, rounds %llu, popped %llu, grab ticks %llu in %llu calls, max wave ticks %llu",
-                 h.dbg[0], h.dbg[7], h.dbg[1], h.dbg[2], h.dbg[6], h.dbg[3], h.dbg[5], h.dbg[4]);
     return MIPT_SUCCESS;
 }
 
