@@ -462,20 +462,27 @@ __device__ __forceinline__ bool range_grab(const TraceArgs& a, RayRange& r, uint
 // ROWS: entries of a lane's stack = rows of the LDS block (24 when the tree is at most 24 deep -- 7.5 KB of LDS per
 // wave and <= 96 VGPRs let 20 waves share a CU instead of 16 -- else 32)
 template <int MODE, int ROWS, bool TILED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? 5 : 4, ROWS == 24 ? 5 : 4))) void k_trace_pool(TraceArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? (TILED ? 6 : 5) : 5, ROWS == 24 ? (TILED ? 6 : 5) : 5)))
+void k_trace_pool(TraceArgs a)
 {
-    constexpr int kPoolCap = ROWS * 64;
-    __shared__ uint32_t           stk[kPoolCap];         // bulk: [entry][lane] stacks; tail: the entry pool
-    __shared__ unsigned long long sh_best[64];           // per ray slot
-    __shared__ float              sh_u[64], sh_v[64];
-    __shared__ int                sh_pending[64];        // pool entries of the slot's ray
-    __shared__ uint32_t           sh_done[64];           // any-hit: an occluder was found
+    // ONE LDS block per wave: in the bulk phase ROWS rows of 64 lanes (the lanes' stacks), in the tail phase the entry
+    // pool in its first kPoolCap words and the per-slot merge state in the last 384 (written only after the stacks
+    // have been moved into the pool).  ROWS = 24: 6 KB, 26 waves per CU by LDS; 24 by registers (<= 80 VGPRs).
+    constexpr int kPoolCap = ROWS * 64 - 384;
+    __shared__ uint32_t stk[ROWS * 64];
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);   // per ray slot
+    float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
+    int* const sh_pending = reinterpret_cast<int*>(stk + kPoolCap + 256);       // pool entries of the slot's ray
+    uint32_t* const sh_done = stk + kPoolCap + 320;                             // any-hit: an occluder was found
     const int lane = (int)threadIdx.x;
     const bool cull_back = MODE == 0 && (a.ray_flags & 16u) != 0u;   // MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES: det < 0 is a back face
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
-    const int steal_min = a.steal_min < 64 ? a.steal_min : 64;       // 64: switch when the wave is empty
+    // the stacks of the still busy lanes must fit the pool: at most (kPoolCap - 168) / ROWS busy lanes at the switch
+    const int steal_floor = 64 - (kPoolCap - 168) / ROWS;
+    const int steal_min = a.steal_min < 64 ? (a.steal_min > steal_floor ? a.steal_min : steal_floor) : 64;   // 64: switch when the wave is empty
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
     // a launch with many rays is cut into tiles of 64 consecutive rays, dealt out to the waves without any atomic;
     // one with few rays runs on the entry pool from the start and fetches rays 16 at a time
@@ -518,9 +525,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
     }
 
     // ================================================================ tail: one entry pool per wave
-    // open the merge slots with what each lane has found so far
-    sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
-    sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
     // move the per-lane stacks into the pool, row by row and in place: row e is read before at most
     // (entries so far) + 64 <= (e + 1) * 64 words are written
     int psize = 0;
@@ -539,6 +543,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ?
         if (has_ray) stk[psize + (int)lane_rank(m)] = pool_pack(T.node, (uint32_t)lane);
         psize += __popcll(m);
     }
+    // open the merge slots (they overlay the top rows of the stacks: only now) with what each lane has found so far
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
+    sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
     sh_pending[lane] = has_ray ? T.sp + 1 : 0;
     bool occ = has_ray;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
