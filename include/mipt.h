@@ -162,18 +162,20 @@ typedef enum MiptOption {
     MIPT_OPT_MAX_DEPTH    = 1, /* 0 = unbounded (reference behaviour, Russian roulette only);
                                   k = at most k closest-hit queries per path (build extension) */
     MIPT_OPT_COUNT_VISITS = 2, /* 1 = traversal kernels count node visits / triangle tests */
-    MIPT_OPT_TRACE_GRID   = 3, /* persistent-kernel workgroups per CU (0 = default) */
-    MIPT_OPT_PERSISTENT   = 4, /* traversal kernel: 3 (default) streaming persistent waves that go over to a per-wave
-                                  entry pool for the tail of a launch (and for launches with few rays); 2 streaming waves
-                                  with subtree stealing (also used when a BVH does not fit the pool's packed entries:
-                                  >= 2^25 nodes, >= 2^22 triangles or leaves of more than 7); 0 one thread per ray
-                                  (tight while-while loop; also the fallback for trees deeper than 32). */
+    MIPT_OPT_TRACE_GRID   = 3, /* traversal workgroups (one wave each) per CU; 0 = default: one per 64-ray tile of the launch,
+                                  16 .. 128 per CU */
+    MIPT_OPT_PERSISTENT   = 4, /* traversal kernel: 3 (default) 64-ray tiles per wave, one ray per lane, then a per-wave entry
+                                  pool for the tail of each tile; launches with few rays run on the pool from the start;
+                                  2 persistent streaming waves with lane refill and subtree stealing (also used when a BVH
+                                  does not fit the pool's packed entries: >= 2^25 nodes, >= 2^22 triangles or leaves of more
+                                  than 7, and by counting launches); 0 one thread per ray (tight while-while loop; also the
+                                  fallback for trees deeper than 32). */
     MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings),
                                   2 = only the two traversal kernels (10 -> 4 event records per frame) */
-    MIPT_OPT_REFILL_MIN   = 7, /* streaming waves: idle lanes that trigger a swap-in/prefetch round (default 8) */
-    MIPT_OPT_STEAL_MIN    = 8, /* streaming waves: once the ray range is exhausted, this many idle lanes make the wave
-                                  go over to its entry pool (variant 3) / trigger a round in which idle lanes take
-                                  stack entries of busy rays (variant 2); default 32, 65 = never (3: when all are idle) */
+    MIPT_OPT_REFILL_MIN   = 7, /* variant 2: idle lanes that trigger a swap-in/prefetch round (default 16) */
+    MIPT_OPT_STEAL_MIN    = 8, /* finished lanes of a tile that make the wave go over to its entry pool (variant 3) / idle
+                                  lanes that trigger a round in which they take stack entries of busy rays once the ray
+                                  range is exhausted (variant 2); default 32, 65 = never (3: when all are finished) */
     MIPT_OPT_BATCH_SAMPLES = 10, /* 0 (default): one wavefront pass per sample, contributions added in the reference's
                                   order (bit-identical to the oracle); 1: all samples_per_launch samples of a launch are
                                   paths of ONE pass with per-sample accumulators (same values to rounding, far fewer passes) */
