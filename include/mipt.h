@@ -175,7 +175,7 @@ typedef enum MiptOption {
     MIPT_OPT_REFILL_MIN   = 7, /* variant 2: idle lanes that trigger a swap-in/prefetch round (default 16) */
     MIPT_OPT_STEAL_MIN    = 8, /* finished lanes of a tile that make the wave go over to its entry pool (variant 3) / idle
                                   lanes that trigger a round in which they take stack entries of busy rays once the ray
-                                  range is exhausted (variant 2); default 32, 65 = never (3: when all are finished) */
+                                  range is exhausted (variant 2); default 24, 65 = never (3: when all are finished) */
     MIPT_OPT_BATCH_SAMPLES = 10, /* 0 (default): one wavefront pass per sample, contributions added in the reference's
                                   order (bit-identical to the oracle); 1: all samples_per_launch samples of a launch are
                                   paths of ONE pass with per-sample accumulators (same values to rounding, far fewer passes) */

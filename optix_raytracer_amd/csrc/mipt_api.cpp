@@ -101,7 +101,7 @@ struct MiptContext {
     ShadowQueue im_sq{};
     uint32_t*   im_flags = nullptr;
     size_t      im_cap = 0;
-    int      refill_min = 16, steal_min = 32, burst_bulk = 16, burst_dry = 8;   // tools/tune.py sweep, profiles/r01_tuning.txt
+    int      refill_min = 16, steal_min = 24, burst_bulk = 12, burst_dry = 8;   // tools/tune.py sweeps, profiles/r01_tuning*.txt
     int      profile = 0;
 
     // launch buffers
