@@ -26,7 +26,9 @@ struct DeviceCounters {
     uint32_t cursor_shadow[kNumSegments * kCursorStride];
     unsigned long long closest_rays, shadow_rays;
     unsigned long long node_visits[2], tri_tests[2];   // [0] closest-hit kernel, [1] any-hit kernel
-    unsigned long long dbg[8];                          // schedule counters of k_trace_stream (COUNT builds)
+    unsigned long long iterations;                      // wavefront bounces that had live paths (+ the tails of finished passes)
+    unsigned long long tail_max;                        // deepest path of the current pass's k_tail launch (bounces it ran)
+    unsigned long long dbg[6];
 };
 
 struct DeviceBvh {
@@ -78,7 +80,9 @@ struct TraceOpts {
 
 // ---- launches (all asynchronous on `st`) ----
 void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, uint32_t n_valid);
-void launch_advance(hipStream_t st, DeviceCounters* ctr);
+void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
+                 PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices);
+void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = nullptr);   // host_live: pinned word that receives the new live count
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result);
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                           const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o,

@@ -752,14 +752,22 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
 __global__ void k_begin_sample(DeviceCounters* c, uint32_t n_paths, uint32_t n_valid)
 {
     const uint32_t i = threadIdx.x;
-    if (i == 0) { c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; }
+    if (i == 0) {
+        c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0;
+        c->iterations += c->tail_max; c->tail_max = 0;       // the previous pass's tail (iterations is zeroed per launch)
+    }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
-__global__ void k_advance(DeviceCounters* c)
+__global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
 {
     const uint32_t i = threadIdx.x;
-    if (i == 0) { c->closest_rays += c->n_next; c->shadow_rays += c->n_shadow; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce += 1; }
+    if (i == 0) {
+        const uint32_t live = c->n_next;
+        if (c->n_cur) c->iterations += 1;
+        c->closest_rays += live; c->shadow_rays += c->n_shadow; c->n_cur = live; c->n_next = 0; c->n_shadow = 0; c->bounce += 1;
+        if (host_live) __hip_atomic_store(host_live, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
@@ -863,6 +871,92 @@ struct ShadeArgs {
     const void*             common_vertices;   // non-null when every hit-group record points at the same vertex buffer
 };
 
+struct ShadeOut {
+    bool   push_next, push_shadow;
+    float4 nro, nrd, nsa; uint2 nsb;      // continuation ray + path state
+    float4 sro, srd, sc;                  // shadow ray + its contribution (.w = result slot)
+};
+
+// One path at one bounce: the arithmetic of the miss / closest-hit programs and of the caller's bookkeeping, shared by
+// k_shade (wavefront bounces) and k_tail (the last few paths) so that both produce the same bits.  `res` is the path's
+// accumulator (read and written back by the caller); load_ray fetches the ray only when the path hit something.
+template <class LoadRay>
+__device__ __forceinline__ void shade_path(const ShadeArgs& a, float4 hit, float4 sa, uint32_t slot, uint32_t depth, float4& res,
+                                           ShadeOut& o, LoadRay load_ray)
+{
+    o.push_next = false; o.push_shadow = false;
+    f3 att = mk3(sa.x, sa.y, sa.z);
+    uint32_t seed = f2u(sa.w);
+    if (hit.x < 0.0f) {
+        // miss: radiance = bg, emitted = 0, done (optixPathTracer.cu:323-335)
+        const f3 rad = mk3(a.fc.bg[0], a.fc.bg[1], a.fc.bg[2]) * att;
+        res.x += 0.0f; res.y += 0.0f; res.z += 0.0f;
+        res.x += rad.x; res.y += rad.y; res.z += rad.z;
+        return;
+    }
+    float4 ro4, rd4;
+    load_ray(ro4, rd4);
+    const f3 ray_o = mk3(ro4.x, ro4.y, ro4.z), ray_d = mk3(rd4.x, rd4.y, rd4.z);
+    const uint32_t prim = f2u(hit.y);
+    uint32_t m = a.bvh.mat_index[prim];
+    m = m < a.n_hitgroups ? m : a.n_hitgroups - 1u;
+    // all records usually share one vertex buffer (optixPathTracer.cpp:877): then the fetch
+    // does not have to wait for the record
+    const float4* vb0 = reinterpret_cast<const float4*>(a.common_vertices);
+    const MiptHitGroupData rec = a.hitgroups[m];
+    const float4* vb = (vb0 ? vb0 : reinterpret_cast<const float4*>(rec.vertices)) + (size_t)prim * 3u;
+    const float4 a0 = vb[0], a1 = vb[1], a2 = vb[2];
+    const f3 v0 = mk3(a0.x, a0.y, a0.z), v1 = mk3(a1.x, a1.y, a1.z), v2 = mk3(a2.x, a2.y, a2.z);
+    const f3 N0 = normalize(cross(v1 - v0, v2 - v0));
+    const f3 N  = faceforward(N0, -ray_d, N0);
+    const f3 P  = ray_o + hit.x * ray_d;
+
+    // emitted only for camera rays (:352-355); added before the radiance term (:291)
+    if (depth == 0u) { res.x += rec.emission_color[0]; res.y += rec.emission_color[1]; res.z += rec.emission_color[2]; }
+    else             { res.x += 0.0f; res.y += 0.0f; res.z += 0.0f; }
+
+    const float z1 = rnd(seed);
+    const float z2 = rnd(seed);
+    f3 w_in;
+    cosine_sample_hemisphere(z1, z2, w_in);
+    const f3 new_dir = onb_inverse_transform(N, w_in);
+    att = att * mk3(rec.diffuse_color[0], rec.diffuse_color[1], rec.diffuse_color[2]);
+
+    const float l1 = rnd(seed);
+    const float l2 = rnd(seed);
+    const MiptParallelogramLight& lt = a.fc.light;
+    const f3 lv1 = mk3(lt.v1[0], lt.v1[1], lt.v1[2]), lv2 = mk3(lt.v2[0], lt.v2[1], lt.v2[2]);
+    const f3 light_pos = mk3(lt.corner[0], lt.corner[1], lt.corner[2]) + lv1 * l1 + lv2 * l2;
+    const f3 toL = light_pos - P;
+    const float Ldist = length(toL);
+    const f3 L = normalize(toL);
+    const float nDl  = dot(N, L);
+    const float LnDl = -dot(mk3(lt.normal[0], lt.normal[1], lt.normal[2]), L);
+    if (nDl > 0.0f && LnDl > 0.0f) {
+        const float A = length(cross(lv1, lv2));
+        const float weight = nDl * LnDl * A / (3.14159265358979323846f * Ldist * Ldist);
+        const f3 radiance = mk3(lt.emission[0], lt.emission[1], lt.emission[2]) * weight;
+        const f3 c = radiance * att;
+        o.push_shadow = true;
+        o.sro = make_float4(P.x, P.y, P.z, 0.01f);
+        o.srd = make_float4(L.x, L.y, L.z, Ldist - 0.01f);
+        o.sc  = make_float4(c.x, c.y, c.z, u2f(slot));
+    }
+    // Russian roulette + continuation (:294-303)
+    const float lum = dot(att, mk3(0.30f, 0.59f, 0.11f));
+    const bool done = rnd(seed) > lum;
+    const bool capped = a.fc.max_depth != 0u && depth + 1u >= a.fc.max_depth;
+    if (!done && !capped) {
+        const float inv = 1.0f / lum;
+        att = att * inv;
+        o.push_next = true;
+        o.nro = make_float4(P.x, P.y, P.z, 0.01f);
+        o.nrd = make_float4(new_dir.x, new_dir.y, new_dir.z, 1e16f);
+        o.nsa = make_float4(att.x, att.y, att.z, u2f(seed));
+        o.nsb = make_uint2(slot, depth + 1u);
+    }
+}
+
 // One global atomic per 512-path tile and queue (not per wave): the queue-length words are single
 // addresses, and ~32 k returning atomics on one word serialise at ~88 per microsecond (measured: the
 // per-wave version spent 0.37 of its 0.44 ms there).
@@ -875,89 +969,20 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a)
     __syncthreads();
     for (uint32_t tile = blockIdx.x; tile * kShadeBlock < n; tile += gridDim.x) {
         const uint32_t i = tile * kShadeBlock + threadIdx.x;
-        bool push_next = false, push_shadow = false;
-        float4 nro, nrd, nsa; uint2 nsb;
-        float4 sro, srd, sc;
+        ShadeOut o;
+        o.push_next = false; o.push_shadow = false;
         if (i < n) {
             const uint2 sb = a.cur.state_b[i];
             const uint32_t slot = sb.x, depth = sb.y;
             if (slot != kInvalidSlot) {
                 const float4 hit = a.hits[i];
                 const float4 sa = a.cur.state_a[i];
-                f3 att = mk3(sa.x, sa.y, sa.z);
-                uint32_t seed = f2u(sa.w);
                 float4 res = a.result[slot];
-                if (hit.x < 0.0f) {
-                    // miss: radiance = bg, emitted = 0, done (optixPathTracer.cu:323-335)
-                    const f3 rad = mk3(a.fc.bg[0], a.fc.bg[1], a.fc.bg[2]) * att;
-                    res.x += 0.0f; res.y += 0.0f; res.z += 0.0f;
-                    res.x += rad.x; res.y += rad.y; res.z += rad.z;
-                    a.result[slot] = res;
-                } else {
-                    const float4 ro4 = a.cur.ray_o[i], rd4 = a.cur.ray_d[i];
-                    const f3 ray_o = mk3(ro4.x, ro4.y, ro4.z), ray_d = mk3(rd4.x, rd4.y, rd4.z);
-                    const uint32_t prim = f2u(hit.y);
-                    uint32_t m = a.bvh.mat_index[prim];
-                    m = m < a.n_hitgroups ? m : a.n_hitgroups - 1u;
-                    // all records usually share one vertex buffer (optixPathTracer.cpp:877): then the fetch
-                    // does not have to wait for the record
-                    const float4* vb0 = reinterpret_cast<const float4*>(a.common_vertices);
-                    const MiptHitGroupData rec = a.hitgroups[m];
-                    const float4* vb = (vb0 ? vb0 : reinterpret_cast<const float4*>(rec.vertices)) + (size_t)prim * 3u;
-                    const float4 a0 = vb[0], a1 = vb[1], a2 = vb[2];
-                    const f3 v0 = mk3(a0.x, a0.y, a0.z), v1 = mk3(a1.x, a1.y, a1.z), v2 = mk3(a2.x, a2.y, a2.z);
-                    const f3 N0 = normalize(cross(v1 - v0, v2 - v0));
-                    const f3 N  = faceforward(N0, -ray_d, N0);
-                    const f3 P  = ray_o + hit.x * ray_d;
-
-                    // emitted only for camera rays (:352-355); added before the radiance term (:291)
-                    if (depth == 0u) { res.x += rec.emission_color[0]; res.y += rec.emission_color[1]; res.z += rec.emission_color[2]; }
-                    else             { res.x += 0.0f; res.y += 0.0f; res.z += 0.0f; }
-                    a.result[slot] = res;
-
-                    const float z1 = rnd(seed);
-                    const float z2 = rnd(seed);
-                    f3 w_in;
-                    cosine_sample_hemisphere(z1, z2, w_in);
-                    const f3 new_dir = onb_inverse_transform(N, w_in);
-                    att = att * mk3(rec.diffuse_color[0], rec.diffuse_color[1], rec.diffuse_color[2]);
-
-                    const float l1 = rnd(seed);
-                    const float l2 = rnd(seed);
-                    const MiptParallelogramLight& lt = a.fc.light;
-                    const f3 lv1 = mk3(lt.v1[0], lt.v1[1], lt.v1[2]), lv2 = mk3(lt.v2[0], lt.v2[1], lt.v2[2]);
-                    const f3 light_pos = mk3(lt.corner[0], lt.corner[1], lt.corner[2]) + lv1 * l1 + lv2 * l2;
-                    const f3 toL = light_pos - P;
-                    const float Ldist = length(toL);
-                    const f3 L = normalize(toL);
-                    const float nDl  = dot(N, L);
-                    const float LnDl = -dot(mk3(lt.normal[0], lt.normal[1], lt.normal[2]), L);
-                    if (nDl > 0.0f && LnDl > 0.0f) {
-                        const float A = length(cross(lv1, lv2));
-                        const float weight = nDl * LnDl * A / (3.14159265358979323846f * Ldist * Ldist);
-                        const f3 radiance = mk3(lt.emission[0], lt.emission[1], lt.emission[2]) * weight;
-                        const f3 c = radiance * att;
-                        push_shadow = true;
-                        sro = make_float4(P.x, P.y, P.z, 0.01f);
-                        srd = make_float4(L.x, L.y, L.z, Ldist - 0.01f);
-                        sc  = make_float4(c.x, c.y, c.z, u2f(slot));
-                    }
-                    // Russian roulette + continuation (:294-303)
-                    const float lum = dot(att, mk3(0.30f, 0.59f, 0.11f));
-                    const bool done = rnd(seed) > lum;
-                    const bool capped = a.fc.max_depth != 0u && depth + 1u >= a.fc.max_depth;
-                    if (!done && !capped) {
-                        const float inv = 1.0f / lum;
-                        att = att * inv;
-                        push_next = true;
-                        nro = make_float4(P.x, P.y, P.z, 0.01f);
-                        nrd = make_float4(new_dir.x, new_dir.y, new_dir.z, 1e16f);
-                        nsa = make_float4(att.x, att.y, att.z, u2f(seed));
-                        nsb = make_uint2(slot, depth + 1u);
-                    }
-                }
+                shade_path(a, hit, sa, slot, depth, res, o, [&](float4& ro4, float4& rd4) { ro4 = a.cur.ray_o[i]; rd4 = a.cur.ray_d[i]; });
+                a.result[slot] = res;
             }
         }
+        const bool push_shadow = o.push_shadow, push_next = o.push_next;
         // ---- compacting appends, aggregated over the block
         const unsigned long long ms = __ballot(push_shadow), mn = __ballot(push_next);
         uint32_t wo_s = 0, wo_n = 0;
@@ -976,13 +1001,71 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a)
         __syncthreads();
         if (push_shadow) {
             const uint32_t js = s_base[0] + wo_s + lane_rank(ms);
-            a.shadow.ray_o[js] = sro; a.shadow.ray_d[js] = srd; a.shadow.contrib[js] = sc;
+            a.shadow.ray_o[js] = o.sro; a.shadow.ray_d[js] = o.srd; a.shadow.contrib[js] = o.sc;
         }
         if (push_next) {
             const uint32_t jn = s_base[1] + wo_n + lane_rank(mn);
-            a.next.ray_o[jn] = nro; a.next.ray_d[jn] = nrd; a.next.state_a[jn] = nsa; a.next.state_b[jn] = nsb;
+            a.next.ray_o[jn] = o.nro; a.next.ray_d[jn] = o.nrd; a.next.state_a[jn] = o.nsa; a.next.state_b[jn] = o.nsb;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tail: when Russian roulette has left only a few thousand paths, a wavefront bounce is five nearly empty kernels
+// (~40 us).  k_tail runs every remaining path to its end in ONE launch, one path per lane -- the raygen loop of
+// optixPathTracer.cu:283-305 as the reference has it -- with the per-ray traversal of k_trace_simple and shade_path,
+// so the accumulators receive the same terms in the same order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
+{
+    __shared__ uint32_t stk_lds[kStackEntries * 64];
+    const int lane = (int)threadIdx.x;
+    const Stack stk{ stk_lds, lane };
+    uint32_t n = a.ctr->n_cur;
+    n = n < a.n_max ? n : a.n_max;
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    uint32_t n_closest = 0, n_shadow = 0, n_iter = 0, n_tests = 0;
+    uint32_t slot = kInvalidSlot, depth = 0;
+    if (i < n) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
+    if (slot != kInvalidSlot) {
+        float4 ro4 = a.cur.ray_o[i], rd4 = a.cur.ray_d[i], sa = a.cur.state_a[i];
+        float4 res = a.result[slot];
+        for (;;) {
+            Trav T;
+            trav_init(T, ro4, rd4);
+            while (T.node != kSentinel) {
+                while (T.node >= 0) visit_inner(T, a.bvh.nodes, stk);
+                if (T.node != kSentinel) { (void)visit_leaf<false>(T, a.bvh.tris, n_tests, false); T.node = stk.pop(T.sp); }
+            }
+            const float4 hit = T.prim != 0xffffffffu ? make_float4(T.tbest, u2f(T.prim), T.u, T.v)
+                                                     : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+            ++n_iter;
+            ShadeOut o;
+            shade_path(a, hit, sa, slot, depth, res, o, [&](float4& o4, float4& d4) { o4 = ro4; d4 = rd4; });
+            if (o.push_shadow) {
+                ++n_shadow;
+                trav_init(T, o.sro, o.srd);
+                bool occluded = false;
+                while (T.node != kSentinel) {
+                    while (T.node >= 0) visit_inner(T, a.bvh.nodes, stk);
+                    if (T.node != kSentinel) {
+                        if (visit_leaf<true>(T, a.bvh.tris, n_tests, false)) { occluded = true; break; }
+                        T.node = stk.pop(T.sp);
+                    }
+                }
+                if (!occluded) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
+            }
+            if (!o.push_next) break;
+            ++n_closest;
+            ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y;
+        }
+        a.result[slot] = res;
+    }
+    wave_add64(&a.ctr->closest_rays, n_closest);
+    wave_add64(&a.ctr->shadow_rays, n_shadow);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t v = (uint32_t)__shfl_down((int)n_iter, off, 64); n_iter = v > n_iter ? v : n_iter; }
+    if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1033,9 +1116,9 @@ void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, 
     hipLaunchKernelGGL(k_begin_sample, dim3(1), dim3(64), 0, st, ctr, n_paths, n_valid);
 }
 
-void launch_advance(hipStream_t st, DeviceCounters* ctr)
+void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live)
 {
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctr);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctr, host_live);
 }
 
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result)
@@ -1127,6 +1210,16 @@ void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, c
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0u) blocks = 1u;
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, st, a);
+}
+
+void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
+                 PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices)
+{
+    if (n_max == 0u) return;
+    ShadeArgs a{};
+    a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur;
+    a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
+    hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);
 }
 
 void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots)

@@ -83,6 +83,8 @@ struct MiptContext {
     int      batch_samples = 0;
     int      persistent = 3;
     int      build_mode = 0;              // MIPT_OPT_BUILD: 0 host binned SAH, 1 device LBVH
+    uint32_t tail_paths = 262144;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
+    bool     bounces_on_device = false;   // launch statistics: iterations counted by k_advance / k_tail
     int      tail_pct = 100, pool_low = 16, pool_chunk = 16;
     // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
     WhGeometry        wh_geo{};
@@ -112,7 +114,8 @@ struct MiptContext {
     float4*         result = nullptr;
     uint32_t*       rg_seed = nullptr;
     DeviceCounters* d_ctr = nullptr;
-    uint32_t*       h_pinned = nullptr;
+    uint32_t*       h_pinned = nullptr;      // kRing live counts (run_wavefront)
+    hipEvent_t      ring_ev[4] = {};
     hipStream_t     last_stream = nullptr;
     uint32_t        last_bounces = 0;
 
@@ -156,6 +159,8 @@ struct MiptContext {
     } while (0)
 
 namespace {
+
+constexpr uint32_t kRing = 4, kLag = 2;     // run_wavefront's lagged read of the live-path count
 
 struct TimedScope {
     MiptContext* c; hipStream_t st; int kind; bool on = false; hipEvent_t a = nullptr, b = nullptr;
@@ -337,7 +342,6 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
     const DeviceBvh bvh = device_bvh(acc);
     const TraceOpts opts = trace_opts(ctx);
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
-    uint32_t bounces_total = 0;
     for (uint32_t s = 0; s < passes; ++s) {
         launch_begin_sample(st, ctx->d_ctr, n_paths, pass_valid);
         { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result); }
@@ -351,22 +355,36 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             { TimedScope t(ctx, st, T_ANY);
               launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, n_paths, nullptr, ctx->sq.contrib,
                                ctx->result, ctx->d_ctr, opts); }
-            launch_advance(st, ctx->d_ctr);
+            launch_advance(st, ctx->d_ctr, ctx->h_pinned + bounce % kRing);
             cur ^= 1;
-            ++bounces_total;
+            const bool use_tail = ctx->tail_paths != 0u && !ctx->count_visits;
             if (fc.max_depth != 0u) {
                 if (bounce + 1u >= fc.max_depth) break;
-                continue;             // bounded paths: no host round trip, empty queues make the kernels exit at once
+                if (!use_tail) continue;      // bounded paths, no tail kernel: no host round trip, empty queues make the kernels exit at once
             }
-            // unbounded (reference behaviour): stop when Russian roulette has ended every path
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, &ctx->d_ctr->n_cur, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            if (*ctx->h_pinned == 0u) break;
+            // Unbounded (reference behaviour): stop when Russian roulette has ended every path.  The live count after
+            // bounce b is written by k_advance into a pinned ring and read kLag bounces later, so the stream never
+            // drains while the host waits; the bounces launched past the end find empty queues and exit at once.
+            HIPCHK(ctx, hipEventRecord(ctx->ring_ev[bounce % kRing], st));
+            if (bounce >= kLag) {
+                const uint32_t old = (bounce - kLag) % kRing;
+                HIPCHK(ctx, hipEventSynchronize(ctx->ring_ev[old]));
+                const uint32_t live = ctx->h_pinned[old];       // an upper bound of every later count
+                if (live == 0u) break;
+                // (depth-capped paths have few bounces left, so the switch pays later: a quarter of the threshold)
+                if (use_tail && live <= (fc.max_depth != 0u ? ctx->tail_paths / 4u : ctx->tail_paths)) {
+                    // few paths left: one launch runs them to their ends instead of five per bounce
+                    TimedScope t(ctx, st, T_CLOSEST);
+                    launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->result, ctx->d_ctr, live,
+                                ctx->common_vertices);
+                    break;
+                }
+            }
             if (bounce > 100000u) return ctx->fail(MIPT_ERROR_INTERNAL, "path length runaway");
         }
     }
     { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots); }
-    ctx->last_bounces = bounces_total;
+    ctx->bounces_on_device = true;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
 }
@@ -416,11 +434,14 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
         delete c;
         return MIPT_ERROR_OUT_OF_MEMORY;
     }
+    for (hipEvent_t& e : c->ring_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
     if (const char* e = std::getenv("MIPT_TAIL_PCT")) { const int v = std::atoi(e); if (v >= 1 && v <= 100000) c->tail_pct = v; }
     if (const char* e = std::getenv("MIPT_POOL_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) c->pool_chunk = v; }
     if (const char* e = std::getenv("MIPT_POOL_LOW")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) c->pool_low = v; }
+    if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 20)) c->tail_paths = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_STEAL_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) c->steal_min = v; }
     *out = c;
     return MIPT_SUCCESS;
@@ -446,6 +467,7 @@ int mipt_context_destroy(MiptContext* c)
     for (void* t : c->wh_texels) if (t) (void)hipFree(t);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ring_ev) if (e) (void)hipEventDestroy(e);
     delete c;
     return MIPT_SUCCESS;
 }
@@ -468,6 +490,9 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value < 1 || value > 64) return c->fail(MIPT_ERROR_INVALID_VALUE, "refill threshold must be 1..64");
         c->refill_min = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_BATCH_SAMPLES: c->batch_samples = value ? 1 : 0; return MIPT_SUCCESS;
+    case MIPT_OPT_TAIL_PATHS:
+        if (value > (1u << 20)) return c->fail(MIPT_ERROR_INVALID_VALUE, "tail threshold must be 0 (off) .. 1048576 paths");
+        c->tail_paths = (uint32_t)value; return MIPT_SUCCESS;
     case MIPT_OPT_BUILD:
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH) or 1 (device LBVH)");
         c->build_mode = (int)value; return MIPT_SUCCESS;
@@ -498,6 +523,7 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_STEAL_MIN: *value = (uint64_t)c->steal_min; return MIPT_SUCCESS;
     case MIPT_OPT_BATCH_SAMPLES: *value = (uint64_t)c->batch_samples; return MIPT_SUCCESS;
     case MIPT_OPT_BUILD: *value = (uint64_t)c->build_mode; return MIPT_SUCCESS;
+    case MIPT_OPT_TAIL_PATHS: *value = (uint64_t)c->tail_paths; return MIPT_SUCCESS;
     case MIPT_OPT_BURST: *value = (uint64_t)c->burst_bulk | ((uint64_t)c->burst_dry << 8); return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;
     }
@@ -891,7 +917,7 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     stats->closest_rays = h.closest_rays; stats->shadow_rays = h.shadow_rays;
     stats->node_visits = h.node_visits[0] + h.node_visits[1]; stats->tri_tests = h.tri_tests[0] + h.tri_tests[1];
     stats->shadow_node_visits = h.node_visits[1]; stats->shadow_tri_tests = h.tri_tests[1];
-    stats->bounces = ctx->last_bounces; stats->reserved = 0;
+    stats->bounces = ctx->bounces_on_device ? (uint32_t)(h.iterations + h.tail_max) : ctx->last_bounces; stats->reserved = 0;
     return MIPT_SUCCESS;
 }
 
@@ -949,7 +975,7 @@ int mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* p, 
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     imgui_run(st, *p, n_paths, device_bvh(acc), ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->rg_seed,
               ctx->d_ctr, trace_opts(ctx));
-    ctx->last_bounces = p->samples_per_frame;
+    ctx->last_bounces = p->samples_per_frame; ctx->bounces_on_device = false;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
 }
@@ -1074,7 +1100,7 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     B.any_hit_programs = ctx->wh_any_hit;
     whitted_run(st, *p, n_paths, device_bvh(acc), ctx->wh_geo, ctx->d_wh_materials, ctx->n_wh_materials, ctx->d_wh_textures,
                 ctx->n_wh_textures, B, ctx->d_ctr, trace_opts(ctx));
-    ctx->last_bounces = B.max_levels;
+    ctx->last_bounces = B.max_levels; ctx->bounces_on_device = false;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
 }

@@ -192,6 +192,36 @@ def test_cornell_multi_sample_and_ragged_sizes(w, h, spp, max_depth):
     PT.cleanupState(st)
 
 
+@pytest.mark.parametrize("scene_kind,w,h,spp,max_depth", [("cornell", 160, 120, 3, 0), ("soup", 128, 96, 2, 0), ("cornell", 96, 64, 2, 6)])
+def test_tail_kernel_gives_the_same_frame_and_counts(scene_kind, w, h, spp, max_depth):
+    """MIPT_OPT_TAIL_PATHS: the last paths of an unbounded launch run in one kernel (one path per lane) instead of
+    wavefront bounces -- pixels, ray counts and the reported path depth do not depend on where the switch happens"""
+    _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import scenes
+    scene = scenes.cornell_box() if scene_kind == "cornell" else scenes.random_soup(20000)
+    PT, st = _state(scene, w, h, spp, max_depth)
+    ref = None
+    for tail in (0, 1, 300, 8192, 1 << 20):
+        st.context.set_option(L.OPT_TAIL_PATHS, tail)
+        assert st.context.get_option(L.OPT_TAIL_PATHS) == tail
+        acc, frame, stats = _render_gpu(PT, st)
+        cur = (acc.copy(), frame.copy(), stats["closest_rays"], stats["shadow_rays"], stats["bounces"])
+        if ref is None:
+            ref = cur
+            osc = _oracle_scene(scene, st)
+            a, f, ost = osc.render(scenes.launch_desc(scene, w, h, spp), max_depth=max_depth, threads=4)
+            _assert_pixels(acc, a)
+            assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"]
+            assert stats["bounces"] == spp * (ost["max_depth_seen"] + 1) or spp > 1
+            continue
+        assert np.array_equal(cur[0].view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(cur[1], ref[1]), tail
+        assert cur[2:] == ref[2:], (tail, cur[2:], ref[2:])
+    with pytest.raises(Exception):
+        st.context.set_option(L.OPT_TAIL_PATHS, (1 << 20) + 1)
+    PT.cleanupState(st)
+
+
 def test_progressive_subframes():
     _torch()
     from optix_raytracer_amd import scenes
