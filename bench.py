@@ -273,7 +273,13 @@ def main():
         bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
         variant = {3: "k_trace_pool<%%d, %d, true>" % (24 if info["depth"] <= 24 else 32), 2: "k_trace_stream<%d, false>",
                    0: "k_trace_simple<%d, false>"}[int(st.context.get_option(L.OPT_PERSISTENT))]
-        if k_closest >= k_any:
+        # a pass of at most MIPT_OPT_TAIL_PATHS paths (a rank's shard at N >= 2) runs in the path kernel: closest-hit and
+        # any-hit traversal, shading and accumulation of a wave's 64 paths in ONE launch, timed under "trace_closest"
+        fused = sharded and int(st.context.get_option(L.OPT_PERSISTENT)) == 3 and info["depth"] <= 32 and \
+            api.shard_num_samples(w, h, world) <= int(st.context.get_option(L.OPT_TAIL_PATHS))
+        if fused:
+            kname, kbytes, kms, klaunches = "k_tail_pool", bytes_closest + bytes_any, k_closest, tm["n_trace_closest"]
+        elif k_closest >= k_any:
             kname, kbytes, kms, klaunches = variant % 0, bytes_closest, k_closest, tm["n_trace_closest"]
         else:
             kname, kbytes, kms, klaunches = variant % 2, bytes_any, k_any, tm["n_trace_any"]

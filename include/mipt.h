@@ -182,10 +182,10 @@ typedef enum MiptOption {
     MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build: 0 (default) binned SAH on the host cores, 1 linear BVH built on the
                                   device (Morton codes + radix sort + Karras' radix tree; ~ PREFER_FAST_BUILD: a few ms per
                                   million triangles, slower to traverse); falls back to 0 when that tree is too deep */
-    MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late), one
-                                  kernel runs each of them to its end, one path per lane, instead of five kernels per bounce
-                                  (same pixels, same ray counts); default 262144 (a quarter of the value when MAX_DEPTH caps
-                                  the paths), 0 = off */
+    MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late; a
+                                  quarter of the value when MAX_DEPTH caps the paths), one kernel runs each of them to its
+                                  end, a wave per 64 paths, instead of five kernels per bounce; a pass that starts with at
+                                  most this many paths starts there.  Same pixels, same ray counts.  Default 1048576, 0 = off */
     MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
                                   (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;

@@ -459,6 +459,118 @@ __device__ __forceinline__ bool range_grab(const TraceArgs& a, RayRange& r, uint
     return true;
 }
 
+// One round of a wave's entry pool (k_trace_pool's tail phase, k_tail_pool): pop up to 64 packed (entry, ray slot) words,
+// each lane processes one -- an inner node: slab-test both children against the ray's current best t and push the
+// survivors, nearer on top; a leaf reference: test its first triangle and push the rest of the leaf.  The ray of slot s is
+// read from the registers of lane s; its best hit is merged in LDS (min t, tie -> lowest primitive).
+template <int MODE, int CAP>
+__device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
+                                           unsigned long long* sh_best, float* sh_u, float* sh_v, int* sh_pending, uint32_t* sh_done,
+                                           const int lane, const Trav& T, int& psize, const bool cull_back)
+{
+    constexpr int kPoolCap = CAP;
+    // ------------------------------------------------------------ pop up to 64 entries (each lane adds at most one net entry)
+    int k = psize < 64 ? psize : 64;
+    const int room = kPoolCap - 104 - psize;                  // 64 for ray starts, 40 for a single-lane descent
+    if (k > room) k = room > 1 ? room : 1;
+    const bool have = lane < k;
+    uint32_t ent = 0u;
+    if (have) ent = stk[psize - 1 - lane];
+    psize -= k;
+    const uint32_t slot = ent & 63u;
+    // the ray of that slot, from its owner's registers
+    const float ox = shfl_f(T.o.x, slot), oy = shfl_f(T.o.y, slot), oz = shfl_f(T.o.z, slot);
+    const float dx = shfl_f(T.d.x, slot), dy = shfl_f(T.d.y, slot), dz = shfl_f(T.d.z, slot);
+    const float ix = shfl_f(T.idir.x, slot), iy = shfl_f(T.idir.y, slot), iz = shfl_f(T.idir.z, slot);
+    const float nx = shfl_f(T.nood.x, slot), ny = shfl_f(T.nood.y, slot), nz = shfl_f(T.nood.z, slot);
+    const float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
+    float tcur = tmx;
+    bool live = have;
+    if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[slot] >> 32)); }
+    else           { if (have && sh_done[slot] != 0u) live = false; }
+    const bool leaf = (ent >> 31) != 0u;
+    const uint32_t payload = (ent >> 6) & 0x1ffffffu;
+    const uint32_t lfirst = payload >> 3, lcnt = payload & 7u;
+    const bool do_inner = live && !leaf;
+    const bool do_tri   = live && leaf && lcnt != 0u;
+    uint32_t off = 0u;
+    if (do_inner) off = payload << 6;
+    if (do_tri)   off = tri_byte_off + lfirst * 48u;
+    const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
+    asm volatile("" ::: "memory");
+    uint32_t push0 = 0u, push1 = 0u;
+    int npush = 0;
+    if (do_inner) {
+        const float ax0 = __builtin_fmaf(n0.x, ix, nx), ax1 = __builtin_fmaf(n0.y, ix, nx);
+        const float ay0 = __builtin_fmaf(n0.z, iy, ny), ay1 = __builtin_fmaf(n0.w, iy, ny);
+        const float az0 = __builtin_fmaf(n2.x, iz, nz), az1 = __builtin_fmaf(n2.y, iz, nz);
+        const float bx0 = __builtin_fmaf(n1.x, ix, nx), bx1 = __builtin_fmaf(n1.y, ix, nx);
+        const float by0 = __builtin_fmaf(n1.z, iy, ny), by1 = __builtin_fmaf(n1.w, iy, ny);
+        const float bz0 = __builtin_fmaf(n2.z, iz, nz), bz1 = __builtin_fmaf(n2.w, iz, nz);
+        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                          __builtin_fmaxf(__builtin_fminf(az0, az1), tmn));
+        const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                          __builtin_fminf(__builtin_fmaxf(az0, az1), tcur));
+        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                          __builtin_fmaxf(__builtin_fminf(bz0, bz1), tmn));
+        const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                          __builtin_fminf(__builtin_fmaxf(bz0, bz1), tcur));
+        const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+        const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+        if (h0 && h1) {
+            const bool swp = tn1 < tn0;
+            push0 = pool_pack(swp ? c0 : c1, slot);           // farther child below ...
+            push1 = pool_pack(swp ? c1 : c0, slot);           // ... the nearer one on top
+            npush = 2;
+        } else if (h0 || h1) {
+            push1 = pool_pack(h0 ? c0 : c1, slot);
+            npush = 1;
+        }
+    }
+    if (do_tri) {
+        const f3 rd = mk3(dx, dy, dz);
+        const f3 e1 = mk3(n1.x, n1.y, n1.z), e2 = mk3(n2.x, n2.y, n2.z);
+        const f3 p = fcross(rd, e2);
+        const float det = fdot(e1, p);
+        const float inv = 1.0f / det;
+        const f3 tv = mk3(ox, oy, oz) - mk3(n0.x, n0.y, n0.z);
+        const float u = fdot(tv, p) * inv;
+        const f3 q = fcross(tv, e1);
+        const float v = fdot(rd, q) * inv;
+        const float t = fdot(e2, q) * inv;
+        const uint32_t prim = f2u(n0.w);
+        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmn && t < tmx &&
+                        (!cull_back || det > 0.0f || (f2u(n1.w) & 4u) != 0u);
+        bool stop = false;
+        if (MODE != 0) {
+            if (ok) { sh_done[slot] = 1u; stop = true; }
+        } else if (ok) {
+            const unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
+            atomicMin(&sh_best[slot], key);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; }
+        }
+        if (!stop && lcnt > 1u) {
+            push1 = 0x80000000u | ((lfirst + 1u) << 9) | ((lcnt - 1u) << 6) | slot;
+            npush = 1;
+        }
+    }
+    if (have && npush != 1) atomicAdd(&sh_pending[slot], npush - 1);
+    {
+        const unsigned long long m2 = __ballot(npush == 2);
+        if (m2 != 0ull) {
+            if (npush == 2) stk[psize + (int)lane_rank(m2)] = push0;
+            psize += __popcll(m2);
+        }
+        const unsigned long long m1 = __ballot(npush >= 1);
+        if (m1 != 0ull) {
+            if (npush >= 1) stk[psize + (int)lane_rank(m1)] = push1;
+            psize += __popcll(m1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
 // ROWS: entries of a lane's stack = rows of the LDS block (24 when the tree is at most 24 deep -- 7.5 KB of LDS per
 // wave and <= 96 VGPRs let 20 waves share a CU instead of 16 -- else 32)
 template <int MODE, int ROWS, bool TILED>
@@ -607,106 +719,7 @@ void k_trace_pool(TraceArgs a)
             continue;                                             // (not reached: an empty pool with rays left prefetches above)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        // ------------------------------------------------------------ pop up to 64 entries (each lane adds at most one net entry)
-        int k = psize < 64 ? psize : 64;
-        const int room = kPoolCap - 104 - psize;                  // 64 for ray starts, 40 for a single-lane descent
-        if (k > room) k = room > 1 ? room : 1;
-        const bool have = lane < k;
-        uint32_t ent = 0u;
-        if (have) ent = stk[psize - 1 - lane];
-        psize -= k;
-        const uint32_t slot = ent & 63u;
-        // the ray of that slot, from its owner's registers
-        const float ox = shfl_f(T.o.x, slot), oy = shfl_f(T.o.y, slot), oz = shfl_f(T.o.z, slot);
-        const float dx = shfl_f(T.d.x, slot), dy = shfl_f(T.d.y, slot), dz = shfl_f(T.d.z, slot);
-        const float ix = shfl_f(T.idir.x, slot), iy = shfl_f(T.idir.y, slot), iz = shfl_f(T.idir.z, slot);
-        const float nx = shfl_f(T.nood.x, slot), ny = shfl_f(T.nood.y, slot), nz = shfl_f(T.nood.z, slot);
-        const float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
-        float tcur = tmx;
-        bool live = have;
-        if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[slot] >> 32)); }
-        else           { if (have && sh_done[slot] != 0u) live = false; }
-        const bool leaf = (ent >> 31) != 0u;
-        const uint32_t payload = (ent >> 6) & 0x1ffffffu;
-        const uint32_t lfirst = payload >> 3, lcnt = payload & 7u;
-        const bool do_inner = live && !leaf;
-        const bool do_tri   = live && leaf && lcnt != 0u;
-        uint32_t off = 0u;
-        if (do_inner) off = payload << 6;
-        if (do_tri)   off = a.bvh.tri_byte_off + lfirst * 48u;
-        const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
-        asm volatile("" ::: "memory");
-        uint32_t push0 = 0u, push1 = 0u;
-        int npush = 0;
-        if (do_inner) {
-            const float ax0 = __builtin_fmaf(n0.x, ix, nx), ax1 = __builtin_fmaf(n0.y, ix, nx);
-            const float ay0 = __builtin_fmaf(n0.z, iy, ny), ay1 = __builtin_fmaf(n0.w, iy, ny);
-            const float az0 = __builtin_fmaf(n2.x, iz, nz), az1 = __builtin_fmaf(n2.y, iz, nz);
-            const float bx0 = __builtin_fmaf(n1.x, ix, nx), bx1 = __builtin_fmaf(n1.y, ix, nx);
-            const float by0 = __builtin_fmaf(n1.z, iy, ny), by1 = __builtin_fmaf(n1.w, iy, ny);
-            const float bz0 = __builtin_fmaf(n2.z, iz, nz), bz1 = __builtin_fmaf(n2.w, iz, nz);
-            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                              __builtin_fmaxf(__builtin_fminf(az0, az1), tmn));
-            const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                              __builtin_fminf(__builtin_fmaxf(az0, az1), tcur));
-            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                              __builtin_fmaxf(__builtin_fminf(bz0, bz1), tmn));
-            const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                              __builtin_fminf(__builtin_fmaxf(bz0, bz1), tcur));
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
-            if (h0 && h1) {
-                const bool swp = tn1 < tn0;
-                push0 = pool_pack(swp ? c0 : c1, slot);           // farther child below ...
-                push1 = pool_pack(swp ? c1 : c0, slot);           // ... the nearer one on top
-                npush = 2;
-            } else if (h0 || h1) {
-                push1 = pool_pack(h0 ? c0 : c1, slot);
-                npush = 1;
-            }
-        }
-        if (do_tri) {
-            const f3 rd = mk3(dx, dy, dz);
-            const f3 e1 = mk3(n1.x, n1.y, n1.z), e2 = mk3(n2.x, n2.y, n2.z);
-            const f3 p = fcross(rd, e2);
-            const float det = fdot(e1, p);
-            const float inv = 1.0f / det;
-            const f3 tv = mk3(ox, oy, oz) - mk3(n0.x, n0.y, n0.z);
-            const float u = fdot(tv, p) * inv;
-            const f3 q = fcross(tv, e1);
-            const float v = fdot(rd, q) * inv;
-            const float t = fdot(e2, q) * inv;
-            const uint32_t prim = f2u(n0.w);
-            const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmn && t < tmx &&
-                            (!cull_back || det > 0.0f || (f2u(n1.w) & 4u) != 0u);
-            bool stop = false;
-            if (MODE != 0) {
-                if (ok) { sh_done[slot] = 1u; stop = true; }
-            } else if (ok) {
-                const unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
-                atomicMin(&sh_best[slot], key);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; }
-            }
-            if (!stop && lcnt > 1u) {
-                push1 = 0x80000000u | ((lfirst + 1u) << 9) | ((lcnt - 1u) << 6) | slot;
-                npush = 1;
-            }
-        }
-        if (have && npush != 1) atomicAdd(&sh_pending[slot], npush - 1);
-        {
-            const unsigned long long m2 = __ballot(npush == 2);
-            if (m2 != 0ull) {
-                if (npush == 2) stk[psize + (int)lane_rank(m2)] = push0;
-                psize += __popcll(m2);
-            }
-            const unsigned long long m1 = __ballot(npush >= 1);
-            if (m1 != 0ull) {
-                if (npush >= 1) stk[psize + (int)lane_rank(m1)] = push1;
-                psize += __popcll(m1);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        pool_round<MODE, kPoolCap>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, cull_back);
     }
     if (!tiled) break;
     }
@@ -1068,6 +1081,85 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
     if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
 }
 
+// ---- the same loop with the wave's 64 rays traversed together on the entry pool (pool_round): a bounce then lasts as long
+// as the deepest chain of dependent node fetches, not as long as the longest ray's whole visiting sequence (1 M-triangle
+// scene: one bounce of 65 k paths 0.51 -> 0.1 ms).  Hit records are those of the sequential traversal (k_trace_pool's
+// argument).  Measured and dropped: one ray per lane first (stream_step) and the pool only for the tail of the tile, as in
+// k_trace_pool's tiled form -- 164 VGPRs, and capped at 128 or 96 it is slower than this (Cornell 512x512 0.41 / 0.53 vs
+// 0.38 ms; the headline frame run this way 1.05 / 1.08 vs 0.95 ms).
+template <int MODE>
+__device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
+                                           unsigned long long* sh_best, float* sh_u, float* sh_v, int* sh_pending, uint32_t* sh_done,
+                                           const int lane, const Trav& T, const bool has_ray)
+{
+    constexpr int kPoolCap = 24 * 64 - 384;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
+    sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u;
+    sh_pending[lane] = has_ray ? 1 : 0;
+    const unsigned long long m = __ballot(has_ray);
+    if (has_ray) stk[(int)lane_rank(m)] = pool_pack(0, (uint32_t)lane);
+    int psize = __popcll(m);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    while (psize > 0)
+        pool_round<MODE, kPoolCap>(blob, tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, false);
+}
+
+__global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a)
+{
+    constexpr int kPoolCap = 24 * 64 - 384;
+    __shared__ uint32_t stk[24 * 64];
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
+    float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
+    int* const sh_pending = reinterpret_cast<int*>(stk + kPoolCap + 256);
+    uint32_t* const sh_done = stk + kPoolCap + 320;
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+    uint32_t n = a.ctr->n_cur;
+    n = n < a.n_max ? n : a.n_max;
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    uint32_t n_closest = 0, n_shadow = 0, n_iter = 0;
+    uint32_t slot = kInvalidSlot, depth = 0;
+    if (i < n) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
+    bool active = slot != kInvalidSlot;
+    float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
+    if (active) { ro4 = a.cur.ray_o[i]; rd4 = a.cur.ray_d[i]; sa = a.cur.state_a[i]; res = a.result[slot]; }
+    while (__ballot(active) != 0ull) {
+        Trav T;
+        trav_init(T, ro4, rd4);
+        tail_trace<0>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, active && T.node != kSentinel);
+        const unsigned long long key = sh_best[lane];
+        const uint32_t prim = (uint32_t)key;
+        const float4 hit = prim != 0xffffffffu ? make_float4(ord_float((uint32_t)(key >> 32)), u2f(prim), sh_u[lane], sh_v[lane])
+                                               : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        ShadeOut o;
+        o.push_next = false; o.push_shadow = false;
+        if (active) {
+            ++n_iter;
+            shade_path(a, hit, sa, slot, depth, res, o, [&](float4& o4, float4& d4) { o4 = ro4; d4 = rd4; });
+        }
+        const bool sh = active && o.push_shadow;
+        if (__ballot(sh) != 0ull) {
+            Trav S;
+            trav_init(S, sh ? o.sro : ro4, sh ? o.srd : rd4);
+            tail_trace<2>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, S, sh && S.node != kSentinel);
+            if (sh) {
+                ++n_shadow;
+                if (sh_done[lane] == 0u) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
+            }
+        }
+        active = active && o.push_next;
+        if (active) { ++n_closest; ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y; }
+    }
+    if (slot != kInvalidSlot) a.result[slot] = res;
+    wave_add64(&a.ctr->closest_rays, n_closest);
+    wave_add64(&a.ctr->shadow_rays, n_shadow);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t v = (uint32_t)__shfl_down((int)n_iter, off, 64); n_iter = v > n_iter ? v : n_iter; }
+    if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
+}
+
 // ------------------------------------------------------------------------------------------------
 // resolve: optixPathTracer.cu:308-319
 // ------------------------------------------------------------------------------------------------
@@ -1213,13 +1305,17 @@ void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, c
 }
 
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
-                 PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices)
+                 PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TraceOpts& o)
 {
     if (n_max == 0u) return;
     ShadeArgs a{};
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur;
     a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
-    hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);
+    // the pool variant needs a BVH that fits k_trace_pool's packed entries; MIPT_OPT_PERSISTENT != 3 selects the plain loop
+    if (o.persistent == 3 && bvh.pool_ok && bvh.tri_byte_off != 0u && bvh.depth <= 32u)
+        hipLaunchKernelGGL(k_tail_pool, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);
 }
 
 void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots)

@@ -83,7 +83,7 @@ struct MiptContext {
     int      batch_samples = 0;
     int      persistent = 3;
     int      build_mode = 0;              // MIPT_OPT_BUILD: 0 host binned SAH, 1 device LBVH
-    uint32_t tail_paths = 262144;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
+    uint32_t tail_paths = 1048576;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
     bool     bounces_on_device = false;   // launch statistics: iterations counted by k_advance / k_tail
     int      tail_pct = 100, pool_low = 16, pool_chunk = 16;
     // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
@@ -346,13 +346,18 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         launch_begin_sample(st, ctx->d_ctr, n_paths, pass_valid);
         { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result); }
         int cur = 0;
+        // MIPT_OPT_TAIL_PATHS is meant for the pool form of the tail kernel; the plain loop (BVHs that do not fit the pool's
+        // packed entries, other kernel variants) pays off at a quarter of it, and not at all for depth-capped passes from
+        // the start.  Depth-capped paths have few bounces left, so a switch inside the loop pays later: a quarter again.
         const bool use_tail = ctx->tail_paths != 0u && !ctx->count_visits;
-        // (depth-capped paths have few bounces left, so the switch pays later: a quarter of the threshold)
-        const uint32_t tail_limit = !use_tail ? 0u : (fc.max_depth != 0u ? ctx->tail_paths / 4u : ctx->tail_paths);
-        if (fc.max_depth == 0u && n_paths <= tail_limit) {
-            // an unbounded pass this small runs in the tail kernel from the first bounce on (Cornell 512x512: 0.73 -> 0.37 ms)
+        const bool pool_tail = opts.persistent == 3 && bvh.pool_ok != 0u && bvh.tri_byte_off != 0u && bvh.depth <= 32u;
+        const uint32_t tail_paths = !use_tail ? 0u : (pool_tail ? ctx->tail_paths : ctx->tail_paths / 4u);
+        const uint32_t tail_limit = fc.max_depth != 0u ? tail_paths / 4u : tail_paths;
+        const uint32_t first_limit = (pool_tail || fc.max_depth == 0u) ? tail_paths : 0u;
+        if (n_paths <= first_limit) {
+            // a pass this small runs in the tail kernel from the first bounce on (Cornell 512x512: 0.73 -> 0.37 ms)
             TimedScope t(ctx, st, T_CLOSEST);
-            launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[0], ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices);
+            launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[0], ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, opts);
             continue;
         }
         for (uint32_t bounce = 0;; ++bounce) {
@@ -383,7 +388,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                     // few paths left: one launch runs them to their ends instead of five per bounce
                     TimedScope t(ctx, st, T_CLOSEST);
                     launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->result, ctx->d_ctr, live,
-                                ctx->common_vertices);
+                                ctx->common_vertices, opts);
                     break;
                 }
             }
@@ -448,7 +453,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_TAIL_PCT")) { const int v = std::atoi(e); if (v >= 1 && v <= 100000) c->tail_pct = v; }
     if (const char* e = std::getenv("MIPT_POOL_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) c->pool_chunk = v; }
     if (const char* e = std::getenv("MIPT_POOL_LOW")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) c->pool_low = v; }
-    if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 20)) c->tail_paths = (uint32_t)v; }
+    if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 30)) c->tail_paths = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_STEAL_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) c->steal_min = v; }
     *out = c;
     return MIPT_SUCCESS;
@@ -498,7 +503,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         c->refill_min = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_BATCH_SAMPLES: c->batch_samples = value ? 1 : 0; return MIPT_SUCCESS;
     case MIPT_OPT_TAIL_PATHS:
-        if (value > (1u << 20)) return c->fail(MIPT_ERROR_INVALID_VALUE, "tail threshold must be 0 (off) .. 1048576 paths");
+        if (value > (1u << 30)) return c->fail(MIPT_ERROR_INVALID_VALUE, "tail threshold must be 0 (off) .. 2^30 paths");
         c->tail_paths = (uint32_t)value; return MIPT_SUCCESS;
     case MIPT_OPT_BUILD:
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH) or 1 (device LBVH)");

@@ -202,7 +202,8 @@ def test_tail_kernel_gives_the_same_frame_and_counts(scene_kind, w, h, spp, max_
     scene = scenes.cornell_box() if scene_kind == "cornell" else scenes.random_soup(20000)
     PT, st = _state(scene, w, h, spp, max_depth)
     ref = None
-    for tail in (0, 1, 300, 8192, 1 << 20):
+    for tail, variant in ((0, 3), (1, 3), (300, 3), (8192, 3), (1 << 20, 3), (300, 0), (1 << 20, 2)):
+        st.context.set_option(L.OPT_PERSISTENT, variant)     # 3: pool tail kernel (k_tail_pool), else the plain loop (k_tail)
         st.context.set_option(L.OPT_TAIL_PATHS, tail)
         assert st.context.get_option(L.OPT_TAIL_PATHS) == tail
         acc, frame, stats = _render_gpu(PT, st)
@@ -216,9 +217,9 @@ def test_tail_kernel_gives_the_same_frame_and_counts(scene_kind, w, h, spp, max_
             assert stats["bounces"] == spp * (ost["max_depth_seen"] + 1) or spp > 1
             continue
         assert np.array_equal(cur[0].view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(cur[1], ref[1]), tail
-        assert cur[2:] == ref[2:], (tail, cur[2:], ref[2:])
+        assert cur[2:] == ref[2:], (tail, variant, cur[2:], ref[2:])
     with pytest.raises(Exception):
-        st.context.set_option(L.OPT_TAIL_PATHS, (1 << 20) + 1)
+        st.context.set_option(L.OPT_TAIL_PATHS, (1 << 30) + 1)
     PT.cleanupState(st)
 
 
