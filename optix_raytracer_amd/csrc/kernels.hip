@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, co
         pool_round<MODE, kPoolCap>(blob, tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, false);
 }
 
-__global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a)
+__global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
 {
     constexpr int kPoolCap = 24 * 64 - 384;
     __shared__ uint32_t stk[24 * 64];
@@ -1118,10 +1118,10 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a)
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
     uint32_t n = a.ctr->n_cur;
     n = n < a.n_max ? n : a.n_max;
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t i = blockIdx.x * ppw + threadIdx.x;
     uint32_t n_closest = 0, n_shadow = 0, n_iter = 0;
     uint32_t slot = kInvalidSlot, depth = 0;
-    if (i < n) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
+    if (i < n && threadIdx.x < ppw) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
     bool active = slot != kInvalidSlot;
     float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
     if (active) { ro4 = a.cur.ray_o[i]; rd4 = a.cur.ray_d[i]; sa = a.cur.state_a[i]; res = a.result[slot]; }
@@ -1313,7 +1313,20 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
     a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
     // the pool variant needs a BVH that fits k_trace_pool's packed entries; MIPT_OPT_PERSISTENT != 3 selects the plain loop
     if (o.persistent == 3 && bvh.pool_ok && bvh.tri_byte_off != 0u && bvh.depth <= 32u)
-        hipLaunchKernelGGL(k_tail_pool, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);
+    {
+        // paths per wave: 64, except for a pass of few bounces (depth cap <= 8) that is too small to give every wave slot two
+        // waves -- there the step is the time ONE wave needs for its paths, and fewer paths per wave (the idle lanes still
+        // work in the pool rounds) are faster: a 1/8 shard of the headline frame 0.36 -> 0.28 ms, 65 k paths of depth 4
+        // 2.37 -> 1.62 ms.  Long paths (unbounded depth) prefer 64: most of a wave's paths die early and the survivors of
+        // 64 fill the pool better than those of 16 (profiles/r01_tail_paths.txt).
+        uint32_t ppw = 64u;
+        if (fc.max_depth >= 1u && fc.max_depth <= 8u) {
+            const uint32_t slots = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256) * 32u;
+            ppw = ((n_max + slots - 1u) / slots + 15u) & ~15u;
+            ppw = ppw < 16u ? 16u : (ppw > 64u ? 64u : ppw);
+        }
+        hipLaunchKernelGGL(k_tail_pool, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+    }
     else
         hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);
 }
