@@ -276,13 +276,14 @@ def main():
         # a pass of at most MIPT_OPT_TAIL_PATHS paths (a rank's shard at N >= 2) runs in the path kernel: closest-hit and
         # any-hit traversal, shading and accumulation of a wave's 64 paths in ONE launch, timed under "trace_closest"
         fused = sharded and int(st.context.get_option(L.OPT_PERSISTENT)) == 3 and info["depth"] <= 32 and \
-            api.shard_num_samples(w, h, world) <= int(st.context.get_option(L.OPT_TAIL_PATHS))
+            api.shard_num_samples(w, h, world) <= int(st.context.get_option(L.OPT_TAIL_PATHS)) // 4 * 3
         if fused:
             kname, kbytes, kms, klaunches = "k_tail_pool", bytes_closest + bytes_any, k_closest, tm["n_trace_closest"]
         elif k_closest >= k_any:
             kname, kbytes, kms, klaunches = variant % 0, bytes_closest, k_closest, tm["n_trace_closest"]
         else:
-            kname, kbytes, kms, klaunches = variant % 2, bytes_any, k_any, tm["n_trace_any"]
+            any_name = "k_trace_static<2>" if int(st.context.get_option(L.OPT_PERSISTENT)) == 3 else variant % 2
+            kname, kbytes, kms, klaunches = any_name, bytes_any, k_any, tm["n_trace_any"]
         launches_per_step = max(klaunches // args.steps, 1)
         kms_avg = kms / launches_per_step          # average duration of one launch of that kernel
         kbytes_launch = kbytes / launches_per_step

@@ -70,9 +70,10 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
 };
 
 struct TraceOpts {
-    int  persistent;           // 2: streaming waves (default), 0: one thread per ray
+    int  persistent;           // 3: tiles + entry pool (default), 2: streaming waves, 0: one thread per ray
     int  refill_min, steal_min, burst_bulk, burst_dry; // k_trace_stream knobs
     int  tail_pct, pool_low, pool_chunk;   // k_trace_pool knobs (0 = default)
+    int  tile_group;           // k_trace_pool, tiled: consecutive tiles dealt to one XCD at a time (0: a contiguous eighth each)
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
     int  blocks_user, num_cus; // the grid was set with MIPT_OPT_TRACE_GRID; CUs of the device

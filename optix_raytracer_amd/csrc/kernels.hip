@@ -77,6 +77,7 @@ struct TraceArgs {
     int             burst_dry;    // ... and once the ray range is exhausted
     uint32_t        ray_flags;    // MiptRayFlags of every ray of the launch (closest hit: back-face culling)
     uint32_t        tail_len;     // k_trace_pool: launches of at most this many rays run on the entry pool from the start
+    uint32_t        tile_group;   // k_trace_pool, tiled: consecutive tiles dealt to one XCD at a time (0: a contiguous eighth each)
     int             pool_low;     // k_trace_pool: pool size below which the next chunk of rays is prefetched
     int             pool_chunk;   // k_trace_pool: rays per chunk in the tail phase
 };
@@ -614,9 +615,17 @@ void k_trace_pool(TraceArgs a)
     for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
     if (tiled) {
         // ============================================================ bulk: one ray per lane, one tile at a time
-        // XCD x (= blockIdx % 8) works through the x-th eighth of the tiles: a contiguous band of the image per L2
-        const uint32_t tile = xcd * tiles_seg + k;
-        if (k >= tiles_seg || tile >= tiles) break;
+        // Groups of tile_group consecutive tiles (256: two rows of 8x8-pixel tiles at 1080p) are dealt to the XCDs in turn: a
+        // group keeps an XCD's L2 on one region of the image, and dealing them round balances the XCDs -- with one contiguous
+        // eighth of the image per XCD the ones that get its top and bottom (rays that miss everything) idle while the middle
+        // ones work: closest-hit kernel of the headline frame 0.514 -> 0.458 ms, imgui_test at 1080p 5.49 -> 4.76 ms
+        // (group size 1 / 8 / 64 / 256 / 512 / 1024 / 2048: frame 0.804 / 0.795 / 0.797 / 0.792 / 0.789 / 0.802 / 0.825 ms).
+        uint32_t tile = xcd * tiles_seg + k;
+        if (a.tile_group != 0u) {
+            const uint32_t gq = k / a.tile_group, r = k - gq * a.tile_group;
+            tile = (gq * kNumSegments + xcd) * a.tile_group + r;
+        } else if (k >= tiles_seg) break;
+        if (tile >= tiles) break;
         ray = tile * 64u + (uint32_t)lane;
         has_ray = false;
         if (ray < n) {
@@ -1160,6 +1169,40 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
     if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
 }
 
+// Any-hit launches of the default variant: static chunks of `ppw` rays per wave, traversed together on the entry pool from
+// the root (tail_trace).  Occlusion rays start at scattered hit points and stop at the first hit, so the one-ray-per-lane
+// bulk phase of k_trace_pool's tiled form buys nothing for them: 421 k shadow rays of the headline frame 0.265 -> 0.228 ms
+// with 32 rays per wave, 8.3 M occlusion rays of the MeshViewer frame at 4K 6.64 -> 6.07 ms with 64 (closest-hit launches:
+// 0.512 -> 0.529 ms, they keep the tiled form).
+template <int MODE>
+__global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
+{
+    constexpr int kPoolCap = 24 * 64 - 384;
+    __shared__ uint32_t stk[24 * 64];
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
+    float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
+    int* const sh_pending = reinterpret_cast<int*>(stk + kPoolCap + 256);
+    uint32_t* const sh_done = stk + kPoolCap + 320;
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    const uint32_t chunks = (n + ppw - 1u) / ppw;
+    // consecutive chunks go to different XCDs: occlusion rays of neighbouring image regions cost very different amounts, and
+    // a contiguous band of the queue per XCD (as the tiled closest-hit kernel has it) leaves XCDs idle (MeshViewer 4K: 6.73 vs 6.07 ms)
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint32_t ray = chunk * ppw + (uint32_t)lane;
+        const bool mine = (uint32_t)lane < ppw && ray < n;
+        Trav T;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
+        T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
+        if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+        tail_trace<MODE>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, mine && T.node != kSentinel);
+        if (mine) finish_ray<MODE>(a, T, ray, sh_done[lane] != 0u);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // resolve: optixPathTracer.cu:308-319
 // ------------------------------------------------------------------------------------------------
@@ -1235,11 +1278,12 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
     if (o.persistent >= 2 && a.bvh.tri_byte_off != 0u && a.bvh.depth <= (uint32_t)kStreamStack) {
         int blocks = ((o.blocks > 0 ? o.blocks : 4096) + kNumSegments - 1) / kNumSegments * kNumSegments;
         const bool pool = o.persistent == 3 && !o.count_visits && a.bvh.pool_ok;
-        // launches with at most this many rays run on the entry pool from the start: 1.25 rays per lane of a 16-waves-per-CU
-        // grid for closest hit, 0.4 for any hit (crossovers measured on shards of the headline frame, profiles/)
+        // closest-hit launches with at most this many rays run on the entry pool from the start: 1.25 rays per lane of a
+        // 16-waves-per-CU grid (crossover measured on shards of the headline frame, profiles/)
         const unsigned long long lanes16 = (unsigned long long)(o.num_cus > 0 ? o.num_cus : 256) * 16ull * 64ull;
-        a.tail_len = (uint32_t)((lanes16 * (unsigned long long)(o.tail_pct > 0 ? o.tail_pct : 100) * (MODE == 0 ? 125ull : 40ull)) / 10000ull);
+        a.tail_len = (uint32_t)((lanes16 * (unsigned long long)(o.tail_pct > 0 ? o.tail_pct : 100) * 125ull) / 10000ull);
         a.pool_low = o.pool_low > 0 ? o.pool_low : 16;
+        a.tile_group = o.tile_group > 0 ? (uint32_t)o.tile_group : 0u;
         a.pool_chunk = o.pool_chunk > 0 ? o.pool_chunk : kPoolChunk;
         if (pool) {
             // default grid: one wave per tile of 64 rays, between 16 and 128 waves per CU (beyond that a wave takes several
@@ -1250,15 +1294,28 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
                 want = want < cus * 16ull ? cus * 16ull : (want > cus * 128ull ? cus * 128ull : want);
                 blocks = (int)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
             }
-            // the host only knows the capacity of a launch; the shadow-ray queue is sized for one ray per path and typically
-            // holds a fifth to a quarter of that
-            const bool tiled = (MODE == 0 ? a.n_max : a.n_max / 4u) > a.tail_len;
-            if (a.bvh.depth <= 24u) {
-                if (tiled) hipLaunchKernelGGL((k_trace_pool<MODE, 24, true>), dim3(blocks), dim3(64), 0, st, a);
-                else       hipLaunchKernelGGL((k_trace_pool<MODE, 24, false>), dim3(blocks), dim3(64), 0, st, a);
+            if constexpr (MODE != 0) {
+                // any hit: static chunks on the entry pool (k_trace_static).  The host only knows the capacity of the launch;
+                // a shadow-ray queue sized for one ray per path typically holds a fifth to a quarter of it.  32 rays per wave
+                // while that estimate is below 2048 rays per CU (421 k rays: 24 / 32 / 40 / 48 / 64 rays per wave take
+                // 0.241 / 0.228 / 0.238 / 0.247 / 0.258 ms), else 64
+                const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
+                const uint32_t n_est = a.n_max / 4u;
+                const uint32_t ppw = n_est <= cus * 2048u ? 32u : 64u;
+                unsigned long long want = ((unsigned long long)n_est + ppw - 1u) / ppw;
+                want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
+                if (o.blocks_user) want = (unsigned long long)blocks;
+                const uint32_t g = (uint32_t)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
+                hipLaunchKernelGGL((k_trace_static<MODE>), dim3(g), dim3(64), 0, st, a, ppw);
             } else {
-                if (tiled) hipLaunchKernelGGL((k_trace_pool<MODE, 32, true>), dim3(blocks), dim3(64), 0, st, a);
-                else       hipLaunchKernelGGL((k_trace_pool<MODE, 32, false>), dim3(blocks), dim3(64), 0, st, a);
+                const bool tiled = a.n_max > a.tail_len;
+                if (a.bvh.depth <= 24u) {
+                    if (tiled) hipLaunchKernelGGL((k_trace_pool<0, 24, true>), dim3(blocks), dim3(64), 0, st, a);
+                    else       hipLaunchKernelGGL((k_trace_pool<0, 24, false>), dim3(blocks), dim3(64), 0, st, a);
+                } else {
+                    if (tiled) hipLaunchKernelGGL((k_trace_pool<0, 32, true>), dim3(blocks), dim3(64), 0, st, a);
+                    else       hipLaunchKernelGGL((k_trace_pool<0, 32, false>), dim3(blocks), dim3(64), 0, st, a);
+                }
             }
         }
         else if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
