@@ -164,8 +164,9 @@ typedef enum MiptOption {
     MIPT_OPT_COUNT_VISITS = 2, /* 1 = traversal kernels count node visits / triangle tests */
     MIPT_OPT_TRACE_GRID   = 3, /* traversal workgroups (one wave each) per CU; 0 = default: one per 64-ray tile of the launch,
                                   16 .. 128 per CU */
-    MIPT_OPT_PERSISTENT   = 4, /* traversal kernel: 3 (default) 64-ray tiles per wave, one ray per lane, then a per-wave entry
-                                  pool for the tail of each tile; launches with few rays run on the pool from the start;
+    MIPT_OPT_PERSISTENT   = 4, /* traversal kernels: 3 (default) closest hit in 64-ray tiles per wave, one ray per lane, then a
+                                  per-wave entry pool for the tail of each tile (launches with few rays: on the pool from the
+                                  start); any hit in static chunks of 32 / 64 rays per wave, on the pool from the root;
                                   2 persistent streaming waves with lane refill and subtree stealing (also used when a BVH
                                   does not fit the pool's packed entries: >= 2^25 nodes, >= 2^22 triangles or leaves of more
                                   than 7, and by counting launches); 0 one thread per ray (tight while-while loop; also the
@@ -182,10 +183,10 @@ typedef enum MiptOption {
     MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build: 0 (default) binned SAH on the host cores, 1 linear BVH built on the
                                   device (Morton codes + radix sort + Karras' radix tree; ~ PREFER_FAST_BUILD: a few ms per
                                   million triangles, slower to traverse); falls back to 0 when that tree is too deep */
-    MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late; a
-                                  quarter of the value when MAX_DEPTH caps the paths), one kernel runs each of them to its
+    MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late;
+                                  half the value when MAX_DEPTH caps the paths), one kernel runs each of them to its
                                   end, a wave per 64 paths, instead of five kernels per bounce; a pass that starts with at
-                                  most this many paths starts there.  Same pixels, same ray counts.  Default 1048576, 0 = off */
+                                  most this many paths (three quarters of it when capped) starts there.  Same pixels, same ray counts.  Default 1048576, 0 = off */
     MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
                                   (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;

@@ -348,11 +348,12 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         int cur = 0;
         // MIPT_OPT_TAIL_PATHS is meant for the pool form of the tail kernel; the plain loop (BVHs that do not fit the pool's
         // packed entries, other kernel variants) pays off at a quarter of it, and not at all for depth-capped passes from
-        // the start.  Depth-capped paths have few bounces left, so a switch inside the loop pays later: a quarter again.
+        // the start.  Depth-capped paths have few bounces left, so a switch inside the loop pays later: at half the count
+        // (1 M-triangle scene, 1080p, depth 8: limit 2^18 / 2^19 / 2^20 -> 3.79 / 3.61 / 4.28 ms).
         const bool use_tail = ctx->tail_paths != 0u && !ctx->count_visits;
         const bool pool_tail = opts.persistent == 3 && bvh.pool_ok != 0u && bvh.tri_byte_off != 0u && bvh.depth <= 32u;
         const uint32_t tail_paths = !use_tail ? 0u : (pool_tail ? ctx->tail_paths : ctx->tail_paths / 4u);
-        const uint32_t tail_limit = fc.max_depth != 0u ? tail_paths / 4u : tail_paths;
+        const uint32_t tail_limit = fc.max_depth != 0u ? tail_paths / 2u : tail_paths;
         // (a capped pass of a million paths is as fast in the wavefront kernels: half the headline frame 0.54 vs 0.56 ms)
         const uint32_t first_limit = fc.max_depth == 0u ? tail_paths : (pool_tail ? tail_paths / 4u * 3u : 0u);
         if (n_paths <= first_limit) {
