@@ -325,7 +325,7 @@ typedef struct MiptMaterialData {
 
 /* one glTF texture = sampler state + decoded image (Scene::addImage / addSampler, Scene.cpp:576-652).
  * texels: RGBA, 8 or 16 bits per component, row 0 = top row of the image; owned by the scene (host memory).
- * An image the loader cannot decode (not a non-interlaced PNG or a baseline JPEG) yields width = height = 0 and
+ * An image the loader cannot decode (not a non-interlaced PNG or a Huffman-coded 8-bit JPEG) yields width = height = 0 and
  * texels = NULL: materials that use it render untextured. */
 typedef struct MiptTextureData {
     uint32_t    width, height, bits;

@@ -16,7 +16,7 @@ struct DecodedImage {
 // false + `why` when the bytes are not a PNG this decoder handles (Adam7 interlacing is not supported)
 bool decode_png(const uint8_t* data, size_t size, DecodedImage& out, std::string& why);
 
-// baseline / extended sequential JPEG (8 bit, Huffman, 1 or 3 components) -> RGBA8 (jpeg_decode.cpp)
+// baseline / extended sequential / progressive JPEG (8 bit, Huffman, 1 or 3 components) -> RGBA8 (jpeg_decode.cpp)
 bool decode_jpeg(const uint8_t* data, size_t size, DecodedImage& out, std::string& why);
 
 // raw DEFLATE (RFC 1951); false on a malformed stream

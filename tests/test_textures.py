@@ -135,6 +135,36 @@ def test_samplers_transforms_and_attributes(tmp_path):
     assert hasc.tolist() == [0, 0, 1] and np.array_equal(c[6:], col) and (c[:6] == 1).all()
 
 
+def test_jpeg_decoder_progressive(tmp_path):
+    """SOF2 files (DC / AC first scans, successive-approximation refinements, EOB runs, interleaved and single-component
+    scans, restart intervals) decode to exactly the pixels of a baseline file with the same coefficients
+    (tests/golden/make_jpeg_progressive.py wrote both with Pillow)"""
+    import pathlib
+    gold = pathlib.Path(__file__).parent / "golden"
+    names = "abcde"
+    blobs = []
+    for k in names:
+        blobs += [(gold / ("jpeg_prog_%s.jpg" % k)).read_bytes(), (gold / ("jpeg_base_%s.jpg" % k)).read_bytes()]
+    assert all(b"\xff\xc2" in b for b in blobs[0::2]) and not any(b"\xff\xc2" in b for b in blobs[1::2])
+    sc = api.Scene(_gltf_with_images(tmp_path, blobs))
+    tex = sc.textures()
+    shapes = {"a": (37, 53), "b": (45, 70), "c": (24, 40), "d": (45, 70), "e": (37, 53)}
+    for i, k in enumerate(names):
+        prog, base = tex[2 * i], tex[2 * i + 1]
+        assert prog["texels"] is not None and base["texels"] is not None, k
+        assert prog["texels"].shape == shapes[k] + (4,) and prog["bits"] == 8, k
+        assert np.array_equal(prog["texels"], base["texels"]), k
+        assert prog["texels"][..., :3].std() > 10, k
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    import io
+    for i, k in enumerate(names):                 # sanity against libjpeg's own decode (other IDCT and chroma filter: loose)
+        ref = np.asarray(Image.open(io.BytesIO(blobs[2 * i])).convert("RGB")).astype(int)
+        assert np.abs(tex[2 * i]["texels"][..., :3].astype(int) - ref).mean() < (3.0 if k in "cd" else 12.0), k
+
+
 def test_jpeg_decoder_baseline(tmp_path):
     import _jpeg_fixture as JF
     rng = np.random.default_rng(9)
