@@ -1301,7 +1301,11 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
                 // 0.241 / 0.228 / 0.238 / 0.247 / 0.258 ms), else 64
                 const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
                 const uint32_t n_est = a.n_max / 4u;
-                const uint32_t ppw = n_est <= cus * 2048u ? 32u : 64u;
+                // ... and fewer for small launches, whose duration is the time one wave needs for its chunk: 16 / 8 rays per wave
+                // below 384 / 192 estimated rays per CU (53 k rays: 32 / 16 / 8 per wave take 0.086 / 0.064 / 0.073 ms, 26 k rays:
+                // 0.081 / 0.057 / 0.047 ms)
+                const uint32_t q = n_est / (cus * 16u);
+                const uint32_t ppw = n_est > cus * 2048u ? 64u : (q >= 24u ? 32u : (q >= 12u ? 16u : 8u));
                 unsigned long long want = ((unsigned long long)n_est + ppw - 1u) / ppw;
                 want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
                 if (o.blocks_user) want = (unsigned long long)blocks;

@@ -362,14 +362,15 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[0], ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, opts);
             continue;
         }
+        uint32_t bound = n_paths;      // upper bound of the live-path count (it only falls): the latest count the host has seen
         for (uint32_t bounce = 0;; ++bounce) {
             { TimedScope t(ctx, st, T_CLOSEST);
-              launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, n_paths, ctx->hits, ctx->d_ctr, opts); }
+              launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, bound, ctx->hits, ctx->d_ctr, opts); }
             { TimedScope t(ctx, st, T_SHADE);
               launch_shade(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->hits, ctx->q[cur ^ 1], ctx->sq,
-                           ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices); }
+                           ctx->result, ctx->d_ctr, bound, ctx->common_vertices); }
             { TimedScope t(ctx, st, T_ANY);
-              launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, n_paths, nullptr, ctx->sq.contrib,
+              launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, bound, nullptr, ctx->sq.contrib,
                                ctx->result, ctx->d_ctr, opts); }
             launch_advance(st, ctx->d_ctr, ctx->h_pinned + bounce % kRing);
             cur ^= 1;
@@ -386,6 +387,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                 HIPCHK(ctx, hipEventSynchronize(ctx->ring_ev[old]));
                 const uint32_t live = ctx->h_pinned[old];       // an upper bound of every later count
                 if (live == 0u) break;
+                bound = live < bound ? live : bound;            // sizes the grids and picks the kernel forms of the next bounces
                 if (live <= tail_limit) {
                     // few paths left: one launch runs them to their ends instead of five per bounce
                     TimedScope t(ctx, st, T_CLOSEST);
