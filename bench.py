@@ -271,7 +271,7 @@ def main():
         tt_c = counts["tri_tests"] - counts["shadow_tri_tests"]
         bytes_closest = 64 * nv_c + 48 * tt_c + (32 + 16) * counts["closest_rays"]
         bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
-        variant = {3: "k_trace_pool<%%d, %d, true>" % (24 if info["depth"] <= 24 else 32), 2: "k_trace_stream<%d, false>",
+        variant = {3: "k_trace_pool<%%d, %d>" % (24 if info["depth"] <= 24 else 32), 2: "k_trace_stream<%d, false>",
                    0: "k_trace_simple<%d, false>"}[int(st.context.get_option(L.OPT_PERSISTENT))]
         # a pass of at most MIPT_OPT_TAIL_PATHS paths (a rank's shard at N >= 2) runs in the path kernel: closest-hit and
         # any-hit traversal, shading and accumulation of a wave's 64 paths in ONE launch, timed under "trace_closest"

@@ -165,8 +165,8 @@ typedef enum MiptOption {
     MIPT_OPT_TRACE_GRID   = 3, /* traversal workgroups (one wave each) per CU; 0 = default: one per 64-ray tile of the launch,
                                   16 .. 128 per CU */
     MIPT_OPT_PERSISTENT   = 4, /* traversal kernels: 3 (default) closest hit in 64-ray tiles per wave, one ray per lane, then a
-                                  per-wave entry pool for the tail of each tile (launches with few rays: on the pool from the
-                                  start); any hit in static chunks of 32 / 64 rays per wave, on the pool from the root;
+                                  per-wave entry pool for the tail of each tile; any-hit launches and closest-hit launches
+                                  with few rays in static chunks of 8 .. 64 rays per wave, on the pool from the root;
                                   2 persistent streaming waves with lane refill and subtree stealing (also used when a BVH
                                   does not fit the pool's packed entries: >= 2^25 nodes, >= 2^22 triangles or leaves of more
                                   than 7, and by counting launches); 0 one thread per ray (tight while-while loop; also the

@@ -72,7 +72,6 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
 struct TraceOpts {
     int  persistent;           // 3: tiles + entry pool (default), 2: streaming waves, 0: one thread per ray
     int  refill_min, steal_min, burst_bulk, burst_dry; // k_trace_stream knobs
-    int  tail_pct, pool_low, pool_chunk;   // k_trace_pool knobs (0 = default)
     int  tile_group;           // k_trace_pool, tiled: consecutive tiles dealt to one XCD at a time (0: a contiguous eighth each)
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)

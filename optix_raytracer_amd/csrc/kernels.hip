@@ -76,10 +76,7 @@ struct TraceArgs {
     int             burst_bulk;   // k_trace_stream: traversal steps per bookkeeping round while fresh rays remain
     int             burst_dry;    // ... and once the ray range is exhausted
     uint32_t        ray_flags;    // MiptRayFlags of every ray of the launch (closest hit: back-face culling)
-    uint32_t        tail_len;     // k_trace_pool: launches of at most this many rays run on the entry pool from the start
     uint32_t        tile_group;   // k_trace_pool, tiled: consecutive tiles dealt to one XCD at a time (0: a contiguous eighth each)
-    int             pool_low;     // k_trace_pool: pool size below which the next chunk of rays is prefetched
-    int             pool_chunk;   // k_trace_pool: rays per chunk in the tail phase
 };
 
 template <int MODE>
@@ -400,7 +397,6 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
 // the pool visits -- same result, but visit counters differ, so COUNT launches use k_trace_stream.
 // Packed entry: bit 31 leaf | 25-bit payload | 6-bit slot; inner payload = node index, leaf payload =
 // first << 3 | count.  The launcher only selects this kernel for BVHs that fit (DeviceBvh::pool_ok).
-constexpr int kPoolChunk = 16;            // rays fetched at a time in the tail phase
 
 __device__ __forceinline__ uint32_t pool_pack(int ref, uint32_t slot)
 {
@@ -574,8 +570,8 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
 
 // ROWS: entries of a lane's stack = rows of the LDS block (24 when the tree is at most 24 deep -- 7.5 KB of LDS per
 // wave and <= 96 VGPRs let 20 waves share a CU instead of 16 -- else 32)
-template <int MODE, int ROWS, bool TILED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? (TILED ? 6 : 5) : 5, ROWS == 24 ? (TILED ? 6 : 5) : 5)))
+template <int MODE, int ROWS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? 6 : 5, ROWS == 24 ? 6 : 5)))
 void k_trace_pool(TraceArgs a)
 {
     // ONE LDS block per wave: in the bulk phase ROWS rows of 64 lanes (the lanes' stacks), in the tail phase the entry
@@ -592,28 +588,17 @@ void k_trace_pool(TraceArgs a)
     const bool cull_back = MODE == 0 && (a.ray_flags & 16u) != 0u;   // MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES: det < 0 is a back face
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
-    const uint32_t seg_len = (((n + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
     // the stacks of the still busy lanes must fit the pool: at most (kPoolCap - 168) / ROWS busy lanes at the switch
     const int steal_floor = 64 - (kPoolCap - 168) / ROWS;
     const int steal_min = a.steal_min < 64 ? (a.steal_min > steal_floor ? a.steal_min : steal_floor) : 64;   // 64: switch when the wave is empty
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
-    // a launch with many rays is cut into tiles of 64 consecutive rays, dealt out to the waves without any atomic;
-    // one with few rays runs on the entry pool from the start and fetches rays 16 at a time
-    constexpr bool tiled = TILED;                        // the host decides by the capacity of the launch (n_max)
+    // the launch is cut into tiles of 64 consecutive rays, dealt out to the waves without any atomic
     const uint32_t tiles = (n + 63u) >> 6, tiles_seg = (tiles + kNumSegments - 1) / kNumSegments;
     const uint32_t xcd = blockIdx.x & (kNumSegments - 1), waves_seg = gridDim.x / kNumSegments;   // gridDim.x is a multiple of 8
-    RayRange rr;
-    range_init(rr, n, seg_len, (uint32_t)a.pool_chunk);
-
-    bool     has_ray = false, nxt_valid = false;
-    uint32_t ray = 0, nxt_idx = 0;
-    float4   nxt_o = make_float4(0.f, 0.f, 0.f, 0.f), nxt_d = nxt_o;
     Trav T;
     T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
-    bool dry = tiled;                                    // tiled: the tail phase never fetches
 
     for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
-    if (tiled) {
         // ============================================================ bulk: one ray per lane, one tile at a time
         // Groups of tile_group consecutive tiles (256: two rows of 8x8-pixel tiles at 1080p) are dealt to the XCDs in turn: a
         // group keeps an XCD's L2 on one region of the image, and dealing them round balances the XCDs -- with one contiguous
@@ -626,8 +611,8 @@ void k_trace_pool(TraceArgs a)
             tile = (gq * kNumSegments + xcd) * a.tile_group + r;
         } else if (k >= tiles_seg) break;
         if (tile >= tiles) break;
-        ray = tile * 64u + (uint32_t)lane;
-        has_ray = false;
+        const uint32_t ray = tile * 64u + (uint32_t)lane;
+        bool has_ray = false;
         if (ray < n) {
             trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
             has_ray = T.node != kSentinel;
@@ -643,94 +628,40 @@ void k_trace_pool(TraceArgs a)
             if (done) { finish_ray<MODE>(a, T, ray, T.prim != 0xffffffffu); has_ray = false; }
         }
         if (__ballot(has_ray) == 0ull) continue;                     // the whole tile is finished
-    }
 
-    // ================================================================ tail: one entry pool per wave
-    // move the per-lane stacks into the pool, row by row and in place: row e is read before at most
-    // (entries so far) + 64 <= (e + 1) * 64 words are written
-    int psize = 0;
-    for (int e = 0; e < ROWS; ++e) {
-        const bool in = has_ray && T.sp > e;
-        const unsigned long long m = __ballot(in);
-        if (m == 0ull) break;
-        uint32_t v = 0u;
-        if (in) v = stk[e * 64 + lane];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (in) stk[psize + (int)lane_rank(m)] = pool_pack((int)v, (uint32_t)lane);
-        psize += __popcll(m);
-    }
-    {
-        const unsigned long long m = __ballot(has_ray);           // the node each busy lane stands at
-        if (has_ray) stk[psize + (int)lane_rank(m)] = pool_pack(T.node, (uint32_t)lane);
-        psize += __popcll(m);
-    }
-    // open the merge slots (they overlay the top rows of the stacks: only now) with what each lane has found so far
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
-    sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
-    sh_pending[lane] = has_ray ? T.sp + 1 : 0;
-    bool occ = has_ray;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-
-    for (;;) {
-        // ------------------------------------------------------------ retire finished rays, start prefetched ones
-        if (occ && sh_pending[lane] == 0) {
-            const unsigned long long key = sh_best[lane];
-            Trav R = T;
-            R.tbest = ord_float((uint32_t)(key >> 32)); R.prim = (uint32_t)key; R.u = sh_u[lane]; R.v = sh_v[lane];
-            finish_ray<MODE>(a, R, ray, MODE == 0 ? R.prim != 0xffffffffu : sh_done[lane] != 0u);
-            occ = false;
-        }
-        bool start = !tiled && !occ && nxt_valid;
-        if (start) {
-            ray = nxt_idx;
-            trav_init(T, nxt_o, nxt_d);
-            nxt_valid = false;
-            if (T.node == kSentinel) { finish_ray<MODE>(a, T, ray, false); start = false; }
-            else {
-                occ = true;
-                sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
-                sh_done[lane] = 0u; sh_pending[lane] = 1;
-            }
+        // ============================================================ tail: one entry pool per wave
+        // move the per-lane stacks into the pool, row by row and in place: row e is read before at most
+        // (entries so far) + 64 <= (e + 1) * 64 words are written
+        int psize = 0;
+        for (int e = 0; e < ROWS; ++e) {
+            const bool in = has_ray && T.sp > e;
+            const unsigned long long m = __ballot(in);
+            if (m == 0ull) break;
+            uint32_t v = 0u;
+            if (in) v = stk[e * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (in) stk[psize + (int)lane_rank(m)] = pool_pack((int)v, (uint32_t)lane);
+            psize += __popcll(m);
         }
         {
-            const unsigned long long m = __ballot(start);
-            if (m != 0ull) {
-                if (start) stk[psize + (int)lane_rank(m)] = pool_pack(0, (uint32_t)lane);
-                psize += __popcll(m);
-            }
+            const unsigned long long m = __ballot(has_ray);           // the node each busy lane stands at
+            if (has_ray) stk[psize + (int)lane_rank(m)] = pool_pack(T.node, (uint32_t)lane);
+            psize += __popcll(m);
         }
-        // ------------------------------------------------------------ pool running low: prefetch a small chunk of rays
-        if (!tiled && !dry && psize < a.pool_low && __ballot(nxt_valid) == 0ull) {
-            const unsigned long long want = __ballot(!occ);
-            uint32_t n_want = (uint32_t)__popcll(want);
-            n_want = n_want < (uint32_t)a.pool_chunk ? n_want : (uint32_t)a.pool_chunk;
-            const uint32_t rank = lane_rank(want);
-            uint32_t given = 0;
-            while (given < n_want) {
-                if (!range_grab(a, rr, n, seg_len, (uint32_t)a.pool_chunk, lane)) { dry = true; break; }
-                const uint32_t avail = rr.end - rr.next;
-                const uint32_t need  = n_want - given;
-                const uint32_t take  = avail < need ? avail : need;
-                if (!occ && rank >= given && rank < given + take) {
-                    nxt_idx = rr.next + (rank - given);
-                    nxt_o = a.ray_o[(size_t)nxt_idx * a.stride];
-                    nxt_d = a.ray_d[(size_t)nxt_idx * a.stride];
-                    nxt_valid = true;
-                }
-                rr.next += take;
-                given += take;
-            }
-        }
-        if (psize == 0) {
-            if (!tiled && __ballot(nxt_valid) != 0ull) continue;  // rays on their way: start them next round
-            if (dry) break;
-            continue;                                             // (not reached: an empty pool with rays left prefetches above)
-        }
+        // open the merge slots (they overlay the top rows of the stacks: only now) with what each lane has found so far
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        pool_round<MODE, kPoolCap>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, cull_back);
-    }
-    if (!tiled) break;
+        sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
+        sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
+        sh_pending[lane] = has_ray ? T.sp + 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        while (psize > 0)
+            pool_round<MODE, kPoolCap>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, cull_back);
+        if (has_ray) {
+            const unsigned long long key = sh_best[lane];
+            T.tbest = ord_float((uint32_t)(key >> 32)); T.prim = (uint32_t)key; T.u = sh_u[lane]; T.v = sh_v[lane];
+            finish_ray<MODE>(a, T, ray, MODE == 0 ? T.prim != 0xffffffffu : sh_done[lane] != 0u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the next tile's stacks overwrite the merge slots
     }
 }
 
@@ -1099,7 +1030,7 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
 template <int MODE>
 __device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, int* sh_pending, uint32_t* sh_done,
-                                           const int lane, const Trav& T, const bool has_ray)
+                                           const int lane, const Trav& T, const bool has_ray, const bool cull_back = false)
 {
     constexpr int kPoolCap = 24 * 64 - 384;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1111,7 +1042,7 @@ __device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, co
     int psize = __popcll(m);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     while (psize > 0)
-        pool_round<MODE, kPoolCap>(blob, tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, false);
+        pool_round<MODE, kPoolCap>(blob, tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, cull_back);
 }
 
 __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
@@ -1169,11 +1100,12 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
     if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
 }
 
-// Any-hit launches of the default variant: static chunks of `ppw` rays per wave, traversed together on the entry pool from
-// the root (tail_trace).  Occlusion rays start at scattered hit points and stop at the first hit, so the one-ray-per-lane
-// bulk phase of k_trace_pool's tiled form buys nothing for them: 421 k shadow rays of the headline frame 0.265 -> 0.228 ms
-// with 32 rays per wave, 8.3 M occlusion rays of the MeshViewer frame at 4K 6.64 -> 6.07 ms with 64 (closest-hit launches:
-// 0.512 -> 0.529 ms, they keep the tiled form).
+// Static chunks of `ppw` rays per wave, traversed together on the entry pool from the root (tail_trace): every any-hit launch
+// of the default variant and its closest-hit launches with few rays (launch_trace has the sizes and the measurements).
+// Occlusion rays start at scattered hit points and stop at the first hit, so the one-ray-per-lane bulk phase of k_trace_pool
+// buys nothing for them: 421 k shadow rays of the headline frame 0.265 -> 0.228 ms with 32 rays per wave, 8.3 M occlusion rays
+// of the MeshViewer frame at 4K 6.64 -> 6.07 ms with 64 (big closest-hit launches: 0.512 -> 0.529 ms, they keep the tiled form).
+// A launch with few rays lasts as long as ONE wave needs for its rays, so there a wave gets 8 .. 32 and all 64 lanes serve them.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
 {
@@ -1198,8 +1130,15 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
-        tail_trace<MODE>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, mine && T.node != kSentinel);
-        if (mine) finish_ray<MODE>(a, T, ray, sh_done[lane] != 0u);
+        tail_trace<MODE>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, mine && T.node != kSentinel,
+                         MODE == 0 && (a.ray_flags & 16u) != 0u);
+        if (mine) {
+            if (MODE == 0) {
+                const unsigned long long key = sh_best[lane];
+                T.tbest = ord_float((uint32_t)(key >> 32)); T.prim = (uint32_t)key; T.u = sh_u[lane]; T.v = sh_v[lane];
+            }
+            finish_ray<MODE>(a, T, ray, MODE == 0 ? T.prim != 0xffffffffu : sh_done[lane] != 0u);
+        }
     }
 }
 
@@ -1278,48 +1217,40 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
     if (o.persistent >= 2 && a.bvh.tri_byte_off != 0u && a.bvh.depth <= (uint32_t)kStreamStack) {
         int blocks = ((o.blocks > 0 ? o.blocks : 4096) + kNumSegments - 1) / kNumSegments * kNumSegments;
         const bool pool = o.persistent == 3 && !o.count_visits && a.bvh.pool_ok;
-        // closest-hit launches with at most this many rays run on the entry pool from the start: 1.25 rays per lane of a
-        // 16-waves-per-CU grid (crossover measured on shards of the headline frame, profiles/)
-        const unsigned long long lanes16 = (unsigned long long)(o.num_cus > 0 ? o.num_cus : 256) * 16ull * 64ull;
-        a.tail_len = (uint32_t)((lanes16 * (unsigned long long)(o.tail_pct > 0 ? o.tail_pct : 100) * 125ull) / 10000ull);
-        a.pool_low = o.pool_low > 0 ? o.pool_low : 16;
         a.tile_group = o.tile_group > 0 ? (uint32_t)o.tile_group : 0u;
-        a.pool_chunk = o.pool_chunk > 0 ? o.pool_chunk : kPoolChunk;
         if (pool) {
-            // default grid: one wave per tile of 64 rays, between 16 and 128 waves per CU (beyond that a wave takes several
-            // tiles); the ray count may be smaller on the device (n_ptr), surplus waves leave at once
-            if (!o.blocks_user) {
-                const unsigned long long cus = (unsigned long long)(o.num_cus > 0 ? o.num_cus : 256);
-                unsigned long long want = ((unsigned long long)a.n_max + 63ull) / 64ull;
-                want = want < cus * 16ull ? cus * 16ull : (want > cus * 128ull ? cus * 128ull : want);
-                blocks = (int)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
-            }
-            if constexpr (MODE != 0) {
-                // any hit: static chunks on the entry pool (k_trace_static).  The host only knows the capacity of the launch;
-                // a shadow-ray queue sized for one ray per path typically holds a fifth to a quarter of it.  32 rays per wave
-                // while that estimate is below 2048 rays per CU (421 k rays: 24 / 32 / 40 / 48 / 64 rays per wave take
-                // 0.241 / 0.228 / 0.238 / 0.247 / 0.258 ms), else 64
-                const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
-                const uint32_t n_est = a.n_max / 4u;
-                // ... and fewer for small launches, whose duration is the time one wave needs for its chunk: 16 / 8 rays per wave
-                // below 384 / 192 estimated rays per CU (53 k rays: 32 / 16 / 8 per wave take 0.086 / 0.064 / 0.073 ms, 26 k rays:
-                // 0.081 / 0.057 / 0.047 ms)
-                const uint32_t q = n_est / (cus * 16u);
-                const uint32_t ppw = n_est > cus * 2048u ? 64u : (q >= 24u ? 32u : (q >= 12u ? 16u : 8u));
+            const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
+            // Static chunks of a few rays per wave, on the entry pool from the root (k_trace_static): every any-hit launch,
+            // and closest-hit launches of at most 2560 rays per CU (655 k) -- there a wave per 64-ray tile would leave the
+            // step at the time one wave needs for its tile.  The host only knows the capacity of a launch; a shadow-ray
+            // queue sized for one ray per path typically holds a fifth to a quarter of it.
+            //   any hit, rays per wave: 64 from an estimated 2048 rays per CU on, 32 below (421 k rays: 24 / 32 / 40 / 48 / 64
+            //   take 0.241 / 0.228 / 0.238 / 0.247 / 0.258 ms), 16 / 8 below 384 / 192 per CU (53 k rays: 32 / 16 / 8 take
+            //   0.086 / 0.064 / 0.073 ms; 26 k rays: 0.081 / 0.057 / 0.047 ms)
+            //   closest hit: 32 from 1536 rays per CU on (518 k rays: 16 / 32 / 64 take 0.236 / 0.226 / 0.256 ms, the tiled form
+            //   0.248; 1.04 M rays: 0.438 / 0.344 / 0.327 against 0.300 tiled), 16 below (259 k: 0.164 / 0.169 / 0.247, the
+            //   cursor-fed pool this replaces 0.215; 130 k: 0.115 against 0.149), 8 below 192 per CU (32 k: 0.067 against 0.086)
+            const uint32_t n_est = MODE != 0 ? a.n_max / 4u : a.n_max;
+            const uint32_t q = n_est / (cus * 16u);
+            uint32_t ppw = 0u;
+            if (MODE != 0)                    ppw = n_est > cus * 2048u ? 64u : (q >= 24u ? 32u : (q >= 12u ? 16u : 8u));
+            else if (n_est <= cus * 2560u)    ppw = q >= 96u ? 32u : (q >= 12u ? 16u : 8u);
+            if (ppw != 0u) {
                 unsigned long long want = ((unsigned long long)n_est + ppw - 1u) / ppw;
                 want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
                 if (o.blocks_user) want = (unsigned long long)blocks;
                 const uint32_t g = (uint32_t)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
                 hipLaunchKernelGGL((k_trace_static<MODE>), dim3(g), dim3(64), 0, st, a, ppw);
-            } else {
-                const bool tiled = a.n_max > a.tail_len;
-                if (a.bvh.depth <= 24u) {
-                    if (tiled) hipLaunchKernelGGL((k_trace_pool<0, 24, true>), dim3(blocks), dim3(64), 0, st, a);
-                    else       hipLaunchKernelGGL((k_trace_pool<0, 24, false>), dim3(blocks), dim3(64), 0, st, a);
-                } else {
-                    if (tiled) hipLaunchKernelGGL((k_trace_pool<0, 32, true>), dim3(blocks), dim3(64), 0, st, a);
-                    else       hipLaunchKernelGGL((k_trace_pool<0, 32, false>), dim3(blocks), dim3(64), 0, st, a);
+            } else if constexpr (MODE == 0) {
+                // tiled form: one wave per tile of 64 rays, at most 128 waves per CU (beyond that a wave takes several tiles);
+                // the ray count may be smaller on the device (n_ptr), surplus waves leave at once
+                if (!o.blocks_user) {
+                    unsigned long long want = ((unsigned long long)a.n_max + 63ull) / 64ull;
+                    want = want < cus * 16ull ? cus * 16ull : (want > cus * 128ull ? cus * 128ull : want);
+                    blocks = (int)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
                 }
+                if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24>), dim3(blocks), dim3(64), 0, st, a);
+                else                    hipLaunchKernelGGL((k_trace_pool<0, 32>), dim3(blocks), dim3(64), 0, st, a);
             }
         }
         else if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);

@@ -85,7 +85,7 @@ struct MiptContext {
     int      build_mode = 0;              // MIPT_OPT_BUILD: 0 host binned SAH, 1 device LBVH
     uint32_t tail_paths = 1048576;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
     bool     bounces_on_device = false;   // launch statistics: iterations counted by k_advance / k_tail
-    int      tail_pct = 100, pool_low = 16, pool_chunk = 16, tile_group = 256;
+    int      tile_group = 256;
     // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
     WhGeometry        wh_geo{};
     MiptMaterialData* d_wh_materials = nullptr;
@@ -253,7 +253,7 @@ TraceOpts trace_opts(const MiptContext* c)
     o.blocks = c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 16);
     o.blocks_user = c->blocks_per_cu > 0 ? 1 : 0; o.num_cus = c->num_cus;
     o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.burst_bulk = c->burst_bulk; o.burst_dry = c->burst_dry;
-    o.tail_pct = c->tail_pct; o.pool_low = c->pool_low; o.pool_chunk = c->pool_chunk; o.tile_group = c->tile_group;
+    o.tile_group = c->tile_group;
     return o;
 }
 
@@ -454,10 +454,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
-    if (const char* e = std::getenv("MIPT_TAIL_PCT")) { const int v = std::atoi(e); if (v >= 1 && v <= 100000) c->tail_pct = v; }
     if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
-    if (const char* e = std::getenv("MIPT_POOL_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) c->pool_chunk = v; }
-    if (const char* e = std::getenv("MIPT_POOL_LOW")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) c->pool_low = v; }
     if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 30)) c->tail_paths = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_STEAL_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) c->steal_min = v; }
     *out = c;
