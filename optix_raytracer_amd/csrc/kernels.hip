@@ -1309,11 +1309,16 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
         // paths per wave: 64, except for a pass of few bounces (depth cap <= 8) that is too small to give every wave slot two
         // waves -- there the step is the time ONE wave needs for its paths, and fewer paths per wave (the idle lanes still
         // work in the pool rounds) are faster: a 1/8 shard of the headline frame 0.36 -> 0.28 ms, 65 k paths of depth 4
-        // 2.37 -> 1.62 ms.  Long paths (unbounded depth) prefer 64: most of a wave's paths die early and the survivors of
-        // 64 fill the pool better than those of 16 (profiles/r01_tail_paths.txt).
+        // 2.37 -> 1.62 ms (profiles/r01_tail_paths.txt).
         uint32_t ppw = 64u;
         if (fc.max_depth >= 1u && fc.max_depth <= 8u) {
             const uint32_t slots = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256) * 32u;
+            ppw = ((n_max + slots - 1u) / slots + 15u) & ~15u;
+            ppw = ppw < 16u ? 16u : (ppw > 64u ? 64u : ppw);
+        } else {
+            // longer paths: as thin as ONE set of resident waves allows (16 per CU) -- a second set would only start when the long
+            // tails of the first have ended (65 k paths of unbounded depth, 1 M-triangle scene: 1.67 -> 1.50 ms)
+            const uint32_t slots = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256) * 16u;
             ppw = ((n_max + slots - 1u) / slots + 15u) & ~15u;
             ppw = ppw < 16u ? 16u : (ppw > 64u ? 64u : ppw);
         }

@@ -38,6 +38,9 @@ run("S4 soup 1M 512x512 spp1 (RR depth)", lambda: scenes.random_soup(1_000_000),
 run("S5 soup 1M 256x256 spp4 depth 4", lambda: scenes.random_soup(1_000_000), 256, 256, 4, 4, 5)
 run("S6 soup 1M 960x540 spp1 depth 8", lambda: scenes.random_soup(1_000_000), 960, 540, 1, 8, 5)
 run("S7 soup 1M 960x540 spp1 depth 1", lambda: scenes.random_soup(1_000_000), 960, 540, 1, 1, 5)
+run("S8 soup 1M 256x256 spp1 (RR depth)", lambda: scenes.random_soup(1_000_000), 256, 256, 1, 0, 5)
+run("S9 Cornell 256x256 spp1 (RR depth)", scenes.cornell_box, 256, 256, 1, 0, 5)
+run("S10 soup 1M 384x384 spp1 (RR depth)", lambda: scenes.random_soup(1_000_000), 384, 384, 1, 0, 5)
 run("S2 soup 100k 1920x1080 spp4 (RR depth)", lambda: scenes.random_soup(100_000), 1920, 1080, 4, 0, 3)
 
 # glTF configurations: the tree's Duck.gltf does not travel to the GPU box and there is no Sponza-class asset, so both
