@@ -158,7 +158,7 @@ def _oracle_for_state(st, nodes, tris):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,subframes,custom", [(160, 120, 1, False), (97, 61, 3, True)])
+@pytest.mark.parametrize("w,h,subframes,custom", [(160, 120, 1, False), (97, 61, 3, True), (1024, 768, 1, True)])   # the last: tiled closest-hit kernel with back-face culling
 def test_whitted_programs_match_the_oracle(tmp_path, w, h, subframes, custom):
     import torch
     assert torch.cuda.is_available()
