@@ -3,18 +3,20 @@
 // Wavefront replacement of the OptiX megakernel that optixLaunch runs in
 // SDK/optixPathTracer (file:line below relative to /root/reference):
 //
-//   k_raygen        <- __raygen__rg prologue            optixPathTracer.cu:249-281
-//   k_trace<0>      <- optixTraverse closest hit        optixPathTracer.cu:184-197   (driver-internal BVH walk)
-//   k_shade         <- __closesthit__radiance / __miss__radiance + the raygen bounce loop body
-//                                                         optixPathTracer.cu:291-303, 323-413
-//   k_trace<2>      <- traceOcclusion (any hit)         optixPathTracer.cu:218-240 + radiance add :292
-//   k_resolve       <- raygen epilogue                  optixPathTracer.cu:308-319
-//   k_unpermute     <- multi-GPU merge                  optixMultiGPU.cu:282-292 (scatter by StaticWorkDistribution)
+//   k_raygen          <- __raygen__rg prologue            optixPathTracer.cu:249-281
+//   k_trace_pool<0>   <- optixTraverse closest hit        optixPathTracer.cu:184-197   (driver-internal BVH walk)
+//   k_shade           <- __closesthit__radiance / __miss__radiance + the raygen bounce loop body
+//                                                           optixPathTracer.cu:291-303, 323-413
+//   k_trace_static<2> <- traceOcclusion (any hit)         optixPathTracer.cu:218-240 + radiance add :292
+//   k_resolve         <- raygen epilogue                  optixPathTracer.cu:308-319
+//   k_tail_pool       <- the raygen bounce loop as one kernel, for the last paths of a pass  optixPathTracer.cu:283-305
+//   k_unpermute       <- multi-GPU merge                  optixMultiGPU.cu:282-292 (scatter by StaticWorkDistribution)
 //
-// Traversal is HBM/cache-latency bound pointer chasing (64-B nodes, 48-B triangles); MFMA is not used.
-// One ray per lane, per-lane traversal stack in LDS ([entry][lane] -> conflict free), persistent waves
-// that refill idle lanes from per-XCD ray-range cursors and share long rays in the drain phase,
-// wave-ballot compaction of the output queues.
+// Traversal is cache-latency / instruction-issue bound pointer chasing (64-B nodes, 48-B triangles); MFMA is not used.
+// Default closest-hit kernel: 64-ray tiles, one ray per lane with the per-lane traversal stack in LDS ([entry][lane] ->
+// conflict free), then a per-wave pool of stack entries that all 64 lanes work on; any-hit launches and small launches run
+// on that pool from the root.  Other variants: k_trace_stream (persistent waves, lane refill from per-XCD cursors, subtree
+// stealing; also the counting launches), k_trace_simple (one thread per ray).  Wave-ballot compaction of the output queues.
 // Floating point: -ffp-contract=off, explicit fmaf only where the specification says so.
 #include "kernels.h"
 #include "detmath.h"
