@@ -216,6 +216,11 @@ int         mipt_get_option(const MiptContext* ctx, int option, uint64_t* value)
  * ------------------------------------------------------------------------- */
 int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs,
                      unsigned long long* handle_out);
+/* Refit (= optixAccelBuild with OPTIX_BUILD_OPERATION_UPDATE, include/optix_types.h; used by SDK/optixDynamicGeometry): the
+ * same inputs as the build with moved vertices -- triangle count, order, SBT offsets and flags unchanged.  The tree keeps
+ * its topology, triangle records and boxes are recomputed on the device; traversal results are those of a fresh build
+ * (hits do not depend on the tree), traversal cost grows as the geometry drifts from the layout it was built for. */
+int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBuildInput* inputs, uint32_t num_inputs);
 int mipt_accel_destroy(MiptContext* ctx, unsigned long long handle);
 int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccelInfo* info);
 /* copies the linear BVH to host arrays sized from mipt_accel_info (inspection, external checkers) */

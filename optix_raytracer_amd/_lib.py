@@ -148,6 +148,7 @@ SYMBOLS = [
     ("mipt_set_option", C.c_int, [_vp, C.c_int, _u64]),
     ("mipt_get_option", C.c_int, [_vp, C.c_int, C.POINTER(_u64)]),
     ("mipt_accel_build", C.c_int, [_vp, C.POINTER(MiptBuildInput), _u32, C.POINTER(C.c_ulonglong)]),
+    ("mipt_accel_update", C.c_int, [_vp, C.c_ulonglong, C.POINTER(MiptBuildInput), _u32]),
     ("mipt_accel_destroy", C.c_int, [_vp, C.c_ulonglong]),
     ("mipt_accel_info", C.c_int, [_vp, C.c_ulonglong, C.POINTER(MiptAccelInfo)]),
     ("mipt_accel_export", C.c_int, [_vp, C.c_ulonglong, _vp, _vp]),

@@ -240,9 +240,7 @@ class Context:
         return v.value
 
     # ---- accel
-    def accel_build(self, inputs):
-        """inputs: list of dicts {vertices(ptr|ndarray), num_vertices, stride, indices, index_format,
-        num_triangles, sbt_index_offsets, transform, flags (one MiptGeometryFlags word per SBT record)}"""
+    def _build_inputs(self, inputs):
         arr = (L.MiptBuildInput * len(inputs))()
         keep = []
         for i, d in enumerate(inputs):
@@ -274,9 +272,20 @@ class Context:
                 t = np.ascontiguousarray(t, dtype=np.float32).reshape(12)
                 keep.append(t)
                 bi.transform3x4 = t.ctypes.data
+        return arr, keep
+
+    def accel_build(self, inputs):
+        """inputs: list of dicts {vertices(ptr|ndarray), num_vertices, stride, indices, index_format,
+        num_triangles, sbt_index_offsets, transform, flags (one MiptGeometryFlags word per SBT record)}"""
+        arr, keep = self._build_inputs(inputs)
         h = C.c_ulonglong()
         self._check(self._lib.mipt_accel_build(self._h, arr, len(inputs), C.byref(h)))
         return h.value
+
+    def accel_update(self, handle, inputs):
+        """refit of `handle` to moved vertices (same inputs as accel_build otherwise)"""
+        arr, keep = self._build_inputs(inputs)
+        self._check(self._lib.mipt_accel_update(self._h, handle, arr, len(inputs)))
 
     def accel_destroy(self, handle):
         self._check(self._lib.mipt_accel_destroy(self._h, handle))

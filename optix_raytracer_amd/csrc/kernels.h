@@ -107,6 +107,8 @@ struct GatherInput {
 };
 void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, uint32_t* mats, uint32_t* gflags, uint32_t base, uint32_t* error);
 // *ok = false when the tree is deeper than depth_cap
+// refit of an existing BVH2 (same topology) to new world-space vertices (9 floats per original primitive)
+hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris);
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok);
 

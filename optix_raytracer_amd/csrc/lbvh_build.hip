@@ -196,6 +196,80 @@ __global__ __launch_bounds__(256) void k_lbvh_depth(const int* parent_inner, con
     atomicMax(depth, d);
 }
 
+// ---- refit (mipt_accel_update): same topology, new vertex positions -------------------------------------------------------
+// triangle records of the existing leaf order from the new world-space vertices
+__global__ __launch_bounds__(256) void k_refit_tris(const float* __restrict__ world, uint32_t n, MiptBvhTri* tris)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t p = tris[k].prim;
+    if (p >= n) return;
+    const float* v = world + (size_t)p * 9;
+    for (int c = 0; c < 3; ++c) { tris[k].v0[c] = v[c]; tris[k].e1[c] = v[3 + c] - v[c]; tris[k].e2[c] = v[6 + c] - v[c]; }
+}
+
+// parent[child] = node * 2 + slot for every inner child; the root keeps -1
+__global__ __launch_bounds__(256) void k_refit_parents(const MiptBvhNode* nodes, uint32_t nn, int* parent)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    const int c0 = nodes[i].c0, c1 = nodes[i].c1;
+    if (c0 >= 0 && (uint32_t)c0 < nn) parent[c0] = (int)(i * 2u);
+    if (c1 >= 0 && (uint32_t)c1 < nn) parent[c1] = (int)(i * 2u + 1u);
+}
+
+__device__ __forceinline__ void refit_store_slot(MiptBvhNode* nd, int slot, const float lo[3], const float hi[3])
+{
+    float* x = slot == 0 ? nd->c0x : nd->c1x;
+    float* y = slot == 0 ? nd->c0y : nd->c1y;
+    float* z = slot == 0 ? nd->c0z : nd->c1z;
+    x[0] = lo[0]; x[1] = hi[0]; y[0] = lo[1]; y[1] = hi[1]; z[0] = lo[2]; z[1] = hi[2];
+}
+
+// Every thread fits the leaf children of its node from the new vertices and then reports the node "done"; a node is complete
+// when its own thread and every inner child have reported, and whoever reports last carries the node's box (the union of
+// its two child boxes) into the parent's slot and reports there.  No thread ever waits for another.
+__global__ __launch_bounds__(256) void k_refit_nodes(MiptBvhNode* nodes, uint32_t nn, const MiptBvhTri* tris, uint32_t nt,
+                                                     const float* __restrict__ world, const int* parent, uint32_t* arrived)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    {
+        MiptBvhNode* nd = &nodes[i];
+        for (int slot = 0; slot < 2; ++slot) {
+            const int ref = slot == 0 ? nd->c0 : nd->c1;
+            if (ref >= 0) continue;
+            const uint32_t desc = ~(uint32_t)ref, first = desc >> 4, cnt = desc & 15u;
+            float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+            for (uint32_t j = 0; j < cnt && first + j < nt; ++j) {
+                const uint32_t p = tris[first + j].prim;
+                if (p >= nt) continue;
+                const float* v = world + (size_t)p * 9;
+                for (int c = 0; c < 9; ++c) { const float f = v[c]; lo[c % 3] = fminf(lo[c % 3], f); hi[c % 3] = fmaxf(hi[c % 3], f); }
+            }
+            refit_store_slot(nd, slot, lo, hi);
+        }
+    }
+    for (;;) {
+        MiptBvhNode* nd = &nodes[i];
+        const uint32_t need = 1u + (nd->c0 >= 0 ? 1u : 0u) + (nd->c1 >= 0 ? 1u : 0u);
+        __threadfence();
+        if (atomicAdd(&arrived[i], 1u) + 1u < need) return;
+        __threadfence();
+        const int pr = parent[i];
+        if (pr < 0) return;                                   // the root is complete
+        // the boxes of node i were written by other threads before their fence + atomic: read them past the L1
+        float b[12];
+        const float* src = nd->c0x;
+        for (int k = 0; k < 12; ++k) b[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // b: c0x[2] c0y[2] c1x[2] c1y[2] c0z[2] c1z[2]
+        const float lo[3] = { fminf(b[0], b[4]), fminf(b[2], b[6]), fminf(b[8], b[10]) };
+        const float hi[3] = { fmaxf(b[1], b[5]), fmaxf(b[3], b[7]), fmaxf(b[9], b[11]) };
+        refit_store_slot(&nodes[pr >> 1], pr & 1, lo, hi);
+        i = (uint32_t)(pr >> 1);
+    }
+}
+
 // build-input assembly on the device: one OptixBuildInputTriangleArray-like input -> world-space triangles, SBT index
 // and geometry flags per triangle, appended at `base`
 __global__ __launch_bounds__(256) void k_gather_input(GatherInput in, float* world, uint32_t* mats, uint32_t* gflags, uint32_t base, uint32_t* error)
@@ -226,6 +300,27 @@ __global__ __launch_bounds__(256) void k_gather_input(GatherInput in, float* wor
 }
 
 }  // namespace
+
+hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris)
+{
+    int* parent = nullptr; uint32_t* arrived = nullptr;
+    hipError_t e = hipMalloc((void**)&parent, (size_t)nn * 4u);
+    if (e == hipSuccess) e = hipMalloc((void**)&arrived, (size_t)nn * 4u);
+    if (e == hipSuccess) e = hipMemsetAsync(parent, 0xff, (size_t)nn * 4u, st);
+    if (e == hipSuccess) e = hipMemsetAsync(arrived, 0, (size_t)nn * 4u, st);
+    if (e == hipSuccess) {
+        MiptBvhNode* nodes = reinterpret_cast<MiptBvhNode*>(d_nodes);
+        MiptBvhTri* tris = reinterpret_cast<MiptBvhTri*>(d_tris);
+        hipLaunchKernelGGL(k_refit_tris, dim3((n + 255u) / 256u), dim3(256), 0, st, d_world, n, tris);
+        hipLaunchKernelGGL(k_refit_parents, dim3((nn + 255u) / 256u), dim3(256), 0, st, nodes, nn, parent);
+        hipLaunchKernelGGL(k_refit_nodes, dim3((nn + 255u) / 256u), dim3(256), 0, st, nodes, nn, tris, n, d_world, parent, arrived);
+        e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (parent) (void)hipFree(parent);
+    if (arrived) (void)hipFree(arrived);
+    return e;
+}
 
 void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, uint32_t* mats, uint32_t* gflags, uint32_t base, uint32_t* error)
 {

@@ -548,10 +548,19 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
 // gather kernel makes world-space triangles / SBT indices / geometry flags, lbvh_build.hip builds the tree.
 // Returns MIPT_SUCCESS with *handle_out = 0 when the caller should use the host builder instead (tiny scenes, a
 // tree deeper than the traversal stack).
-static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs, unsigned long long* handle_out)
+// world-space triangles (9 floats each), SBT index and geometry flags per triangle of the build inputs, assembled on the
+// device (k_gather_input); host arrays are uploaded as they are.  *n_out = 0: nothing to do on the device (tiny or huge input).
+struct DeviceGather {
+    std::vector<void*> temps;
+    float* world = nullptr; uint32_t* mats = nullptr; uint32_t* gflags = nullptr;
+    uint32_t n = 0, err = 0;
+    hipError_t e = hipSuccess;
+    ~DeviceGather() { for (void* p : temps) if (p) (void)hipFree(p); if (mats) (void)hipFree(mats); }
+    uint32_t* release_mats() { uint32_t* m = mats; mats = nullptr; return m; }
+};
+
+static int gather_on_device(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs, DeviceGather& G)
 {
-    *handle_out = 0;
-    const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint32_t> counts(num_inputs);
     uint64_t total = 0;
     for (uint32_t k = 0; k < num_inputs; ++k) {
@@ -571,9 +580,7 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     }
     if (total <= 4u || total * 36u >= (1ull << 31)) return MIPT_SUCCESS;
     const uint32_t n = (uint32_t)total;
-    std::vector<void*> temps;
-    auto cleanup = [&]() { for (void* p : temps) if (p) (void)hipFree(p); };
-    auto dev_alloc = [&](size_t bytes, void** out) { hipError_t e = hipMalloc(out, bytes ? bytes : 4); if (e == hipSuccess) temps.push_back(*out); return e; };
+    auto dev_alloc = [&](size_t bytes, void** out) { hipError_t e = hipMalloc(out, bytes ? bytes : 4); if (e == hipSuccess) G.temps.push_back(*out); return e; };
     auto on_device = [&](const void* p, size_t bytes, const void** out) {          // device copy of a host array, or the pointer itself
         if (!p || bytes == 0) { *out = p; return hipSuccess; }
         if (is_device_pointer(p)) { *out = p; return hipSuccess; }
@@ -583,10 +590,10 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
         *out = d;
         return e;
     };
-    float* d_world = nullptr; uint32_t* d_mats = nullptr; uint32_t* d_gf = nullptr; uint32_t* d_err = nullptr;
-    hipError_t e = dev_alloc((size_t)n * 36u, (void**)&d_world);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_mats, (size_t)n * 4u);
-    if (e == hipSuccess) e = dev_alloc((size_t)n * 4u, (void**)&d_gf);
+    uint32_t* d_err = nullptr;
+    hipError_t e = dev_alloc((size_t)n * 36u, (void**)&G.world);
+    if (e == hipSuccess) e = hipMalloc((void**)&G.mats, (size_t)n * 4u);
+    if (e == hipSuccess) e = dev_alloc((size_t)n * 4u, (void**)&G.gflags);
     if (e == hipSuccess) e = dev_alloc(4, (void**)&d_err);
     if (e == hipSuccess) e = hipMemset(d_err, 0, 4);
     uint32_t base = 0;
@@ -609,21 +616,34 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
             g.flags = (const uint32_t*)d; g.num_sbt_records = in.num_sbt_records;
         }
         if (in.transform3x4) { g.has_transform = 1u; std::memcpy(g.m, in.transform3x4, 48); }
-        if (e == hipSuccess) launch_gather_input(nullptr, g, d_world, d_mats, d_gf, base, d_err);
+        if (e == hipSuccess) launch_gather_input(nullptr, g, G.world, G.mats, G.gflags, base, d_err);
         base += counts[k];
     }
-    uint32_t err = 0;
-    if (e == hipSuccess) e = hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&G.err, d_err, 4, hipMemcpyDeviceToHost);
+    G.e = e; G.n = n;
+    return MIPT_SUCCESS;
+}
+
+static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs, unsigned long long* handle_out)
+{
+    *handle_out = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    DeviceGather G;
+    const int grc = gather_on_device(ctx, inputs, num_inputs, G);
+    if (grc != MIPT_SUCCESS || G.n == 0u) return grc;
+    const uint32_t n = G.n;
+    hipError_t e = G.e;
+    const uint32_t err = G.err;
+    float* d_world = G.world; uint32_t* d_gf = G.gflags;
     float4* blob = nullptr; uint32_t nn = 0, dep = 0; bool ok = false;
     if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, 4, kStackEntries, &blob, &nn, &dep, &ok);
-    cleanup();
-    if (e != hipSuccess) { if (d_mats) (void)hipFree(d_mats); return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e)); }
-    if (err != 0u) { (void)hipFree(d_mats); return ctx->fail(MIPT_ERROR_INVALID_VALUE, err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records"); }
+    if (e != hipSuccess) return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e));
+    if (err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
     if (!ok) {
-        (void)hipFree(d_mats);
         ctx->log(3, "ACCEL", "device LBVH is %u deep (stack holds %d): falling back to the host builder", dep, kStackEntries);
         return MIPT_SUCCESS;
     }
+    uint32_t* d_mats = G.release_mats();
     Accel* a = new Accel();
     const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
     a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
@@ -747,6 +767,29 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     *handle_out = h;
     ctx->log(4, "ACCEL", "built BVH2 (%s): %u tris, %u nodes, depth %u, %.1f MB, %.3f s", a->builder ? "device LBVH" : "host SAH", n_tris,
              a->num_nodes, a->depth, (double)a->bytes / 1e6, a->seconds);
+    return MIPT_SUCCESS;
+}
+
+int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBuildInput* inputs, uint32_t num_inputs)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!inputs || num_inputs == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update: null argument");
+    Accel* a = find_accel(ctx, handle);
+    if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());                         // launches that still read the old boxes
+    const auto t0 = std::chrono::steady_clock::now();
+    DeviceGather G;
+    const int grc = gather_on_device(ctx, inputs, num_inputs, G);
+    if (grc != MIPT_SUCCESS) return grc;
+    if (G.n == 0u || G.n != a->num_tris || a->num_nodes == 0u)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update: the inputs hold %u triangles, the traversable was built from %u", G.n, a->num_tris);
+    if (G.e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(G.e));
+    if (G.err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, G.err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
+    const hipError_t e = lbvh_refit(nullptr, G.world, G.n, a->d_nodes, a->num_nodes, a->d_tris);
+    if (e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(e));
+    ctx->log(4, "ACCEL", "refitted BVH2: %u tris, %u nodes, %.4f s", a->num_tris, a->num_nodes,
+             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return MIPT_SUCCESS;
 }
 

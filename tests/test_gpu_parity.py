@@ -501,6 +501,64 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n):
     assert infos[0]["num_triangles"] == infos[1]["num_triangles"] and infos[1]["depth"] <= 32 and infos[1]["leaf_max"] <= 4
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_accel_update_refits_to_moved_vertices(mode):
+    """mipt_accel_update (= OPTIX_BUILD_OPERATION_UPDATE): after the vertices have moved, the refitted tree is a sound BVH of
+    the new triangles (oracle validation) and frames over it are bit-identical to frames over a fresh build"""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    scene = scenes.random_soup(20000)
+    rng = np.random.default_rng(17)
+    moved = dict(scene)
+    v = np.array(scene["vertices"], np.float32, copy=True)
+    v[:, :3] += rng.normal(0.0, 0.004, (v.shape[0], 3)).astype(np.float32)
+    tri = np.arange(v.shape[0]) // 3
+    v[(tri % 5) == 0, 1] += np.float32(0.05)                      # a fifth of the triangles move as a block
+    moved["vertices"] = v
+    w, h = 128, 96
+
+    def make(sc):
+        st = PT.PathTracerState()
+        PT.createContext(st, 0)
+        st.context.set_option(L.OPT_BUILD, mode)
+        PT.buildMeshAccel(st, sc)
+        PT.createSBT(st)
+        PT.initLaunchParams(st, w, h, 2)
+        cam = sc["camera"]
+        PT.handleCameraUpdate(st, PT.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], 1.0))
+        st.context.set_option(L.OPT_MAX_DEPTH, 3)
+        return st
+
+    st = make(scene)
+    before = _render_gpu(PT, st)
+    info0 = st.context.accel_info(st.gas_handle)
+    d_mat = torch.from_numpy(np.ascontiguousarray(scene["mat_index"]).astype(np.int32)).cuda()
+    st.d_vertices.copy_(torch.from_numpy(v))                      # the hit-group records point at this buffer
+    st.context.accel_update(st.gas_handle, [{"vertices": st.d_vertices.data_ptr(), "num_vertices": v.shape[0], "stride": 16,
+                                             "sbt_index_offsets": d_mat.data_ptr()}])
+    refit = _render_gpu(PT, st)
+    info1 = st.context.accel_info(st.gas_handle)
+    assert (info0["num_nodes"], info0["depth"], info0["num_triangles"]) == (info1["num_nodes"], info1["depth"], info1["num_triangles"])
+    nodes, tris = st.context.accel_export(st.gas_handle)
+    osc = O.Scene(moved).set_bvh(nodes, tris)                       # raises if the refitted tree is not a sound BVH of the moved scene
+    a, f, ost = osc.render(scenes.launch_desc(moved, w, h, 2), max_depth=3, threads=4)
+    assert np.array_equal(refit[0].view(np.uint32), a.view(np.uint32)) and np.array_equal(refit[1], f)
+    assert refit[2]["closest_rays"] == ost["closest_rays"] and refit[2]["shadow_rays"] == ost["shadow_rays"]
+    assert not np.array_equal(before[0], refit[0])
+    with pytest.raises(Exception):
+        st.context.accel_update(st.gas_handle, [{"vertices": st.d_vertices.data_ptr(), "num_vertices": v.shape[0] - 3, "stride": 16}])
+    with pytest.raises(Exception):
+        st.context.accel_update(st.gas_handle + 99, [{"vertices": st.d_vertices.data_ptr(), "num_vertices": v.shape[0], "stride": 16}])
+    PT.cleanupState(st)
+    st2 = make(moved)
+    fresh = _render_gpu(PT, st2)
+    PT.cleanupState(st2)
+    assert np.array_equal(refit[0].view(np.uint32), fresh[0].view(np.uint32)) and np.array_equal(refit[1], fresh[1])
+    assert refit[2]["closest_rays"] == fresh[2]["closest_rays"] and refit[2]["shadow_rays"] == fresh[2]["shadow_rays"]
+
+
 def test_device_build_reads_every_input_form():
     """indexed u16 / u32 / non-indexed inputs, strided vertices, a 3x4 transform, SBT offsets + geometry flags, host and
     device pointers: the device-side input assembly makes the same triangles as the host builder's"""

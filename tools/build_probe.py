@@ -32,4 +32,25 @@ for mode in (0, 1, 1):
     info = st.context.accel_info(st.gas_handle)
     print("builder %d: build %.4f s (accel_build call incl. input upload %.3f s), %d nodes, depth %d; frame %.3f ms" % (
         mode, info["build_seconds"], wall, info["num_nodes"], info["depth"], ms), flush=True)
+    # refit to slightly moved vertices (mipt_accel_update), then the frame again
+    import numpy as np
+    rng = np.random.default_rng(3)
+    v = np.array(scene["vertices"], np.float32, copy=True)
+    v[:, :3] += rng.normal(0.0, 0.002, (v.shape[0], 3)).astype(np.float32)
+    st.d_vertices.copy_(torch.from_numpy(v))
+    d_mat = torch.from_numpy(np.ascontiguousarray(scene["mat_index"]).astype(np.int32)).cuda()
+    inputs = [{"vertices": st.d_vertices.data_ptr(), "num_vertices": v.shape[0], "stride": 16, "sbt_index_offsets": d_mat.data_ptr()}]
+    st.context.accel_update(st.gas_handle, inputs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        st.context.accel_update(st.gas_handle, inputs)
+    torch.cuda.synchronize()
+    upd = (time.perf_counter() - t0) / 5 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(20):
+        PT.launchSubframe(ob, st)
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) / 20 * 1e3
+    print("           refit %.3f ms; frame over the refitted tree %.3f ms" % (upd, ms2), flush=True)
     PT.cleanupState(st)
