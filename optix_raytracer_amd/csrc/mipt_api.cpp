@@ -446,12 +446,12 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     }
     if (hipMalloc((void**)&c->d_ctr, sizeof(DeviceCounters)) != hipSuccess ||
         hipMemset(c->d_ctr, 0, sizeof(DeviceCounters)) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_pinned, 64) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocCoherent) != hipSuccess) {
         delete c;
         return MIPT_ERROR_OUT_OF_MEMORY;
     }
     for (hipEvent_t& e : c->ring_ev)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
     if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
