@@ -168,8 +168,8 @@ typedef enum MiptOption {
                                   per-wave entry pool for the tail of each tile; any-hit launches and closest-hit launches
                                   with few rays in static chunks of 8 .. 64 rays per wave, on the pool from the root;
                                   2 persistent streaming waves with lane refill and subtree stealing (also used when a BVH
-                                  does not fit the pool's packed entries: >= 2^25 nodes, >= 2^22 triangles or leaves of more
-                                  than 7, and by counting launches); 0 one thread per ray (tight while-while loop; also the
+                                  does not fit the pool's packed entries: >= 2^25 nodes or >= 2^23 triangles, and by counting
+                                  launches); 0 one thread per ray (tight while-while loop; also the
                                   fallback for trees deeper than 32). */
     MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings),
                                   2 = only the two traversal kernels (10 -> 4 event records per frame) */

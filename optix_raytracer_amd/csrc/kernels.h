@@ -38,7 +38,7 @@ struct DeviceBvh {
     uint32_t tri_byte_off;     // tris == (char*)nodes + tri_byte_off (one allocation); 0 if that offset needs > 32 bits
     uint32_t blob_bytes;       // size of that allocation (buffer-descriptor range)
     uint32_t depth;            // deepest leaf (stack entries a ray can need)
-    uint32_t pool_ok;          // fits k_trace_pool's packed entries: < 2^25 nodes, < 2^22 triangles, leaves of <= 7
+    uint32_t pool_ok;          // fits the entry pool's packed words: < 2^25 nodes, 2 .. 2^23 - 1 triangles, leaves of 1 .. 4
 };
 
 // SoA path queues, capacity `cap` entries each

@@ -398,13 +398,15 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
 // min t, tie -> lowest primitive, the conventions of the sequential traversal, which visits a subset of what
 // the pool visits -- same result, but visit counters differ, so COUNT launches use k_trace_stream.
 // Packed entry: bit 31 leaf | 25-bit payload | 6-bit slot; inner payload = node index, leaf payload =
-// first << 3 | count.  The launcher only selects this kernel for BVHs that fit (DeviceBvh::pool_ok).
+// first << 2 | (count - 1): leaves of 1 .. 4 triangles, < 2^23 triangles.  The launcher only selects this kernel for BVHs
+// that fit (DeviceBvh::pool_ok; the builders make leaves of at most 4, and only the forced root over 0 or 1 triangles has
+// an empty one).
 
 __device__ __forceinline__ uint32_t pool_pack(int ref, uint32_t slot)
 {
     if (ref >= 0) return ((uint32_t)ref << 6) | slot;
     const uint32_t desc = ~(uint32_t)ref;
-    return 0x80000000u | ((desc >> 4) << 9) | ((desc & 7u) << 6) | slot;
+    return 0x80000000u | ((desc >> 4) << 8) | (((desc - 1u) & 3u) << 6) | slot;
 }
 __device__ __forceinline__ uint32_t ord_bits(float f) { const uint32_t b = f2u(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
 __device__ __forceinline__ float    ord_float(uint32_t k) { return u2f(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
@@ -489,9 +491,9 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
     else           { if (have && sh_done[slot] != 0u) live = false; }
     const bool leaf = (ent >> 31) != 0u;
     const uint32_t payload = (ent >> 6) & 0x1ffffffu;
-    const uint32_t lfirst = payload >> 3, lcnt = payload & 7u;
+    const uint32_t lfirst = payload >> 2, lcnt = (payload & 3u) + 1u;
     const bool do_inner = live && !leaf;
-    const bool do_tri   = live && leaf && lcnt != 0u;
+    const bool do_tri   = live && leaf;
     uint32_t off = 0u;
     if (do_inner) off = payload << 6;
     if (do_tri)   off = tri_byte_off + lfirst * 48u;
@@ -550,7 +552,7 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
             if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; }
         }
         if (!stop && lcnt > 1u) {
-            push1 = 0x80000000u | ((lfirst + 1u) << 9) | ((lcnt - 1u) << 6) | slot;
+            push1 = 0x80000000u | ((lfirst + 1u) << 8) | ((lcnt - 2u) << 6) | slot;
             npush = 1;
         }
     }

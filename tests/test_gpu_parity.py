@@ -559,6 +559,41 @@ def test_accel_update_refits_to_moved_vertices(mode):
     assert refit[2]["closest_rays"] == fresh[2]["closest_rays"] and refit[2]["shadow_rays"] == fresh[2]["shadow_rays"]
 
 
+def test_entry_pool_beyond_four_million_triangles():
+    """the pool's packed entries address 2^23 triangles: a scene past the former 2^22 limit still runs on the default
+    kernels and agrees with the oracle walking the same tree"""
+    _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    n = (1 << 22) + 150_000
+    scene = scenes.random_soup(n, edge_scale=0.004)
+    st = PT.PathTracerState()
+    PT.createContext(st, 0)
+    st.context.set_option(L.OPT_BUILD, 1)                     # the device builder: a few ms
+    PT.buildMeshAccel(st, scene)
+    PT.createSBT(st)
+    w, h = 96, 64
+    PT.initLaunchParams(st, w, h, 1)
+    cam = scene["camera"]
+    PT.handleCameraUpdate(st, PT.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], 1.0))
+    st.context.set_option(L.OPT_MAX_DEPTH, 2)
+    info = st.context.accel_info(st.gas_handle)
+    assert info["num_triangles"] == n and info["leaf_max"] <= 4
+    acc, frame, stats = _render_gpu(PT, st)
+    nodes, tris = st.context.accel_export(st.gas_handle)
+    assert int(tris[:, 3].view(np.uint32).max()) == n - 1
+    osc = O.Scene(scene).set_bvh(nodes, tris)
+    a, f, ost = osc.render(scenes.launch_desc(scene, w, h, 1), max_depth=2, threads=8)
+    _assert_pixels(acc, a)
+    assert np.array_equal(frame, f)
+    assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"]
+    st.context.set_option(L.OPT_PERSISTENT, 2)                # and the streaming variant on the same tree
+    acc2, frame2, _ = _render_gpu(PT, st)
+    assert np.array_equal(acc2.view(np.uint32), acc.view(np.uint32))
+    PT.cleanupState(st)
+
+
 def test_device_build_reads_every_input_form():
     """indexed u16 / u32 / non-indexed inputs, strided vertices, a 3x4 transform, SBT offsets + geometry flags, host and
     device pointers: the device-side input assembly makes the same triangles as the host builder's"""
