@@ -83,7 +83,9 @@ void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, 
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
                  PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const struct TraceOpts& o);
 void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = nullptr);   // host_live: pinned word that receives the new live count
-void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result);
+// ctr != null: the kernel also does launch_begin_sample's work for the pass (and clears the launch statistics when zero_stats)
+void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
+                   DeviceCounters* ctr = nullptr, uint32_t n_valid = 0, bool zero_stats = false);
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                           const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o,
                           uint32_t ray_flags = 0u /* MiptRayFlags */);
@@ -94,7 +96,8 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
                   float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices);
-void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots);
+void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots,
+                    DeviceCounters* advance_ctr = nullptr);   // advance_ctr: also do the last bounce's launch_advance
 // SDK/imgui_test pipeline (imgui_kernels.hip)
 void imgui_run(hipStream_t st, const MiptImguiParams& p, uint32_t n_paths, const DeviceBvh& bvh, PathQueue q, float4* hits,
                ShadowQueue sh, uint32_t* occluded, float4* result, uint32_t* rg_seed, DeviceCounters* ctr, const TraceOpts& opts);

@@ -706,19 +706,27 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
 // ------------------------------------------------------------------------------------------------
 // queue bookkeeping
 // ------------------------------------------------------------------------------------------------
-__global__ void k_begin_sample(DeviceCounters* c, uint32_t n_paths, uint32_t n_valid)
+// what a pass starts with; zero_stats: the first pass of a launch also clears the launch statistics (14 words from closest_rays on)
+__device__ __forceinline__ void begin_sample(DeviceCounters* c, uint32_t i, uint32_t n_paths, uint32_t n_valid, uint32_t zero_stats)
 {
-    const uint32_t i = threadIdx.x;
     if (i == 0) {
+        if (zero_stats) {
+            unsigned long long* w = &c->closest_rays;
+            for (int k = 0; k < 14; ++k) w[k] = 0ull;
+        }
         c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0;
         c->iterations += c->tail_max; c->tail_max = 0;       // the previous pass's tail (iterations is zeroed per launch)
     }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
-__global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
+__global__ void k_begin_sample(DeviceCounters* c, uint32_t n_paths, uint32_t n_valid)
 {
-    const uint32_t i = threadIdx.x;
+    begin_sample(c, threadIdx.x, n_paths, n_valid, 0u);
+}
+
+__device__ __forceinline__ void advance(DeviceCounters* c, uint32_t i, uint32_t* host_live)
+{
     if (i == 0) {
         const uint32_t live = c->n_next;
         if (c->n_cur) c->iterations += 1;
@@ -726,6 +734,11 @@ __global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
         if (host_live) __hip_atomic_store(host_live, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
+}
+
+__global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
+{
+    advance(c, threadIdx.x, host_live);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -736,8 +749,11 @@ __global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
 // With fc.batch_spp != 0 every sample of the launch is a path of its own (path i -> sample i / paths_per_sample)
 // with its own accumulator slot `sample * n_slots + slot`; the raygen seed of sample s is reached by 2*s LCG
 // steps from the pixel's tea<4> seed, exactly the state the sequential loop would have.
-__global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result)
+// The first workgroup also does the pass's queue bookkeeping (begin_sample: a launch of its own costs ~8 us with its gap).
+__global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
+                                                DeviceCounters* ctr, uint32_t n_valid, uint32_t zero_stats)
 {
+    if (ctr && blockIdx.x == 0u) begin_sample(ctr, threadIdx.x, fc.n_paths, n_valid, zero_stats);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= fc.n_paths) return;
     uint32_t i0 = i;
@@ -1149,8 +1165,11 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
 // ------------------------------------------------------------------------------------------------
 // resolve: optixPathTracer.cu:308-319
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resolve(FrameConsts fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots)
+// advance_ctr != null: the first workgroup also does the queue bookkeeping of the launch's last bounce (k_advance's work)
+__global__ __launch_bounds__(256) void k_resolve(FrameConsts fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots,
+                                                 DeviceCounters* advance_ctr)
 {
+    if (advance_ctr && blockIdx.x == 0u) advance(advance_ctr, threadIdx.x, nullptr);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     float4 r = result[i];
@@ -1199,10 +1218,11 @@ void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live)
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctr, host_live);
 }
 
-void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result)
+void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
+                   DeviceCounters* ctr, uint32_t n_valid, bool zero_stats)
 {
     const uint32_t blocks = (fc.n_paths + 255u) / 256u;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, fc, sample, q, rg_seed, result);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, fc, sample, q, rg_seed, result, ctr, n_valid, zero_stats ? 1u : 0u);
 }
 
 template <int MODE>
@@ -1332,10 +1352,11 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
         hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);
 }
 
-void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots)
+void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots,
+                    DeviceCounters* advance_ctr)
 {
     const uint32_t blocks = (n_slots + 255u) / 256u;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, st, fc, result, accum, frame, n_slots);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, st, fc, result, accum, frame, n_slots, advance_ctr);
 }
 
 void launch_unpermute(hipStream_t st, const float4* gathered, uint32_t world, uint32_t width, uint32_t height,

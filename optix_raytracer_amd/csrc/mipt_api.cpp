@@ -341,10 +341,10 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
     ctx->last_stream = st;
     const DeviceBvh bvh = device_bvh(acc);
     const TraceOpts opts = trace_opts(ctx);
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    bool advance_in_resolve = false;
     for (uint32_t s = 0; s < passes; ++s) {
-        launch_begin_sample(st, ctx->d_ctr, n_paths, pass_valid);
-        { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result); }
+        // raygen's first workgroup resets the queue counters (and, for the first pass, the launch statistics)
+        { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result, ctx->d_ctr, pass_valid, s == 0u); }
         int cur = 0;
         // MIPT_OPT_TAIL_PATHS is meant for the pool form of the tail kernel; the plain loop (BVHs that do not fit the pool's
         // packed entries, other kernel variants) pays off at a quarter of it, and not at all for depth-capped passes from
@@ -372,6 +372,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             { TimedScope t(ctx, st, T_ANY);
               launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, bound, nullptr, ctx->sq.contrib,
                                ctx->result, ctx->d_ctr, opts); }
+            if (fc.max_depth != 0u && bounce + 1u >= fc.max_depth && s + 1u == passes) { advance_in_resolve = true; break; }   // k_resolve does it
             launch_advance(st, ctx->d_ctr, ctx->h_pinned + bounce % kRing);
             cur ^= 1;
             if (fc.max_depth != 0u) {
@@ -399,7 +400,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             if (bounce > 100000u) return ctx->fail(MIPT_ERROR_INTERNAL, "path length runaway");
         }
     }
-    { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots); }
+    { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots, advance_in_resolve ? ctx->d_ctr : nullptr); }
     ctx->bounces_on_device = true;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
