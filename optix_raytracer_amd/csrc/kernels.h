@@ -61,12 +61,13 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
     MiptParallelogramLight light;
     float bg[4];
     uint32_t max_depth;
-    // sharding: world == 0 -> full frame (slot = pixel index, 8x8-tile path order)
+    // sharding: world == 0 -> full frame (slot = pixel index, path order by pixel tiles of 64: tile_shift)
     uint32_t world, rank, n_paths;   // n_paths: padded path count of one wavefront pass
     // batched samples (MIPT_OPT_BATCH_SAMPLES): all samples_per_launch samples are paths of ONE pass
     uint32_t batch_spp;              // 0 = one pass per sample (reference accumulation order), else samples_per_launch
     uint32_t paths_per_sample;       // padded paths of one sample
     uint32_t n_slots;                // accumulator slots of one sample
+    uint32_t tile_shift;             // full frames: a tile of 64 paths covers (1 << tile_shift) x (64 >> tile_shift) pixels
 };
 
 struct TraceOpts {

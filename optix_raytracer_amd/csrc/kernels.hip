@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
 }
 
 // ---- tiles + entry pool: the default traversal kernel -------------------------------------------------------
-// Bulk phase: the launch's rays are cut into tiles of 64 consecutive rays (one 8x8 pixel tile for primary rays);
+// Bulk phase: the launch's rays are cut into tiles of 64 consecutive rays (one 16x4 pixel tile for primary rays);
 // a wave takes tile after tile (statically: wave w of XCD x takes tiles w, w + W, ... of the x-th eighth -- no
 // cursor, no atomic; with the default grid of one wave per tile up to 128 per CU the hardware's workgroup
 // dispatcher is the load balancer) and walks its 64 rays with the lane state machine of stream_step.
@@ -604,7 +604,7 @@ void k_trace_pool(TraceArgs a)
 
     for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
         // ============================================================ bulk: one ray per lane, one tile at a time
-        // Groups of tile_group consecutive tiles (256: two rows of 8x8-pixel tiles at 1080p) are dealt to the XCDs in turn: a
+        // Groups of tile_group consecutive tiles (256: two rows of 16x4-pixel tiles at 1080p) are dealt to the XCDs in turn: a
         // group keeps an XCD's L2 on one region of the image, and dealing them round balances the XCDs -- with one contiguous
         // eighth of the image per XCD the ones that get its top and bottom (rays that miss everything) idle while the middle
         // ones work: closest-hit kernel of the headline frame 0.514 -> 0.458 ms, imgui_test at 1080p 5.49 -> 4.76 ms
@@ -742,7 +742,7 @@ __global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
 }
 
 // ------------------------------------------------------------------------------------------------
-// raygen: optixPathTracer.cu:249-281.  Path i -> pixel by 8x8 tiles (one wave = one tile) for full
+// raygen: optixPathTracer.cu:249-281.  Path i -> pixel by 16x4-pixel tiles (one wave = one tile; fc.tile_shift) for full
 // frames, or by the StaticWorkDistribution map for a rank's shard.  The raygen-local seed advances
 // by the two jitter draws only (the path's own stream is discarded, :260-278), so it is kept per slot.
 // ------------------------------------------------------------------------------------------------
@@ -760,11 +760,12 @@ __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample,
     if (fc.batch_spp != 0u) { sample = i / fc.paths_per_sample; i0 = i - sample * fc.paths_per_sample; }
     int px, py; uint32_t slot; bool valid;
     if (fc.world == 0u) {
-        const uint32_t tiles_x = (fc.width + 7u) >> 3;
+        const uint32_t ts = fc.tile_shift, tw = 1u << ts, th = 64u >> ts;
+        const uint32_t tiles_x = (fc.width + tw - 1u) >> ts;
         const uint32_t tile = i0 >> 6, in = i0 & 63u;
         const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        px = (int)(tx * 8u + (in & 7u));
-        py = (int)(ty * 8u + (in >> 3));
+        px = (int)(tx * tw + (in & (tw - 1u)));
+        py = (int)(ty * th + (in >> ts));
         valid = (uint32_t)px < fc.width && (uint32_t)py < fc.height;
         slot = (uint32_t)py * fc.width + (uint32_t)px;
     } else {

@@ -86,6 +86,9 @@ struct MiptContext {
     uint32_t tail_paths = 1048576;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
     bool     bounces_on_device = false;   // launch statistics: iterations counted by k_advance / k_tail
     int      tile_group = 256;
+    int      tile_shift = 4;              // path tracer, full frames: 64 paths cover 16 x 4 pixels (8 x 8: closest-hit kernel of the
+                                          // headline frame 0.440 instead of 0.413 ms; the Whitted and imgui_test raygens keep 8 x 8,
+                                          // which is 1-3 % faster on their scenes)
     // whitted.cu launches: geometry arrays of the scene (caller-owned) + material table (library copy)
     WhGeometry        wh_geo{};
     MiptMaterialData* d_wh_materials = nullptr;
@@ -455,6 +458,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
+    if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
     if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
     if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 30)) c->tail_paths = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_STEAL_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) c->steal_min = v; }
@@ -907,7 +911,9 @@ int mipt_launch(MiptContext* ctx, void* stream, const MiptParams* p, unsigned in
     if (!p->accum_buffer) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "params.accum_buffer is null");
     FrameConsts fc = make_consts(ctx, p);
     fc.world = 0; fc.rank = 0;
-    const uint32_t tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
+    fc.tile_shift = (uint32_t)ctx->tile_shift;
+    const uint32_t tw = 1u << fc.tile_shift, th = 64u >> fc.tile_shift;
+    const uint32_t tiles = ((width + tw - 1u) / tw) * ((height + th - 1u) / th);
     fc.n_paths = tiles * 64u;
     return run_wavefront(ctx, (hipStream_t)stream, fc, acc, (size_t)width * height, (float4*)p->accum_buffer, (uint32_t*)p->frame_buffer);
 }
