@@ -594,6 +594,47 @@ def test_entry_pool_beyond_four_million_triangles():
     PT.cleanupState(st)
 
 
+@pytest.mark.parametrize("kind", ["none", "one", "two", "five_with_degenerates"])
+def test_tiny_and_degenerate_scenes(kind):
+    """0, 1, 2 triangles (the forced root with an empty leaf), zero-area and duplicated triangles: the launch terminates and
+    equals the oracle"""
+    _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    base = scenes.cornell_box()
+    quad = np.asarray([[-200, 100, 300], [700, 100, 300], [250, 500, 300],          # a big triangle in front of the camera
+                       [0, 0, 100], [556, 0, 100], [278, 548, 500]], np.float32)
+    tris = {"none": np.zeros((0, 3), np.float32), "one": quad[:3], "two": quad,
+            "five_with_degenerates": np.concatenate([quad, quad[:3],                            # a duplicate
+                                                     np.asarray([[100, 100, 200]] * 3, np.float32),       # a point
+                                                     np.asarray([[0, 0, 50], [100, 100, 50], [200, 200, 50]], np.float32)])}[kind]  # a line
+    scene = dict(base)
+    v = np.zeros((tris.shape[0], 4), np.float32); v[:, :3] = tris
+    scene["vertices"] = v
+    scene["mat_index"] = (np.arange(tris.shape[0] // 3) % 4).astype(np.uint32)
+    w, h = 64, 48
+    if kind == "none":
+        # an empty vertex buffer is a null device pointer: the hit-group records are refused, not dereferenced
+        with pytest.raises(Exception, match="null vertex pointer"):
+            _state(scene, w, h, 2, 4)
+        return
+    PT2, st = _state(scene, w, h, 2, 4)
+    info = st.context.accel_info(st.gas_handle)
+    assert info["num_triangles"] == tris.shape[0] // 3
+    acc, frame, stats = _render_gpu(PT2, st)
+    osc = _oracle_scene(scene, st)
+    a, f, ost = osc.render(scenes.launch_desc(scene, w, h, 2), max_depth=4, threads=2)
+    _assert_pixels(acc, a)
+    assert np.array_equal(frame, f)
+    assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"]
+    for variant in (0, 2):
+        st.context.set_option(L.OPT_PERSISTENT, variant)
+        acc2, _, _ = _render_gpu(PT2, st)
+        assert np.array_equal(acc2.view(np.uint32), acc.view(np.uint32)), variant
+    PT2.cleanupState(st)
+
+
 def test_device_build_reads_every_input_form():
     """indexed u16 / u32 / non-indexed inputs, strided vertices, a 3x4 transform, SBT offsets + geometry flags, host and
     device pointers: the device-side input assembly makes the same triangles as the host builder's"""
