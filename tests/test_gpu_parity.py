@@ -635,6 +635,53 @@ def test_tiny_and_degenerate_scenes(kind):
     PT2.cleanupState(st)
 
 
+def test_non_finite_rays_terminate_and_agree():
+    """NaN / infinite / zero ray components: every traversal kernel terminates and all of them -- and the oracle -- report
+    the same hits (comparisons with NaN are false everywhere, min / max return the non-NaN operand on both sides)"""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import scenes
+    scene = scenes.random_soup(30000)
+    PT, st = _state(scene, 32, 32)
+    osc = _oracle_scene(scene, st)
+    rng = np.random.default_rng(23)
+    n = 4096
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3] = rng.uniform(-0.2, 1.2, (n, 3))
+    rays[:, 4:7] = rng.normal(size=(n, 3))
+    rays[:, 3], rays[:, 7] = 0.01, 1e16
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    k = 0
+    for col, val in ((0, nan), (4, nan), (5, inf), (6, -inf), (3, nan), (7, nan), (7, inf), (3, -inf), (0, inf), (1, -inf)):
+        rays[k:k + 64, col] = val; k += 64
+    rays[k:k + 64, 4:7] = 0.0; k += 64                                   # zero direction
+    rays[k:k + 64, 4:7] = [inf, inf, inf]; k += 64
+    rays[k:k + 64, 4:7] = nan; k += 64
+    rays[k:k + 64, 3] = -1.0; k += 64                                    # negative tmin
+    d_rays = torch.from_numpy(rays).cuda()
+    results = {}
+    for variant in (3, 2, 0):
+        st.context.set_option(L.OPT_PERSISTENT, variant)
+        d_hits = torch.full((n, 4), 7.0, dtype=torch.float32, device="cuda")
+        d_occ = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+        st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), n, d_hits.data_ptr())
+        st.context.trace_any(st.gas_handle, d_rays.data_ptr(), n, d_occ.data_ptr())
+        st.context.sync()
+        results[variant] = (d_hits.cpu().numpy(), d_occ.cpu().numpy())
+    h3, o3 = results[3]
+    for variant in (2, 0):
+        hv, ov = results[variant]
+        assert np.array_equal(hv[:, :2].view(np.uint32), h3[:, :2].view(np.uint32)), variant
+        assert np.array_equal(ov, o3), variant
+    t, prim, u, v = osc.trace_closest(rays, O.MODE_BVH)
+    assert np.array_equal(h3[:, 1].view(np.uint32), prim)
+    assert np.array_equal(h3[:, 0].view(np.uint32), t.view(np.uint32))
+    occ = osc.trace_any(rays, O.MODE_BVH)
+    assert np.array_equal(o3 != 0, np.asarray(occ) != 0)
+    assert (prim[k:] != 0xffffffff).mean() > 0.05                        # the ordinary rays still hit things
+    PT.cleanupState(st)
+
+
 def test_device_build_reads_every_input_form():
     """indexed u16 / u32 / non-indexed inputs, strided vertices, a 3x4 transform, SBT offsets + geometry flags, host and
     device pointers: the device-side input assembly makes the same triangles as the host builder's"""
