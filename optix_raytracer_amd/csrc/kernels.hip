@@ -466,7 +466,7 @@ __device__ __forceinline__ bool range_grab(const TraceArgs& a, RayRange& r, uint
 // read from the registers of lane s; its best hit is merged in LDS (min t, tie -> lowest primitive).
 template <int MODE, int CAP>
 __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
-                                           unsigned long long* sh_best, float* sh_u, float* sh_v, int* sh_pending, uint32_t* sh_done,
+                                           unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, int& psize, const bool cull_back)
 {
     constexpr int kPoolCap = CAP;
@@ -556,7 +556,6 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
             npush = 1;
         }
     }
-    if (have && npush != 1) atomicAdd(&sh_pending[slot], npush - 1);
     {
         const unsigned long long m2 = __ballot(npush == 2);
         if (m2 != 0ull) {
@@ -586,7 +585,6 @@ void k_trace_pool(TraceArgs a)
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);   // per ray slot
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
-    int* const sh_pending = reinterpret_cast<int*>(stk + kPoolCap + 256);       // pool entries of the slot's ray
     uint32_t* const sh_done = stk + kPoolCap + 320;                             // any-hit: an occluder was found
     const int lane = (int)threadIdx.x;
     const bool cull_back = MODE == 0 && (a.ray_flags & 16u) != 0u;   // MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES: det < 0 is a back face
@@ -656,10 +654,9 @@ void k_trace_pool(TraceArgs a)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
         sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
-        sh_pending[lane] = has_ray ? T.sp + 1 : 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         while (psize > 0)
-            pool_round<MODE, kPoolCap>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, cull_back);
+            pool_round<MODE, kPoolCap>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back);
         if (has_ray) {
             const unsigned long long key = sh_best[lane];
             T.tbest = ord_float((uint32_t)(key >> 32)); T.prim = (uint32_t)key; T.u = sh_u[lane]; T.v = sh_v[lane];
@@ -1050,20 +1047,19 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
 // 0.38 ms; the headline frame run this way 1.05 / 1.08 vs 0.95 ms).
 template <int MODE>
 __device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
-                                           unsigned long long* sh_best, float* sh_u, float* sh_v, int* sh_pending, uint32_t* sh_done,
+                                           unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, const bool has_ray, const bool cull_back = false)
 {
     constexpr int kPoolCap = 24 * 64 - 384;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
     sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u;
-    sh_pending[lane] = has_ray ? 1 : 0;
     const unsigned long long m = __ballot(has_ray);
     if (has_ray) stk[(int)lane_rank(m)] = pool_pack(0, (uint32_t)lane);
     int psize = __popcll(m);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     while (psize > 0)
-        pool_round<MODE, kPoolCap>(blob, tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, psize, cull_back);
+        pool_round<MODE, kPoolCap>(blob, tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back);
 }
 
 __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
@@ -1073,7 +1069,6 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
-    int* const sh_pending = reinterpret_cast<int*>(stk + kPoolCap + 256);
     uint32_t* const sh_done = stk + kPoolCap + 320;
     const int lane = (int)threadIdx.x;
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
@@ -1089,7 +1084,7 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
     while (__ballot(active) != 0ull) {
         Trav T;
         trav_init(T, ro4, rd4);
-        tail_trace<0>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, active && T.node != kSentinel);
+        tail_trace<0>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, T, active && T.node != kSentinel);
         const unsigned long long key = sh_best[lane];
         const uint32_t prim = (uint32_t)key;
         const float4 hit = prim != 0xffffffffu ? make_float4(ord_float((uint32_t)(key >> 32)), u2f(prim), sh_u[lane], sh_v[lane])
@@ -1104,7 +1099,7 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
         if (__ballot(sh) != 0ull) {
             Trav S;
             trav_init(S, sh ? o.sro : ro4, sh ? o.srd : rd4);
-            tail_trace<2>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, S, sh && S.node != kSentinel);
+            tail_trace<2>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel);
             if (sh) {
                 ++n_shadow;
                 if (sh_done[lane] == 0u) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
@@ -1135,7 +1130,6 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
-    int* const sh_pending = reinterpret_cast<int*>(stk + kPoolCap + 256);
     uint32_t* const sh_done = stk + kPoolCap + 320;
     const int lane = (int)threadIdx.x;
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
@@ -1151,7 +1145,7 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
-        tail_trace<MODE>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_pending, sh_done, lane, T, mine && T.node != kSentinel,
+        tail_trace<MODE>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel,
                          MODE == 0 && (a.ray_flags & 16u) != 0u);
         if (mine) {
             if (MODE == 0) {
