@@ -38,6 +38,7 @@ struct DeviceBvh {
     uint32_t tri_byte_off;     // tris == (char*)nodes + tri_byte_off (one allocation); 0 if that offset needs > 32 bits
     uint32_t blob_bytes;       // size of that allocation (buffer-descriptor range)
     uint32_t depth;            // deepest leaf (stack entries a ray can need)
+    uint32_t pool2_ok;         // ... and k_tail_pool2's (7-bit slots): < 2^24 nodes, < 2^22 triangles
     uint32_t pool_ok;          // fits the entry pool's packed words: < 2^25 nodes, 2 .. 2^23 - 1 triangles, leaves of 1 .. 4
 };
 

@@ -1116,6 +1116,214 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
     if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
 }
 
+// ---- k_tail_pool2: the occlusion ray of bounce b and the closest-hit ray of bounce b + 1 of every path in ONE pool pass ------
+// The tail of a pass is bound by the chain of dependent fetches per bounce (closest hit, then shading, then the occlusion ray);
+// the two rays are independent once bounce b is shaded, so tracing them together halves the chain.  Entries carry a 7-bit slot
+// (bit 6: the lane's occlusion ray, kept in LDS; else its closest-hit ray, in the lane's registers): bit 31 leaf | 24-bit
+// payload | 7-bit slot, i.e. < 2^24 nodes and < 2^22 triangles (DeviceBvh::pool2_ok).  The accumulator still receives its terms
+// in the reference's order: the occlusion result of bounce b is added after the pass, before bounce b + 1 is shaded.
+__device__ __forceinline__ uint32_t pool_pack2(int ref, uint32_t slot7)
+{
+    if (ref >= 0) return ((uint32_t)ref << 7) | slot7;
+    const uint32_t desc = ~(uint32_t)ref;
+    return 0x80000000u | ((desc >> 4) << 9) | (((desc - 1u) & 3u) << 7) | slot7;
+}
+
+template <int CAP>
+__device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
+                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done, const float* sray,
+                                            const int lane, const Trav& T, int& psize)
+{
+    int k = psize < 64 ? psize : 64;
+    const int room = CAP - 104 - psize;
+    if (k > room) k = room > 1 ? room : 1;
+    const bool have = lane < k;
+    uint32_t ent = 0u;
+    if (have) ent = stk[psize - 1 - lane];
+    psize -= k;
+    const uint32_t slot7 = ent & 127u, ls = slot7 & 63u;
+    const bool is_s = have && (slot7 & 64u) != 0u;
+    float ox = shfl_f(T.o.x, ls), oy = shfl_f(T.o.y, ls), oz = shfl_f(T.o.z, ls);
+    float dx = shfl_f(T.d.x, ls), dy = shfl_f(T.d.y, ls), dz = shfl_f(T.d.z, ls);
+    float ix = shfl_f(T.idir.x, ls), iy = shfl_f(T.idir.y, ls), iz = shfl_f(T.idir.z, ls);
+    float nx = shfl_f(T.nood.x, ls), ny = shfl_f(T.nood.y, ls), nz = shfl_f(T.nood.z, ls);
+    float tmn = shfl_f(T.tmin, ls), tmx = shfl_f(T.tmax, ls);
+    if (__ballot(is_s) != 0ull) {
+        if (is_s) {
+            ox = sray[0 * 64 + ls]; oy = sray[1 * 64 + ls]; oz = sray[2 * 64 + ls];
+            dx = sray[3 * 64 + ls]; dy = sray[4 * 64 + ls]; dz = sray[5 * 64 + ls];
+            ix = sray[6 * 64 + ls]; iy = sray[7 * 64 + ls]; iz = sray[8 * 64 + ls];
+            nx = sray[9 * 64 + ls]; ny = sray[10 * 64 + ls]; nz = sray[11 * 64 + ls];
+            tmn = sray[12 * 64 + ls]; tmx = sray[13 * 64 + ls];
+        }
+    }
+    float tcur = tmx;
+    bool live = have;
+    if (have) {
+        if (is_s) { if (sh_done[ls] != 0u) live = false; }
+        else      tcur = ord_float((uint32_t)(sh_best[ls] >> 32));
+    }
+    const bool leaf = (ent >> 31) != 0u;
+    const uint32_t payload = (ent >> 7) & 0xffffffu;
+    const uint32_t lfirst = payload >> 2, lcnt = (payload & 3u) + 1u;
+    const bool do_inner = live && !leaf;
+    const bool do_tri   = live && leaf;
+    uint32_t off = 0u;
+    if (do_inner) off = payload << 6;
+    if (do_tri)   off = tri_byte_off + lfirst * 48u;
+    const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
+    asm volatile("" ::: "memory");
+    uint32_t push0 = 0u, push1 = 0u;
+    int npush = 0;
+    if (do_inner) {
+        const float ax0 = __builtin_fmaf(n0.x, ix, nx), ax1 = __builtin_fmaf(n0.y, ix, nx);
+        const float ay0 = __builtin_fmaf(n0.z, iy, ny), ay1 = __builtin_fmaf(n0.w, iy, ny);
+        const float az0 = __builtin_fmaf(n2.x, iz, nz), az1 = __builtin_fmaf(n2.y, iz, nz);
+        const float bx0 = __builtin_fmaf(n1.x, ix, nx), bx1 = __builtin_fmaf(n1.y, ix, nx);
+        const float by0 = __builtin_fmaf(n1.z, iy, ny), by1 = __builtin_fmaf(n1.w, iy, ny);
+        const float bz0 = __builtin_fmaf(n2.z, iz, nz), bz1 = __builtin_fmaf(n2.w, iz, nz);
+        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                          __builtin_fmaxf(__builtin_fminf(az0, az1), tmn));
+        const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                          __builtin_fminf(__builtin_fmaxf(az0, az1), tcur));
+        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
+                                          __builtin_fmaxf(__builtin_fminf(bz0, bz1), tmn));
+        const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
+                                          __builtin_fminf(__builtin_fmaxf(bz0, bz1), tcur));
+        const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+        const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+        if (h0 && h1) {
+            const bool swp = tn1 < tn0;
+            push0 = pool_pack2(swp ? c0 : c1, slot7);
+            push1 = pool_pack2(swp ? c1 : c0, slot7);
+            npush = 2;
+        } else if (h0 || h1) {
+            push1 = pool_pack2(h0 ? c0 : c1, slot7);
+            npush = 1;
+        }
+    }
+    if (do_tri) {
+        const f3 rd = mk3(dx, dy, dz);
+        const f3 e1 = mk3(n1.x, n1.y, n1.z), e2 = mk3(n2.x, n2.y, n2.z);
+        const f3 p = fcross(rd, e2);
+        const float det = fdot(e1, p);
+        const float inv = 1.0f / det;
+        const f3 tv = mk3(ox, oy, oz) - mk3(n0.x, n0.y, n0.z);
+        const float u = fdot(tv, p) * inv;
+        const f3 q = fcross(tv, e1);
+        const float v = fdot(rd, q) * inv;
+        const float t = fdot(e2, q) * inv;
+        const uint32_t prim = f2u(n0.w);
+        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmn && t < tmx;
+        bool stop = false;
+        if (ok) {
+            if (is_s) { sh_done[ls] = 1u; stop = true; }
+            else {
+                const unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
+                atomicMin(&sh_best[ls], key);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (*(volatile unsigned long long*)&sh_best[ls] == key) { sh_u[ls] = u; sh_v[ls] = v; }
+            }
+        }
+        if (!stop && lcnt > 1u) {
+            push1 = 0x80000000u | ((lfirst + 1u) << 9) | ((lcnt - 2u) << 7) | slot7;
+            npush = 1;
+        }
+    }
+    {
+        const unsigned long long m2 = __ballot(npush == 2);
+        if (m2 != 0ull) {
+            if (npush == 2) stk[psize + (int)lane_rank(m2)] = push0;
+            psize += __popcll(m2);
+        }
+        const unsigned long long m1 = __ballot(npush >= 1);
+        if (m1 != 0ull) {
+            if (npush >= 1) stk[psize + (int)lane_rank(m1)] = push1;
+            psize += __popcll(m1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+__global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
+{
+    constexpr int kCap = 1152;
+    __shared__ uint32_t lds[kCap + 128 + 3 * 64 + 14 * 64];
+    uint32_t* const stk = lds;
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(lds + kCap);
+    float* const sh_u = reinterpret_cast<float*>(lds + kCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(lds + kCap + 192);
+    uint32_t* const sh_done = lds + kCap + 256;
+    float* const sray = reinterpret_cast<float*>(lds + kCap + 320);
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+    uint32_t n = a.ctr->n_cur;
+    n = n < a.n_max ? n : a.n_max;
+    const uint32_t i = blockIdx.x * ppw + threadIdx.x;
+    uint32_t n_closest = 0, n_shadow = 0, n_iter = 0;
+    uint32_t slot = kInvalidSlot, depth = 0;
+    if (i < n && threadIdx.x < ppw) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
+    bool active = slot != kInvalidSlot;
+    float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
+    if (active) { ro4 = a.cur.ray_o[i]; rd4 = a.cur.ray_d[i]; sa = a.cur.state_a[i]; res = a.result[slot]; }
+    bool has_s = false;                          // an occlusion ray of the previous bounce is waiting (in LDS)
+    float cx = 0.f, cy = 0.f, cz = 0.f;          // what it adds when nothing is in its way
+    while (__ballot(active || has_s) != 0ull) {
+        Trav T;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
+        T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
+        if (active) trav_init(T, ro4, rd4);
+        const bool has_c = active && T.node != kSentinel;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
+        sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u;
+        const unsigned long long mc = __ballot(has_c), ms = __ballot(has_s);
+        if (has_c) stk[(int)lane_rank(mc)] = pool_pack2(0, (uint32_t)lane);
+        int psize = __popcll(mc);
+        if (has_s) stk[psize + (int)lane_rank(ms)] = pool_pack2(0, 64u + (uint32_t)lane);
+        psize += __popcll(ms);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        while (psize > 0) pool_round2<kCap>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, sray, lane, T, psize);
+        // the previous bounce's light term first: the accumulator gets its terms in the reference's order
+        if (has_s) {
+            if (sh_done[lane] == 0u) { res.x += cx; res.y += cy; res.z += cz; }      // finish_ray<2>
+            has_s = false;
+        }
+        if (active) {
+            const unsigned long long key = sh_best[lane];
+            const uint32_t prim = (uint32_t)key;
+            const float4 hit = prim != 0xffffffffu ? make_float4(ord_float((uint32_t)(key >> 32)), u2f(prim), sh_u[lane], sh_v[lane])
+                                                   : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+            ShadeOut o;
+            ++n_iter;
+            shade_path(a, hit, sa, slot, depth, res, o, [&](float4& o4, float4& d4) { o4 = ro4; d4 = rd4; });
+            if (o.push_shadow) {
+                ++n_shadow;
+                Trav S;
+                trav_init(S, o.sro, o.srd);
+                if (S.node != kSentinel) {
+                    sray[0 * 64 + lane] = S.o.x;    sray[1 * 64 + lane] = S.o.y;     sray[2 * 64 + lane] = S.o.z;
+                    sray[3 * 64 + lane] = S.d.x;    sray[4 * 64 + lane] = S.d.y;     sray[5 * 64 + lane] = S.d.z;
+                    sray[6 * 64 + lane] = S.idir.x; sray[7 * 64 + lane] = S.idir.y;  sray[8 * 64 + lane] = S.idir.z;
+                    sray[9 * 64 + lane] = S.nood.x; sray[10 * 64 + lane] = S.nood.y; sray[11 * 64 + lane] = S.nood.z;
+                    sray[12 * 64 + lane] = S.tmin;  sray[13 * 64 + lane] = S.tmax;
+                    has_s = true; cx = o.sc.x; cy = o.sc.y; cz = o.sc.z;
+                } else {
+                    res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z;              // an empty interval is not occluded
+                }
+            }
+            active = o.push_next;
+            if (active) { ++n_closest; ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y; }
+        }
+    }
+    if (slot != kInvalidSlot) a.result[slot] = res;
+    wave_add64(&a.ctr->closest_rays, n_closest);
+    wave_add64(&a.ctr->shadow_rays, n_shadow);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t v = (uint32_t)__shfl_down((int)n_iter, off, 64); n_iter = v > n_iter ? v : n_iter; }
+    if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
+}
+
 // Static chunks of `ppw` rays per wave, traversed together on the entry pool from the root (tail_trace): every any-hit launch
 // of the default variant and its closest-hit launches with few rays (launch_trace has the sizes and the measurements).
 // Occlusion rays start at scattered hit points and stop at the first hit, so the one-ray-per-lane bulk phase of k_trace_pool
@@ -1341,7 +1549,10 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
             ppw = ((n_max + slots - 1u) / slots + 15u) & ~15u;
             ppw = ppw < 16u ? 16u : (ppw > 64u ? 64u : ppw);
         }
-        hipLaunchKernelGGL(k_tail_pool, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+        if (fc.max_depth != 1u && bvh.pool2_ok != 0u)
+            hipLaunchKernelGGL(k_tail_pool2, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);     // more than one bounce: two rays per pass
+        else
+            hipLaunchKernelGGL(k_tail_pool, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
     }
     else
         hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);

@@ -277,6 +277,7 @@ DeviceBvh device_bvh(const Accel* a)
     DeviceBvh b{};
     b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes; b.depth = a->depth;
     b.pool_ok = (a->num_nodes < (1u << 25) && a->num_tris >= 2u && a->num_tris < (1u << 23) && a->leaf_max <= 4u) ? 1u : 0u;
+    b.pool2_ok = (b.pool_ok && a->num_nodes < (1u << 24) && a->num_tris < (1u << 22)) ? 1u : 0u;
     return b;
 }
 

@@ -43,3 +43,4 @@ soak("soup 1M 512x512 unbounded (path kernel, long tails)", soup, 512, 512, 1, 0
 soak("soup 1M 1080p depth 8 (wavefront, then path kernel)", soup, 1920, 1080, 1, 8)
 soak("shards of the headline frame, world 8", soup, 1920, 1080, 1, 1, shard_world=8)
 soak("Cornell 512x512 unbounded", scenes.cornell_box(), 512, 512, 1, 0)
+soak("soup 1M 256x256 spp 4 depth 4 (two rays per pool pass)", soup, 256, 256, 4, 4)
