@@ -203,7 +203,7 @@ struct Aabb {
 
 // ------------------------------------------------------------------------------------------------ scene
 struct View {                     // cuda/BufferView.h:33-49 on host memory
-    int buffer = -1; size_t offset = 0; uint32_t count = 0; uint16_t byte_stride = 0, elmt_byte_size = 0;
+    int buffer = -1; size_t offset = 0; uint32_t count = 0; uint16_t byte_stride = 0, elmt_byte_size = 0, ncomp = 0;
     bool valid() const { return buffer >= 0; }
 };
 struct Primitive { View indices, positions, normals, texcoords[2], colors; int material = -1; };
@@ -229,7 +229,30 @@ struct MiptScene {
 
 namespace {
 
-View view_from_accessor(const Json& root, const MiptScene& sc, int accessor_idx)     // Scene.cpp:83-123
+// A glTF number that is used as a byte offset, a count or a stride: finite, >= 0, an integer below 2^53 (what a double holds
+// exactly); anything else is rejected before the cast (a negative or huge double -> size_t is undefined behaviour).
+size_t checked_size(const Json& o, const char* key, const char* what)
+{
+    const double d = o.number(key, 0);
+    if (!(d >= 0.0) || !(d <= 9007199254740992.0) || d != std::floor(d))
+        throw std::runtime_error(std::string("glTF: ") + what + " is not a non-negative integer");
+    return (size_t)d;
+}
+
+int accessor_components(const std::string& t)
+{
+    if (t == "SCALAR") return 1;
+    if (t == "VEC2") return 2;
+    if (t == "VEC3") return 3;
+    if (t == "VEC4" || t == "MAT2") return 4;
+    if (t == "MAT3") return 9;
+    if (t == "MAT4") return 16;
+    throw std::runtime_error("glTF: unknown accessor type");
+}
+
+// want_comp != 0: the accessor must have exactly that many components (POSITION / NORMAL 3, TEXCOORD 2, COLOR_0 4, indices 1),
+// because that is how many the flatten functions read per element.
+View view_from_accessor(const Json& root, const MiptScene& sc, int accessor_idx, int want_comp = 0)     // Scene.cpp:83-123
 {
     View v;
     if (accessor_idx < 0) return v;
@@ -242,21 +265,27 @@ View view_from_accessor(const Json& root, const MiptScene& sc, int accessor_idx)
     const int ct = a.integer("componentType", 0);
     const int esz = ct == 5123 ? 2 : ct == 5125 ? 4 : ct == 5126 ? 4 : 0;
     if (!esz) throw std::runtime_error("gltf accessor component type not supported");
+    const int ncomp = accessor_components(a.string("type", "SCALAR"));
+    if (want_comp != 0 && ncomp != want_comp) throw std::runtime_error("glTF: accessor type does not match the attribute it is used for");
+    const size_t elem = (size_t)esz * (size_t)ncomp;                       // bytes read per element
     v.buffer = bv.integer("buffer", -1);
     if (v.buffer < 0 || (size_t)v.buffer >= sc.buffers.size()) throw std::runtime_error("glTF: bufferView.buffer out of range");
-    v.offset = (size_t)bv.number("byteOffset", 0) + (size_t)a.number("byteOffset", 0);
-    v.byte_stride = (uint16_t)bv.integer("byteStride", 0);
-    v.count = (uint32_t)a.number("count", 0);
+    const size_t buf_size = sc.buffers[(size_t)v.buffer].size();
+    const size_t off_bv = checked_size(bv, "byteOffset", "bufferView.byteOffset"), off_a = checked_size(a, "byteOffset", "accessor.byteOffset");
+    const size_t count = checked_size(a, "count", "accessor.count"), stride_in = checked_size(bv, "byteStride", "bufferView.byteStride");
+    if (off_bv > buf_size || off_a > buf_size - off_bv) throw std::runtime_error("glTF: accessor starts past the end of its buffer");
+    if (count > 0xffffffffull) throw std::runtime_error("glTF: accessor.count does not fit 32 bits");
+    if (stride_in >= 65536 || (stride_in != 0 && stride_in < elem)) throw std::runtime_error("glTF: bufferView.byteStride is smaller than an element or >= 65536");
+    v.offset = off_bv + off_a;
+    v.byte_stride = (uint16_t)(stride_in ? stride_in : elem);
+    v.count = (uint32_t)count;
     v.elmt_byte_size = (uint16_t)esz;
-    if (v.byte_stride == 0) {
-        const std::string t = a.string("type", "SCALAR");
-        int n = 1;
-        if (t == "VEC2") n = 2; else if (t == "VEC3") n = 3; else if (t == "VEC4" || t == "MAT2") n = 4;
-        else if (t == "MAT3") n = 9; else if (t == "MAT4") n = 16;
-        v.byte_stride = (uint16_t)(esz * n);
+    v.ncomp = (uint16_t)ncomp;
+    if (count) {
+        // offset + (count - 1) * stride + elem <= buf_size, without overflow (count < 2^32, stride < 2^16, offset <= buf_size)
+        const size_t room = buf_size - v.offset;
+        if (elem > room || (count - 1) > (room - elem) / v.byte_stride) throw std::runtime_error("glTF: accessor reaches past the end of its buffer");
     }
-    const size_t need = v.count ? v.offset + (size_t)(v.count - 1) * v.byte_stride + (size_t)esz : v.offset;
-    if (need > sc.buffers[(size_t)v.buffer].size()) throw std::runtime_error("glTF: accessor reaches past the end of its buffer");
     return v;
 }
 
@@ -335,7 +364,7 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
                 if (comma == std::string::npos) throw std::runtime_error("glTF: bad data URI");
                 data = base64_decode(uri, comma + 1);
             } else data = read_file(dir + uri);
-            const size_t want = (size_t)b.number("byteLength", 0);
+            const size_t want = checked_size(b, "byteLength", "buffer.byteLength");
             if (data.size() < want) throw std::runtime_error("glTF: buffer shorter than byteLength");
             data.resize(want);
             sc.buffers.push_back(std::move(data));
@@ -357,8 +386,8 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
                 } else if (bv_idx >= 0 && (size_t)bv_idx < root.at("bufferViews").size()) {
                     const Json& bv = root.at("bufferViews").arr[(size_t)bv_idx];
                     const int b = bv.integer("buffer", -1);
-                    const size_t off = (size_t)bv.number("byteOffset", 0), len = (size_t)bv.number("byteLength", 0);
-                    if (b < 0 || (size_t)b >= sc.buffers.size() || off + len > sc.buffers[(size_t)b].size()) throw std::runtime_error("image bufferView out of range");
+                    const size_t off = checked_size(bv, "byteOffset", "bufferView.byteOffset"), len = checked_size(bv, "byteLength", "bufferView.byteLength");
+                    if (b < 0 || (size_t)b >= sc.buffers.size() || off > sc.buffers[(size_t)b].size() || len > sc.buffers[(size_t)b].size() - off) throw std::runtime_error("image bufferView out of range");
                     bytes.assign(sc.buffers[(size_t)b].begin() + (long)off, sc.buffers[(size_t)b].begin() + (long)(off + len));
                 } else throw std::runtime_error("image without uri or bufferView");
             } catch (const std::exception& e) { why = e.what(); }
@@ -436,21 +465,22 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
                 for (const Json& gp : prims->arr) {
                     if (gp.integer("mode", 4) != 4) continue;        // ignore non-triangle primitives (:459-463)
                     Primitive p;
-                    p.indices = view_from_accessor(root, sc, gp.integer("indices", -1));
+                    p.indices = view_from_accessor(root, sc, gp.integer("indices", -1), 1);
                     p.material = gp.integer("material", -1);
                     const Json& attrs = gp.at("attributes");
                     const int pos_idx = attrs.integer("POSITION", -1);
                     if (pos_idx < 0) throw std::runtime_error("glTF: primitive without POSITION");
-                    p.positions = view_from_accessor(root, sc, pos_idx);
-                    if (p.positions.elmt_byte_size != 4) throw std::runtime_error("glTF: POSITION must be float");
-                    p.normals = view_from_accessor(root, sc, attrs.integer("NORMAL", -1));           // Scene.cpp:490-498
+                    if ((size_t)pos_idx >= root.at("accessors").size()) throw std::runtime_error("glTF: accessor index out of range");
+                    if (root.at("accessors").arr[(size_t)pos_idx].integer("componentType", 0) != 5126) throw std::runtime_error("glTF: POSITION must be float");
+                    p.positions = view_from_accessor(root, sc, pos_idx, 3);                          // float VEC3: flatten reads 12 bytes per vertex
                     auto float_view = [&](const char* name, const char* type) {                        // :502-531, float accessors only
                         const int ai = attrs.integer(name, -1);
                         if (ai < 0 || (size_t)ai >= root.at("accessors").size()) return View();
                         const Json& acc = root.at("accessors").arr[(size_t)ai];
                         if (acc.integer("componentType", 0) != 5126 || acc.string("type", "") != type) return View();
-                        return view_from_accessor(root, sc, ai);
+                        return view_from_accessor(root, sc, ai, accessor_components(type));
                     };
+                    p.normals = float_view("NORMAL", "VEC3");                                          // Scene.cpp:490-498; read as 3 floats
                     p.texcoords[0] = float_view("TEXCOORD_0", "VEC2");
                     p.texcoords[1] = float_view("TEXCOORD_1", "VEC2");
                     p.colors = float_view("COLOR_0", "VEC4");

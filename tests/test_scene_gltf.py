@@ -72,6 +72,57 @@ def test_default_camera_and_errors(tmp_path):
     assert "not supported" in str(e.value)
 
 
+def test_malformed_accessors_are_refused(tmp_path):
+    """An accessor whose `type` is narrower than what the attribute is read as, or whose numbers are negative, huge or
+    non-finite, must be refused at load -- not read past the end of its buffer in mipt_scene_flatten (found with ASan:
+    a SCALAR float POSITION of count 3 over a 12-byte buffer used to load)."""
+    import base64
+    import json
+    tri = np.array([0, 0, 0], np.float32).tobytes()                     # 12 bytes: ONE vec3, or three scalars
+    def doc(acc, bv=None, extra_attr=None):
+        attrs = {"POSITION": 0}
+        accs = [acc]
+        if extra_attr:
+            attrs[extra_attr[0]] = 1
+            accs.append(extra_attr[1])
+        return {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+                "meshes": [{"primitives": [{"attributes": attrs}]}],
+                "buffers": [{"byteLength": 12, "uri": "data:application/octet-stream;base64," + base64.b64encode(tri).decode()}],
+                "bufferViews": [bv or {"buffer": 0, "byteOffset": 0, "byteLength": 12}], "accessors": accs}
+    good = {"bufferView": 0, "componentType": 5126, "count": 1, "type": "VEC3"}
+    ok = tmp_path / "ok.gltf"
+    ok.write_text(json.dumps(doc(good)))
+    assert api.Scene(ok).info()["num_triangles"] == 0
+    cases = {
+        "scalar_position": doc(dict(good, type="SCALAR", count=3)),
+        "vec2_position": doc(dict(good, type="VEC2", count=1)),
+        "count_past_end": doc(dict(good, count=2)),
+        "negative_offset": doc(dict(good, byteOffset=-4)),
+        "huge_offset": doc(dict(good, byteOffset=1e300)),
+        "fractional_count": doc(dict(good, count=1.5)),
+        "huge_count": doc(dict(good, count=2 ** 40)),
+        "stride_smaller_than_element": doc(good, bv={"buffer": 0, "byteOffset": 0, "byteLength": 12, "byteStride": 4}),
+        "stride_too_large": doc(good, bv={"buffer": 0, "byteOffset": 0, "byteLength": 12, "byteStride": 70000}),
+        "negative_view_offset": doc(good, bv={"buffer": 0, "byteOffset": -1, "byteLength": 12}),
+        "unknown_type": doc(dict(good, type="VEC5")),
+        "scalar_normal_is_ignored_not_read": None,
+    }
+    for name, d in cases.items():
+        if d is None:
+            continue
+        p = tmp_path / (name + ".gltf")
+        p.write_text(json.dumps(d).replace("1e+300", "1e300"))
+        with pytest.raises(api.MiptError):
+            api.Scene(p)
+    # a NORMAL / TEXCOORD / COLOR accessor of the wrong shape is treated as absent (the reference reads float VEC2 / VEC4 only,
+    # Scene.cpp:502-531), never read as a wider element
+    d = doc(dict(good, count=1), extra_attr=("NORMAL", {"bufferView": 0, "componentType": 5126, "count": 3, "type": "SCALAR"}))
+    p = tmp_path / "scalar_normal.gltf"
+    p.write_text(json.dumps(d))
+    sc = api.Scene(p)
+    assert sc.info()["num_triangles"] == 0
+
+
 @pytest.mark.skipif(not os.path.exists(DUCK), reason="reference assets are only present in the build container")
 def test_duck_kats_from_the_reference_loader():
     """values printed by the reference's own Scene/Matrix/Aabb/Camera code for Duck.gltf"""
