@@ -22,7 +22,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SPP, N_TRIS, MAX_DEPTH = 1920, 1080, 1, 1_000_000, 1
-HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# ceilings, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # HBM3E 8.0 TB/s spec (:36)
+L2_PEAK_GBS = 34500.0      # aggregate L2, 8 XCDs (:316)
+CLOCK_HZ = 2.4e9           # max clock (:34)
+N_CUS, N_SIMDS = 256, 1024
+VALU_CYCLES = 2.0          # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles when other waves fill the SIMD (:54, :473)
+L1_PEAK_ACC_PER_CU_CLK = 1.0   # the vector L1 (TCP) looks up one cache line per cycle: a lane-divergent 16-byte load costs a
+                               # lookup per lane (DESIGN.md 3.1 "what bounds it": measured 64 per wave instruction)
 
 
 def parse():
@@ -48,16 +55,43 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    written by tools/prof_traffic.sh + tools/traffic_json.py): 2*FETCH_SIZE + WRITE_SIZE, in bytes -- FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950.  None when no profile of this kernel is on file."""
+def pmc_counters(kernel):
+    """Per-launch PMC counters of `kernel` from the COMMITTED rocprofv3 passes (profiles/pmc_kernels.json, written by
+    tools/prof_l1.sh + tools/pmc_json.py; the file names the commit it was measured on).  They are properties of the
+    kernel on this workload, not of this run: bench.py cannot collect them itself (that takes ~20 rocprofv3 passes).
+    None when no profile of this kernel is on file."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        e = d["kernels"][kernel]
-        return int((2.0 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024)
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_kernels.json")))
+        return d["kernels"][kernel], {"file": "profiles/pmc_kernels.json", "commit": d.get("commit"), "source": d.get("source")}
     except Exception:
-        return None
+        return None, None
+
+
+def ceilings(counters, t_s, alg_bytes):
+    """The ceilings that can bind a traversal kernel, each as achieved / peak (MI355X_MICROARCH.md figures above):
+    hbm   fabric bytes (2 * FETCH_SIZE + WRITE_SIZE: FETCH_SIZE doubled as the guide prescribes for gfx950) / t / 8 TB/s
+    l2    TCC_REQ * 128 B / t / 34.5 TB/s
+    l1    vector-L1 cache-line lookups per CU-cycle, TCP_TOTAL_CACHE_ACCESSES / (256 CUs * t * 2.4 GHz), peak 1
+    valu  wave64 VALU instructions * 2 cycles / (1024 SIMDs * t * 2.4 GHz)
+    Counter values come from the committed profile, the duration t from THIS run's HIP events."""
+    c = {}
+    if not counters or t_s <= 0:
+        return c
+    cyc = t_s * CLOCK_HZ
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        b = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+        c["hbm"] = {"achieved": round(b / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / t_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "bytes_per_launch": int(b)}
+    if "TCC_REQ_sum" in counters:
+        b = counters["TCC_REQ_sum"] * 128.0
+        c["l2"] = {"achieved": round(b / t_s / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(b / t_s / 1e9 / L2_PEAK_GBS, 4)}
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in counters:
+        a = counters["TCP_TOTAL_CACHE_ACCESSES_sum"] / (N_CUS * cyc)
+        c["l1"] = {"achieved": round(a, 4), "peak": L1_PEAK_ACC_PER_CU_CLK, "unit": "line lookups per CU-cycle", "frac": round(a / L1_PEAK_ACC_PER_CU_CLK, 4)}
+    if "SQ_INSTS_VALU" in counters:
+        a = counters["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMDS * cyc)
+        c["valu"] = {"achieved": round(a, 4), "peak": 1.0, "unit": "SIMD issue cycles per cycle", "frac": round(a, 4)}
+    return c
 
 
 def effective_cpus():
@@ -79,56 +113,110 @@ def effective_cpus():
     return n
 
 
+def physical_cores(limit):
+    """One logical CPU per physical core of this process's affinity mask (first hardware thread of each core), at most
+    `limit` of them: the CPUs the baseline's threads are pinned to."""
+    seen, picked = set(), []
+    for cpu in sorted(os.sched_getaffinity(0)):
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu).read().strip()
+        except Exception:
+            sib = str(cpu)
+        if sib in seen:
+            continue
+        seen.add(sib)
+        picked.append(cpu)
+    return picked[:max(1, limit)]
+
+
+def build_cpubench():
+    """libcpubench.so is -march=native code: built on the host it runs on, under a name that carries that host's CPU."""
+    import hashlib
+    import subprocess
+    try:
+        info = open("/proc/cpuinfo").read()
+        key = "".join(l for l in info.splitlines(True) if l.startswith(("model name", "flags")))[:8192]
+    except Exception:
+        key = "unknown"
+    name = "libcpubench.%s.so" % hashlib.sha1(key.encode()).hexdigest()[:10]
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), name, "BENCH_OUT=" + name], stdout=subprocess.DEVNULL)
+    return os.path.join(ROOT, "oracle", name)
+
+
 def cpu_baseline(st, scene, width, height, max_depth, budget_s):
-    """The CPU oracle (oracle/pt_oracle.c, kind "port": this build's C restatement, one single-threaded
-    traversal per core) rendering the same frame over the same BVH, repeated until ~budget_s of wall
-    time has passed (bounded sample; the BVH export/validation is outside the timing)."""
+    """The CPU oracle (oracle/pt_oracle.c, kind "port": this build's C restatement; the reference has no CPU path)
+    rendering the same frame over the same BVH: oracle/cpu_bench.c -- built -O3 -march=native -fno-fast-math
+    -ffp-contract=off on this host -- runs one PINNED native thread per physical core (at most the cgroup's CPU quota),
+    4-row bands from an atomic counter, three repetitions of budget_s / 3, median rate."""
     import ctypes as C
-    import threading
 
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     from optix_raytracer_amd import scenes
-    nodes, tris = st.context.accel_export(st.gas_handle)
-    osc = O.Scene(scene).set_bvh(nodes, tris)
-    launch = scenes.launch_desc(scene, width, height, SPP)
-    cores = effective_cpus()
-    accum = np.zeros((height, width, 4), np.float32)      # must outlive the render calls
-    p = osc.make_params(launch, accum, None)
-    lib = O.lib()
-    n_bands = (height + 3) // 4
-    stats = [O.OrcStats() for _ in range(cores)]
-    lock = threading.Lock()
-    state = {"next": 0, "stop": False}
-    t_start = time.perf_counter()
 
-    def work(tid):
-        while True:
-            with lock:                                  # work queue of 4-row bands, frame after frame
-                if state["stop"]:
-                    return
-                b = state["next"]
-                state["next"] += 1
-                if b % n_bands == 0 and b > 0 and time.perf_counter() - t_start > budget_s:
-                    state["stop"] = True
-                    state["next"] = b
-                    return
-            y = (b % n_bands) * 4
-            lib.orc_render_rows(osc._h, O.MODE_BVH, C.byref(p), max_depth, y, y + 4, C.byref(stats[tid]))
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    [t.start() for t in ts]
-    [t.join() for t in ts]
-    dt = time.perf_counter() - t_start
-    rays = sum(s.closest_rays + s.shadow_rays for s in stats)
-    frames = state["next"] / n_bands
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": "%.2f frames of the same %dx%d workload (%d rays) in %.1f s wall, %d threads pulling 4-row bands" % (
-                frames, width, height, rays, dt, cores)}
+    class OrcBenchResult(C.Structure):
+        _fields_ = [("mray_per_s", C.c_double), ("rep_mray_per_s", C.c_double * 3), ("seconds", C.c_double), ("frames", C.c_double),
+                    ("rays", C.c_uint64), ("threads", C.c_int32), ("pinned", C.c_int32)]
+    lib = C.CDLL(build_cpubench())
+    lib.orc_scene_create.restype = C.c_void_p
+    lib.orc_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.orc_scene_set_bvh.restype = C.c_int
+    lib.orc_scene_set_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    lib.orc_scene_destroy.argtypes = [C.c_void_p]
+    lib.orc_bench_render.restype = C.c_int
+    lib.orc_bench_render.argtypes = [C.c_void_p, C.POINTER(O.OrcParams), C.c_uint32, C.c_int, C.POINTER(C.c_int), C.c_double,
+                                     C.POINTER(OrcBenchResult)]
+    nodes, tris = st.context.accel_export(st.gas_handle)
+    nodes, tris = np.ascontiguousarray(nodes), np.ascontiguousarray(tris)
+    verts = np.ascontiguousarray(scene["vertices"], np.float32).reshape(-1, 4)
+    mat = np.ascontiguousarray(scene["mat_index"], np.uint32)
+    em = np.ascontiguousarray(scene["emission"], np.float32).reshape(-1, 3)
+    df = np.ascontiguousarray(scene["diffuse"], np.float32).reshape(-1, 3)
+    bg = np.ascontiguousarray(scene.get("bg", np.zeros(4)), np.float32)
+    h = lib.orc_scene_create(verts.ctypes.data, verts.shape[0] // 3, mat.ctypes.data, em.ctypes.data, df.ctypes.data, em.shape[0], bg.ctypes.data)
+    if lib.orc_scene_set_bvh(h, nodes.ctypes.data, nodes.nbytes // 64, tris.ctypes.data, tris.nbytes // 48):
+        raise SystemExit("cpu_baseline: the exported BVH failed the oracle's validation")
+    launch = scenes.launch_desc(scene, width, height, SPP)
+    accum = np.zeros((height, width, 4), np.float32)
+    p = O.Scene.make_params(None, launch, accum, None)
+    cpus = physical_cores(effective_cpus())
+    ids = (C.c_int * len(cpus))(*cpus)
+    res = OrcBenchResult()
+    rc = lib.orc_bench_render(h, C.byref(p), max_depth, len(cpus), ids, float(budget_s), C.byref(res))
+    lib.orc_scene_destroy(h)
+    if rc:
+        raise SystemExit("cpu_baseline: orc_bench_render failed (%d)" % rc)
+    return {"value": round(res.mray_per_s, 3), "unit": "Mray/s", "cores": len(cpus), "kind": "port",
+            "per_core": round(res.mray_per_s / len(cpus), 3),
+            "sample": "%.1f frames of the same %dx%d workload (%d rays) in %.1f s wall: %d native threads pinned one per physical core "
+                      "(%d pinned), 4-row bands from an atomic counter, median of 3 repetitions (%s Mray/s), gcc -O3 -march=native "
+                      "-fno-fast-math -ffp-contract=off" % (
+                          res.frames, width, height, res.rays, res.seconds, len(cpus), res.pinned,
+                          " / ".join("%.2f" % v for v in res.rep_mray_per_s))}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` started plainly: start the N ranks as CHILD processes (torch.distributed.run, one per GPU)
+    before this process has touched the GPU, let rank 0's JSON line through on the inherited stdout, exit with the
+    children's code.  (Never exec from a process that has initialised HIP.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     from optix_raytracer_amd import _lib as L
@@ -139,10 +227,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if args.backend != "nccl":
@@ -271,23 +356,34 @@ def main():
         tt_c = counts["tri_tests"] - counts["shadow_tri_tests"]
         bytes_closest = 64 * nv_c + 48 * tt_c + (32 + 16) * counts["closest_rays"]
         bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
-        variant = {3: "k_trace_pool<%%d, %d>" % (24 if info["depth"] <= 24 else 32), 2: "k_trace_stream<%d, false>",
+        q = "true" if info.get("node_format", 0) else "false"
+        variant = {3: "k_trace_pool<%%d, %d, %s>" % (24 if info["depth"] <= 24 else 32, q), 2: "k_trace_stream<%d, false>",
                    0: "k_trace_simple<%d, false>"}[int(st.context.get_option(L.OPT_PERSISTENT))]
         # a pass of at most MIPT_OPT_TAIL_PATHS paths (a rank's shard at N >= 2) runs in the path kernel: closest-hit and
         # any-hit traversal, shading and accumulation of a wave's 64 paths in ONE launch, timed under "trace_closest"
         fused = sharded and int(st.context.get_option(L.OPT_PERSISTENT)) == 3 and info["depth"] <= 32 and \
             api.shard_num_samples(w, h, world) <= int(st.context.get_option(L.OPT_TAIL_PATHS)) // 4 * 3
         if fused:
-            kname, kbytes, kms, klaunches = "k_tail_pool", bytes_closest + bytes_any, k_closest, tm["n_trace_closest"]
+            kname, kbytes, kms, klaunches = "k_tail_pool<%s>" % q, bytes_closest + bytes_any, k_closest, tm["n_trace_closest"]
         elif k_closest >= k_any:
             kname, kbytes, kms, klaunches = variant % 0, bytes_closest, k_closest, tm["n_trace_closest"]
         else:
-            any_name = "k_trace_static<2>" if int(st.context.get_option(L.OPT_PERSISTENT)) == 3 else variant % 2
+            any_name = "k_trace_static<2, %s>" % q if int(st.context.get_option(L.OPT_PERSISTENT)) == 3 else variant % 2
             kname, kbytes, kms, klaunches = any_name, bytes_any, k_any, tm["n_trace_any"]
         launches_per_step = max(klaunches // args.steps, 1)
         kms_avg = kms / launches_per_step          # average duration of one launch of that kernel
         kbytes_launch = kbytes / launches_per_step
-        achieved = kbytes_launch / (kms_avg * 1e-3) / 1e9 if kms_avg > 0 else 0.0
+        alg_gbs = kbytes_launch / (kms_avg * 1e-3) / 1e9 if kms_avg > 0 else 0.0
+        # ---- the ceilings that can bind: HBM (counter bytes), L2, vector L1, VALU issue.  The BVH (~115 MB) is resident in L2 /
+        # Infinity Cache, so algorithmic bytes / t exceeds what HBM could deliver and is reported as information only.
+        counters, counters_from = pmc_counters(kname) if world == 1 else (None, None)
+        ceil = ceilings(counters, kms_avg * 1e-3, kbytes_launch)
+        if ceil:
+            bound = max(ceil, key=lambda k: ceil[k]["frac"])
+            top = ceil[bound]
+            assert top["frac"] <= 1.0 + 1e-9, "roofline fraction above 1: %s" % ceil
+        else:
+            bound, top = "hbm", {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
         out = {
             "metric": "Mray/s (primary+shadow), 1920x1080 spp=1, 1M-tri scene",
             "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -300,9 +396,11 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather%s" % (
                            world, " (frame k's gather overlaps frame k+1's tracing)" if args.overlap else ""),
                        "bvh_build_s": round(info["build_seconds"], 3), "setup_s": round(build_s, 3)},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname) if world == 1 else None,
-                         "algorithmic_bytes_per_launch": int(kbytes_launch),
+            "roofline": {"bound": bound, "kernel": kname, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                         "frac": top["frac"],
+                         "traffic": ceil["hbm"]["bytes_per_launch"] if "hbm" in ceil else None,
+                         "ceilings": ceil, "counters_from": counters_from,
+                         "algorithmic_bytes_per_launch": int(kbytes_launch), "algorithmic_GBps_informational": round(alg_gbs, 1),
                          "kernel_ms_avg": round(kms_avg, 4),
                          "per_frame_ms": {"trace_closest": round(k_closest, 4), "trace_any": round(k_any, 4),
                                           "shade": round(k_shade, 4), "raygen+resolve": round(k_other, 4)}},

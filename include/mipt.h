@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 1
+#define MIPT_ABI_VERSION 2   /* 2: MiptAccelInfo.node_format, MIPT_OPT_NODE_FORMAT, mipt_group_* */
 
 typedef enum MiptResult {
     MIPT_SUCCESS                 = 0,
@@ -102,6 +102,18 @@ typedef struct MiptBvhNode {
     uint32_t pad0, pad1;
 } MiptBvhNode;
 
+/* Node format 1 (MIPT_OPT_NODE_FORMAT, the default where the scene suits it): every child box of the nodes above is
+ * rounded OUTWARD to fp16-representable values when the BVH is built or refitted, and the entry-pool traversal kernels fetch
+ * this packed mirror instead -- 32 bytes, two 16-byte loads per visit instead of four.  Both arrays hold the SAME box
+ * values (a half converts to float exactly), so every kernel, mipt_accel_export and an external checker see one BVH.
+ * Wider boxes only weaken pruning: hit records do not change.  c0/c1 as in MiptBvhNode. */
+typedef struct MiptBvhNode32 {
+    uint16_t c0x[2], c0y[2], c0z[2];   /* child0 lo.x hi.x lo.y hi.y lo.z hi.z, IEEE binary16 bit patterns */
+    int32_t  c0;
+    uint16_t c1x[2], c1y[2], c1z[2];
+    int32_t  c1;
+} MiptBvhNode32;
+
 /* triangle in leaf order: v0, e1 = v1 - v0, e2 = v2 - v0 (fp32), original index */
 typedef struct MiptBvhTri {
     float v0[3]; uint32_t prim;
@@ -116,6 +128,8 @@ typedef struct MiptAccelInfo {
     uint32_t leaf_max;
     uint64_t device_bytes;
     double   build_seconds;
+    uint32_t node_format;      /* 1: the boxes are fp16 values and a packed 32-byte mirror exists (MiptBvhNode32); 0: fp32 boxes */
+    uint32_t reserved;
 } MiptAccelInfo;
 
 /* one triangle build input == OptixBuildInputTriangleArray as the samples use it
@@ -187,6 +201,10 @@ typedef enum MiptOption {
                                   half the value when MAX_DEPTH caps the paths), one kernel runs each of them to its
                                   end, a wave per 64 paths, instead of five kernels per bounce; a pass that starts with at
                                   most this many paths (three quarters of it when capped) starts there.  Same pixels, same ray counts.  Default 1048576, 0 = off */
+    MIPT_OPT_NODE_FORMAT  = 14, /* set before mipt_accel_build.  1 (default): child boxes rounded outward to fp16 values + the packed
+                                  32-byte node mirror (MiptBvhNode32) for the entry-pool kernels; scenes that do not suit fp16
+                                  boxes (a coordinate beyond +-32768, or the largest extent below a quarter of the largest
+                                  coordinate) silently keep format 0.  0: fp32 boxes, 64-byte nodes only. */
     MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
                                   (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmipt.so")
+# MIPT_LIBRARY: an experiment build of the library (tools/probe_bound.sh), always under optix_raytracer_amd/lib/
+LIB_PATH = os.path.join(_HERE, "lib", os.path.basename(os.environ.get("MIPT_LIBRARY", "libmipt.so")))
 
 
 class MiptParallelogramLight(C.Structure):
@@ -34,7 +35,8 @@ class MiptHitGroupData(C.Structure):
 
 class MiptAccelInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_uint32), ("num_triangles", C.c_uint32), ("depth", C.c_uint32),
-                ("leaf_max", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double)]
+                ("leaf_max", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double),
+                ("node_format", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MiptBuildInput(C.Structure):
@@ -134,7 +136,7 @@ GEOMETRY_FLAG_NONE, GEOMETRY_FLAG_DISABLE_ANYHIT, GEOMETRY_FLAG_REQUIRE_SINGLE_A
 GEOMETRY_FLAG_DISABLE_TRIANGLE_FACE_CULLING = 4
 RAY_FLAG_NONE, RAY_FLAG_CULL_BACK_FACING_TRIANGLES = 0, 16
 OPT_MAX_DEPTH, OPT_COUNT_VISITS, OPT_TRACE_GRID, OPT_PERSISTENT, OPT_PROFILE = 1, 2, 3, 4, 5
-OPT_REFILL_MIN, OPT_STEAL_MIN, OPT_BURST, OPT_BATCH_SAMPLES, OPT_BUILD, OPT_TAIL_PATHS = 7, 8, 9, 10, 12, 13
+OPT_REFILL_MIN, OPT_STEAL_MIN, OPT_BURST, OPT_BATCH_SAMPLES, OPT_BUILD, OPT_TAIL_PATHS, OPT_NODE_FORMAT = 7, 8, 9, 10, 12, 13, 14
 
 # every symbol include/mipt.h declares: (name, restype, argtypes)
 _vp, _u32, _u64 = C.c_void_p, C.c_uint32, C.c_uint64
@@ -209,7 +211,7 @@ def load():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if L.mipt_abi_version() != 1:
+    if L.mipt_abi_version() != 2:
         raise RuntimeError("libmipt.so ABI version mismatch")
     _lib = L
     return L

@@ -40,6 +40,8 @@ struct DeviceBvh {
     uint32_t depth;            // deepest leaf (stack entries a ray can need)
     uint32_t pool2_ok;         // ... and k_tail_pool2's (7-bit slots): < 2^24 nodes, < 2^22 triangles
     uint32_t pool_ok;          // fits the entry pool's packed words: < 2^25 nodes, 2 .. 2^23 - 1 triangles, leaves of 1 .. 4
+    uint32_t node32_off;       // byte offset, in the same allocation, of the packed 32-byte nodes (MiptBvhNode32: the boxes of
+                               // `nodes` as fp16 -- the two arrays hold the SAME values); 0 = this BVH has none
 };
 
 // SoA path queues, capacity `cap` entries each
@@ -113,6 +115,10 @@ struct GatherInput {
 void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, uint32_t* mats, uint32_t* gflags, uint32_t base, uint32_t* error);
 // *ok = false when the tree is deeper than depth_cap
 // refit of an existing BVH2 (same topology) to new world-space vertices (9 floats per original primitive)
+// Node format 1 (MIPT_OPT_NODE_FORMAT): rounds every child box of the 64-byte nodes OUTWARD to fp16-representable values, in
+// place, and writes the packed 32-byte mirror (MiptBvhNode32) the entry-pool kernels fetch.  *ok = false (nothing changed)
+// when the scene does not suit fp16 boxes: a coordinate beyond +-32768, or an extent below a quarter of the largest one.
+hipError_t pack_nodes32(hipStream_t st, float4* d_nodes, uint32_t nn, void* d_nodes32, bool* ok);
 hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris);
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok);

@@ -129,47 +129,154 @@ __device__ __forceinline__ float4 ld16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byt
     return make_float4(u2f(v.x), u2f(v.y), u2f(v.z), u2f(v.w));
 }
 
+__device__ __forceinline__ u32x4 ldq(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+}
+
+// ---- the slab test of both children of an inner node, from either node format ------------------------------------------------
+// Q = false: the 64-byte fp32 node (MiptBvhNode) in pieces n0 .. n3.  Q = true: the packed 32-byte node (MiptBvhNode32) in
+// pieces n0, n1 -- child c: {lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16} as fp16, then its reference.  The fp16
+// values ARE the values the 64-byte node holds (pack_nodes32 rounds the fp32 boxes outward to them), a half converts to float
+// exactly, and the plane enters the same fmaf -- so both formats give the same tn / tf bit for bit (v_fma_mix_f32 reads the
+// half operand directly: no conversion instruction).
+__device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+struct SlabOut { float tn0, tf0, tn1, tf1; int c0, c1; };
+
+template <bool Q>
+__device__ __forceinline__ SlabOut slab_children(const u32x4 n0, const u32x4 n1, const u32x4 n2, const u32x4 n3, const float ix, const float iy,
+                                                 const float iz, const float nx, const float ny, const float nz, const float tmn, const float tcur)
+{
+    float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
+    SlabOut o;
+    if (Q) {
+        // (halves taken by shift / truncate of each dword: a bit_cast of the dword to a half2 vector miscompiles on ROCm 7.2 --
+        // every v_fma_mix_f32 then reads element 0 of the loaded vector, whichever element the source names)
+        ax0 = __builtin_fmaf(half_lo(n0.x), ix, nx); ax1 = __builtin_fmaf(half_hi(n0.x), ix, nx);
+        ay0 = __builtin_fmaf(half_lo(n0.y), iy, ny); ay1 = __builtin_fmaf(half_hi(n0.y), iy, ny);
+        az0 = __builtin_fmaf(half_lo(n0.z), iz, nz); az1 = __builtin_fmaf(half_hi(n0.z), iz, nz);
+        bx0 = __builtin_fmaf(half_lo(n1.x), ix, nx); bx1 = __builtin_fmaf(half_hi(n1.x), ix, nx);
+        by0 = __builtin_fmaf(half_lo(n1.y), iy, ny); by1 = __builtin_fmaf(half_hi(n1.y), iy, ny);
+        bz0 = __builtin_fmaf(half_lo(n1.z), iz, nz); bz1 = __builtin_fmaf(half_hi(n1.z), iz, nz);
+        o.c0 = (int)n0.w; o.c1 = (int)n1.w;
+    } else {
+        ax0 = __builtin_fmaf(u2f(n0.x), ix, nx); ax1 = __builtin_fmaf(u2f(n0.y), ix, nx);
+        ay0 = __builtin_fmaf(u2f(n0.z), iy, ny); ay1 = __builtin_fmaf(u2f(n0.w), iy, ny);
+        az0 = __builtin_fmaf(u2f(n2.x), iz, nz); az1 = __builtin_fmaf(u2f(n2.y), iz, nz);
+        bx0 = __builtin_fmaf(u2f(n1.x), ix, nx); bx1 = __builtin_fmaf(u2f(n1.y), ix, nx);
+        by0 = __builtin_fmaf(u2f(n1.z), iy, ny); by1 = __builtin_fmaf(u2f(n1.w), iy, ny);
+        bz0 = __builtin_fmaf(u2f(n2.z), iz, nz); bz1 = __builtin_fmaf(u2f(n2.w), iz, nz);
+        o.c0 = (int)n3.x; o.c1 = (int)n3.y;
+    }
+    o.tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)), __builtin_fmaxf(__builtin_fminf(az0, az1), tmn));
+    o.tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)), __builtin_fminf(__builtin_fmaxf(az0, az1), tcur));
+    o.tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)), __builtin_fmaxf(__builtin_fminf(bz0, bz1), tmn));
+    o.tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)), __builtin_fminf(__builtin_fmaxf(bz0, bz1), tcur));
+    return o;
+}
+
+// this step's 64 (fp32 nodes) or 32 / 48 (packed nodes / triangles) bytes of a lane: inner lanes fetch their node, leaf
+// lanes their next triangle, idle lanes re-read node 0 (a broadcast).  The memory pipeline (TA / TD) spends 16 cycles per
+// dwordx4 wave instruction whatever the exec mask (profiles/r02_l1_*), so the packed form's third piece is fetched by leaf
+// lanes only and skipped by the wave when no lane stands at a leaf.
+// ---- sensitivity probes (tools/probe_bound.sh; never defined in the product build) -------------------------------------------------
+// MIPT_PROBE_VMEM = n: n more 16-byte loads per step (of the lane's own first piece: L1 hits) -- what a step costs in the
+// vector-memory pipeline.  MIPT_PROBE_VALU = n: n more independent VALU instructions per step -- what it costs in issue slots.
+// The time a probe adds per instruction, against the kernel's time per instruction, says which resource the kernel is bound by.
+#ifndef MIPT_PROBE_VMEM
+#define MIPT_PROBE_VMEM 0
+#endif
+#ifndef MIPT_PROBE_VALU
+#define MIPT_PROBE_VALU 0
+#endif
+// MIPT_PROBE_STAMP: s_memtime stamps around a step's loads (issue -> data back) in k_trace_pool; per wave: cycles waited, cycles
+// in the rest of the step, steps; summed into DeviceCounters::dbg (tools/probe_bound.sh prints them)
+#ifndef MIPT_PROBE_STAMP
+#define MIPT_PROBE_STAMP 0
+#endif
+#if MIPT_PROBE_STAMP
+#define PROBE_PARAM , unsigned long long& pw_wait
+#define PROBE_ARG , pw_wait
+#else
+#define PROBE_PARAM
+#define PROBE_ARG
+#endif
+__device__ __forceinline__ float probe_valu(float seed)
+{
+    float a0 = seed, a1 = seed + 1.0f, a2 = seed + 2.0f, a3 = seed + 3.0f;
+#pragma unroll
+    for (int k = 0; k < MIPT_PROBE_VALU / 4; ++k) {
+        a0 = __builtin_fmaf(a0, 1.0000001f, 1e-30f); a1 = __builtin_fmaf(a1, 1.0000002f, 1e-30f);
+        a2 = __builtin_fmaf(a2, 1.0000003f, 1e-30f); a3 = __builtin_fmaf(a3, 1.0000004f, 1e-30f);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+template <bool Q>
+__device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, const bool inner, const bool tri,
+                                          const uint32_t node, const uint32_t lfirst, u32x4& n0, u32x4& n1, u32x4& n2, u32x4& n3 PROBE_PARAM)
+{
+#if MIPT_PROBE_STAMP
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
+    uint32_t off = Q ? bvh.node32_off : 0u;
+    if (inner) off = Q ? bvh.node32_off + (node << 5) : node << 6;
+    if (tri)   off = bvh.tri_byte_off + lfirst * 48u;
+    n0 = ldq(blob, off); n1 = ldq(blob, off + 16u);
+    if (Q) {
+        n2 = u32x4{ 0u, 0u, 0u, 0u }; n3 = n2;
+        if (tri) n2 = ldq(blob, off + 32u);
+    } else {
+        n2 = ldq(blob, off + 32u); n3 = ldq(blob, off + 48u);
+    }
+#if MIPT_PROBE_VMEM > 0
+    {
+        u32x4 acc = u32x4{ 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (int k = 0; k < MIPT_PROBE_VMEM; ++k) {
+            uint32_t o2 = off + 16u * (uint32_t)(k & 1);
+            asm volatile("" : "+v"(o2));                   // opaque: not merged with the step's own loads
+            const u32x4 t = ldq(blob, o2); acc.x ^= t.x; acc.y ^= t.y; acc.z ^= t.z; acc.w ^= t.w;
+        }
+        if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u && n0.x == 0x12345678u) n1.x ^= 1u;     // keeps the loads alive, never changes a result
+    }
+#endif
+#if MIPT_PROBE_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pw_wait += __builtin_amdgcn_s_memtime() - pt0;
+#endif
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float shfl_f(float v, uint32_t src) { return __shfl(v, (int)src, 64); }
 __device__ __forceinline__ uint32_t shfl_u(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
 
 // One step of the lane state machine (see k_trace_stream): every lane loads 64 bytes -- its node, or its next
 // triangle -- then inner lanes do a slab step and leaf lanes one branch-free triangle test.  `sb` is the bottom of
 // the lane's stack (entries below it were given away); shared by k_trace_stream and the bulk phase of k_trace_pool.
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool Q = false>
 __device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_buffer_rsrc_t blob, uint32_t* stk, int lane, bool has_ray, Trav& T,
-                                            int sb, bool cull_back, uint32_t& n_visits, uint32_t& n_tests)
+                                            int sb, bool cull_back, uint32_t& n_visits, uint32_t& n_tests PROBE_PARAM)
 {
-    // ------------------------------------------------------------ this iteration's load: 64 B per lane
+    // ------------------------------------------------------------ this iteration's load
     const bool inner   = has_ray && T.node >= 0;
     const bool at_leaf = has_ray && T.node < 0 && T.node != kSentinel;
     const uint32_t ldesc = ~(uint32_t)T.node;
     const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
-    uint32_t off = 0u;                                             // idle lanes re-read node 0 (a broadcast)
-    if (inner) off = (uint32_t)T.node << 6;
-    if (at_leaf && lcnt != 0u) off = a.bvh.tri_byte_off + lfirst * 48u;
-    const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
-    asm volatile("" ::: "memory");
+    u32x4 q0, q1, q2, q3;
+    load_step<Q>(blob, a.bvh, inner, at_leaf && lcnt != 0u, (uint32_t)T.node, lfirst, q0, q1, q2, q3 PROBE_ARG);
+#if MIPT_PROBE_VALU > 0
+    if (probe_valu(T.tmin) == 12345.678f) T.tbest = 0.0f;                 // never true (tmin is 0.01 or a hit distance)
+#endif
     // ------------------------------------------------------------ one inner-node step
     if (inner) {
         if (COUNT) ++n_visits;
-        const float ax0 = __builtin_fmaf(n0.x, T.idir.x, T.nood.x), ax1 = __builtin_fmaf(n0.y, T.idir.x, T.nood.x);
-        const float ay0 = __builtin_fmaf(n0.z, T.idir.y, T.nood.y), ay1 = __builtin_fmaf(n0.w, T.idir.y, T.nood.y);
-        const float az0 = __builtin_fmaf(n2.x, T.idir.z, T.nood.z), az1 = __builtin_fmaf(n2.y, T.idir.z, T.nood.z);
-        const float bx0 = __builtin_fmaf(n1.x, T.idir.x, T.nood.x), bx1 = __builtin_fmaf(n1.y, T.idir.x, T.nood.x);
-        const float by0 = __builtin_fmaf(n1.z, T.idir.y, T.nood.y), by1 = __builtin_fmaf(n1.w, T.idir.y, T.nood.y);
-        const float bz0 = __builtin_fmaf(n2.z, T.idir.z, T.nood.z), bz1 = __builtin_fmaf(n2.w, T.idir.z, T.nood.z);
-        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                          __builtin_fmaxf(__builtin_fminf(az0, az1), T.tmin));
-        const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                          __builtin_fminf(__builtin_fmaxf(az0, az1), T.tbest));
-        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                          __builtin_fmaxf(__builtin_fminf(bz0, bz1), T.tmin));
-        const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                          __builtin_fminf(__builtin_fmaxf(bz0, bz1), T.tbest));
-        const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-        const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+        const SlabOut b = slab_children<Q>(q0, q1, q2, q3, T.idir.x, T.idir.y, T.idir.z, T.nood.x, T.nood.y, T.nood.z, T.tmin, T.tbest);
+        const bool h0 = b.tn0 <= b.tf0, h1 = b.tn1 <= b.tf1;
+        const int c0 = b.c0, c1 = b.c1;
         if (h0 && h1) {
-            const bool swp = tn1 < tn0;
+            const bool swp = b.tn1 < b.tn0;
             stk[T.sp * 64 + lane] = (uint32_t)(swp ? c0 : c1);
             ++T.sp;
             T.node = swp ? c1 : c0;
@@ -187,7 +294,8 @@ __device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_b
         bool stop = false;
         if (lcnt != 0u) {
             if (COUNT) ++n_tests;
-            const float4 ta = n0, tb = n1, tc = n2;
+            const float4 ta = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), tb = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
+                         tc = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
             const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
             const f3 p = fcross(T.d, e2);
             const float det = fdot(e1, p);
@@ -338,7 +446,10 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
         const int burst = dry ? a.burst_dry : a.burst_bulk;
         for (int bi = 0; bi < burst; ++bi) {
             if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
-            stream_step<MODE, COUNT>(a, blob, stk, lane, has_ray, T, sb, cull_back, n_visits, n_tests);
+#if MIPT_PROBE_STAMP
+            unsigned long long pw_wait = 0ull;
+#endif
+            stream_step<MODE, COUNT>(a, blob, stk, lane, has_ray, T, sb, cull_back, n_visits, n_tests PROBE_ARG);
         }
         // ------------------------------------------------------------ retire
         const bool done = has_ray && T.node == kSentinel;
@@ -464,10 +575,10 @@ __device__ __forceinline__ bool range_grab(const TraceArgs& a, RayRange& r, uint
 // each lane processes one -- an inner node: slab-test both children against the ray's current best t and push the
 // survivors, nearer on top; a leaf reference: test its first triangle and push the rest of the leaf.  The ray of slot s is
 // read from the registers of lane s; its best hit is merged in LDS (min t, tie -> lowest primitive).
-template <int MODE, int CAP>
-__device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
+template <int MODE, int CAP, bool Q>
+__device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
-                                           const int lane, const Trav& T, int& psize, const bool cull_back)
+                                           const int lane, const Trav& T, int& psize, const bool cull_back PROBE_PARAM)
 {
     constexpr int kPoolCap = CAP;
     // ------------------------------------------------------------ pop up to 64 entries (each lane adds at most one net entry)
@@ -494,32 +605,21 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
     const uint32_t lfirst = payload >> 2, lcnt = (payload & 3u) + 1u;
     const bool do_inner = live && !leaf;
     const bool do_tri   = live && leaf;
-    uint32_t off = 0u;
-    if (do_inner) off = payload << 6;
-    if (do_tri)   off = tri_byte_off + lfirst * 48u;
-    const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
-    asm volatile("" ::: "memory");
+    u32x4 q0, q1, q2, q3;
+    load_step<Q>(blob, bvh, do_inner, do_tri, payload, lfirst, q0, q1, q2, q3 PROBE_ARG);
+#if MIPT_PROBE_VALU > 0
+    if (probe_valu(tmn) == 12345.678f) tcur = 0.0f;
+#endif
+    const float4 n0 = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), n1 = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
+                 n2 = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
     uint32_t push0 = 0u, push1 = 0u;
     int npush = 0;
     if (do_inner) {
-        const float ax0 = __builtin_fmaf(n0.x, ix, nx), ax1 = __builtin_fmaf(n0.y, ix, nx);
-        const float ay0 = __builtin_fmaf(n0.z, iy, ny), ay1 = __builtin_fmaf(n0.w, iy, ny);
-        const float az0 = __builtin_fmaf(n2.x, iz, nz), az1 = __builtin_fmaf(n2.y, iz, nz);
-        const float bx0 = __builtin_fmaf(n1.x, ix, nx), bx1 = __builtin_fmaf(n1.y, ix, nx);
-        const float by0 = __builtin_fmaf(n1.z, iy, ny), by1 = __builtin_fmaf(n1.w, iy, ny);
-        const float bz0 = __builtin_fmaf(n2.z, iz, nz), bz1 = __builtin_fmaf(n2.w, iz, nz);
-        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                          __builtin_fmaxf(__builtin_fminf(az0, az1), tmn));
-        const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                          __builtin_fminf(__builtin_fmaxf(az0, az1), tcur));
-        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                          __builtin_fmaxf(__builtin_fminf(bz0, bz1), tmn));
-        const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                          __builtin_fminf(__builtin_fmaxf(bz0, bz1), tcur));
-        const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-        const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+        const SlabOut b = slab_children<Q>(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
+        const bool h0 = b.tn0 <= b.tf0, h1 = b.tn1 <= b.tf1;
+        const int c0 = b.c0, c1 = b.c1;
         if (h0 && h1) {
-            const bool swp = tn1 < tn0;
+            const bool swp = b.tn1 < b.tn0;
             push0 = pool_pack(swp ? c0 : c1, slot);           // farther child below ...
             push1 = pool_pack(swp ? c1 : c0, slot);           // ... the nearer one on top
             npush = 2;
@@ -573,7 +673,7 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
 
 // ROWS: entries of a lane's stack = rows of the LDS block (24 when the tree is at most 24 deep -- 7.5 KB of LDS per
 // wave and <= 96 VGPRs let 20 waves share a CU instead of 16 -- else 32)
-template <int MODE, int ROWS>
+template <int MODE, int ROWS, bool Q>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? 6 : 5, ROWS == 24 ? 6 : 5)))
 void k_trace_pool(TraceArgs a)
 {
@@ -599,6 +699,10 @@ void k_trace_pool(TraceArgs a)
     const uint32_t xcd = blockIdx.x & (kNumSegments - 1), waves_seg = gridDim.x / kNumSegments;   // gridDim.x is a multiple of 8
     Trav T;
     T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
+#if MIPT_PROBE_STAMP
+    unsigned long long pw_wait = 0ull, pw_bulk = 0ull, pw_pool = 0ull, pw_steps = 0ull, pw_rounds = 0ull;
+    const unsigned long long pw_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
         // ============================================================ bulk: one ray per lane, one tile at a time
@@ -620,15 +724,25 @@ void k_trace_pool(TraceArgs a)
             has_ray = T.node != kSentinel;
             if (!has_ray) finish_ray<MODE>(a, T, ray, false);      // empty interval: a miss, no BVH access
         }
+#if MIPT_PROBE_STAMP
+        const unsigned long long pw_b0 = __builtin_amdgcn_s_memtime();
+#endif
         while (__popcll(__ballot(!has_ray)) < steal_min) {
             for (int bi = 0; bi < a.burst_bulk; ++bi) {
                 if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
                 uint32_t nv_ = 0u, nt_ = 0u;
-                stream_step<MODE, false>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_);
+                stream_step<MODE, false, Q>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_ PROBE_ARG);
+#if MIPT_PROBE_STAMP
+                ++pw_steps;
+#endif
             }
             const bool done = has_ray && T.node == kSentinel;
             if (done) { finish_ray<MODE>(a, T, ray, T.prim != 0xffffffffu); has_ray = false; }
         }
+#if MIPT_PROBE_STAMP
+        const unsigned long long pw_b1 = __builtin_amdgcn_s_memtime();
+        pw_bulk += pw_b1 - pw_b0;
+#endif
         if (__ballot(has_ray) == 0ull) continue;                     // the whole tile is finished
 
         // ============================================================ tail: one entry pool per wave
@@ -655,8 +769,15 @@ void k_trace_pool(TraceArgs a)
         sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
         sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        while (psize > 0)
-            pool_round<MODE, kPoolCap>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back);
+        while (psize > 0) {
+            pool_round<MODE, kPoolCap, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back PROBE_ARG);
+#if MIPT_PROBE_STAMP
+            ++pw_rounds;
+#endif
+        }
+#if MIPT_PROBE_STAMP
+        pw_pool += __builtin_amdgcn_s_memtime() - pw_b1;
+#endif
         if (has_ray) {
             const unsigned long long key = sh_best[lane];
             T.tbest = ord_float((uint32_t)(key >> 32)); T.prim = (uint32_t)key; T.u = sh_u[lane]; T.v = sh_v[lane];
@@ -664,6 +785,14 @@ void k_trace_pool(TraceArgs a)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the next tile's stacks overwrite the merge slots
     }
+#if MIPT_PROBE_STAMP
+    if (lane == 0) {
+        atomicAdd(&a.ctr->dbg[0], __builtin_amdgcn_s_memtime() - pw_t0);     // wave lifetime
+        atomicAdd(&a.ctr->dbg[1], pw_wait);                                  // loads issued -> data back, all steps and rounds
+        atomicAdd(&a.ctr->dbg[2], pw_bulk);  atomicAdd(&a.ctr->dbg[3], pw_pool);
+        atomicAdd(&a.ctr->dbg[4], pw_steps); atomicAdd(&a.ctr->dbg[5], pw_rounds);
+    }
+#endif
 }
 
 // ---- one thread per ray (no refill); same per-ray visiting order ----
@@ -1045,8 +1174,8 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
 // argument).  Measured and dropped: one ray per lane first (stream_step) and the pool only for the tail of the tile, as in
 // k_trace_pool's tiled form -- 164 VGPRs, and capped at 128 or 96 it is slower than this (Cornell 512x512 0.41 / 0.53 vs
 // 0.38 ms; the headline frame run this way 1.05 / 1.08 vs 0.95 ms).
-template <int MODE>
-__device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
+template <int MODE, bool Q>
+__device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, const bool has_ray, const bool cull_back = false)
 {
@@ -1058,10 +1187,14 @@ __device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, co
     if (has_ray) stk[(int)lane_rank(m)] = pool_pack(0, (uint32_t)lane);
     int psize = __popcll(m);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#if MIPT_PROBE_STAMP
+    unsigned long long pw_wait = 0ull;
+#endif
     while (psize > 0)
-        pool_round<MODE, kPoolCap>(blob, tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back);
+        pool_round<MODE, kPoolCap, Q>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back PROBE_ARG);
 }
 
+template <bool Q>
 __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
 {
     constexpr int kPoolCap = 24 * 64 - 384;
@@ -1084,7 +1217,7 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
     while (__ballot(active) != 0ull) {
         Trav T;
         trav_init(T, ro4, rd4);
-        tail_trace<0>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, T, active && T.node != kSentinel);
+        tail_trace<0, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, active && T.node != kSentinel);
         const unsigned long long key = sh_best[lane];
         const uint32_t prim = (uint32_t)key;
         const float4 hit = prim != 0xffffffffu ? make_float4(ord_float((uint32_t)(key >> 32)), u2f(prim), sh_u[lane], sh_v[lane])
@@ -1099,7 +1232,7 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
         if (__ballot(sh) != 0ull) {
             Trav S;
             trav_init(S, sh ? o.sro : ro4, sh ? o.srd : rd4);
-            tail_trace<2>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel);
+            tail_trace<2, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel);
             if (sh) {
                 ++n_shadow;
                 if (sh_done[lane] == 0u) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
@@ -1129,8 +1262,8 @@ __device__ __forceinline__ uint32_t pool_pack2(int ref, uint32_t slot7)
     return 0x80000000u | ((desc >> 4) << 9) | (((desc - 1u) & 3u) << 7) | slot7;
 }
 
-template <int CAP>
-__device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, const uint32_t tri_byte_off, uint32_t* stk,
+template <int CAP, bool Q>
+__device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                             unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done, const float* sray,
                                             const int lane, const Trav& T, int& psize)
 {
@@ -1168,32 +1301,21 @@ __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, c
     const uint32_t lfirst = payload >> 2, lcnt = (payload & 3u) + 1u;
     const bool do_inner = live && !leaf;
     const bool do_tri   = live && leaf;
-    uint32_t off = 0u;
-    if (do_inner) off = payload << 6;
-    if (do_tri)   off = tri_byte_off + lfirst * 48u;
-    const float4 n0 = ld16(blob, off), n1 = ld16(blob, off + 16u), n2 = ld16(blob, off + 32u), n3 = ld16(blob, off + 48u);
-    asm volatile("" ::: "memory");
+    u32x4 q0, q1, q2, q3;
+#if MIPT_PROBE_STAMP
+    unsigned long long pw_wait = 0ull;
+#endif
+    load_step<Q>(blob, bvh, do_inner, do_tri, payload, lfirst, q0, q1, q2, q3 PROBE_ARG);
+    const float4 n0 = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), n1 = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
+                 n2 = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
     uint32_t push0 = 0u, push1 = 0u;
     int npush = 0;
     if (do_inner) {
-        const float ax0 = __builtin_fmaf(n0.x, ix, nx), ax1 = __builtin_fmaf(n0.y, ix, nx);
-        const float ay0 = __builtin_fmaf(n0.z, iy, ny), ay1 = __builtin_fmaf(n0.w, iy, ny);
-        const float az0 = __builtin_fmaf(n2.x, iz, nz), az1 = __builtin_fmaf(n2.y, iz, nz);
-        const float bx0 = __builtin_fmaf(n1.x, ix, nx), bx1 = __builtin_fmaf(n1.y, ix, nx);
-        const float by0 = __builtin_fmaf(n1.z, iy, ny), by1 = __builtin_fmaf(n1.w, iy, ny);
-        const float bz0 = __builtin_fmaf(n2.z, iz, nz), bz1 = __builtin_fmaf(n2.w, iz, nz);
-        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                          __builtin_fmaxf(__builtin_fminf(az0, az1), tmn));
-        const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                          __builtin_fminf(__builtin_fmaxf(az0, az1), tcur));
-        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)),
-                                          __builtin_fmaxf(__builtin_fminf(bz0, bz1), tmn));
-        const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)),
-                                          __builtin_fminf(__builtin_fmaxf(bz0, bz1), tcur));
-        const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-        const int c0 = (int)f2u(n3.x), c1 = (int)f2u(n3.y);
+        const SlabOut b = slab_children<Q>(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
+        const bool h0 = b.tn0 <= b.tf0, h1 = b.tn1 <= b.tf1;
+        const int c0 = b.c0, c1 = b.c1;
         if (h0 && h1) {
-            const bool swp = tn1 < tn0;
+            const bool swp = b.tn1 < b.tn0;
             push0 = pool_pack2(swp ? c0 : c1, slot7);
             push1 = pool_pack2(swp ? c1 : c0, slot7);
             npush = 2;
@@ -1245,6 +1367,7 @@ __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, c
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
+template <bool Q>
 __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
 {
     constexpr int kCap = 1152;
@@ -1283,7 +1406,7 @@ __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
         if (has_s) stk[psize + (int)lane_rank(ms)] = pool_pack2(0, 64u + (uint32_t)lane);
         psize += __popcll(ms);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        while (psize > 0) pool_round2<kCap>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, sray, lane, T, psize);
+        while (psize > 0) pool_round2<kCap, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, sray, lane, T, psize);
         // the previous bounce's light term first: the accumulator gets its terms in the reference's order
         if (has_s) {
             if (sh_done[lane] == 0u) { res.x += cx; res.y += cy; res.z += cz; }      // finish_ray<2>
@@ -1330,7 +1453,7 @@ __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
 // buys nothing for them: 421 k shadow rays of the headline frame 0.265 -> 0.228 ms with 32 rays per wave, 8.3 M occlusion rays
 // of the MeshViewer frame at 4K 6.64 -> 6.07 ms with 64 (big closest-hit launches: 0.512 -> 0.529 ms, they keep the tiled form).
 // A launch with few rays lasts as long as ONE wave needs for its rays, so there a wave gets 8 .. 32 and all 64 lanes serve them.
-template <int MODE>
+template <int MODE, bool Q>
 __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
 {
     constexpr int kPoolCap = 24 * 64 - 384;
@@ -1353,7 +1476,7 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
-        tail_trace<MODE>(blob, a.bvh.tri_byte_off, stk, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel,
+        tail_trace<MODE, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel,
                          MODE == 0 && (a.ray_flags & 16u) != 0u);
         if (mine) {
             if (MODE == 0) {
@@ -1467,7 +1590,8 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
                 want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
                 if (o.blocks_user) want = (unsigned long long)blocks;
                 const uint32_t g = (uint32_t)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
-                hipLaunchKernelGGL((k_trace_static<MODE>), dim3(g), dim3(64), 0, st, a, ppw);
+                if (a.bvh.node32_off) hipLaunchKernelGGL((k_trace_static<MODE, true>), dim3(g), dim3(64), 0, st, a, ppw);
+                else                  hipLaunchKernelGGL((k_trace_static<MODE, false>), dim3(g), dim3(64), 0, st, a, ppw);
             } else if constexpr (MODE == 0) {
                 // tiled form: one wave per tile of 64 rays, at most 128 waves per CU (beyond that a wave takes several tiles);
                 // the ray count may be smaller on the device (n_ptr), surplus waves leave at once
@@ -1476,8 +1600,13 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
                     want = want < cus * 16ull ? cus * 16ull : (want > cus * 128ull ? cus * 128ull : want);
                     blocks = (int)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
                 }
-                if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24>), dim3(blocks), dim3(64), 0, st, a);
-                else                    hipLaunchKernelGGL((k_trace_pool<0, 32>), dim3(blocks), dim3(64), 0, st, a);
+                if (a.bvh.node32_off) {
+                    if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, true>), dim3(blocks), dim3(64), 0, st, a);
+                    else                    hipLaunchKernelGGL((k_trace_pool<0, 32, true>), dim3(blocks), dim3(64), 0, st, a);
+                } else {
+                    if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, false>), dim3(blocks), dim3(64), 0, st, a);
+                    else                    hipLaunchKernelGGL((k_trace_pool<0, 32, false>), dim3(blocks), dim3(64), 0, st, a);
+                }
             }
         }
         else if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
@@ -1550,9 +1679,12 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
             ppw = ppw < 16u ? 16u : (ppw > 64u ? 64u : ppw);
         }
         if (fc.max_depth != 1u && bvh.pool2_ok != 0u)
-            hipLaunchKernelGGL(k_tail_pool2, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);     // more than one bounce: two rays per pass
-        else
-            hipLaunchKernelGGL(k_tail_pool, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+        {                                                                                                    // more than one bounce: two rays per pass
+            if (bvh.node32_off) hipLaunchKernelGGL(k_tail_pool2<true>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+            else                hipLaunchKernelGGL(k_tail_pool2<false>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+        }
+        else if (bvh.node32_off) hipLaunchKernelGGL(k_tail_pool<true>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+        else                     hipLaunchKernelGGL(k_tail_pool<false>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
     }
     else
         hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);

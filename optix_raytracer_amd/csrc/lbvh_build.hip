@@ -299,7 +299,79 @@ __global__ __launch_bounds__(256) void k_gather_input(GatherInput in, float* wor
     mats[base + t] = m; gflags[base + t] = gf;
 }
 
+// ---- node format 1: fp16 boxes -----------------------------------------------------------------------------------------------
+// fp16 bit patterns of the largest representable value <= x (down) / the smallest >= x (up).  Subnormal halves are avoided
+// (flushed outward to 0 / +-2^-14) so that no reader depends on the fp16 denormal mode; +-inf stays +-inf (empty boxes).
+__device__ __forceinline__ uint32_t half_bits_dir(float x, bool up)
+{
+    const _Float16 h = (_Float16)x;                       // round to nearest even; overflow -> +-inf
+    const float back = (float)h;
+    unsigned short b = __builtin_bit_cast(unsigned short, h);
+    if (up ? back < x : back > x) {                       // one step in the wanted direction
+        const bool neg = (b & 0x8000u) != 0u;
+        if ((b & 0x7fffu) == 0u) b = up ? 0x0001u : 0x8001u;          // +-0 -> the smallest subnormal of the wanted sign
+        else if (neg == up) b = (unsigned short)(b - 1u);              // towards zero: magnitude down
+        else b = (unsigned short)(b + 1u);                             // away from zero: magnitude up (max finite -> inf)
+    }
+    if ((b & 0x7c00u) == 0u && (b & 0x03ffu) != 0u) {                  // subnormal: flush outward
+        const bool neg = (b & 0x8000u) != 0u;
+        b = neg ? (up ? 0x8000u : 0x8400u) : (up ? 0x0400u : 0x0000u);
+    }
+    return b;
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t b) { return (float)__builtin_bit_cast(_Float16, (unsigned short)b); }
+
+__global__ __launch_bounds__(256) void k_pack_nodes32(MiptBvhNode* nodes, uint32_t nn, uint4* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    MiptBvhNode nd = nodes[i];
+    uint32_t w[2][3];
+    for (int c = 0; c < 2; ++c) {
+        float* x = c == 0 ? nd.c0x : nd.c1x;
+        float* y = c == 0 ? nd.c0y : nd.c1y;
+        float* z = c == 0 ? nd.c0z : nd.c1z;
+        float* ax[3] = { x, y, z };
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t lo = half_bits_dir(ax[k][0], false), hi = half_bits_dir(ax[k][1], true);
+            ax[k][0] = half_bits_to_float(lo); ax[k][1] = half_bits_to_float(hi);
+            w[c][k] = lo | (hi << 16);
+        }
+    }
+    nodes[i] = nd;
+    out[2u * i]      = make_uint4(w[0][0], w[0][1], w[0][2], (uint32_t)nd.c0);
+    out[2u * i + 1u] = make_uint4(w[1][0], w[1][1], w[1][2], (uint32_t)nd.c1);
+}
+
 }  // namespace
+
+hipError_t pack_nodes32(hipStream_t st, float4* d_nodes, uint32_t nn, void* d_nodes32, bool* ok)
+{
+    *ok = false;
+    if (nn == 0u) return hipSuccess;
+    // the root's two child boxes bound the scene
+    MiptBvhNode root;
+    hipError_t e = hipMemcpyAsync(&root, d_nodes, sizeof root, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    float lo[3], hi[3], mag = 0.0f, ext = 0.0f;
+    lo[0] = std::fmin(root.c0x[0], root.c1x[0]); hi[0] = std::fmax(root.c0x[1], root.c1x[1]);
+    lo[1] = std::fmin(root.c0y[0], root.c1y[0]); hi[1] = std::fmax(root.c0y[1], root.c1y[1]);
+    lo[2] = std::fmin(root.c0z[0], root.c1z[0]); hi[2] = std::fmax(root.c0z[1], root.c1z[1]);
+    for (int k = 0; k < 3; ++k) {
+        if (!(lo[k] <= hi[k])) return hipSuccess;                                  // empty or NaN scene box
+        mag = std::fmax(mag, std::fmax(std::fabs(lo[k]), std::fabs(hi[k])));
+        ext = std::fmax(ext, hi[k] - lo[k]);
+    }
+    // an fp16 ulp is at most |x| / 1024: the largest extent must span >= 256 of the coarsest steps, and nothing may overflow
+    if (!(mag <= 32768.0f) || !(ext >= 0.25f * mag)) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_nodes32, dim3((nn + 255u) / 256u), dim3(256), 0, st, reinterpret_cast<MiptBvhNode*>(d_nodes), nn,
+                       reinterpret_cast<uint4*>(d_nodes32));
+    e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) *ok = true;
+    return e;
+}
 
 hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris)
 {
@@ -382,7 +454,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     if ((int)dep > depth_cap) { (void)hipFree(tmp); return hipSuccess; }                 // ok stays false
     const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
     float4* blob = nullptr;
-    if ((e = hipMalloc((void**)&blob, nb + tb + 64)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void**)&blob, nb + tb + 64 + 128 + (size_t)nn * 32u)) != hipSuccess) return fail(e);     // + room for the packed nodes
     hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks), dim3(256), 0, st, left, right, rlo, rhi, n_inner, leaf_max, emit, idx, boxes, vals2, nboxes, (MiptBvhNode*)blob);
     hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb));
     if ((e = hipMemsetAsync((char*)blob + nb + tb, 0, 64, st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }

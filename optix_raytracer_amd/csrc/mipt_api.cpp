@@ -51,6 +51,7 @@ struct Accel {
     float4*   d_tris  = nullptr;   // = d_nodes + num_nodes * 4
     uint32_t  tri_byte_off = 0;    // 0 when the blob does not fit 32-bit offsets (then no streaming kernel)
     uint32_t  blob_bytes = 0;
+    uint32_t  node32_off = 0;      // byte offset of the packed 32-byte nodes behind the triangles (node format 1); 0 = none
     uint32_t* d_mat   = nullptr;
     uint32_t  n_prims = 0;
     uint64_t  bytes   = 0;
@@ -83,6 +84,7 @@ struct MiptContext {
     int      batch_samples = 0;
     int      persistent = 3;
     int      build_mode = 0;              // MIPT_OPT_BUILD: 0 host binned SAH, 1 device LBVH
+    int      node_format = 1;             // MIPT_OPT_NODE_FORMAT: 1 fp16 boxes + packed 32-byte nodes (where the scene suits them), 0 fp32
     uint32_t tail_paths = 1048576;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
     bool     bounces_on_device = false;   // launch statistics: iterations counted by k_advance / k_tail
     int      tile_group = 256;
@@ -266,6 +268,26 @@ int default_build_threads()
     return threads < 1 ? 1 : (threads > 32 ? 32 : threads);
 }
 
+// Byte layout of the one BVH allocation: nodes (64 B each) | triangles (48 B each) | 64 B pad | packed nodes (32 B each).
+// Sets the 32-bit offsets the streaming kernels use (0 when the allocation does not fit them) and, for node format 1, rounds the
+// boxes to fp16 and writes the packed mirror (pack_nodes32); a scene that does not suit fp16 boxes keeps its fp32 nodes.
+hipError_t finish_blob(const MiptContext* c, Accel* a)
+{
+    const size_t nb = (size_t)a->num_nodes * sizeof(MiptBvhNode), tb = (size_t)std::max<uint32_t>(a->num_tris, 1u) * sizeof(MiptBvhTri);
+    const size_t n32 = (nb + tb + 64 + 127) & ~(size_t)127;                     // a packed node never straddles a 128-byte line
+    const size_t total = n32 + (size_t)a->num_nodes * 32u;
+    a->tri_byte_off = total < (1ull << 31) ? (uint32_t)nb : 0u;
+    a->blob_bytes = a->tri_byte_off ? (uint32_t)total : 0u;
+    a->node32_off = 0u;
+    if (c->node_format == 1 && a->tri_byte_off != 0u && a->num_tris >= 2u) {
+        bool ok = false;
+        const hipError_t e = pack_nodes32(nullptr, a->d_nodes, a->num_nodes, (char*)a->d_nodes + n32, &ok);
+        if (e != hipSuccess) return e;
+        if (ok) a->node32_off = (uint32_t)n32;
+    }
+    return hipSuccess;
+}
+
 Accel* find_accel(const MiptContext* c, unsigned long long h)
 {
     auto it = c->accels.find(h);
@@ -278,6 +300,7 @@ DeviceBvh device_bvh(const Accel* a)
     b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes; b.depth = a->depth;
     b.pool_ok = (a->num_nodes < (1u << 25) && a->num_tris >= 2u && a->num_tris < (1u << 23) && a->leaf_max <= 4u) ? 1u : 0u;
     b.pool2_ok = (b.pool_ok && a->num_nodes < (1u << 24) && a->num_tris < (1u << 22)) ? 1u : 0u;
+    b.node32_off = a->node32_off;
     return b;
 }
 
@@ -459,6 +482,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
+    if (const char* e = std::getenv("MIPT_NODE_FORMAT")) { const int v = std::atoi(e); if (v == 0 || v == 1) c->node_format = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
     if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
     if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 30)) c->tail_paths = (uint32_t)v; }
@@ -516,6 +540,9 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_BUILD:
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH) or 1 (device LBVH)");
         c->build_mode = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_NODE_FORMAT:
+        if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "node format must be 0 (fp32 boxes) or 1 (fp16 boxes, packed 32-byte nodes)");
+        c->node_format = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_BURST:
         if ((value & 0xffu) < 1 || (value & 0xffu) > 64 || ((value >> 8) & 0xffu) < 1 || ((value >> 8) & 0xffu) > 64)
             return c->fail(MIPT_ERROR_INVALID_VALUE, "burst lengths must be 1..64 (bulk | dry << 8)");
@@ -543,6 +570,7 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_STEAL_MIN: *value = (uint64_t)c->steal_min; return MIPT_SUCCESS;
     case MIPT_OPT_BATCH_SAMPLES: *value = (uint64_t)c->batch_samples; return MIPT_SUCCESS;
     case MIPT_OPT_BUILD: *value = (uint64_t)c->build_mode; return MIPT_SUCCESS;
+    case MIPT_OPT_NODE_FORMAT: *value = (uint64_t)c->node_format; return MIPT_SUCCESS;
     case MIPT_OPT_TAIL_PATHS: *value = (uint64_t)c->tail_paths; return MIPT_SUCCESS;
     case MIPT_OPT_BURST: *value = (uint64_t)c->burst_bulk | ((uint64_t)c->burst_dry << 8); return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;
@@ -654,9 +682,8 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
     a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
     a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = 1;
-    a->tri_byte_off = (nb + tb + 64 < (1ull << 31)) ? (uint32_t)nb : 0u;
-    a->blob_bytes = a->tri_byte_off ? (uint32_t)(nb + tb + 64) : 0u;
-    a->bytes = nb + tb + (size_t)n * 4u;
+    if ((e = finish_blob(ctx, a)) != hipSuccess) { free_accel(a); return ctx->fail(MIPT_ERROR_HIP, "device BVH build: %s", hipGetErrorString(e)); }
+    a->bytes = nb + tb + (size_t)nn * 32u + (size_t)n * 4u;
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
@@ -746,7 +773,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         for (MiptBvhTri& t : a->host.tris) t.pad1 = gflags[t.prim];
         nb = a->host.nodes.size() * sizeof(MiptBvhNode);
         tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
-        e = hipMalloc((void**)&a->d_nodes, nb + tb + 64);
+        e = hipMalloc((void**)&a->d_nodes, nb + tb + 64 + 128 + a->host.nodes.size() * 32u);      // + room for the packed nodes (finish_blob)
         if (e == hipSuccess) {
             a->d_tris = a->d_nodes + nb / sizeof(float4);
             e = hipMemset((char*)a->d_nodes + nb + tb, 0, 64);
@@ -757,17 +784,14 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         a->depth = a->host.depth; a->leaf_max = a->host.leaf_max; a->seconds = a->host.seconds;
         a->host = HostBvh();                                   // the device copy is the one that is used from here on
     }
-    if (e == hipSuccess) {
-        a->tri_byte_off = (nb + tb + 64 < (1ull << 31)) ? (uint32_t)nb : 0u;
-        a->blob_bytes = a->tri_byte_off ? (uint32_t)(nb + tb + 64) : 0u;
-        e = hipMalloc((void**)&a->d_mat, mb);
-    }
+    if (e == hipSuccess) e = finish_blob(ctx, a);
+    if (e == hipSuccess) e = hipMalloc((void**)&a->d_mat, mb);
     if (e == hipSuccess && n_tris) e = hipMemcpy(a->d_mat, mats.data(), (size_t)n_tris * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         free_accel(a);
         return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "accel upload failed: %s", hipGetErrorString(e));
     }
-    a->bytes = nb + tb + mb;
+    a->bytes = nb + tb + (size_t)a->num_nodes * 32u + mb;
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
     *handle_out = h;
@@ -792,7 +816,8 @@ int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBui
         return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update: the inputs hold %u triangles, the traversable was built from %u", G.n, a->num_tris);
     if (G.e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(G.e));
     if (G.err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, G.err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
-    const hipError_t e = lbvh_refit(nullptr, G.world, G.n, a->d_nodes, a->num_nodes, a->d_tris);
+    hipError_t e = lbvh_refit(nullptr, G.world, G.n, a->d_nodes, a->num_nodes, a->d_tris);
+    if (e == hipSuccess) e = finish_blob(ctx, a);            // the refitted boxes are fp32: round and pack them again
     if (e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(e));
     ctx->log(4, "ACCEL", "refitted BVH2: %u tris, %u nodes, %.4f s", a->num_tris, a->num_nodes,
              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -822,6 +847,7 @@ int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccel
     info->leaf_max = a->leaf_max;
     info->device_bytes = a->bytes;
     info->build_seconds = a->seconds;
+    info->node_format = a->node32_off ? 1u : 0u; info->reserved = 0u;
     return MIPT_SUCCESS;
 }
 
@@ -859,6 +885,7 @@ int mipt_host_bvh_info(const MiptHostBvh* h, MiptAccelInfo* info)
     info->leaf_max = h->bvh.leaf_max;
     info->device_bytes = 0;
     info->build_seconds = h->bvh.seconds;
+    info->node_format = 0u; info->reserved = 0u;
     return MIPT_SUCCESS;
 }
 
@@ -982,6 +1009,8 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     stats->closest_rays = h.closest_rays; stats->shadow_rays = h.shadow_rays;
     stats->node_visits = h.node_visits[0] + h.node_visits[1]; stats->tri_tests = h.tri_tests[0] + h.tri_tests[1];
     stats->shadow_node_visits = h.node_visits[1]; stats->shadow_tri_tests = h.tri_tests[1];
+    if (std::getenv("MIPT_PROBE_PRINT"))       // probe builds (csrc/Makefile probe-%): the in-kernel stamps of the last launch
+        std::fprintf(stderr, "probe dbg: %llu %llu %llu %llu %llu %llu\n", h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[3], h.dbg[4], h.dbg[5]);
     stats->bounces = ctx->bounces_on_device ? (uint32_t)(h.iterations + h.tail_max) : ctx->last_bounces; stats->reserved = 0;
     return MIPT_SUCCESS;
 }

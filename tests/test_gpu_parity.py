@@ -726,3 +726,76 @@ def test_device_build_reads_every_input_form():
         with pytest.raises(api.MiptError, match="out of range"):
             ctx.accel_build([bad])
         ctx.destroy()
+
+
+def test_packed_fp16_nodes_give_the_same_hits(monkeypatch):
+    """MIPT_OPT_NODE_FORMAT: format 1 rounds every child box outward to fp16 values and gives the entry-pool kernels a packed
+    32-byte node (two 16-byte loads per visit instead of four).  Wider boxes only weaken pruning: frames, ray counters and hit
+    records equal those over the fp32 boxes bit for bit; the exported nodes ARE the fp16 values (the oracle walks the same
+    boxes, so visit counters agree too); a scene that does not suit fp16 boxes keeps format 0."""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import scenes
+    scene = scenes.random_soup(60000)
+    w, h = 320, 180
+    launch = scenes.launch_desc(scene, w, h, 2)
+    got = {}
+    for fmt in (0, 1):
+        monkeypatch.setenv("MIPT_NODE_FORMAT", str(fmt))
+        PT, st = _state(scene, w, h, spp=2)
+        info = st.context.accel_info(st.gas_handle)
+        assert info["node_format"] == fmt
+        nodes, tris = st.context.accel_export(st.gas_handle)
+        acc, frame, stats = _render_gpu(PT, st)
+        osc = O.Scene(scene).set_bvh(nodes, tris)
+        a, f, ost = osc.render(launch, threads=4)
+        _assert_pixels(acc, a)
+        assert np.array_equal(frame, f)
+        assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"]
+        # counting launch: the per-ray order of the oracle over the SAME boxes
+        st.context.set_option(L.OPT_COUNT_VISITS, 1)
+        st.context.set_option(L.OPT_MAX_DEPTH, 2)
+        acc2, _, stats2 = _render_gpu(PT, st)
+        a2, _, ost2 = osc.render(launch, max_depth=2, threads=4)
+        _assert_pixels(acc2, a2)
+        assert stats2["node_visits"] == ost2["node_visits"] and stats2["tri_tests"] == ost2["tri_tests"]
+        # ray-buffer queries through the pool kernels
+        rays = osc.primary_rays(launch)[:: 3]
+        d_rays = torch.from_numpy(np.ascontiguousarray(rays)).cuda()
+        d_hits = torch.zeros((rays.shape[0], 4), dtype=torch.float32, device="cuda")
+        st.context.set_option(L.OPT_COUNT_VISITS, 0)
+        st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), rays.shape[0], d_hits.data_ptr())
+        st.context.sync()
+        got[fmt] = (acc, nodes, d_hits.cpu().numpy(), stats, stats2)
+        PT.cleanupState(st)
+    assert np.array_equal(got[0][0].view(np.uint32), got[1][0].view(np.uint32))
+    assert np.array_equal(got[0][2].view(np.uint32), got[1][2].view(np.uint32))
+    assert got[0][3]["closest_rays"] == got[1][3]["closest_rays"] and got[0][3]["shadow_rays"] == got[1][3]["shadow_rays"]
+    n0, n1 = got[0][1], got[1][1]
+    assert np.array_equal(n0[:, 12:].view(np.uint32), n1[:, 12:].view(np.uint32))          # same tree
+    box1 = n1[:, :12]
+    assert np.array_equal(box1.astype(np.float16).astype(np.float32), box1)                # every plane is an fp16 value
+    lo, hi = [0, 2, 4, 6, 8, 10], [1, 3, 5, 7, 9, 11]
+    assert (n1[:, lo] <= n0[:, lo]).all() and (n1[:, hi] >= n0[:, hi]).all()               # rounded outward
+    assert (n0[:, lo] - n1[:, lo]).max() <= 2.0 ** -10 and (n1[:, hi] - n0[:, hi]).max() <= 2.0 ** -10    # by less than one fp16 step at |x| <= 2
+    assert got[1][4]["node_visits"] >= got[0][4]["node_visits"]
+    assert got[1][4]["node_visits"] <= 1.1 * got[0][4]["node_visits"]
+    # a scene 5000 units from the origin, 1 unit across: fp16 steps of 4 units would make the boxes useless -> fp32 kept
+    monkeypatch.setenv("MIPT_NODE_FORMAT", "1")
+    far = dict(scene)
+    v = np.array(scene["vertices"], np.float32, copy=True)
+    v[:, :3] += np.float32(5000.0)
+    far["vertices"] = v
+    cam = dict(scene["camera"])
+    cam["eye"] = tuple(np.float32(x) + np.float32(5000.0) for x in cam["eye"])
+    cam["lookat"] = tuple(np.float32(x) + np.float32(5000.0) for x in cam["lookat"])
+    far["camera"] = cam
+    lt = dict(scene["light"])
+    lt["corner"] = np.asarray(lt["corner"], np.float32) + np.float32(5000.0)
+    far["light"] = lt
+    PT, st = _state(far, 160, 96)
+    assert st.context.accel_info(st.gas_handle)["node_format"] == 0
+    acc, frame, stats = _render_gpu(PT, st)
+    a, f, ost = _oracle_scene(far, st).render(scenes.launch_desc(far, 160, 96), threads=4)
+    _assert_pixels(acc, a)
+    PT.cleanupState(st)

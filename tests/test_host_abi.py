@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libmipt.so does not export %s" % name
     assert declared == {n for n, _, _ in L.SYMBOLS}, declared ^ {n for n, _, _ in L.SYMBOLS}
-    assert lib.mipt_abi_version() == 1
+    assert lib.mipt_abi_version() == 2
 
 
 def test_struct_layouts_match_reference_offsets():

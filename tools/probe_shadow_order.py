@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Experiment: does the ORDER of the shadow-ray queue matter to the any-hit kernel?  Builds the headline frame's shadow rays
+(oracle-free: primary hits from mipt_trace_closest, NEE rays towards the light's centre), then times mipt_trace_any on them in
+(a) path order (what k_shade emits), (b) origin-Morton order, (c) random order, (d) sorted by (direction octant, Morton)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from optix_raytracer_amd import _lib as L, pathtracer as PT, scenes
+
+w, h = 1920, 1080
+scene = scenes.random_soup(1_000_000)
+st = PT.make_state(scene, w, h, 1, 0, max_depth=1)
+ctx = st.context
+launch = scenes.launch_desc(scene, w, h, 1)
+eye, U, V, W = (np.asarray(launch[k], np.float32) for k in ("eye", "U", "V", "W"))
+# primary rays in the kernel's path order: 16x4-pixel tiles
+ty, tx = np.meshgrid(np.arange(h // 4), np.arange(w // 16), indexing="ij")
+iy, ix = np.meshgrid(np.arange(4), np.arange(16), indexing="ij")
+px = (tx[..., None, None] * 16 + ix).reshape(-1)
+py = (ty[..., None, None] * 4 + iy).reshape(-1)
+d = (2 * ((px + 0.5) / w) - 1)[:, None] * U + (2 * ((py + 0.5) / h) - 1)[:, None] * V + W
+d /= np.linalg.norm(d, axis=1, keepdims=True)
+rays = np.zeros((px.size, 8), np.float32)
+rays[:, :3], rays[:, 3], rays[:, 4:7], rays[:, 7] = eye, 0.01, d, 1e16
+d_rays = torch.from_numpy(rays).cuda()
+d_hits = torch.zeros((rays.shape[0], 4), dtype=torch.float32, device="cuda")
+ctx.trace_closest(st.gas_handle, d_rays.data_ptr(), rays.shape[0], d_hits.data_ptr())
+ctx.sync()
+hits = d_hits.cpu().numpy()
+hit = hits[:, 0] > 0
+P = rays[hit, :3] + hits[hit, 0:1] * rays[hit, 4:7]
+lt = scene["light"]
+rng = np.random.default_rng(1)
+lp = np.asarray(lt["corner"]) + rng.random((P.shape[0], 1), np.float32) * np.asarray(lt["v1"]) + rng.random((P.shape[0], 1), np.float32) * np.asarray(lt["v2"])
+toL = (lp - P).astype(np.float32)
+dist = np.linalg.norm(toL, axis=1)
+sh = np.zeros((P.shape[0], 8), np.float32)
+sh[:, :3], sh[:, 3], sh[:, 4:7], sh[:, 7] = P, 0.01, toL / dist[:, None], dist - 0.01
+sh = sh[toL[:, 1] > 0][:420_000]                       # the light is above: roughly the rays NEE would cast
+n = sh.shape[0]
+
+
+def morton(p):
+    q = np.clip(((p + 0.25) / 1.5 * 1024).astype(np.int64), 0, 1023)
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    return spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+
+
+orders = {"path order": np.arange(n), "origin Morton": np.argsort(morton(sh[:, :3]), kind="stable"), "random": rng.permutation(n),
+          "tile-local Morton (512 rays)": np.concatenate([i + np.argsort(morton(sh[i:i + 512, :3]), kind="stable") for i in range(0, n, 512)]),
+          "end-point Morton": np.argsort(morton(sh[:, :3] + sh[:, 4:7] * sh[:, 7:8] * 0.5), kind="stable")}
+d_occ = torch.zeros(n, dtype=torch.int32, device="cuda")
+ref = None
+for name, o in orders.items():
+    dr = torch.from_numpy(np.ascontiguousarray(sh[o])).cuda()
+    for _ in range(3):
+        ctx.trace_any(st.gas_handle, dr.data_ptr(), n, d_occ.data_ptr())
+    ctx.sync()
+    ctx.set_option(L.OPT_PROFILE, 2)
+    for _ in range(20):
+        ctx.trace_any(st.gas_handle, dr.data_ptr(), n, d_occ.data_ptr())
+    tm = ctx.launch_timings()
+    ctx.set_option(L.OPT_PROFILE, 0)
+    occ = d_occ.cpu().numpy()
+    back = np.empty_like(occ); back[o] = occ
+    if ref is None:
+        ref = back
+    print("%-30s %d rays  %.4f ms  occluded %.3f  same flags %s" % (name, n, tm["ms_trace_any"] / 20, occ.mean(), bool(np.array_equal(back, ref))), flush=True)
