@@ -179,3 +179,58 @@ def write_rooms_gltf(path, n_boxes=20_000, seed=5):
            "scenes": [{"nodes": [0, 1]}], "scene": 0}
     path.write_text(json.dumps(doc))
     return path
+
+
+def write_duck_like_gltf(path, seed=3):
+    """BASELINE config 3 names SDK/data/Duck/Duck.gltf, which does not travel to the GPU box.  This writes a deterministic
+    stand-in with the properties of that file that matter to the path: ONE mesh with ONE primitive of
+    4 212 triangles, uint16 indices, positions in centimetres (body, head and bill of a duck-like blob, about 170 units
+    across), a root node with scale 0.01 whose children are the mesh node and a perspective camera node (yfov 0.6606 rad,
+    aspectRatio 1.5) placed like Duck's camera, and one dielectric material (metallicFactor 0).  Returns the path."""
+    import base64
+    import json
+    rng = np.random.default_rng(seed)
+
+    def blob(centre, radii, slices, stacks, bump):
+        """closed lat/long surface: 2 * slices * (stacks - 1) triangles, (stacks + 1) * slices + ... vertices"""
+        th = np.linspace(0.0, np.pi, stacks + 1)[1:-1]                       # interior rings
+        ph = np.linspace(0.0, 2.0 * np.pi, slices, endpoint=False)
+        ring = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.cos(th), np.ones_like(ph)), np.outer(np.sin(th), np.sin(ph))], -1).reshape(-1, 3)
+        pts = np.concatenate([[[0.0, 1.0, 0.0]], ring, [[0.0, -1.0, 0.0]]])
+        pts = pts * (1.0 + bump * rng.standard_normal((pts.shape[0], 1))) * np.asarray(radii) + np.asarray(centre)
+        tri = []
+        n_r = stacks - 1
+        for s in range(slices):
+            s1 = (s + 1) % slices
+            tri.append([0, 1 + s1, 1 + s])
+            for r in range(n_r - 1):
+                a, b, c, d = 1 + r * slices + s, 1 + r * slices + s1, 1 + (r + 1) * slices + s, 1 + (r + 1) * slices + s1
+                tri += [[a, b, d], [a, d, c]]
+            tri.append([1 + (n_r - 1) * slices + s, 1 + (n_r - 1) * slices + s1, 1 + n_r * slices])
+        return pts.astype(np.float32), np.asarray(tri, np.uint32)
+    parts = [blob((0.0, 60.0, 0.0), (70.0, 45.0, 50.0), 54, 28, 0.004),      # body   2 * 54 * 27 = 2916 triangles
+             blob((55.0, 125.0, 0.0), (30.0, 28.0, 27.0), 36, 15, 0.004),    # head   2 * 36 * 14 = 1008
+             blob((92.0, 118.0, 0.0), (18.0, 6.0, 11.0), 24, 7, 0.0)]        # bill   2 * 24 * 6  =  288
+    pos, idx, base = [], [], 0
+    for p, t in parts:
+        pos.append(p); idx.append(t + base); base += p.shape[0]
+    pos = np.concatenate(pos); idx = np.concatenate(idx).astype(np.uint16).reshape(-1)
+    assert idx.size == 3 * 4212 and pos.shape[0] < 65536
+    bin0 = pos.tobytes() + idx.tobytes()
+    # camera: placed like Duck's (SURVEY.md 8a17: eye (4.00, 4.63, -4.31) after the 0.01 root scale), rotated about an oblique
+    # axis so that its transformed up vector is not axis aligned
+    q = np.asarray([np.sin(0.2) * 0.6, 0.0, np.sin(0.2) * 0.8, np.cos(0.2)])
+    doc = {"asset": {"version": "2.0"},
+           "buffers": [{"byteLength": len(bin0), "uri": "data:application/octet-stream;base64," + base64.b64encode(bin0).decode()}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": pos.nbytes}, {"buffer": 0, "byteOffset": pos.nbytes, "byteLength": idx.nbytes}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": int(pos.shape[0]), "type": "VEC3",
+                          "min": [float(x) for x in pos.min(0)], "max": [float(x) for x in pos.max(0)]},
+                         {"bufferView": 1, "componentType": 5123, "count": int(idx.size), "type": "SCALAR"}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.85, 0.65, 0.12, 1.0], "metallicFactor": 0.0}}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 0}]}],
+           "cameras": [{"type": "perspective", "perspective": {"yfov": 0.660593, "aspectRatio": 1.5, "znear": 1.0, "zfar": 10000.0}}],
+           "nodes": [{"children": [1, 2], "scale": [0.01, 0.01, 0.01]}, {"mesh": 0},
+                     {"camera": 0, "translation": [400.113, 463.264, -431.078], "rotation": [float(x) for x in q]}],
+           "scenes": [{"nodes": [0]}], "scene": 0}
+    path.write_text(json.dumps(doc))
+    return path

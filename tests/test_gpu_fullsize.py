@@ -125,3 +125,90 @@ def test_config2_cornell_1080p_spp16():
     # one primary ray per pixel and sample plus the Russian-roulette survivors; every sample runs its own bounce loop
     assert stats["closest_rays"] > 1.5 * w * h * spp and stats["bounces"] >= 16 * 10
     PT.cleanupState(st)
+
+
+def _oracle_pixels(osc, launch, idx, max_depth, threads=16):
+    """osc.render_pixels over a thread pool (the C call releases the GIL); returns (values, summed stats)"""
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = np.array_split(idx, threads * 4)
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(lambda c: osc.render_pixels(launch, c, max_depth=max_depth), chunks))
+    return np.concatenate([r[0] for r in res]), res
+
+
+def _gltf_config(tmp_path, writer, w, h, spp, depth, n_check, spp_counters, expect_tris):
+    """One BASELINE glTF configuration at its specified size: the frame of ONE launch of `spp` samples, `n_check` random
+    pixels against the oracle bit for bit; then a launch at spp_counters whose ray counters (and every pixel) are compared
+    with an oracle render of the whole frame.  Returns the timing line."""
+    import time
+    import torch
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    scene = scenes.from_gltf(writer(tmp_path))
+    assert expect_tris[0] <= scene["info"]["num_triangles"] <= expect_tris[1]
+    st = PT.make_state(scene, w, h, spp, 0, max_depth=depth)
+    ob = PT.OutputBuffer(w, h, st.device)
+    PT.launchSubframe(ob, st)                                        # warm-up (allocations, caches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    PT.launchSubframe(ob, st)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    acc, frame, stats = st.accum.cpu().numpy(), ob.getHostPointer(), st.context.launch_stats()
+    nodes, tris = st.context.accel_export(st.gas_handle)
+    osc = O.Scene(scene).set_bvh(nodes, tris)
+    launch = scenes.launch_desc(scene, w, h, spp)
+    rng = np.random.default_rng(3)
+    # half of the checked pixels are drawn among the lit ones (in these scenes most camera rays leave through the open side)
+    lit = np.flatnonzero(acc.reshape(-1, 4)[:, :3].sum(1) > 0)
+    idx = np.concatenate([rng.integers(0, w * h, n_check // 2), rng.choice(lit, n_check - n_check // 2)]).astype(np.uint32)
+    out, _ = _oracle_pixels(osc, launch, idx, depth)
+    got = acc.reshape(-1, 4)[idx]
+    bad = np.flatnonzero((got.view(np.uint32) != out.view(np.uint32)).any(1))
+    assert bad.size == 0, "pixel %d: gpu %s oracle %s" % (idx[bad[0]], got[bad[0]], out[bad[0]])
+    assert (frame[..., 3] == 255).all() and stats["closest_rays"] >= w * h * spp
+    line = "%s: %dx%d spp %d depth cap %d, %d triangles: %.1f ms per launch, %.2f Gray/s (%d closest + %d shadow rays)" % (
+        scene["name"], w, h, spp, depth, scene["info"]["num_triangles"], ms, (stats["closest_rays"] + stats["shadow_rays"]) / ms / 1e6,
+        stats["closest_rays"], stats["shadow_rays"])
+    # batched samples (one wavefront pass for all samples): same values to rounding
+    st.context.set_option(L.OPT_BATCH_SAMPLES, 1)
+    if w * h * spp < 2 ** 31 // 2:
+        PT.launchSubframe(ob, st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        PT.launchSubframe(ob, st)
+        torch.cuda.synchronize()
+        line += "; batched %.1f ms" % ((time.perf_counter() - t0) * 1e3)
+        accb = st.accum.cpu().numpy()
+        denom = np.maximum(np.abs(acc), 1e-6)
+        assert (np.abs(accb - acc) / denom).max() <= 1e-5
+        sb = st.context.launch_stats()
+        assert sb["closest_rays"] == stats["closest_rays"] and sb["shadow_rays"] == stats["shadow_rays"]
+    st.context.set_option(L.OPT_BATCH_SAMPLES, 0)
+    # ray-counter equality over the whole frame at a sample count the oracle renders in seconds
+    st.params.samples_per_launch = spp_counters
+    PT.launchSubframe(ob, st)
+    acc2, stats2 = st.accum.cpu().numpy(), st.context.launch_stats()
+    a2, _, ost2 = osc.render(scenes.launch_desc(scene, w, h, spp_counters), max_depth=depth, threads=16, want_frame=False)
+    assert np.array_equal(acc2.view(np.uint32), a2.view(np.uint32))
+    assert stats2["closest_rays"] == ost2["closest_rays"] and stats2["shadow_rays"] == ost2["shadow_rays"] > 0
+    PT.cleanupState(st)
+    print(line)
+    return line
+
+
+def test_config3_duck_like_gltf_1080p_spp64_depth8(tmp_path):
+    """BASELINE config 3: SDK/data Duck.gltf (~4k triangles) 1920x1080 spp 64, max depth 8, NEE shadow rays, 1 GPU.  Duck.gltf
+    itself stays in the reference tree; scenes.write_duck_like_gltf writes a file with its properties (4 212 triangles, u16
+    indices, root scale 0.01, camera node) that goes through the same loader."""
+    from optix_raytracer_amd import scenes
+    _gltf_config(tmp_path, lambda d: scenes.write_duck_like_gltf(d / "duck_like.gltf"), 1920, 1080, 64, 8, 24000, 2, (4212, 4212))
+
+
+def test_config5_rooms_gltf_4k_spp256_rr_depth16(tmp_path):
+    """BASELINE config 5 (its one-GPU share): a Sponza-class glTF (~250 k triangles) through the sutil::Scene-compatible loader,
+    3840x2160 spp 256, Russian roulette at every bounce as the reference's loop has it, depth cap 16.  The tree holds no such
+    asset; scenes.write_rooms_gltf generates one (240 k triangles, u32 indices, six materials, camera node)."""
+    from optix_raytracer_amd import scenes
+    _gltf_config(tmp_path, lambda d: scenes.write_rooms_gltf(d / "rooms.gltf", n_boxes=20_000), 3840, 2160, 256, 16, 20000, 1, (230_000, 260_000))
