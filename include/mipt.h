@@ -302,6 +302,31 @@ int mipt_unpermute(MiptContext* ctx, void* stream, const void* gathered, unsigne
                    unsigned int width, unsigned int height, void* accum_buffer, void* frame_buffer);
 
 /* ---------------------------------------------------------------------------
+ * In-process multi-GPU group (shape of SDK/optixMultiGPU: ONE host thread, every device its own state and stream,
+ * optixMultiGPU.cpp:562-594 launchSubframe, :1093-1102 per-device scene).  The group owns one MiptContext and one stream per
+ * device, the compact shard buffers and the RCCL communicators (ncclCommInitAll; librccl is bound with dlopen when the
+ * group is created).  The caller replicates the scene: for every member it builds the acceleration structure and sets the
+ * hit-group records through that member's context (mipt_group_member), exactly as the sample does per PathTracerState.
+ *   mipt_group_launch    params[i] is member i's Params (its own traversable handle; accum / frame pointers are ignored);
+ *                        every member renders its StaticWorkDistribution shard of the frame on its stream, asynchronously.
+ *   mipt_group_allgather ONE grouped ncclAllGather of the compact float4 shards, then on every member i with
+ *                        accum_buffers[i] != NULL the scatter into its canonical accum_buffer / frame_buffer (device
+ *                        pointers on that member's device; frame_buffers or any of its entries may be NULL).
+ *   mipt_group_sync      waits for every member's stream (the sample's per-device CUDA_SYNC_CHECK).
+ * A one-device group works without RCCL.  Not thread safe.
+ * ------------------------------------------------------------------------- */
+typedef struct MiptGroup MiptGroup;
+int         mipt_group_create(const int* hip_devices, uint32_t n, MiptLogCallback cb, void* cbdata, int log_level, MiptGroup** out);
+int         mipt_group_destroy(MiptGroup* group);
+int         mipt_group_size(const MiptGroup* group, uint32_t* n_out);
+int         mipt_group_member(MiptGroup* group, uint32_t index, MiptContext** ctx_out, int* hip_device_out, void** stream_out);
+int         mipt_group_launch(MiptGroup* group, const MiptParams* params, unsigned int width, unsigned int height);
+int         mipt_group_allgather(MiptGroup* group, void* const* accum_buffers, void* const* frame_buffers);
+int         mipt_group_sync(MiptGroup* group);
+int         mipt_group_uses_rccl(const MiptGroup* group);      /* 1 when the exchange goes through RCCL */
+const char* mipt_group_last_error_string(const MiptGroup* group);
+
+/* ---------------------------------------------------------------------------
  * Layouts of the glTF launch path kept for its drop-in: whitted::LaunchParams
  * (SDK/cuda/whitted.h:59-77, 128 bytes) and BufferView<T> (SDK/cuda/BufferView.h:33-49, 16 bytes).
  * mipt_whitted_launch (below) runs the opaque, untextured subset of cuda/whitted.cu on them.

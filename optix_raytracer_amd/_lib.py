@@ -170,6 +170,15 @@ SYMBOLS = [
     ("mipt_shard_pixel", C.c_int, [C.c_uint, C.c_uint, C.c_uint, C.c_uint, _u32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("mipt_launch_shard", C.c_int, [_vp, _vp, C.POINTER(MiptParams), C.c_uint, C.c_uint, C.c_uint, C.c_uint, _vp]),
     ("mipt_unpermute", C.c_int, [_vp, _vp, _vp, C.c_uint, C.c_uint, C.c_uint, _vp, _vp]),
+    ("mipt_group_create", C.c_int, [C.POINTER(C.c_int), _u32, LOG_CALLBACK, _vp, C.c_int, C.POINTER(_vp)]),
+    ("mipt_group_destroy", C.c_int, [_vp]),
+    ("mipt_group_size", C.c_int, [_vp, C.POINTER(_u32)]),
+    ("mipt_group_member", C.c_int, [_vp, _u32, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(_vp)]),
+    ("mipt_group_launch", C.c_int, [_vp, C.POINTER(MiptParams), C.c_uint, C.c_uint]),
+    ("mipt_group_allgather", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    ("mipt_group_sync", C.c_int, [_vp]),
+    ("mipt_group_uses_rccl", C.c_int, [_vp]),
+    ("mipt_group_last_error_string", C.c_char_p, [_vp]),
     ("mipt_imgui_launch", C.c_int, [_vp, _vp, C.POINTER(MiptImguiParams), C.c_uint, C.c_uint, C.c_uint]),
     ("mipt_imgui_camera_set_fd", None, [C.POINTER(MiptImguiCamera), C.c_float]),
     ("mipt_imgui_camera_compute_uvw", None, [C.POINTER(MiptImguiCamera)]),

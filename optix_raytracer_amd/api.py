@@ -214,15 +214,24 @@ class Context:
             raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_context_create(device=%d)" % device)
         self.device = device
 
+    @classmethod
+    def _borrow(cls, handle, device):
+        """A Context object over a MiptContext that someone else owns (a member of a Group): destroy() does nothing."""
+        self = cls.__new__(cls)
+        self._lib = L.load()
+        self._h = C.c_void_p(handle)
+        self._log_py, self._cb, self.device, self._borrowed = None, None, device, True
+        return self
+
     def _check(self, rc):
         if rc:
             raise MiptError(rc, self._lib.mipt_error_name(rc).decode(),
                             self._lib.mipt_last_error_string(self._h).decode())
 
     def destroy(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             self._lib.mipt_context_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -347,3 +356,63 @@ class Context:
 
     def trace_any(self, handle, rays_ptr, n, occluded_ptr, stream=None):
         self._check(self._lib.mipt_trace_any(self._h, stream, handle, rays_ptr, n, occluded_ptr))
+
+
+class Group:
+    """mipt_group_*: one host thread, n devices (SDK/optixMultiGPU's shape, optixMultiGPU.cpp:562-594).  contexts[i] is member
+    i's Context (owned by the group): build the scene's acceleration structure and hit-group records on each of them."""
+
+    def __init__(self, devices, log=None, log_level=0):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        self._log_py = log
+
+        def _cb(level, tag, msg, _):
+            if self._log_py:
+                self._log_py(level, tag.decode(), msg.decode())
+        self._cb = L.LOG_CALLBACK(_cb)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.mipt_group_create(devs, len(devices), self._cb, None, log_level, C.byref(self._h))
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_group_create(%s)" % list(devices))
+        self.devices = [int(d) for d in devices]
+        self.contexts, self.streams = [], []
+        for i in range(len(devices)):
+            ctx, dev, st = C.c_void_p(), C.c_int(), C.c_void_p()
+            self._check(self._lib.mipt_group_member(self._h, i, C.byref(ctx), C.byref(dev), C.byref(st)))
+            self.contexts.append(Context._borrow(ctx.value, dev.value))
+            self.streams.append(st.value)
+
+    def _check(self, rc):
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), self._lib.mipt_group_last_error_string(self._h).decode())
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.mipt_group_uses_rccl(self._h))
+
+    def launch(self, params_list, width, height):
+        arr = (L.MiptParams * len(params_list))(*params_list)
+        self._check(self._lib.mipt_group_launch(self._h, arr, width, height))
+
+    def allgather(self, accum_ptrs, frame_ptrs=None):
+        n = len(self.devices)
+        acc = (C.c_void_p * n)(*[int(p) if p else None for p in accum_ptrs])
+        frm = (C.c_void_p * n)(*[int(p) if p else None for p in frame_ptrs]) if frame_ptrs is not None else None
+        self._check(self._lib.mipt_group_allgather(self._h, acc, frm))
+
+    def sync(self):
+        self._check(self._lib.mipt_group_sync(self._h))
+
+    def destroy(self):
+        if self._h:
+            for c in self.contexts:
+                c.destroy()
+            self._lib.mipt_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

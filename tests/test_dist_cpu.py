@@ -16,3 +16,16 @@ def test_sharded_frame_reassembles_over_gloo(world, w, h):
            os.path.join(HERE, "_dist_worker.py"), str(w), str(h), "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_sharded_frame_through_the_library_on_ranks_sharing_the_gpu():
+    """world 2, gloo, both ranks on the box's one GPU: every rank renders its shard with mipt_launch_shard and assembles the
+    frame with mipt_unpermute (tests/_dist_worker.py takes the GPU path when a GPU is present)."""
+    import torch
+    assert torch.cuda.is_available()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(HERE, "_dist_worker.py"), "200", "96", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

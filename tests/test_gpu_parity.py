@@ -799,3 +799,55 @@ def test_packed_fp16_nodes_give_the_same_hits(monkeypatch):
     a, f, ost = _oracle_scene(far, st).render(scenes.launch_desc(far, 160, 96), threads=4)
     _assert_pixels(acc, a)
     PT.cleanupState(st)
+
+
+def test_in_process_group_renders_the_full_frame():
+    """mipt_group_create / launch / allgather / sync (the one-host-thread form of SDK/optixMultiGPU, optixMultiGPU.cpp:562-594)
+    on the devices this box has: the member's shard goes through the group's exchange (RCCL's ncclAllGather when librccl loads,
+    also with ONE member) and the scatter kernel, and the assembled frame equals the single-launch frame and the oracle's."""
+    torch = _torch()
+    from optix_raytracer_amd import api
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    n_dev = min(torch.cuda.device_count(), 2)
+    scene = scenes.cornell_box()
+    w, h, spp = 200, 120, 2
+    grp = api.Group(list(range(n_dev)))
+    assert len(grp.contexts) == n_dev
+    states = []
+    for i, ctx in enumerate(grp.contexts):              # the sample replicates the scene per device (optixMultiGPU.cpp:1093-1102)
+        st = PT.PathTracerState()
+        st.device = torch.device("cuda", grp.devices[i])
+        torch.cuda.set_device(st.device)
+        st.context = ctx
+        PT.buildMeshAccel(st, scene)
+        PT.createSBT(st)
+        PT.initLaunchParams(st, w, h, spp)
+        cam = scene["camera"]
+        PT.handleCameraUpdate(st, PT.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], 1.0))
+        st.frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=st.device)
+        states.append(st)
+    for sub in range(2):                                # progressive: the compact shard buffers carry the running average
+        for st in states:
+            st.params.subframe_index = sub
+        grp.launch([st.params for st in states], w, h)
+        grp.allgather([st.accum.data_ptr() for st in states], [st.frame.data_ptr() for st in states])
+        grp.sync()
+    print("group exchange through RCCL:", grp.uses_rccl)
+    # the same two subframes by plain launches, and by the oracle
+    PT2, ref = _state(scene, w, h, spp)
+    for sub in range(2):
+        acc_ref, frame_ref, _ = _render_gpu(PT2, ref, subframe=sub)
+    osc = _oracle_scene(scene, ref)
+    a = None
+    for sub in range(2):
+        a, f, _ = osc.render(scenes.launch_desc(scene, w, h, spp, subframe=sub), accum=a)
+    for st in states:
+        got = st.accum.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), acc_ref.view(np.uint32))
+        assert np.array_equal(got.view(np.uint32), a.view(np.uint32))
+        assert np.array_equal(st.frame.cpu().numpy(), frame_ref)
+    with pytest.raises(api.MiptError):
+        grp.launch([states[0].params] * n_dev, w + 8, h)             # size does not match the params
+    PT2.cleanupState(ref)
+    grp.destroy()
