@@ -1046,6 +1046,21 @@ static v3 imgui_light_lumi(const OrcImguiLight* l)
     return v3_make(l->b[0], l->b[1], l->b[2]);
 }
 
+/* exported for the known-answer tests (tests/golden/ref_kat_imgui.json, made by oracle/ref_kat_imgui.cpp from the reference's
+ * own camera.h / light.h / diffuse.h) */
+void orc_imgui_compute_ray(const OrcImguiCamera* c, uint32_t ix, uint32_t iy, uint32_t dimx, uint32_t dimy, uint32_t* seed,
+                           float origin[3], float direction[3])
+{
+    v3 o, d;
+    imgui_compute_ray(c, ix, iy, dimx, dimy, &o, &d, seed);
+    origin[0] = o.x; origin[1] = o.y; origin[2] = o.z; direction[0] = d.x; direction[1] = d.y; direction[2] = d.z;
+}
+void orc_imgui_light_wi(const OrcImguiLight* l, const float p[3], uint32_t* seed, float wi[3], float lumi[3])
+{
+    v3 r = imgui_light_wi(l, v3_ld(p), seed), e = imgui_light_lumi(l);
+    wi[0] = r.x; wi[1] = r.y; wi[2] = r.z; lumi[0] = e.x; lumi[1] = e.y; lumi[2] = e.z;
+}
+
 /* __closesthit__ch, optixTriangle.cu:174-268 */
 static v3 imgui_closesthit(const OrcScene* s, int mode, const OrcImguiFrame* f, v3 ray_o, v3 ray_d, const HitRec* h,
                            uint32_t ix, uint32_t iy, OrcStats* st)

@@ -140,6 +140,9 @@ typedef struct OrcImguiFrame {
 
 void orc_imgui_camera_compute_uvw(OrcImguiCamera* cam);                       /* camera.h:110-123 */
 void orc_imgui_camera_set_fd(OrcImguiCamera* cam, float new_fd);              /* camera.h:36 */
+void orc_imgui_compute_ray(const OrcImguiCamera* cam, uint32_t ix, uint32_t iy, uint32_t dimx, uint32_t dimy, uint32_t* seed,
+                           float origin[3], float direction[3]);                /* camera.h:127-144 */
+void orc_imgui_light_wi(const OrcImguiLight* l, const float p[3], uint32_t* seed, float wi[3], float lumi[3]);   /* light.h:19-40 */
 int  orc_imgui_render_rows(const OrcScene*, int mode, const OrcImguiFrame* f, uint32_t y0, uint32_t y1, OrcStats* stats);
 
 /* ---- SDK/cuda/whitted.cu programs (__raygen__pinhole :44-97, __miss__constant_radiance :139-142,

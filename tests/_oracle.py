@@ -162,6 +162,10 @@ def lib():
     L.orc_imgui_camera_compute_uvw.argtypes = [C.POINTER(OrcImguiCamera)]
     L.orc_imgui_camera_set_fd.restype = None
     L.orc_imgui_camera_set_fd.argtypes = [C.POINTER(OrcImguiCamera), C.c_float]
+    L.orc_imgui_compute_ray.restype = None
+    L.orc_imgui_compute_ray.argtypes = [C.POINTER(OrcImguiCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, fp]
+    L.orc_imgui_light_wi.restype = None
+    L.orc_imgui_light_wi.argtypes = [C.POINTER(OrcImguiLight), fp, u32p, fp, fp]
     L.orc_imgui_render_rows.restype = C.c_int
     L.orc_imgui_render_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcImguiFrame), C.c_uint32, C.c_uint32,
                                         C.POINTER(OrcStats)]

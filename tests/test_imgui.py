@@ -40,6 +40,110 @@ def test_layouts_and_camera_helpers():
     assert abs(np.linalg.norm(np.array(cam.c.w)) - 1.0) < 1e-5 and len(lights) == 4 and len(mats) == 28     # set_fd(1) scales w to unit length
 
 
+KAT = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "ref_kat_imgui.json")
+
+
+def _fb(bits3):
+    return np.array(bits3, np.uint32).view(np.float32)
+
+
+def test_layouts_equal_the_reference_classes():
+    """sizeof / offsetof of the reference's own classes, printed by oracle/ref_kat_imgui.cpp from SDK/imgui_test/*.h: the
+    product's C structs (include/mipt.h via _lib.py) and the oracle's have the same layouts."""
+    import json
+    lay = json.load(open(KAT))["layout"]
+    cam_map = {"m_eye": "eye", "m_lookat": "lookat", "m_up": "up", "m_ortho": "ortho", "m_fov": "fov", "m_fd": "fd",
+               "m_aperture": "aperture", "m_speed": "speed", "u": "u", "v": "v", "w": "w"}
+    for T in (L.MiptImguiCamera, O.OrcImguiCamera):
+        assert C.sizeof(T) == lay["Camera"]["size"]
+        for ref, ours in cam_map.items():
+            assert getattr(T, ours).offset == lay["Camera"][ref], ref
+    for T in (L.MiptImguiLight, O.OrcImguiLight):
+        assert C.sizeof(T) == lay["LightVariant"]["size"] and T.tag.offset == lay["LightVariant"]["_tag"] and T.a.offset == lay["LightVariant"]["_payload"]
+    # the union members as MiptImguiLight documents them: a = first float3; b = next four floats; c = the rest
+    assert lay["PointLight"] == {"size": 36, "m_position": 0, "m_lumi": 12, "m_dark": 24}
+    assert lay["DirectionalLight"] == {"size": 40, "m_direction": 0, "m_lumi": 12, "m_jitter": 24, "m_dark": 28}
+    assert lay["VolumetricLight"] == {"size": 40, "m_position": 0, "m_radius": 12, "m_lumi": 16, "m_dark": 28}
+    assert lay["DiffuseMaterial"] == {"size": 12, "m_color": 0}
+    P = L.MiptImguiParams
+    assert C.sizeof(P) == lay["Params"]["size"]
+    for k, off in lay["Params"].items():
+        if k != "size":
+            assert getattr(P, k).offset == off, k
+
+
+def test_camera_known_answers_from_the_reference():
+    """Camera::set_fd / compute_uvw / compute_ray of SDK/imgui_test/camera.h, run on the host by oracle/ref_kat_imgui.cpp (clang++:
+    the two aperture draws are sibling arguments, evaluated left to right as nvcc's device compiler does)."""
+    import json
+    lib, plib = O.lib(), L.load()
+    for e in json.load(open(KAT))["camera"]:
+        for which in ("oracle", "product"):
+            cam = (O.OrcImguiCamera if which == "oracle" else L.MiptImguiCamera)()
+            cam.eye, cam.lookat, cam.up = (C.c_float * 3)(*_fb(e["eye"])), (C.c_float * 3)(*_fb(e["lookat"])), (C.c_float * 3)(*_fb(e["up"]))
+            cam.ortho, cam.fov, cam.aperture, cam.speed = e["ortho"], _fb([e["fov"]])[0], _fb([e["aperture"]])[0], np.float32(0.01)
+            if which == "oracle":
+                lib.orc_imgui_camera_set_fd(C.byref(cam), _fb([e["fd_in"]])[0])
+                lib.orc_imgui_camera_compute_uvw(C.byref(cam))
+            else:
+                plib.mipt_imgui_camera_set_fd(C.byref(cam), _fb([e["fd_in"]])[0])
+                plib.mipt_imgui_camera_compute_uvw(C.byref(cam))
+            assert np.float32(cam.fd).view(np.uint32) == e["m_fd"], which
+            for k in ("u", "v", "w"):
+                assert np.array(getattr(cam, k), np.float32).view(np.uint32).tolist() == e[k], (which, k)
+            # the whole object, byte for byte (the three padding bytes behind `m_ortho` excepted)
+            got = np.frombuffer(bytes(cam), np.uint32).copy()
+            ref = np.array(e["object"], np.uint32)
+            got[9] &= 0xff
+            ref[9] &= 0xff
+            assert np.array_equal(got, ref), which
+        ocam = O.OrcImguiCamera.from_buffer_copy(bytes(cam))
+        for r in e["rays"]:
+            seed = C.c_uint32(r["seed0"])
+            o, d = (C.c_float * 3)(), (C.c_float * 3)()
+            lib.orc_imgui_compute_ray(C.byref(ocam), r["idx"][0], r["idx"][1], r["dim"][0], r["dim"][1], C.byref(seed), o, d)
+            assert np.array(o, np.float32).view(np.uint32).tolist() == r["origin"] and np.array(d, np.float32).view(np.uint32).tolist() == r["direction"]
+            lib.orc_imgui_compute_ray(C.byref(ocam), r["idx"][0], r["idx"][1], r["dim"][0], r["dim"][1], C.byref(seed), o, d)
+            assert np.array(o, np.float32).view(np.uint32).tolist() == r["origin2"] and np.array(d, np.float32).view(np.uint32).tolist() == r["direction2"]
+            assert seed.value == r["seed_after"]
+
+
+def test_light_and_material_known_answers_from_the_reference():
+    """LightVariant::wi / lumi (light.h:19-40) for point, directional (jittered) and volumetric lights and DiffuseMaterial::f:
+    the reference object's 44 bytes are used AS the oracle's / the product's light struct, so the layout mapping is pinned too."""
+    import json
+    lib = O.lib()
+    kat = json.load(open(KAT))
+    for e in kat["lights"]:
+        raw = np.array(e["object"], np.uint32).tobytes()
+        assert len(raw) == 44
+        ol = O.OrcImguiLight.from_buffer_copy(raw)
+        pl = L.MiptImguiLight.from_buffer_copy(raw)
+        assert ol.tag == pl.tag == e["tag"]
+        for q in e["wi"]:
+            seed = C.c_uint32(q["seed0"])
+            wi, lumi = (C.c_float * 3)(), (C.c_float * 3)()
+            p = (C.c_float * 3)(*_fb(q["p"]))
+            lib.orc_imgui_light_wi(C.byref(ol), p, C.byref(seed), wi, lumi)
+            assert np.array(wi, np.float32).view(np.uint32).tolist() == q["wi"]
+            assert np.array(lumi, np.float32).view(np.uint32).tolist() == e["lumi"]
+            lib.orc_imgui_light_wi(C.byref(ol), p, C.byref(seed), wi, lumi)
+            assert np.array(wi, np.float32).view(np.uint32).tolist() == q["wi2"] and seed.value == q["seed_after"]
+    # the host mirror builds the same bytes from (kind, parameters)
+    from optix_raytracer_amd import imgui_test as IT2
+    for e in kat["lights"]:
+        w = np.array(e["object"], np.uint32).view(np.float32)
+        if e["tag"] == 0:
+            made = IT2.PointLight(w[0:3], w[3:6])
+        elif e["tag"] == 1:
+            made = IT2.DirectionalLight(w[0:3], w[3:6], w[6])
+        else:
+            made = IT2.VolumetricLight(w[0:3], w[3], w[4:7])
+        assert bytes(made) == np.array(e["object"], np.uint32).tobytes()
+    for e in kat["diffuse"]:
+        assert e["f"] == e["color"] == e["object"] and e["seed_after"] == 5          # f() returns the colour, draws nothing
+
+
 def test_nbt_round_trip(tmp_path):
     v, n, _ = _mesh(50)
     for compress in (True, False):
