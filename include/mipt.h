@@ -129,7 +129,7 @@ typedef struct MiptAccelInfo {
     uint64_t device_bytes;
     double   build_seconds;
     uint32_t node_format;      /* 1: the boxes are fp16 values and a packed 32-byte mirror exists (MiptBvhNode32); 0: fp32 boxes */
-    uint32_t reserved;
+    uint32_t num_instances;    /* > 0: an instance (two-level) structure; num_nodes = its top level, num_triangles = all referenced */
 } MiptAccelInfo;
 
 /* one triangle build input == OptixBuildInputTriangleArray as the samples use it
@@ -244,6 +244,36 @@ int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccel
 /* copies the linear BVH to host arrays sized from mipt_accel_info (inspection, external checkers) */
 int mipt_accel_export(const MiptContext* ctx, unsigned long long handle,
                       MiptBvhNode* nodes_out, MiptBvhTri* tris_out);
+
+/* ---------------------------------------------------------------------------
+ * Instance (two-level) acceleration structures   (replaces optixAccelBuild over OPTIX_BUILD_INPUT_TYPE_INSTANCES as
+ * Scene::buildInstanceAccel uses it, SDK/sutil/Scene.cpp:1134-1212).  MiptInstance IS OptixInstance (include/optix_types.h,
+ * 80 bytes: row-major 3x4 object->world transform, instanceId, sbtOffset, visibilityMask, flags, traversableHandle, pad[2]);
+ * traversableHandle must be a triangle structure of mipt_accel_build in the same context, built from OBJECT-space vertices.
+ * The library builds a BVH over the instances' world boxes and keeps the world->object matrices; rays are transformed at the
+ * instance boundary.  A hit in an instance structure reports the FLATTENED primitive index
+ *     sum of the triangle counts of instances 0 .. k-1  +  the mesh-local primitive index
+ * i.e. the order of mipt_scene_flatten*, so hit-group records, the Whitted geometry arrays and the launch functions are used
+ * exactly as with one flattened BVH.  instanceId / sbtOffset / visibilityMask / flags are stored but not interpreted (the samples
+ * use mask 1 and no flags).  mipt_accel_update_instances takes the same instances with new transforms (an instance moved).
+ * Alpha-tested / blended materials (any-hit programs) are not supported over an instance structure yet.
+ * ------------------------------------------------------------------------- */
+typedef struct MiptInstance {
+    float              transform[12];
+    unsigned int       instanceId;
+    unsigned int       sbtOffset;
+    unsigned int       visibilityMask;
+    unsigned int       flags;
+    unsigned long long traversableHandle;
+    unsigned int       pad[2];
+} MiptInstance;
+int mipt_accel_build_instances(MiptContext* ctx, const MiptInstance* instances /* host */, uint32_t num_instances,
+                               unsigned long long* handle_out);
+int mipt_accel_update_instances(MiptContext* ctx, unsigned long long handle, const MiptInstance* instances, uint32_t num_instances);
+/* for external checkers: top-level nodes (num_nodes of mipt_accel_info), then per instance (num_instances entries each, nullable):
+ * order_out = instance index per leaf slot, inv12_out = world->object matrices (12 floats each), prim_base_out, gas_handles_out */
+int mipt_accel_export_instances(const MiptContext* ctx, unsigned long long handle, MiptBvhNode* nodes_out, uint32_t* order_out,
+                                float* inv12_out, uint32_t* prim_base_out, unsigned long long* gas_handles_out);
 
 /* Host-only build (no device needed): the same builder, for inspection and for checking the BVH
  * without a GPU.  vertices9: num_triangles * 9 floats (v0 v1 v2, world space). */
@@ -497,6 +527,12 @@ int mipt_scene_camera(const MiptScene* scene, float eye[3], float lookat[3], flo
 int mipt_scene_material(const MiptScene* scene, uint32_t index, MiptMaterialData* out);
 /* vertices4_out: num_triangles*3 float4 {x,y,z,0}; material_index_out: num_triangles (0xffffffff = none) */
 int mipt_scene_flatten(const MiptScene* scene, float* vertices4_out, uint32_t* material_index_out);
+/* Per-mesh OBJECT-space triangles and the instance records, for two-level builds (Scene::buildMeshAccels /
+ * buildInstanceAccel, Scene.cpp:817-1212): mesh m's triangles in the order mipt_scene_flatten emits them inside one instance
+ * (vertices4_out: n*3 float4 {x,y,z,0}; material_index_out nullable); instance i's mesh and row-major 3x4 object->world matrix. */
+int mipt_scene_mesh_num_triangles(const MiptScene* scene, uint32_t mesh, uint32_t* n_out);
+int mipt_scene_mesh_triangles(const MiptScene* scene, uint32_t mesh, float* vertices4_out, uint32_t* material_index_out);
+int mipt_scene_instance(const MiptScene* scene, uint32_t index, uint32_t* mesh_out, float transform12_out[12]);
 /* normals4_out: num_triangles*3 float4 {world-space normal (M^-T n, un-normalised), 1}; all 0 where a primitive has no NORMAL */
 int mipt_scene_flatten_normals(const MiptScene* scene, float* normals4_out);
 /* texture i of the scene (glTF "textures"); the texel pointer stays valid until mipt_scene_destroy */

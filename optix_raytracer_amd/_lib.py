@@ -36,7 +36,13 @@ class MiptHitGroupData(C.Structure):
 class MiptAccelInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_uint32), ("num_triangles", C.c_uint32), ("depth", C.c_uint32),
                 ("leaf_max", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double),
-                ("node_format", C.c_uint32), ("reserved", C.c_uint32)]
+                ("node_format", C.c_uint32), ("num_instances", C.c_uint32)]
+
+
+class MiptInstance(C.Structure):
+    """OptixInstance (include/optix_types.h), 80 bytes"""
+    _fields_ = [("transform", C.c_float * 12), ("instanceId", C.c_uint), ("sbtOffset", C.c_uint), ("visibilityMask", C.c_uint),
+                ("flags", C.c_uint), ("traversableHandle", C.c_ulonglong), ("pad", C.c_uint * 2)]
 
 
 class MiptBuildInput(C.Structure):
@@ -154,6 +160,9 @@ SYMBOLS = [
     ("mipt_accel_destroy", C.c_int, [_vp, C.c_ulonglong]),
     ("mipt_accel_info", C.c_int, [_vp, C.c_ulonglong, C.POINTER(MiptAccelInfo)]),
     ("mipt_accel_export", C.c_int, [_vp, C.c_ulonglong, _vp, _vp]),
+    ("mipt_accel_build_instances", C.c_int, [_vp, _vp, _u32, C.POINTER(C.c_ulonglong)]),
+    ("mipt_accel_update_instances", C.c_int, [_vp, C.c_ulonglong, _vp, _u32]),
+    ("mipt_accel_export_instances", C.c_int, [_vp, C.c_ulonglong, _vp, _vp, _vp, _vp, _vp]),
     ("mipt_host_bvh_create", C.c_int, [_vp, _u32, C.POINTER(_vp)]),
     ("mipt_host_bvh_info", C.c_int, [_vp, C.POINTER(MiptAccelInfo)]),
     ("mipt_host_bvh_copy", C.c_int, [_vp, _vp, _vp]),
@@ -189,6 +198,9 @@ SYMBOLS = [
     ("mipt_scene_material", C.c_int, [_vp, _u32, C.POINTER(MiptMaterialData)]),
     ("mipt_scene_flatten", C.c_int, [_vp, _vp, _vp]),
     ("mipt_scene_flatten_normals", C.c_int, [_vp, _vp]),
+    ("mipt_scene_mesh_num_triangles", C.c_int, [_vp, _u32, C.POINTER(_u32)]),
+    ("mipt_scene_mesh_triangles", C.c_int, [_vp, _u32, _vp, _vp]),
+    ("mipt_scene_instance", C.c_int, [_vp, _u32, C.POINTER(_u32), _fp]),
     ("mipt_scene_texture", C.c_int, [_vp, _u32, C.POINTER(MiptTextureData)]),
     ("mipt_scene_flatten_texcoords", C.c_int, [_vp, _u32, _vp, _vp]),
     ("mipt_scene_flatten_colors", C.c_int, [_vp, _vp, _vp]),

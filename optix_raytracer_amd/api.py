@@ -95,6 +95,10 @@ class Scene:
         except Exception:
             pass
 
+    def _check(self, rc):
+        if rc:
+            raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_*")
+
     def info(self):
         i = L.MiptSceneInfo()
         self._lib.mipt_scene_info(self._h, C.byref(i))
@@ -132,6 +136,24 @@ class Scene:
         if rc:
             raise MiptError(rc, self._lib.mipt_error_name(rc).decode(), "mipt_scene_flatten")
         return v[:n * 3], m[:n]
+
+    def mesh_triangles(self, mesh):
+        """object-space triangles of mesh `mesh`: (n*3, 4) float32 vertices, (n,) uint32 material index"""
+        n = C.c_uint32()
+        self._check(self._lib.mipt_scene_mesh_num_triangles(self._h, mesh, C.byref(n)))
+        v = np.zeros((n.value * 3, 4), np.float32)
+        m = np.zeros(max(n.value, 1), np.uint32)
+        self._check(self._lib.mipt_scene_mesh_triangles(self._h, mesh, v.ctypes.data, m.ctypes.data))
+        return v, m[:n.value]
+
+    def instances(self):
+        """[(mesh index, (3, 4) float32 row-major object->world matrix)] in Scene::instances() order"""
+        out = []
+        for i in range(self.info()["num_instances"]):
+            mesh, xf = C.c_uint32(), (C.c_float * 12)()
+            self._check(self._lib.mipt_scene_instance(self._h, i, C.byref(mesh), xf))
+            out.append((mesh.value, np.array(xf, np.float32).reshape(3, 4)))
+        return out
 
     def flatten_normals(self):
         """(n*3, 4) float32 {world-space normal, 1}; zero rows where a primitive has no NORMAL accessor"""
@@ -295,6 +317,38 @@ class Context:
         """refit of `handle` to moved vertices (same inputs as accel_build otherwise)"""
         arr, keep = self._build_inputs(inputs)
         self._check(self._lib.mipt_accel_update(self._h, handle, arr, len(inputs)))
+
+    def accel_build_instances(self, instances):
+        """instances: [(gas_handle, (3, 4) object->world matrix)] -> handle of the two-level structure (OptixInstance records with
+        instanceId = index, visibilityMask 1, as Scene::buildInstanceAccel fills them, Scene.cpp:1143-1156)"""
+        arr = self._instance_array(instances)
+        h = C.c_ulonglong()
+        self._check(self._lib.mipt_accel_build_instances(self._h, arr, len(instances), C.byref(h)))
+        return h.value
+
+    def accel_update_instances(self, handle, instances):
+        arr = self._instance_array(instances)
+        self._check(self._lib.mipt_accel_update_instances(self._h, handle, arr, len(instances)))
+
+    @staticmethod
+    def _instance_array(instances):
+        arr = (L.MiptInstance * len(instances))()
+        for i, (gas, xf) in enumerate(instances):
+            arr[i].transform = (C.c_float * 12)(*np.asarray(xf, np.float32).reshape(-1)[:12].tolist())
+            arr[i].instanceId, arr[i].sbtOffset, arr[i].visibilityMask, arr[i].flags = i, 0, 1, 0
+            arr[i].traversableHandle = int(gas)
+        return arr
+
+    def accel_export_instances(self, handle):
+        """(top-level nodes (n,16) f32, order (k,) u32, inv (k,12) f32, prim_base (k,) u32, gas handles (k,) u64)"""
+        info = self.accel_info(handle)
+        k = info["num_instances"]
+        nodes = np.zeros((info["num_nodes"], 16), np.float32)
+        order, base = np.zeros(k, np.uint32), np.zeros(k, np.uint32)
+        inv, gas = np.zeros((k, 12), np.float32), np.zeros(k, np.uint64)
+        self._check(self._lib.mipt_accel_export_instances(self._h, handle, nodes.ctypes.data, order.ctypes.data, inv.ctypes.data,
+                                                         base.ctypes.data, gas.ctypes.data))
+        return nodes, order, inv, base, gas
 
     def accel_destroy(self, handle):
         self._check(self._lib.mipt_accel_destroy(self._h, handle))

@@ -40,8 +40,21 @@ struct DeviceBvh {
     uint32_t depth;            // deepest leaf (stack entries a ray can need)
     uint32_t pool2_ok;         // ... and k_tail_pool2's (7-bit slots): < 2^24 nodes, < 2^22 triangles
     uint32_t pool_ok;          // fits the entry pool's packed words: < 2^25 nodes, 2 .. 2^23 - 1 triangles, leaves of 1 .. 4
+    // two-level (instance) structure: `nodes` is then the BVH over the instance boxes, its leaves list positions of inst_order
+    const struct DeviceInstance* inst;      // null: an ordinary triangle BVH
+    const uint32_t* inst_order;
+    uint32_t n_inst;
     uint32_t node32_off;       // byte offset, in the same allocation, of the packed 32-byte nodes (MiptBvhNode32: the boxes of
                                // `nodes` as fp16 -- the two arrays hold the SAME values); 0 = this BVH has none
+};
+
+// one instance of a two-level structure (built by mipt_accel_build_instances from an OptixInstance-compatible record)
+struct DeviceInstance {
+    float         inv[12];     // world -> object, row-major 3x4
+    const float4* nodes;       // the mesh's BVH (64-byte nodes) ...
+    const float4* tris;        // ... and triangles (48 bytes each), object space
+    uint32_t      prim_base;   // flattened index of the mesh's primitive 0 within this instance
+    uint32_t      pad[3];
 };
 
 // SoA path queues, capacity `cap` entries each

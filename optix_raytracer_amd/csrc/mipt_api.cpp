@@ -34,6 +34,8 @@ static_assert(offsetof(MiptParams, light) == 84 && offsetof(MiptParams, handle) 
 static_assert(sizeof(MiptParallelogramLight) == 60, "ParallelogramLight layout");
 static_assert(sizeof(MiptHitGroupData) == 32, "HitGroupData layout");
 static_assert(sizeof(MiptBvhNode) == 64 && sizeof(MiptBvhTri) == 48, "BVH layout");
+static_assert(sizeof(MiptInstance) == 80 && offsetof(MiptInstance, traversableHandle) == 64, "OptixInstance layout (include/optix_types.h)");
+static_assert(sizeof(MiptBvhNode32) == 32, "packed node layout");
 // whitted::LaunchParams offsets probed from the reference build
 static_assert(sizeof(MiptWhittedLaunchParams) == 128 && sizeof(MiptBufferView) == 16, "whitted::LaunchParams layout");
 static_assert(offsetof(MiptWhittedLaunchParams, accum_buffer) == 16 && offsetof(MiptWhittedLaunchParams, max_depth) == 32, "whitted::LaunchParams layout");
@@ -55,6 +57,15 @@ struct Accel {
     uint32_t* d_mat   = nullptr;
     uint32_t  n_prims = 0;
     uint64_t  bytes   = 0;
+    // two-level structure (mipt_accel_build_instances): d_nodes then holds the BVH over the instance boxes
+    bool                       is_ias = false;
+    DeviceInstance*            d_inst = nullptr;
+    uint32_t*                  d_order = nullptr;
+    std::vector<MiptBvhNode>   h_tlas;           // host copies for mipt_accel_export_instances
+    std::vector<uint32_t>      h_order, h_base;
+    std::vector<float>         h_inv;            // 12 per instance
+    std::vector<unsigned long long> gas;         // child handle per instance
+    uint32_t                   users = 0;        // instance structures that reference this mesh BVH
 };
 
 enum TimedKind { T_RAYGEN = 0, T_CLOSEST, T_SHADE, T_ANY, T_RESOLVE, T_KINDS };
@@ -205,6 +216,8 @@ void free_accel(Accel* a)
     if (!a) return;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_mat) (void)hipFree(a->d_mat);
+    if (a->d_inst) (void)hipFree(a->d_inst);
+    if (a->d_order) (void)hipFree(a->d_order);
     delete a;
 }
 
@@ -301,6 +314,7 @@ DeviceBvh device_bvh(const Accel* a)
     b.pool_ok = (a->num_nodes < (1u << 25) && a->num_tris >= 2u && a->num_tris < (1u << 23) && a->leaf_max <= 4u) ? 1u : 0u;
     b.pool2_ok = (b.pool_ok && a->num_nodes < (1u << 24) && a->num_tris < (1u << 22)) ? 1u : 0u;
     b.node32_off = a->node32_off;
+    if (a->is_ias) { b.inst = a->d_inst; b.inst_order = a->d_order; b.n_inst = (uint32_t)a->gas.size(); b.pool_ok = b.pool2_ok = 0u; b.tri_byte_off = 0u; b.node32_off = 0u; }
     return b;
 }
 
@@ -377,7 +391,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         // packed entries, other kernel variants) pays off at a quarter of it, and not at all for depth-capped passes from
         // the start.  Depth-capped paths have few bounces left, so a switch inside the loop pays later: at half the count
         // (1 M-triangle scene, 1080p, depth 8: limit 2^18 / 2^19 / 2^20 -> 3.79 / 3.61 / 4.28 ms).
-        const bool use_tail = ctx->tail_paths != 0u && !ctx->count_visits;
+        const bool use_tail = ctx->tail_paths != 0u && !ctx->count_visits && !acc->is_ias;      // the path kernels walk one-level BVHs
         const bool pool_tail = opts.persistent == 3 && bvh.pool_ok != 0u && bvh.tri_byte_off != 0u && bvh.depth <= 32u;
         const uint32_t tail_paths = !use_tail ? 0u : (pool_tail ? ctx->tail_paths : ctx->tail_paths / 4u);
         const uint32_t tail_limit = fc.max_depth != 0u ? tail_paths / 2u : tail_paths;
@@ -800,12 +814,161 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     return MIPT_SUCCESS;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-level structures: what optixAccelBuild makes of OPTIX_BUILD_INPUT_TYPE_INSTANCES (Scene::buildInstanceAccel,
+// sutil/Scene.cpp:1134-1212).  The top level is a BVH2 over the instances' world boxes, built by the same binned-SAH builder
+// (every box enters as the degenerate triangle lo-hi-lo, whose bounds are the box).
+namespace {
+
+// world -> object matrix of a row-major 3x4 object -> world transform, in double, rounded once
+bool invert3x4(const float* m, float* out)
+{
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    const double r[9] = { A / det, -(b * i - c * h) / det, (b * f - c * e) / det,
+                          B / det, (a * i - c * g) / det, -(a * f - c * d) / det,
+                          C / det, -(a * h - b * g) / det, (a * e - b * d) / det };
+    const double tx = m[3], ty = m[7], tz = m[11];
+    for (int k = 0; k < 3; ++k) {
+        out[4 * k] = (float)r[3 * k]; out[4 * k + 1] = (float)r[3 * k + 1]; out[4 * k + 2] = (float)r[3 * k + 2];
+        out[4 * k + 3] = (float)-(r[3 * k] * tx + r[3 * k + 1] * ty + r[3 * k + 2] * tz);
+    }
+    for (int k = 0; k < 12; ++k) if (!std::isfinite(out[k])) return false;
+    return true;
+}
+
+// fills `a` (fresh or being rebuilt) from the instance records; on failure leaves a message in ctx
+int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
+{
+    std::vector<float> boxes((size_t)n * 9);                       // lo, hi, lo per instance
+    std::vector<DeviceInstance> recs(n);
+    a->h_inv.assign((size_t)n * 12, 0.0f); a->h_base.assign(n, 0u); a->gas.assign(n, 0ull);
+    uint64_t total_tris = 0; uint32_t max_depth = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        Accel* g = find_accel(ctx, inst[k].traversableHandle);
+        if (!g || g->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "instance %u: traversableHandle 0x%llx is not a triangle acceleration structure of this context",
+                                              k, inst[k].traversableHandle);
+        if (!invert3x4(inst[k].transform, &a->h_inv[(size_t)k * 12])) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance %u: singular transform", k);
+        // the mesh's object-space box = the union of its root's two child boxes, read back from the device
+        MiptBvhNode root;
+        HIPCHK(ctx, hipMemcpy(&root, g->d_nodes, sizeof root, hipMemcpyDeviceToHost));
+        const float lo[3] = { std::fmin(root.c0x[0], root.c1x[0]), std::fmin(root.c0y[0], root.c1y[0]), std::fmin(root.c0z[0], root.c1z[0]) };
+        const float hi[3] = { std::fmax(root.c0x[1], root.c1x[1]), std::fmax(root.c0y[1], root.c1y[1]), std::fmax(root.c0z[1], root.c1z[1]) };
+        // world box (Arvo), grown by a few ulps of its largest coordinate: the box is tested against the WORLD ray, the
+        // triangles against the OBJECT-space ray, and the two roundings must never disagree about a grazing hit
+        const float* m = inst[k].transform;
+        float* bx = &boxes[(size_t)k * 9];
+        float mag = 0.0f;
+        for (int r = 0; r < 3; ++r) {
+            double l = m[4 * r + 3], h = m[4 * r + 3];
+            for (int c = 0; c < 3; ++c) {
+                const double p = (double)m[4 * r + c] * lo[c], q = (double)m[4 * r + c] * hi[c];
+                l += std::fmin(p, q); h += std::fmax(p, q);
+            }
+            bx[r] = (float)l; bx[3 + r] = (float)h;
+            mag = std::fmax(mag, std::fmax(std::fabs(bx[r]), std::fabs(bx[3 + r])));
+        }
+        const float pad = mag * 1.9073486e-6f + 1e-30f;              // 2^-19 of the largest coordinate
+        for (int r = 0; r < 3; ++r) { bx[r] -= pad; bx[3 + r] += pad; bx[6 + r] = bx[r]; }
+        DeviceInstance& d = recs[k];
+        std::memcpy(d.inv, &a->h_inv[(size_t)k * 12], 48);
+        d.nodes = g->d_nodes; d.tris = g->d_tris; d.prim_base = (uint32_t)total_tris;
+        a->h_base[k] = (uint32_t)total_tris; a->gas[k] = inst[k].traversableHandle;
+        total_tris += g->n_prims;
+        max_depth = std::max(max_depth, g->depth);
+        if (total_tris >= (1ull << 31)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instances reference more than 2^31 triangles");
+    }
+    HostBvh top;
+    if (!build_bvh(boxes.data(), n, 1, kStackEntries, 1, top)) return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "instance BVH over %u instances is too deep", n);
+    a->h_order.resize(top.tris.size());
+    for (size_t k = 0; k < top.tris.size(); ++k) a->h_order[k] = top.tris[k].prim;
+    a->h_tlas = top.nodes;
+    // device copies (the previous ones, on a rebuild, are released first)
+    if (a->d_nodes) (void)hipFree(a->d_nodes);
+    if (a->d_inst) (void)hipFree(a->d_inst);
+    if (a->d_order) (void)hipFree(a->d_order);
+    if (a->d_mat) (void)hipFree(a->d_mat);
+    a->d_nodes = nullptr; a->d_inst = nullptr; a->d_order = nullptr; a->d_mat = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&a->d_nodes, top.nodes.size() * sizeof(MiptBvhNode)));
+    HIPCHK(ctx, hipMemcpy(a->d_nodes, top.nodes.data(), top.nodes.size() * sizeof(MiptBvhNode), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void**)&a->d_inst, (size_t)n * sizeof(DeviceInstance)));
+    HIPCHK(ctx, hipMemcpy(a->d_inst, recs.data(), (size_t)n * sizeof(DeviceInstance), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void**)&a->d_order, std::max<size_t>(a->h_order.size(), 1) * 4u));
+    if (!a->h_order.empty()) HIPCHK(ctx, hipMemcpy(a->d_order, a->h_order.data(), a->h_order.size() * 4u, hipMemcpyHostToDevice));
+    // hit-group record index per FLATTENED primitive: the meshes' own tables, one after the other
+    HIPCHK(ctx, hipMalloc((void**)&a->d_mat, std::max<uint64_t>(total_tris, 1) * 4u));
+    for (uint32_t k = 0; k < n; ++k) {
+        const Accel* g = find_accel(ctx, inst[k].traversableHandle);
+        if (g->n_prims) HIPCHK(ctx, hipMemcpy(a->d_mat + a->h_base[k], g->d_mat, (size_t)g->n_prims * 4u, hipMemcpyDeviceToDevice));
+    }
+    a->d_tris = nullptr; a->tri_byte_off = 0; a->blob_bytes = 0; a->node32_off = 0;
+    a->num_nodes = (uint32_t)top.nodes.size(); a->num_tris = (uint32_t)total_tris; a->n_prims = (uint32_t)total_tris;
+    a->depth = top.depth + max_depth; a->leaf_max = 1; a->is_ias = true;
+    a->bytes = top.nodes.size() * sizeof(MiptBvhNode) + (size_t)n * (sizeof(DeviceInstance) + 4u) + total_tris * 4u;
+    return MIPT_SUCCESS;
+}
+
+}  // namespace
+
+int mipt_accel_build_instances(MiptContext* ctx, const MiptInstance* instances, uint32_t num_instances, unsigned long long* handle_out)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!instances || num_instances == 0 || !handle_out) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_build_instances: null argument");
+    if (num_instances >= (1u << 27)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "too many instances");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    Accel* a = new Accel();
+    const int rc = build_ias(ctx, a, instances, num_instances);
+    if (rc != MIPT_SUCCESS) { free_accel(a); return rc; }
+    for (unsigned long long h : a->gas) find_accel(ctx, h)->users++;
+    a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const unsigned long long h = ++ctx->next_handle;
+    ctx->accels[h] = a;
+    *handle_out = h;
+    ctx->log(4, "ACCEL", "built instance structure: %u instances, %u top-level nodes, %u triangles referenced, depth %u, %.4f s", num_instances,
+             a->num_nodes, a->num_tris, a->depth, a->seconds);
+    return MIPT_SUCCESS;
+}
+
+int mipt_accel_update_instances(MiptContext* ctx, unsigned long long handle, const MiptInstance* instances, uint32_t num_instances)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    Accel* a = find_accel(ctx, handle);
+    if (!a || !a->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "0x%llx is not an instance acceleration structure", handle);
+    if (!instances || num_instances != a->gas.size()) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update_instances: %u instances given, built from %zu", num_instances, a->gas.size());
+    for (uint32_t k = 0; k < num_instances; ++k)
+        if (instances[k].traversableHandle != a->gas[k]) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update_instances: instance %u refers to another mesh than at build time", k);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    return build_ias(ctx, a, instances, num_instances);           // a few thousand boxes: rebuilding the top level IS the update
+}
+
+int mipt_accel_export_instances(const MiptContext* ctx, unsigned long long handle, MiptBvhNode* nodes_out, uint32_t* order_out, float* inv12_out,
+                                uint32_t* prim_base_out, unsigned long long* gas_handles_out)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    const Accel* a = find_accel(ctx, handle);
+    if (!a || !a->is_ias) return MIPT_ERROR_INVALID_HANDLE;
+    // the top level straight from device memory, the tables from the host copies they were uploaded from
+    if (hipSetDevice(ctx->device) != hipSuccess) return MIPT_ERROR_HIP;
+    if (nodes_out && hipMemcpy(nodes_out, a->d_nodes, (size_t)a->num_nodes * sizeof(MiptBvhNode), hipMemcpyDeviceToHost) != hipSuccess) return MIPT_ERROR_HIP;
+    if (order_out) std::memcpy(order_out, a->h_order.data(), a->h_order.size() * 4u);
+    if (inv12_out) std::memcpy(inv12_out, a->h_inv.data(), a->h_inv.size() * 4u);
+    if (prim_base_out) std::memcpy(prim_base_out, a->h_base.data(), a->h_base.size() * 4u);
+    if (gas_handles_out) std::memcpy(gas_handles_out, a->gas.data(), a->gas.size() * 8u);
+    return MIPT_SUCCESS;
+}
+
 int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBuildInput* inputs, uint32_t num_inputs)
 {
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     if (!inputs || num_inputs == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update: null argument");
     Accel* a = find_accel(ctx, handle);
     if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
+    if (a->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "0x%llx is an instance structure: use mipt_accel_update_instances", handle);
+
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());                         // launches that still read the old boxes
     const auto t0 = std::chrono::steady_clock::now();
@@ -829,8 +992,10 @@ int mipt_accel_destroy(MiptContext* ctx, unsigned long long handle)
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     auto it = ctx->accels.find(handle);
     if (it == ctx->accels.end()) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
+    if (it->second->users != 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "traversable 0x%llx is still referenced by %u instance structure(s)", handle, it->second->users);
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (unsigned long long g : it->second->gas) if (Accel* m = find_accel(ctx, g)) if (m->users) m->users--;
     free_accel(it->second);
     ctx->accels.erase(it);
     return MIPT_SUCCESS;
@@ -847,7 +1012,7 @@ int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccel
     info->leaf_max = a->leaf_max;
     info->device_bytes = a->bytes;
     info->build_seconds = a->seconds;
-    info->node_format = a->node32_off ? 1u : 0u; info->reserved = 0u;
+    info->node_format = a->node32_off ? 1u : 0u; info->num_instances = a->is_ias ? (uint32_t)a->gas.size() : 0u;
     return MIPT_SUCCESS;
 }
 
@@ -856,6 +1021,7 @@ int mipt_accel_export(const MiptContext* ctx, unsigned long long handle, MiptBvh
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     const Accel* a = find_accel(ctx, handle);
     if (!a) return MIPT_ERROR_INVALID_HANDLE;
+    if (a->is_ias) return MIPT_ERROR_INVALID_HANDLE;             // mipt_accel_export_instances
     // exported from DEVICE memory, so the checker sees what the kernels read
     (void)hipSetDevice(ctx->device);
     if (nodes_out && hipMemcpy(nodes_out, a->d_nodes, (size_t)a->num_nodes * sizeof(MiptBvhNode), hipMemcpyDeviceToHost) != hipSuccess) return MIPT_ERROR_HIP;
@@ -885,7 +1051,7 @@ int mipt_host_bvh_info(const MiptHostBvh* h, MiptAccelInfo* info)
     info->leaf_max = h->bvh.leaf_max;
     info->device_bytes = 0;
     info->build_seconds = h->bvh.seconds;
-    info->node_format = 0u; info->reserved = 0u;
+    info->node_format = 0u; info->num_instances = 0u;
     return MIPT_SUCCESS;
 }
 
@@ -1162,6 +1328,9 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     if (!ctx->wh_geo.vertices4 || !ctx->d_wh_materials) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "mipt_whitted_set_geometry was not called");
     Accel* acc = find_accel(ctx, p->handle);
     if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
+    if (acc->is_ias && ctx->wh_any_hit)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "a MASK / BLEND material needs the any-hit programs, which walk one-level structures only: "
+                         "build one BVH over the flattened triangles (mipt_scene_flatten) for this scene");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
     int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);

@@ -630,6 +630,53 @@ int mipt_scene_flatten(const MiptScene* sc, float* vertices4_out, uint32_t* mate
     return MIPT_SUCCESS;
 }
 
+// ---- per-mesh object-space geometry + instance records: what Scene::buildMeshAccels / buildInstanceAccel consume
+// (Scene.cpp:817-1212).  A mesh's triangles come in the order mipt_scene_flatten emits them inside one instance, so
+//   flattened index = (triangles of the instances before) + mesh-local index.
+int mipt_scene_mesh_num_triangles(const MiptScene* sc, uint32_t mesh, uint32_t* n_out)
+{
+    if (!sc || !n_out || mesh >= sc->meshes.size()) return MIPT_ERROR_INVALID_VALUE;
+    uint32_t n = 0;
+    for (const Primitive& p : sc->meshes[mesh].prims) n += (p.indices.valid() ? p.indices.count : p.positions.count) / 3u;
+    *n_out = n;
+    return MIPT_SUCCESS;
+}
+
+int mipt_scene_mesh_triangles(const MiptScene* sc, uint32_t mesh, float* vertices4_out, uint32_t* material_index_out)
+{
+    if (!sc || mesh >= sc->meshes.size() || !vertices4_out) return MIPT_ERROR_INVALID_VALUE;
+    size_t t_out = 0;
+    for (const Primitive& p : sc->meshes[mesh].prims) {
+        const std::vector<uint8_t>& pb = sc->buffers[(size_t)p.positions.buffer];
+        const uint32_t n_tris = (p.indices.valid() ? p.indices.count : p.positions.count) / 3u;
+        for (uint32_t t = 0; t < n_tris; ++t, ++t_out) {
+            for (int c = 0; c < 3; ++c) {
+                uint32_t vi = 3u * t + (uint32_t)c;
+                if (p.indices.valid()) {
+                    const uint8_t* ip = sc->buffers[(size_t)p.indices.buffer].data() + p.indices.offset + (size_t)vi * p.indices.byte_stride;
+                    if (p.indices.elmt_byte_size == 2) { uint16_t v; std::memcpy(&v, ip, 2); vi = v; } else std::memcpy(&vi, ip, 4);
+                }
+                if (vi >= p.positions.count) return MIPT_ERROR_INVALID_VALUE;
+                float* o = vertices4_out + (t_out * 3 + (size_t)c) * 4;
+                std::memcpy(o, pb.data() + p.positions.offset + (size_t)vi * p.positions.byte_stride, 12);
+                o[3] = 0.0f;
+            }
+            if (material_index_out) material_index_out[t_out] = p.material < 0 ? 0xffffffffu : (uint32_t)p.material;
+        }
+    }
+    return MIPT_SUCCESS;
+}
+
+// instance `index` (the order of Scene::instances(), = the order mipt_scene_flatten walks): its mesh and the first three rows of
+// its row-major object -> world matrix, as Scene::buildInstanceAccel copies them into OptixInstance::transform (Scene.cpp:1153)
+int mipt_scene_instance(const MiptScene* sc, uint32_t index, uint32_t* mesh_out, float transform12_out[12])
+{
+    if (!sc || index >= sc->instances.size()) return MIPT_ERROR_INVALID_VALUE;
+    if (mesh_out) *mesh_out = (uint32_t)sc->instances[index].mesh;
+    if (transform12_out) std::memcpy(transform12_out, sc->instances[index].transform.m, 48);
+    return MIPT_SUCCESS;
+}
+
 // World-space shading normals for the Whitted programs (cuda/LocalGeometry.h:114-126): per triangle 3 float4
 // {n.xyz, 1} = (M^-T) * object normal, un-normalised; w = 0 and xyz = 0 where the primitive has no NORMAL
 // attribute (then the geometric normal is used).  The reference interpolates in object space and transforms

@@ -91,4 +91,48 @@ __device__ __forceinline__ void visit_inner(Trav& T, const float4* __restrict__ 
     }
 }
 
+// ---- arguments and result write-back shared by every traversal kernel (kernels.hip, instances.hip) ----
+struct TraceArgs {
+    DeviceBvh       bvh;
+    const float4*   ray_o;
+    const float4*   ray_d;
+    uint32_t        stride;       // float4 elements between consecutive rays (1 = SoA planes, 2 = interleaved)
+    const uint32_t* n_ptr;        // device-side ray count (may be null)
+    uint32_t        n_max;
+    float4*         hits;         // MODE 0
+    uint32_t*       occluded;     // MODE 1
+    const float4*   contrib;      // MODE 2
+    float4*         result;       // MODE 2
+    uint32_t*       cursors;      // kNumSegments cursors, kCursorStride apart
+    DeviceCounters* ctr;
+    int             refill_min;   // k_trace_stream: idle lanes that trigger a swap-in / prefetch round
+    int             steal_min;    // k_trace_stream: idle lanes that trigger a steal round once the ray range is exhausted
+    int             burst_bulk;   // k_trace_stream: traversal steps per bookkeeping round while fresh rays remain
+    int             burst_dry;    // ... and once the ray range is exhausted
+    uint32_t        ray_flags;    // MiptRayFlags of every ray of the launch (closest hit: back-face culling)
+    uint32_t        tile_group;   // k_trace_pool, tiled: consecutive tiles dealt to one XCD at a time (0: a contiguous eighth each)
+};
+
+template <int MODE>
+__device__ __forceinline__ void finish_ray(const TraceArgs& a, const Trav& T, uint32_t ray, bool hit)
+{
+    if (MODE == 0) {
+        a.hits[ray] = hit ? make_float4(T.tbest, u2f(T.prim), T.u, T.v) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+    } else if (MODE == 1) {
+        a.occluded[ray] = hit ? 1u : 0u;
+    } else {
+        if (!hit) {
+            // result += radiance * attenuation (optixPathTracer.cu:292); one path per slot is in flight
+            const float4 c = a.contrib[ray];
+            const uint32_t slot = f2u(c.w);
+            float4 r = a.result[slot];
+            r.x += c.x; r.y += c.y; r.z += c.z;
+            a.result[slot] = r;
+        }
+    }
+}
+
+
+void launch_trace_inst(hipStream_t st, const TraceArgs& a, int mode, bool count);       // instances.hip
+
 }  // namespace mipt

@@ -8,8 +8,10 @@
     launchSubframe :284                                        -> launchSubframe
 
 Scene::finalize (Scene.cpp:803-815: createContext, buildMeshAccels, buildInstanceAccel, createPTXModule,
-createProgramGroups, createPipeline, createSBT) collapses to one accel build over the flattened instances plus
-mipt_whitted_set_geometry; the programs are fixed-function HIP kernels inside libmipt.so.
+createProgramGroups, createPipeline, createSBT) collapses to the accel build(s) plus mipt_whitted_set_geometry; the programs
+are fixed-function HIP kernels inside libmipt.so.  loadScene(two_level=True) builds what the reference builds -- one
+triangle structure per mesh (object space) and an instance structure over them (mipt_accel_build_instances); the default is
+one BVH over the flattened, world-space triangles (required while a material uses the any-hit programs).
 """
 import ctypes as C
 
@@ -50,7 +52,7 @@ class MeshViewerState:
         self.width, self.height = 1024, 768       # optixMeshViewer.cpp:84-85
 
 
-def loadScene(state, filename, device_index=0, log=None, log_level=0):
+def loadScene(state, filename, device_index=0, log=None, log_level=0, two_level=False):
     """sutil::loadScene( infile, scene ); scene.finalize();"""
     state.device = torch.device("cuda", device_index)
     torch.cuda.set_device(state.device)
@@ -73,10 +75,24 @@ def loadScene(state, filename, device_index=0, log=None, log_level=0):
         state.d_colors = torch.from_numpy(np.ascontiguousarray(col)).to(state.device)
         state.d_color_present = torch.from_numpy(np.ascontiguousarray(has)).to(state.device)
     state.materials = state.scene.material_table()
-    state.handle = state.context.accel_build([{
-        "vertices": state.d_vertices.data_ptr(), "num_vertices": verts.shape[0], "stride": 16,
-        "sbt_index_offsets": np.minimum(mat, len(state.materials) - 1).astype(np.uint32), "flags": geometry_flags(state.materials),
-    }])
+    if two_level:
+        # Scene::buildMeshAccels (one GAS per mesh, object space) + Scene::buildInstanceAccel (Scene.cpp:817-1212)
+        from . import scenes
+        meshes, insts = scenes.gltf_two_level(state.scene)
+        state.mesh_handles, state.d_mesh_vertices = [], []
+        for mv, mm in meshes:
+            dv = torch.from_numpy(np.ascontiguousarray(mv)).to(state.device)
+            state.d_mesh_vertices.append(dv)
+            state.mesh_handles.append(state.context.accel_build([{
+                "vertices": dv.data_ptr(), "num_vertices": mv.shape[0], "stride": 16,
+                "sbt_index_offsets": np.minimum(mm, len(state.materials) - 1).astype(np.uint32), "flags": geometry_flags(state.materials)}]))
+        state.instances = [(state.mesh_handles[m], xf) for m, xf in insts]
+        state.handle = state.context.accel_build_instances(state.instances)
+    else:
+        state.handle = state.context.accel_build([{
+            "vertices": state.d_vertices.data_ptr(), "num_vertices": verts.shape[0], "stride": 16,
+            "sbt_index_offsets": np.minimum(mat, len(state.materials) - 1).astype(np.uint32), "flags": geometry_flags(state.materials),
+        }])
     state.textures = state.scene.texture_table()
     ptr = lambda t: t.data_ptr() if t is not None else None            # noqa: E731
     geo = L.MiptWhittedGeometry()
@@ -192,10 +208,10 @@ def cleanup(state):
     state.d_texcoords = [None, None]; state.d_texcoord_present = [None, None]; state.d_colors = state.d_color_present = None
 
 
-def render(filename, width, height, subframes=1, lights=None, device_index=0):
+def render(filename, width, height, subframes=1, lights=None, device_index=0, two_level=False):
     """main() of the sample in file-output mode (:466-485): returns (state, uchar4 image as numpy)"""
     st = MeshViewerState()
-    loadScene(st, filename, device_index)
+    loadScene(st, filename, device_index, two_level=two_level)
     initCameraState(st)
     initLaunchParams(st, width, height, lights)
     out = OutputBuffer(width, height, st.device)

@@ -234,3 +234,83 @@ def write_duck_like_gltf(path, seed=3):
            "scenes": [{"nodes": [0]}], "scene": 0}
     path.write_text(json.dumps(doc))
     return path
+
+
+def write_instanced_gltf(path, n_instances=150, seed=9):
+    """An instanced scene for the two-level (instance) acceleration structure: TWO meshes -- a bumpy blob of 960 triangles
+    (u16 indices) and a box of 12 -- placed `n_instances` times by nodes with random translation / rotation / NON-uniform
+    scale (some nested under a scaled parent, so matrices are general affine), over a floor quad; three opaque materials, a
+    camera node.  Every node with a mesh becomes one sutil::Scene instance (Scene.cpp:192-205).  Returns the path."""
+    import base64
+    import json
+    rng = np.random.default_rng(seed)
+    st, sl = 17, 30                                                          # 2 * 30 * 16 = 960 triangles
+    th = np.linspace(0.0, np.pi, st + 1)[1:-1]
+    ph = np.linspace(0.0, 2.0 * np.pi, sl, endpoint=False)
+    ring = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.cos(th), np.ones_like(ph)), np.outer(np.sin(th), np.sin(ph))], -1).reshape(-1, 3)
+    pts = np.concatenate([[[0.0, 1.0, 0.0]], ring, [[0.0, -1.0, 0.0]]])
+    pts = (pts * (1.0 + 0.08 * rng.standard_normal((pts.shape[0], 1))) * (0.5, 0.35, 0.4)).astype(np.float32)
+    tri = []
+    for s in range(sl):
+        s1 = (s + 1) % sl
+        tri.append([0, 1 + s1, 1 + s])
+        for r in range(st - 2):
+            a, b, c, d = 1 + r * sl + s, 1 + r * sl + s1, 1 + (r + 1) * sl + s, 1 + (r + 1) * sl + s1
+            tri += [[a, b, d], [a, d, c]]
+        tri.append([1 + (st - 2) * sl + s, 1 + (st - 2) * sl + s1, 1 + (st - 1) * sl])
+    idx_blob = np.asarray(tri, np.uint16).reshape(-1)
+    box = np.asarray([[x, y, z] for x in (-0.3, 0.3) for y in (-0.3, 0.3) for z in (-0.3, 0.3)], np.float32)
+    idx_box = np.asarray([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]],
+                         np.uint16).reshape(-1)
+    floor = np.asarray([[-9, -0.6, -9], [9, -0.6, -9], [9, -0.6, 9], [-9, -0.6, 9]], np.float32)
+    idx_floor = np.asarray([0, 2, 1, 0, 3, 2], np.uint16)
+    blob, views, accs = b"", [], []
+
+    def add(arr, typ, comp):
+        nonlocal blob
+        blob += b"\0" * (-len(blob) % 4)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": arr.nbytes})
+        a = {"bufferView": len(views) - 1, "componentType": comp, "count": int(arr.shape[0] if arr.ndim > 1 else arr.size), "type": typ}
+        if typ == "VEC3":
+            a["min"] = [float(x) for x in arr.min(0)]; a["max"] = [float(x) for x in arr.max(0)]
+        accs.append(a)
+        blob += arr.tobytes()
+        return len(accs) - 1
+    meshes = [{"primitives": [{"attributes": {"POSITION": add(pts, "VEC3", 5126)}, "indices": add(idx_blob, "SCALAR", 5123), "material": 0}]},
+              {"primitives": [{"attributes": {"POSITION": add(box, "VEC3", 5126)}, "indices": add(idx_box, "SCALAR", 5123), "material": 1}]},
+              {"primitives": [{"attributes": {"POSITION": add(floor, "VEC3", 5126)}, "indices": add(idx_floor, "SCALAR", 5123), "material": 2}]}]
+    nodes = [{"mesh": 2}]
+    parents = []
+    for i in range(n_instances):
+        q = rng.standard_normal(4); q /= np.linalg.norm(q)
+        n = {"mesh": int(i % 3 != 2), "translation": [float(x) for x in rng.uniform(-6, 6, 3) * (1, 0.35, 1) + (0, 1.2, 0)],
+             "rotation": [float(x) for x in q], "scale": [float(x) for x in rng.uniform(0.4, 1.6, 3)]}
+        if i % 10 == 0:                                                       # a scaled parent: its child's matrix is a general affine map
+            n = {"children": [len(nodes) + 1], "scale": [1.0, float(rng.uniform(0.6, 1.4)), 1.0], "translation": [0.0, float(rng.uniform(0, 0.5)), 0.0]}
+            nodes.append(n)
+            parents.append(len(nodes) - 1)
+            q2 = rng.standard_normal(4); q2 /= np.linalg.norm(q2)
+            nodes.append({"mesh": 0, "translation": [float(x) for x in rng.uniform(-5, 5, 3) * (1, 0.3, 1) + (0, 1.5, 0)], "rotation": [float(x) for x in q2],
+                          "scale": [float(x) for x in rng.uniform(0.5, 1.2, 3)]})
+        else:
+            nodes.append(n)
+    child = {c for n in nodes for c in n.get("children", [])}
+    nodes.append({"camera": 0, "translation": [0.0, 3.5, 13.0], "rotation": [float(np.sin(-0.12)), 0.0, 0.0, float(np.cos(-0.12))]})
+    roots = [i for i in range(len(nodes)) if i not in child]
+    doc = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+           "bufferViews": views, "accessors": accs,
+           "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.85, 0.55, 0.2, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.6}},
+                         {"pbrMetallicRoughness": {"baseColorFactor": [0.25, 0.5, 0.85, 1.0], "metallicFactor": 0.3, "roughnessFactor": 0.4}},
+                         {"pbrMetallicRoughness": {"baseColorFactor": [0.7, 0.7, 0.7, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.9}}],
+           "meshes": meshes, "cameras": [{"type": "perspective", "perspective": {"yfov": 0.75, "aspectRatio": 16 / 9, "znear": 0.05}}],
+           "nodes": nodes, "scenes": [{"nodes": roots}], "scene": 0}
+    path.write_text(json.dumps(doc))
+    return path
+
+
+def gltf_two_level(sc):
+    """What Scene::buildMeshAccels / buildInstanceAccel consume, from an api.Scene: ([(object-space vertices4, material index)] per
+    mesh, [(mesh index, 3x4 object->world matrix)] per instance).  The instances are in mipt_scene_flatten's order, so a hit's
+    flattened primitive index addresses the arrays of from_gltf()."""
+    n_mesh = sc.info()["num_meshes"]
+    return [sc.mesh_triangles(m) for m in range(n_mesh)], sc.instances()

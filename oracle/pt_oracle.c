@@ -285,6 +285,13 @@ struct OrcScene {
     Tri48*    tris;  uint32_t n_leaf_tris;
     int       depth;
     uint32_t* prim_flags;  /* OptixGeometryFlags per ORIGINAL primitive (NULL = none): 1 DISABLE_ANYHIT, 4 DISABLE_TRIANGLE_FACE_CULLING */
+    /* two-level (instance) acceleration structure adopted from the product (orc_scene_set_instances, ORC_MODE_INST):
+     * a BVH over the instances' world boxes whose leaves list instances; per instance the world->object 3x4 matrix, the
+     * object-space BVH of its mesh and the flattened index of the mesh's primitive 0 (Scene.cpp:1134-1212 builds the IAS the
+     * driver walks; the walk itself is the driver's) */
+    Node64*   tlas; uint32_t n_tlas;
+    uint32_t* inst_order; uint32_t n_inst;
+    struct OrcInst { float inv[12]; uint32_t prim_base; Node64* nodes; uint32_t n_nodes; Tri48* tris; uint32_t n_tris; }* inst;
 };
 
 #define LEAF_REF(first, count) (~(int32_t)(((uint32_t)(first) << 4) | (uint32_t)(count)))
@@ -328,7 +335,38 @@ void orc_scene_destroy(OrcScene* s)
 {
     if (!s) return;
     free(s->verts); free(s->mat); free(s->emission); free(s->diffuse);
-    free(s->brute); free(s->nodes); free(s->tris); free(s->prim_flags); free(s);
+    free(s->brute); free(s->nodes); free(s->tris); free(s->prim_flags);
+    if (s->inst) for (uint32_t i = 0; i < s->n_inst; ++i) { free(s->inst[i].nodes); free(s->inst[i].tris); }
+    free(s->inst); free(s->tlas); free(s->inst_order);
+    free(s);
+}
+
+/* adopts the product's two-level structure (mipt_accel_export_instances + mipt_accel_export of every instance's mesh BVH) */
+int orc_scene_set_instances(OrcScene* s, const void* tlas_nodes, uint32_t n_tlas, const uint32_t* order, uint32_t n_inst,
+                            const float* inv12, const uint32_t* prim_base, const void* const* gas_nodes, const uint32_t* gas_n_nodes,
+                            const void* const* gas_tris, const uint32_t* gas_n_tris)
+{
+    if (!s || !tlas_nodes || n_tlas == 0 || !order || n_inst == 0 || !inv12 || !prim_base || !gas_nodes || !gas_tris) return 1;
+    s->tlas = (Node64*)malloc((size_t)n_tlas * sizeof(Node64));
+    memcpy(s->tlas, tlas_nodes, (size_t)n_tlas * sizeof(Node64));
+    s->n_tlas = n_tlas;
+    s->inst_order = (uint32_t*)malloc((size_t)n_inst * 4);
+    memcpy(s->inst_order, order, (size_t)n_inst * 4);
+    s->n_inst = n_inst;
+    s->inst = (struct OrcInst*)calloc(n_inst, sizeof *s->inst);
+    for (uint32_t i = 0; i < n_inst; ++i) {
+        struct OrcInst* in = &s->inst[i];
+        memcpy(in->inv, inv12 + (size_t)i * 12, 48);
+        in->prim_base = prim_base[i];
+        in->n_nodes = gas_n_nodes[i]; in->n_tris = gas_n_tris[i];
+        if ((uint64_t)in->prim_base + in->n_tris > s->n_tris) return 2;      /* flattened ids must index the scene's arrays */
+        in->nodes = (Node64*)malloc((size_t)in->n_nodes * sizeof(Node64));
+        in->tris = (Tri48*)malloc((size_t)(in->n_tris ? in->n_tris : 1) * sizeof(Tri48));
+        memcpy(in->nodes, gas_nodes[i], (size_t)in->n_nodes * sizeof(Node64));
+        memcpy(in->tris, gas_tris[i], (size_t)in->n_tris * sizeof(Tri48));
+    }
+    for (uint32_t i = 0; i < n_inst; ++i) if (order[i] >= n_inst) return 3;
+    return 0;
 }
 
 /* OptixGeometryFlags per original primitive (copied); NULL clears them */
@@ -724,14 +762,113 @@ static void bvh_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats
     }
 }
 
+/* ---- two-level traversal (ORC_MODE_INST) -----------------------------------------------------------------------
+ * The world ray walks the BVH over the instance boxes; at a leaf, for each listed instance in turn, the ray is taken
+ * into the instance's object space -- o' = M o + t, d' = M d with M = the exported world->object matrix, each row
+ * fmaf(m2, z, fmaf(m1, y, m0 * x)) (+ m3 for points); d' is NOT re-normalised, so a distance t means the same point in
+ * both spaces and tmin / tmax / the running best carry over -- and the mesh's own BVH is walked to the end.  A hit
+ * reports the flattened primitive index prim_base + local index; ties between equal t go to the lower flattened index,
+ * as in the one-level walk.  Same sequence in csrc/instances.hip. */
+static inline v3 xform_vec(const float* m, v3 d)
+{
+    return v3_make(fmaf(m[2], d.z, fmaf(m[1], d.y, m[0] * d.x)), fmaf(m[6], d.z, fmaf(m[5], d.y, m[4] * d.x)),
+                   fmaf(m[10], d.z, fmaf(m[9], d.y, m[8] * d.x)));
+}
+static inline v3 xform_pt(const float* m, v3 p)
+{
+    v3 r = xform_vec(m, p);
+    return v3_make(r.x + m[3], r.y + m[7], r.z + m[11]);
+}
+
+/* one mesh BVH, object-space ray; h is the WORLD hit record: candidates enter it with their flattened index */
+static void gas_traverse(const OrcScene* s, const struct OrcInst* in, Ray* r, int any, HitRec* h, OrcStats* st, const TraceFilter* flt)
+{
+    int32_t stack[STACK_MAX];
+    int     sp = 0;
+    stack[sp++] = SENTINEL;
+    int32_t node = 0;
+    while (node != SENTINEL) {
+        if (node >= 0) {
+            const Node64* n = &in->nodes[node];
+            if (st) { st->node_visits++; if (any) st->shadow_node_visits++; }
+            int   h0, h1;
+            float lim = h->t;
+            float t0 = box_test(n->c0x, n->c0y, n->c0z, r, lim, &h0);
+            float t1 = box_test(n->c1x, n->c1y, n->c1z, r, lim, &h1);
+            if (!h0 && !h1) { node = stack[--sp]; continue; }
+            int32_t a = n->c0, b = n->c1;
+            if (h0 && h1) {
+                if (t1 < t0) { int32_t tmp = a; a = b; b = tmp; }
+                stack[sp++] = b;
+                node = a;
+            } else {
+                node = h0 ? a : b;
+            }
+        } else {
+            uint32_t d = (uint32_t)~node, first = d >> 4, cnt = d & 15u;
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                float t, u, v, det;
+                if (st) { st->tri_tests++; if (any) st->shadow_tri_tests++; }
+                if (tri_test_det(&in->tris[i], r, r->tmax, &t, &u, &v, &det)) {
+                    if (filter_rejects(s, flt, in->prim_base + in->tris[i].prim, det, t, u, v)) continue;
+                    if (any) { h->hit = 1; h->t = t; h->prim = in->prim_base + in->tris[i].prim; return; }
+                    consider(h, t, u, v, in->prim_base + in->tris[i].prim);
+                }
+            }
+            node = stack[--sp];
+        }
+    }
+}
+
+static void inst_traverse(const OrcScene* s, Ray* r, int any, HitRec* h, OrcStats* st, const TraceFilter* flt)
+{
+    int32_t stack[STACK_MAX];
+    int     sp = 0;
+    h->hit = 0; h->t = r->tmax; h->prim = 0xffffffffu; h->u = h->v = 0.0f;
+    stack[sp++] = SENTINEL;
+    if (!(r->tmax > r->tmin)) return;
+    int32_t node = 0;
+    while (node != SENTINEL) {
+        if (node >= 0) {
+            const Node64* n = &s->tlas[node];
+            if (st) { st->node_visits++; if (any) st->shadow_node_visits++; }
+            int   h0, h1;
+            float lim = h->t;
+            float t0 = box_test(n->c0x, n->c0y, n->c0z, r, lim, &h0);
+            float t1 = box_test(n->c1x, n->c1y, n->c1z, r, lim, &h1);
+            if (!h0 && !h1) { node = stack[--sp]; continue; }
+            int32_t a = n->c0, b = n->c1;
+            if (h0 && h1) {
+                if (t1 < t0) { int32_t tmp = a; a = b; b = tmp; }
+                stack[sp++] = b;
+                node = a;
+            } else {
+                node = h0 ? a : b;
+            }
+        } else {
+            uint32_t d = (uint32_t)~node, first = d >> 4, cnt = d & 15u;
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                const struct OrcInst* in = &s->inst[s->inst_order[i]];
+                Ray ro;
+                ro.o = xform_pt(in->inv, r->o); ro.d = xform_vec(in->inv, r->d); ro.tmin = r->tmin; ro.tmax = r->tmax;
+                ray_prepare(&ro);
+                gas_traverse(s, in, &ro, any, h, st, flt);
+                if (any && h->hit) return;
+            }
+            node = stack[--sp];
+        }
+    }
+}
+
 static inline void trace_ex(const OrcScene* s, int mode, v3 o, v3 d, float tmin, float tmax, int any,
                             HitRec* h, OrcStats* st, const TraceFilter* flt)
 {
     Ray r; r.o = o; r.d = d; r.tmin = tmin; r.tmax = tmax;
     ray_prepare(&r);
     if (st) { if (any) st->shadow_rays++; else st->closest_rays++; }
-    if (mode == ORC_MODE_BVH) bvh_traverse(s, &r, any, h, st, flt);
-    else                      brute_force(s, &r, any, h, st, flt);
+    if (mode == ORC_MODE_INST && s->tlas) inst_traverse(s, &r, any, h, st, flt);
+    else if (mode == ORC_MODE_BVH)        bvh_traverse(s, &r, any, h, st, flt);
+    else                                  brute_force(s, &r, any, h, st, flt);
 }
 static inline void trace(const OrcScene* s, int mode, v3 o, v3 d, float tmin, float tmax, int any,
                          HitRec* h, OrcStats* st)

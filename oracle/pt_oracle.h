@@ -56,7 +56,7 @@ typedef struct OrcStats {
 
 typedef struct OrcScene OrcScene;
 
-enum { ORC_MODE_BRUTE = 0, ORC_MODE_BVH = 1 };
+enum { ORC_MODE_BRUTE = 0, ORC_MODE_BVH = 1, ORC_MODE_INST = 2 /* two-level: orc_scene_set_instances */ };
 
 /* ---- scalar pieces (each pinned by a KAT) ---- */
 uint32_t orc_tea4(uint32_t v0, uint32_t v1);
@@ -89,6 +89,13 @@ int       orc_scene_set_bvh(OrcScene*, const void* nodes, uint32_t n_nodes,
                             const void* tris, uint32_t n_tris);
 uint32_t  orc_scene_num_nodes(const OrcScene*);
 int       orc_scene_bvh_depth(const OrcScene*);
+/* adopt the product's two-level (instance) structure: the BVH over the instance boxes (n_tlas 64-byte nodes, leaves list
+ * positions of `order`), order[n_inst] = instance index per leaf slot, per instance the world->object 3x4 matrix, the
+ * flattened index of its primitive 0 and its mesh's BVH (MiptBvhNode / MiptBvhTri arrays).  The scene's vertex / material
+ * arrays stay the flattened world-space ones.  Rendering with mode ORC_MODE_INST then walks this structure. */
+int       orc_scene_set_instances(OrcScene*, const void* tlas_nodes, uint32_t n_tlas, const uint32_t* order, uint32_t n_inst,
+                                  const float* inv12, const uint32_t* prim_base, const void* const* gas_nodes,
+                                  const uint32_t* gas_n_nodes, const void* const* gas_tris, const uint32_t* gas_n_tris);
 /* structural validation of the adopted/built BVH; 0 = ok */
 int       orc_scene_validate_bvh(const OrcScene*);
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
-MODE_BRUTE, MODE_BVH = 0, 1
+MODE_BRUTE, MODE_BVH, MODE_INST = 0, 1, 2
 
 
 class OrcLight(C.Structure):
@@ -141,6 +141,9 @@ def lib():
     L.orc_scene_build_bvh.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_scene_set_bvh.restype = C.c_int
     L.orc_scene_set_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.orc_scene_set_instances.restype = C.c_int
+    L.orc_scene_set_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
     L.orc_scene_num_nodes.restype = C.c_uint32
     L.orc_scene_num_nodes.argtypes = [C.c_void_p]
     L.orc_scene_bvh_depth.restype = C.c_int
@@ -241,6 +244,24 @@ class Scene:
                                      tris.nbytes // 48)
         if rc:
             raise RuntimeError("orc_scene_set_bvh: BVH failed validation: %d" % rc)
+        self.has_bvh = True
+        return self
+
+    def set_instances(self, tlas_nodes, order, inv, prim_base, gas):
+        """gas: [(nodes, tris)] per instance, the arrays of Context.accel_export.  Render with mode=MODE_INST afterwards."""
+        tlas = np.ascontiguousarray(tlas_nodes, np.float32)
+        order, base = np.ascontiguousarray(order, np.uint32), np.ascontiguousarray(prim_base, np.uint32)
+        inv = np.ascontiguousarray(inv, np.float32)
+        k = order.shape[0]
+        keep = [(np.ascontiguousarray(n), np.ascontiguousarray(t)) for n, t in gas]
+        gn = (C.c_void_p * k)(*[n.ctypes.data for n, _ in keep])
+        gt = (C.c_void_p * k)(*[t.ctypes.data for _, t in keep])
+        nn = np.asarray([n.nbytes // 64 for n, _ in keep], np.uint32)
+        nt = np.asarray([t.nbytes // 48 for _, t in keep], np.uint32)
+        rc = lib().orc_scene_set_instances(self._h, tlas.ctypes.data, tlas.nbytes // 64, order.ctypes.data, k, inv.ctypes.data,
+                                           base.ctypes.data, gn, nn.ctypes.data, gt, nt.ctypes.data)
+        if rc:
+            raise RuntimeError("orc_scene_set_instances: %d" % rc)
         self.has_bvh = True
         return self
 

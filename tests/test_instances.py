@@ -1,0 +1,223 @@
+"""Two-level (instance) acceleration structures: mipt_accel_build_instances over per-mesh object-space BVHs (what
+Scene::buildMeshAccels + buildInstanceAccel build, SDK/sutil/Scene.cpp:817-1212) against (a) the oracle's restatement of the
+two-level walk on the SAME exported structure -- bit for bit, the parity bar -- and (b) the same scene flattened to world-space
+triangles under one BVH, where only the roundings of the instance transform differ."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# Flattened: a vertex is rounded once after object->world (m4_apply in the loader).  Two-level: the ray's origin and direction are
+# rounded once after world->object, and the world->object matrix itself is an fp32 rounding of the exact inverse.  With
+# coordinates of a few units (the scenes here span +-9) each of these is a relative 2^-24 .. 2^-22 perturbation of the geometry
+# a ray meets; a hit distance moves by that much times the distance, and a handful of ulps more through the division in the
+# triangle test.  32 ulps of t (4e-6 relative) is the bound asserted for 99.9 % of the rays; a GRAZING ray divides the same
+# perturbation by the cosine of its angle to the triangle's normal, so the worst ray gets 2e-4.  What no bound on t covers is a
+# ray within that distance of a triangle EDGE, which then hits the neighbouring triangle or misses -- counted, and required to
+# stay below 3 in 10 000 rays.
+T_REL_TOL = 4e-6
+T_REL_TOL_GRAZING = 2e-4
+EDGE_FLIPS = 3e-4
+
+
+def _build(ctx, torch, scene_file):
+    """-> (flattened scene dict, handle of the two-level structure, keep-alive list)"""
+    from optix_raytracer_amd import api, scenes
+    gl = api.Scene(scene_file)
+    flat = scenes.from_gltf(scene_file)
+    meshes, insts = scenes.gltf_two_level(gl)
+    keep, gas = [], []
+    n_mat = flat["diffuse"].shape[0]
+    for verts, mat in meshes:
+        dv = torch.from_numpy(np.ascontiguousarray(verts)).cuda()
+        dm = torch.from_numpy(np.where(mat == 0xFFFFFFFF, n_mat - 1, mat).astype(np.int32)).cuda()
+        keep += [dv, dm]
+        gas.append(ctx.accel_build([{"vertices": dv.data_ptr(), "num_vertices": verts.shape[0], "stride": 16, "sbt_index_offsets": dm.data_ptr()}]))
+    inst = [(gas[m], xf) for m, xf in insts]
+    ias = ctx.accel_build_instances(inst)
+    return flat, ias, gas, inst, keep
+
+
+def _oracle_two_level(ctx, flat, ias):
+    nodes, order, inv, base, gas_handles = ctx.accel_export_instances(ias)
+    exports = {}
+    for h in set(int(x) for x in gas_handles):
+        exports[h] = ctx.accel_export(h)
+    osc = O.Scene(flat)
+    osc.set_instances(nodes, order, inv, base, [exports[int(h)] for h in gas_handles])
+    return osc
+
+
+def _state(ctx, torch, flat, handle, w, h, spp, depth):
+    """launch state over `handle`; the hit-group records point at the FLATTENED world-space vertices (a hit reports the flattened index)"""
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    st = PT.PathTracerState()
+    st.device = torch.device("cuda", 0)
+    st.context = ctx
+    st.scene = flat
+    st.d_vertices = torch.from_numpy(np.ascontiguousarray(flat["vertices"], np.float32)).cuda()
+    st.gas_handle = handle
+    PT.createSBT(st)
+    PT.initLaunchParams(st, w, h, spp)
+    cam = flat["camera"]
+    PT.handleCameraUpdate(st, PT.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], 1.0))
+    ctx.set_option(L.OPT_MAX_DEPTH, depth)
+    return PT, st
+
+
+def _render(PT, st):
+    ob = PT.OutputBuffer(st.params.width, st.params.height, st.device)
+    PT.launchSubframe(ob, st)
+    return st.accum.cpu().numpy(), ob.getHostPointer(), st.context.launch_stats()
+
+
+def test_two_level_structure_matches_the_oracle_and_the_flattened_scene(tmp_path):
+    import torch
+    assert torch.cuda.is_available()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import api, scenes
+    path = scenes.write_instanced_gltf(tmp_path / "instanced.gltf")
+    ctx = api.Context(0)
+    flat, ias, gas, inst, keep = _build(ctx, torch, path)
+    info = ctx.accel_info(ias)
+    assert info["num_instances"] == len(inst) == 151 and info["num_triangles"] == flat["vertices"].shape[0] // 3
+    w, h, spp, depth = 320, 180, 2, 4
+    launch = scenes.launch_desc(flat, w, h, spp)
+    # ---- (a) GPU over the two-level structure == the oracle's two-level walk, bit for bit (frames, counters, visit counts)
+    PT, st = _state(ctx, torch, flat, ias, w, h, spp, depth)
+    acc, frame, stats = _render(PT, st)
+    osc = _oracle_two_level(ctx, flat, ias)
+    a, f, ost = osc.render(launch, mode=O.MODE_INST, max_depth=depth, threads=8)
+    assert np.array_equal(acc.view(np.uint32), a.view(np.uint32)) and np.array_equal(frame, f)
+    assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"] > 1000
+    ctx.set_option(L.OPT_COUNT_VISITS, 1)
+    acc_c, _, stats_c = _render(PT, st)
+    ctx.set_option(L.OPT_COUNT_VISITS, 0)
+    assert np.array_equal(acc_c.view(np.uint32), a.view(np.uint32))
+    assert stats_c["node_visits"] == ost["node_visits"] and stats_c["tri_tests"] == ost["tri_tests"]
+    # ---- ray-buffer queries: hit records and occlusion flags equal the oracle's
+    rays = osc.primary_rays(scenes.launch_desc(flat, 640, 360))
+    rng = np.random.default_rng(5)
+    extra = np.zeros((20000, 8), np.float32)
+    extra[:, :3] = rng.uniform(-8, 8, (20000, 3)) * (1, 0.4, 1) + (0, 1.5, 0)
+    extra[:, 4:7] = rng.normal(size=(20000, 3))
+    extra[:, 3], extra[:, 7] = 0.01, 1e16
+    extra[:100, 7] = 0.0
+    rays = np.concatenate([rays, extra])
+    n = rays.shape[0]
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr())
+    ctx.sync()
+    hits2 = d_hits.cpu().numpy()
+    t, prim, u, v = osc.trace_closest(rays, O.MODE_INST)
+    assert np.array_equal(hits2[:, 1].view(np.uint32), prim) and np.array_equal(hits2[:, 0].view(np.uint32), t.view(np.uint32))
+    hit = prim != 0xffffffff
+    assert np.array_equal(hits2[hit, 2].view(np.uint32), u[hit].view(np.uint32)) and np.array_equal(hits2[hit, 3].view(np.uint32), v[hit].view(np.uint32))
+    seg = rays.copy()
+    seg[:, 7] = np.where(seg[:, 7] > 1.0, 6.0, seg[:, 7])
+    d_seg = torch.from_numpy(seg).cuda()
+    d_occ = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.trace_any(ias, d_seg.data_ptr(), n, d_occ.data_ptr())
+    assert np.array_equal(d_occ.cpu().numpy().astype(np.uint8), osc.trace_any(seg, O.MODE_INST))
+    # ---- (b) against the flattened scene under ONE BVH: the same triangles up to the rounding of the instance transform
+    dv = torch.from_numpy(np.ascontiguousarray(flat["vertices"], np.float32)).cuda()
+    dm = torch.from_numpy(flat["mat_index"].astype(np.int32)).cuda()
+    one = ctx.accel_build([{"vertices": dv.data_ptr(), "num_vertices": flat["vertices"].shape[0], "stride": 16, "sbt_index_offsets": dm.data_ptr()}])
+    ctx.trace_closest(one, d_rays.data_ptr(), n, d_hits.data_ptr())
+    ctx.sync()
+    hits1 = d_hits.cpu().numpy()
+    p1, p2 = hits1[:, 1].view(np.uint32), hits2[:, 1].view(np.uint32)
+    same = p1 == p2
+    both = same & (p1 != 0xffffffff)
+    assert (~same).mean() <= EDGE_FLIPS, "%d of %d rays meet another triangle" % ((~same).sum(), n)
+    rel = np.abs(hits1[both, 0] - hits2[both, 0]) / np.maximum(np.abs(hits1[both, 0]), 1.0)
+    assert np.quantile(rel, 0.999) <= T_REL_TOL and rel.max() <= T_REL_TOL_GRAZING, (np.quantile(rel, 0.999), rel.max())
+    ctx.trace_any(one, d_seg.data_ptr(), n, d_occ.data_ptr())
+    assert (d_occ.cpu().numpy().astype(np.uint8) != osc.trace_any(seg, O.MODE_INST)).mean() <= EDGE_FLIPS
+    PT1, st1 = _state(ctx, torch, flat, one, w, h, spp, depth)
+    acc1, frame1, stats1 = _render(PT1, st1)
+    # frames: a path that meets the same triangles differs by rounding only; a path that flips at an edge differs freely
+    close = np.isclose(acc1[..., :3], acc[..., :3], rtol=2e-3, atol=2e-4).all(-1)
+    assert close.mean() >= 0.995, close.mean()
+    assert abs(int(stats1["shadow_rays"]) - int(stats["shadow_rays"])) <= 0.002 * stats["shadow_rays"]
+    print("two-level vs flattened: %d / %d rays meet another triangle, max relative dt %.2e, %.4f of the pixels agree to 2e-3" % (
+        (~same).sum(), n, rel.max(), close.mean()))
+    # ---- an instance moves: mipt_accel_update_instances == a fresh build with the new transforms
+    moved = list(inst)
+    xf = np.array(moved[7][1], np.float32, copy=True)
+    xf[:, 3] += np.float32([0.8, 0.6, -0.5])
+    moved[7] = (moved[7][0], xf)
+    ctx.accel_update_instances(ias, moved)
+    fresh = ctx.accel_build_instances(moved)
+    ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+    h_upd = d_hits.cpu().numpy()
+    ctx.trace_closest(fresh, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+    assert np.array_equal(h_upd.view(np.uint32), d_hits.cpu().numpy().view(np.uint32))
+    assert not np.array_equal(h_upd.view(np.uint32), hits2.view(np.uint32))
+    t_m, prim_m, _, _ = _oracle_two_level(ctx, flat, ias).trace_closest(rays, O.MODE_INST)
+    assert np.array_equal(h_upd[:, 1].view(np.uint32), prim_m) and np.array_equal(h_upd[:, 0].view(np.uint32), t_m.view(np.uint32))
+    # ---- errors: a mesh BVH cannot go away while an instance structure uses it; a singular transform is refused
+    with pytest.raises(api.MiptError):
+        ctx.accel_destroy(gas[0])
+    bad = list(inst)
+    bad[3] = (bad[3][0], np.zeros((3, 4), np.float32))
+    with pytest.raises(api.MiptError):
+        ctx.accel_build_instances(bad)
+    with pytest.raises(api.MiptError):
+        ctx.accel_build_instances([(ias, np.eye(4, dtype=np.float32)[:3])])      # an instance structure as a child
+    ctx.accel_destroy(fresh); ctx.accel_destroy(ias)
+    ctx.accel_destroy(gas[0])
+    ctx.destroy()
+
+
+def test_whitted_programs_over_the_instance_structure(tmp_path):
+    """optixMeshViewer's pipeline as the reference builds it: one triangle structure per mesh + the instance structure
+    (meshviewer.loadScene(two_level=True)); radiance rays cull back faces by the per-triangle geometry flags inside the instance
+    walk, occlusion rays use the any-hit form.  Frames, frame buffer and ray counters equal the oracle's two-level render."""
+    import torch
+    from optix_raytracer_amd import meshviewer as MV
+    from optix_raytracer_amd import scenes
+    path = scenes.write_instanced_gltf(tmp_path / "instanced.gltf", n_instances=60, seed=4)
+    w, h = 256, 144
+    st = MV.MeshViewerState()
+    MV.loadScene(st, path, two_level=True)
+    MV.initCameraState(st)
+    MV.initLaunchParams(st, w, h)
+    out = MV.OutputBuffer(w, h, st.device)
+    tot = [0, 0]
+    for _ in range(2):
+        MV.updateState(st)
+        MV.launchSubframe(out, st)
+        s = st.context.launch_stats()
+        tot[0] += s["closest_rays"]; tot[1] += s["shadow_rays"]
+        st.params.subframe_index += 1
+    ctx = st.context
+    verts = st.d_vertices.cpu().numpy()
+    mat = st.d_material_index.cpu().numpy().view(np.uint32)
+    flat = {"vertices": verts, "mat_index": np.zeros(mat.shape[0], np.uint32), "emission": np.zeros((1, 3), np.float32), "diffuse": np.ones((1, 3), np.float32)}
+    osc = _oracle_two_level(ctx, flat, st.handle)
+    gf = MV.geometry_flags(st.materials)
+    osc.set_prim_flags(gf[np.minimum(mat, len(gf) - 1)])
+    mats = [{"base_color": list(m.base_color), "metallic": m.metallic, "roughness": m.roughness, "emissive_factor": list(m.emissive_factor),
+             "alpha_mode": m.alpha_mode, "alpha_cutoff": m.alpha_cutoff, "double_sided": m.double_sided} for m in st.materials]
+    lights = [{"type": l.type, "color": list(l.color), "intensity": l.intensity, "position": list(l.position), "falloff": l.falloff}
+              for l in list(st.lights)[: st.params.lights.count]]
+    p = st.params
+    acc = np.zeros((h, w, 4), np.float32)
+    oc = [0, 0]
+    for sf in range(2):
+        la = {"width": w, "height": h, "subframe": sf, "eye": list(p.eye), "U": list(p.U), "V": list(p.V), "W": list(p.W), "miss_color": list(p.miss_color)}
+        acc, frame, ost = osc.render_whitted(la, lights, mats, mat, accum=acc, mode=O.MODE_INST)
+        oc[0] += ost["closest_rays"]; oc[1] += ost["shadow_rays"]
+    got = st.accum.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), acc.view(np.uint32)) and np.array_equal(out.getHostPointer(), frame)
+    assert tot == oc and tot[1] > 1000
+    hit = np.abs(acc[..., :3] - np.asarray(list(p.miss_color), np.float32)).sum(2) > 0
+    assert hit.mean() > 0.3
+    MV.cleanup(st)
