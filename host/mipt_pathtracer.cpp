@@ -2,9 +2,8 @@
 //
 // Mirrors SDK/optixPathTracer/optixPathTracer.cpp in file-output mode (main :927-1093): the same state
 // functions in the same order, the same command-line flags (--file/-f, --dim=WxH, --launch-samples/-s),
-// the same Params / ParallelogramLight / HitGroupData / MissData structs, a HIP version of the
-// CUDA_DEVICE mode of sutil::CUDAOutputBuffer<uchar4> (SDK/sutil/CUDAOutputBuffer.h:54-94), sutil::Camera
-// (SDK/sutil/Camera.h:38-76); the image is written by mipt_save_image (sutil::saveImage's rules, sutil.cpp:542-709: rows are
+// the same Params / ParallelogramLight / HitGroupData / MissData structs; sutil::HIPOutputBuffer<uchar4> (= CUDAOutputBuffer,
+// CUDA_DEVICE or ZERO_COPY) and sutil::Camera come from include/mipt_sutil.hpp; the image is written by mipt_save_image (sutil::saveImage's rules, sutil.cpp:542-709: rows are
 // flipped on write, row 0 of the buffer is the bottom of the image).  createModule / createProgramGroups /
 // createPipeline (:686-826) have no counterpart.  Extra flags: --scene cornell|soup, --tris N,
 // --max-depth K (0 = Russian roulette only, the reference's behaviour), --subframes N.
@@ -22,13 +21,16 @@
 #include <string>
 #include <vector>
 
-#include "../include/mipt.h"
+#include "../include/mipt_sutil.hpp"     // sutil::Camera, HIPOutputBuffer<T>, Exception, MIPT_CHECK over include/mipt.h
 
 namespace {
 
-struct float3_ { float x, y, z; };
-struct float4_ { float x, y, z, w; };
-struct uchar4_ { unsigned char x, y, z, w; };
+using sutil::Camera;
+using sutil::Exception;
+using sutil::HIPOutputBuffer;
+typedef float3 float3_;
+typedef float4 float4_;
+typedef uchar4 uchar4_;
 
 // ---- structs of optixPathTracer.h:82-126, unchanged ---------------------------------------------
 struct ParallelogramLight { float3_ corner, v1, v2, normal, emission; };
@@ -43,70 +45,6 @@ struct Params {
 };
 static_assert(sizeof(Params) == sizeof(MiptParams), "Params must stay layout compatible");
 struct Vertex { float x, y, z, pad; };                                     // optixPathTracer.cpp:96-99
-
-class Exception : public std::runtime_error {                              // sutil/Exception.h
-public:
-    explicit Exception(const std::string& m) : std::runtime_error(m) {}
-};
-
-#define HIP_CHECK(call)                                                                                      \
-    do { hipError_t e_ = (call);                                                                             \
-         if (e_ != hipSuccess) { std::stringstream ss; ss << "HIP call '" << #call << "' failed: "            \
-             << hipGetErrorString(e_) << " (" __FILE__ << ":" << __LINE__ << ")"; throw Exception(ss.str()); } } while (0)
-#define MIPT_CHECK(call)                                                                                     \
-    do { int rc_ = (call);                                                                                   \
-         if (rc_ != MIPT_SUCCESS) { std::stringstream ss; ss << "mipt call '" << #call << "' failed: "        \
-             << mipt_error_name(rc_) << ": " << mipt_last_error_string(state.context)                          \
-             << " (" __FILE__ << ":" << __LINE__ << ")"; throw Exception(ss.str()); } } while (0)
-
-// ---- sutil::Camera (Camera.h:38-76), frame computed by the library's host code ------------------
-class Camera {
-public:
-    void setEye(float3_ v) { m_eye = v; }
-    void setLookat(float3_ v) { m_lookat = v; }
-    void setUp(float3_ v) { m_up = v; }
-    void setFovY(float v) { m_fovY = v; }
-    void setAspectRatio(float v) { m_aspectRatio = v; }
-    void setFocalLength(float v) { m_fod = v; }
-    const float3_& eye() const { return m_eye; }
-    void UVWFrame(float3_& U, float3_& V, float3_& W) const
-    {
-        mipt_camera_uvw(&m_eye.x, &m_lookat.x, &m_up.x, m_fovY, m_aspectRatio, m_fod, &U.x, &V.x, &W.x);
-    }
-private:
-    float3_ m_eye{ 1, 1, 1 }, m_lookat{ 0, 0, 0 }, m_up{ 0, 1, 0 };
-    float   m_fovY = 35.0f, m_aspectRatio = 1.0f, m_fod = 1.0f;
-};
-
-// ---- CUDAOutputBuffer<uchar4>, CUDA_DEVICE mode, on HIP --------------------------------------------
-template <typename PIXEL>
-class HIPOutputBuffer {
-public:
-    HIPOutputBuffer(int w, int h) { resize(w, h); }
-    ~HIPOutputBuffer() { if (m_device) (void)hipFree(m_device); }
-    void resize(int w, int h)
-    {
-        if (m_device) HIP_CHECK(hipFree(m_device));
-        m_width = w; m_height = h;
-        HIP_CHECK(hipMalloc((void**)&m_device, (size_t)w * h * sizeof(PIXEL)));
-        m_host.resize((size_t)w * h);
-    }
-    void   setStream(hipStream_t s) { m_stream = s; }
-    PIXEL* map() { return m_device; }
-    void   unmap() { HIP_CHECK(hipStreamSynchronize(m_stream)); }
-    PIXEL* getHostPointer()
-    {
-        HIP_CHECK(hipMemcpy(m_host.data(), m_device, m_host.size() * sizeof(PIXEL), hipMemcpyDeviceToHost));
-        return m_host.data();
-    }
-    int width() const { return m_width; }
-    int height() const { return m_height; }
-private:
-    int m_width = 0, m_height = 0;
-    PIXEL* m_device = nullptr;
-    std::vector<PIXEL> m_host;
-    hipStream_t m_stream = nullptr;
-};
 
 struct PathTracerState {                                                    // optixPathTracer.cpp:110-131
     MiptContext*       context = nullptr;
@@ -185,20 +123,20 @@ void buildMeshAccel(PathTracerState& state)                                 // :
     MiptBuildInput in{};
     in.vertices = state.d_vertices; in.num_vertices = (uint32_t)g_vertices.size(); in.vertex_stride_bytes = sizeof(Vertex);
     in.sbt_index_offsets = g_mat_indices.data();
-    MIPT_CHECK(mipt_accel_build(state.context, &in, 1, &state.gas_handle));
+    MIPT_CHECK(state.context, mipt_accel_build(state.context, &in, 1, &state.gas_handle));
 }
 
 void createSBT(PathTracerState& state)                                      // :829-898
 {
     MiptMissData ms{ { 0.0f, 0.0f, 0.0f, 0.0f } };
-    MIPT_CHECK(mipt_sbt_set_miss(state.context, &ms));
+    MIPT_CHECK(state.context, mipt_sbt_set_miss(state.context, &ms));
     std::vector<MiptHitGroupData> recs(g_emission_colors.size());
     for (size_t i = 0; i < recs.size(); ++i) {
         std::memcpy(recs[i].emission_color, &g_emission_colors[i], 12);
         std::memcpy(recs[i].diffuse_color, &g_diffuse_colors[i], 12);
         recs[i].vertices = state.d_vertices;
     }
-    MIPT_CHECK(mipt_sbt_set_hitgroups(state.context, recs.data(), (uint32_t)recs.size()));
+    MIPT_CHECK(state.context, mipt_sbt_set_hitgroups(state.context, recs.data(), (uint32_t)recs.size()));
 }
 
 void initLaunchParams(PathTracerState& state)                               // :424-445
@@ -222,17 +160,17 @@ void launchSubframe(HIPOutputBuffer<uchar4_>& output_buffer, PathTracerState& st
 {
     state.params.frame_buffer = output_buffer.map();
     output_buffer.setStream(state.stream);
-    MIPT_CHECK(mipt_launch(state.context, state.stream, reinterpret_cast<const MiptParams*>(&state.params),
+    MIPT_CHECK(state.context, mipt_launch(state.context, state.stream, reinterpret_cast<const MiptParams*>(&state.params),
                            state.params.width, state.params.height, 1));
     output_buffer.unmap();
-    MIPT_CHECK(mipt_sync(state.context));
+    MIPT_CHECK(state.context, mipt_sync(state.context));
 }
 
-void saveImage(const char* fname, const uchar4_* data, int width, int height)             // sutil::saveImage, UNSIGNED_BYTE4
+void saveImage(const char* fname, uchar4_* data, int width, int height)                   // :1056-1062
 {
-    char err[256] = { 0 };
-    if (mipt_save_image(fname, data, (uint32_t)width, (uint32_t)height, MIPT_IMAGE_UNSIGNED_BYTE4, 0, err, sizeof err) != MIPT_SUCCESS)
-        throw Exception(err);                                                               // .ppm or .png, as the reference
+    sutil::ImageBuffer buffer;
+    buffer.data = data; buffer.width = (unsigned)width; buffer.height = (unsigned)height; buffer.pixel_format = sutil::UNSIGNED_BYTE4;
+    sutil::saveImage(fname, buffer, false);                                                 // .ppm or .png, as the reference
 }
 
 void cleanupState(PathTracerState& state)                                   // :901-918
@@ -249,7 +187,8 @@ void cleanupState(PathTracerState& state)                                   // :
               << "Options: --file | -f <filename>      File for image output (required: there is no display path)\n"
               << "         --launch-samples | -s       Number of samples per pixel per launch (default 16)\n"
               << "         --dim=<width>x<height>      Set image dimensions; defaults to 768x768\n"
-              << "         --scene cornell|soup        --tris <n>   --max-depth <k>   --subframes <n>\n";
+              << "         --scene cornell|soup        --tris <n>   --max-depth <k>   --subframes <n>\n"
+              << "         --zero-copy                 frame buffer in pinned, mapped host memory (CUDAOutputBufferType::ZERO_COPY)\n";
     std::exit(0);
 }
 
@@ -261,6 +200,7 @@ int main(int argc, char* argv[])
     state.params.width = 768; state.params.height = 768;
     std::string outfile;
     uint64_t max_depth = 0; int subframes = 1;
+    sutil::HIPOutputBufferType output_buffer_type = sutil::HIPOutputBufferType::HIP_DEVICE;
     for (int i = 1; i < argc; ++i) {
         const std::string arg = argv[i];
         if (arg == "--help" || arg == "-h") printUsageAndExit(argv[0]);
@@ -271,6 +211,7 @@ int main(int argc, char* argv[])
             state.params.width = (unsigned)w; state.params.height = (unsigned)h;
         }
         else if ((arg == "--launch-samples" || arg == "-s") && i < argc - 1) samples_per_launch = std::atoi(argv[++i]);
+        else if (arg == "--zero-copy") output_buffer_type = sutil::HIPOutputBufferType::ZERO_COPY;
         else if (arg == "--scene" && i < argc - 1) scene_name = argv[++i];
         else if (arg == "--tris" && i < argc - 1) soup_tris = (uint32_t)std::atoll(argv[++i]);
         else if (arg == "--max-depth" && i < argc - 1) max_depth = (uint64_t)std::atoll(argv[++i]);
@@ -284,15 +225,15 @@ int main(int argc, char* argv[])
         buildMeshAccel(state);
         createSBT(state);
         initLaunchParams(state);
-        MIPT_CHECK(mipt_set_option(state.context, MIPT_OPT_MAX_DEPTH, max_depth));
-        HIPOutputBuffer<uchar4_> output_buffer((int)state.params.width, (int)state.params.height);
+        MIPT_CHECK(state.context, mipt_set_option(state.context, MIPT_OPT_MAX_DEPTH, max_depth));
+        HIPOutputBuffer<uchar4_> output_buffer(output_buffer_type, (int)state.params.width, (int)state.params.height);
         handleCameraUpdate(state.params);
         for (int s = 0; s < subframes; ++s) {                              // the progressive loop of :1021-1045, headless
             state.params.subframe_index = (unsigned)s;
             launchSubframe(output_buffer, state);
         }
         MiptLaunchStats st{};
-        MIPT_CHECK(mipt_get_launch_stats(state.context, &st));
+        MIPT_CHECK(state.context, mipt_get_launch_stats(state.context, &st));
         std::cerr << "last launch: " << st.closest_rays << " closest + " << st.shadow_rays << " shadow rays, "
                   << st.bounces << " wavefront iterations\n";
         saveImage(outfile.c_str(), output_buffer.getHostPointer(), output_buffer.width(), output_buffer.height());

@@ -210,12 +210,21 @@ class Scene:
         return tab, n
 
     def material_table(self):
-        """ctypes array of MiptMaterialData: the scene's materials + one all-zero record, which is what
-        Scene::createSBT gives a primitive without a material (`MaterialData()`, Scene.cpp:1423-1428)"""
+        """ctypes array of MiptMaterialData: the scene's materials + one record with the defaults of `MaterialData()`
+        (cuda/MaterialData.h:44-51: base colour 1, metallic 1, roughness 1, no textures), which is what Scene::createSBT gives a
+        primitive without a material (Scene.cpp:1423-1428)"""
         n = self.info()["num_materials"]
         tab = (L.MiptMaterialData * (n + 1))()
         for k in range(n):
             self._lib.mipt_scene_material(self._h, k, C.byref(tab[k]))
+        d = tab[n]
+        d.base_color = (C.c_float * 4)(1.0, 1.0, 1.0, 1.0)
+        d.metallic, d.roughness = 1.0, 1.0
+        for name in ("base_color_tex", "metallic_roughness_tex", "normal_tex", "emissive_tex"):
+            ti = getattr(d, name)
+            ti.texture, ti.texcoord = -1, 0
+            ti.rotation = (C.c_float * 2)(0.0, 1.0)
+            ti.scale = (C.c_float * 2)(1.0, 1.0)
         return tab
 
 

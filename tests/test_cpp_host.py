@@ -13,8 +13,7 @@ EXE = os.path.join(ROOT, "host", "mipt_pathtracer")
 
 
 def _build():
-    if not os.path.exists(EXE):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
 
 
 def test_no_gpu_is_reported_like_the_reference_reports_errors(tmp_path):
@@ -57,3 +56,70 @@ def test_cpp_sample_writes_the_oracle_frame(tmp_path, args, scene_fn, w, h, spp,
     for sub in range(subframes):
         acc, frame, _ = osc.render(scenes.launch_desc(scene, w, h, spp, subframe=sub), max_depth=depth, accum=acc, threads=4)
     assert np.array_equal(img, frame[::-1, :, :3])       # file rows are top to bottom
+
+
+MV_EXE = os.path.join(ROOT, "host", "mipt_meshviewer")
+MG_EXE = os.path.join(ROOT, "host", "mipt_multigpu")
+
+
+def _build_all():
+    _build()
+
+
+@pytest.mark.gpu
+def test_zero_copy_output_buffer_gives_the_same_file(tmp_path):
+    """sutil::HIPOutputBuffer<uchar4> in ZERO_COPY mode (CUDAOutputBuffer.h:203-216: pinned, mapped host memory the launch writes
+    directly) against the device-memory mode"""
+    _build_all()
+    outs = []
+    for extra in ([], ["--zero-copy"]):
+        out = tmp_path / ("f%d.ppm" % len(outs))
+        r = subprocess.run([EXE, "--file", str(out), "--dim=120x80", "-s", "2", "--scene", "cornell", "--subframes", "2"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(_read_ppm(out))
+    assert np.array_equal(outs[0], outs[1]) and outs[0].max() > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["--two-level", "--flattened"])
+def test_cpp_meshviewer_writes_the_frame_of_the_python_mirror(tmp_path, mode):
+    """host/mipt_meshviewer.cpp (= optixMeshViewer's main() on sutil::Scene / loadScene of include/mipt_sutil.hpp) against
+    meshviewer.render, which the oracle checks (tests/test_whitted.py, tests/test_instances.py)"""
+    from optix_raytracer_amd import meshviewer as MV
+    from optix_raytracer_amd import scenes
+    _build_all()
+    path = scenes.write_instanced_gltf(tmp_path / "instanced.gltf", n_instances=40, seed=2)
+    out = tmp_path / "mv.ppm"
+    w, h = 200, 120
+    r = subprocess.run([MV_EXE, "--model", str(path), "--file", str(out), "--dim=%dx%d" % (w, h), "--subframes", "2", mode, "--zero-copy"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert ("two-level structure" if mode == "--two-level" else "flattened structure") in r.stderr
+    img = _read_ppm(out)
+    st, frame = MV.render(path, w, h, subframes=2, two_level=(mode == "--two-level"))
+    MV.cleanup(st)
+    assert np.array_equal(img, frame[::-1, :, :3])
+    r = subprocess.run([MV_EXE, "--model", str(tmp_path / "missing.gltf"), "--file", str(out)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Caught exception" in r.stderr and "loadScene" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_multigpu_sample_writes_the_oracle_frame(tmp_path):
+    """host/mipt_multigpu.cpp (= optixMultiGPU's main(): one host thread, a state per device, mipt_group_launch / allgather /
+    sync) on the devices of this box; the assembled frame equals the oracle's single-process frame"""
+    from optix_raytracer_amd import scenes
+    _build_all()
+    out = tmp_path / "mg.ppm"
+    w, h, spp = 128, 96, 2
+    r = subprocess.run([MG_EXE, "--file", str(out), "--dim=%dx%d" % (w, h), "-s", str(spp), "--subframes", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "device(s), exchange through" in r.stderr
+    img = _read_ppm(out)
+    scene = scenes.cornell_box()
+    osc = O.Scene(scene).build_bvh()
+    acc = None
+    for sub in range(2):
+        acc, frame, _ = osc.render(scenes.launch_desc(scene, w, h, spp, subframe=sub), accum=acc, threads=4)
+    assert np.array_equal(img, frame[::-1, :, :3])

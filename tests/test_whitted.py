@@ -127,7 +127,8 @@ def test_scene_flatten_normals(tmp_path):
         assert np.allclose(n[:, :3], expect["normals"][:, :3], rtol=2e-5, atol=2e-6)
         tab = sc.material_table()
         assert len(tab) == sc.info()["num_materials"] + 1
-        assert list(tab[len(tab) - 1].base_color) == [0.0] * 4 and tab[len(tab) - 1].roughness == 0.0
+        last = tab[len(tab) - 1]            # MaterialData() (cuda/MaterialData.h:44-51): what a primitive without a material gets (Scene.cpp:1423-1428)
+        assert list(last.base_color) == [1.0] * 4 and last.roughness == 1.0 and last.metallic == 1.0 and last.base_color_tex.texture == -1
 
 
 def test_meshviewer_default_lights_follow_the_sample():
