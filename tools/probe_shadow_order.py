@@ -77,3 +77,45 @@ for name, o in orders.items():
     if ref is None:
         ref = back
     print("%-30s %d rays  %.4f ms  occluded %.3f  same flags %s" % (name, n, tm["ms_trace_any"] / 20, occ.mean(), bool(np.array_equal(back, ref))), flush=True)
+
+# ---- occluder sharing: how often does the triangle that occludes ray i-k also occlude ray i?  (closest occluders from
+# mipt_trace_closest on the shadow segments, path order; the any-hit kernel would find SOME occluder, this is an estimate)
+d_sh = torch.from_numpy(np.ascontiguousarray(sh)).cuda()
+d_h = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+ctx.trace_closest(st.gas_handle, d_sh.data_ptr(), n, d_h.data_ptr())
+ctx.sync()
+hp = d_h.cpu().numpy()
+prim = hp[:, 1].view(np.uint32)
+V = np.asarray(scene["vertices"], np.float32).reshape(-1, 3, 4)[:, :, :3]
+
+
+def hits(ray_idx, tri_idx):
+    o, dd, tmin, tmax = sh[ray_idx, :3], sh[ray_idx, 4:7], sh[ray_idx, 3], sh[ray_idx, 7]
+    v0 = V[tri_idx, 0]; e1 = V[tri_idx, 1] - v0; e2 = V[tri_idx, 2] - v0
+    p = np.cross(dd, e2); det = (e1 * p).sum(1)
+    ok = det != 0
+    inv = 1.0 / np.where(ok, det, 1)
+    tv = o - v0
+    u = (tv * p).sum(1) * inv
+    q = np.cross(tv, e1)
+    v = (dd * q).sum(1) * inv
+    t = (e2 * q).sum(1) * inv
+    return ok & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > tmin) & (t < tmax)
+
+
+occ = prim != 0xffffffff
+print("occluded (closest-hit form): %.3f" % occ.mean())
+idx = np.arange(n)
+for k in (1, 2, 4, 8, 16, 32):
+    src = idx - k
+    valid = (src >= 0) & occ & (prim[np.maximum(src, 0)] != 0xffffffff) & ((idx // 32) == (np.maximum(src, 0) // 32))
+    h = hits(idx[valid], prim[src[valid]])
+    print("lag %2d (same 32-ray chunk): candidate available for %.3f of the rays, of those %.3f are occluded by it" % (k, valid.mean(), h.mean()))
+# best case inside a 32-ray chunk: any earlier ray's occluder
+any_hit = np.zeros(n, bool)
+for k in range(1, 32):
+    src = idx - k
+    valid = (src >= 0) & occ & (prim[np.maximum(src, 0)] != 0xffffffff) & ((idx // 32) == (np.maximum(src, 0) // 32)) & ~any_hit
+    vi = idx[valid]
+    any_hit[vi] |= hits(vi, prim[src[valid]])
+print("occluded by the occluder of ANY earlier ray of its 32-ray chunk: %.3f of all rays" % any_hit.mean())
