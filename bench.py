@@ -366,8 +366,8 @@ def main():
         tt_c = counts["tri_tests"] - counts["shadow_tri_tests"]
         bytes_closest = 64 * nv_c + 48 * tt_c + (32 + 16) * counts["closest_rays"]
         bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
-        q = "true" if info.get("node_format", 0) else "false"
-        variant = {3: "k_trace_pool<%%d, %d, %s>" % (24 if info["depth"] <= 24 else 32, q), 2: "k_trace_stream<%d, false>",
+        q = str(int(info.get("node_format", 0)))
+        variant = {3: "k_trace_pool<%%d, %d, %s>" % (24 if info["depth"] <= 24 else 32, "1" if q != "0" else "0"), 2: "k_trace_stream<%d, false>",
                    0: "k_trace_simple<%d, false>"}[int(st.context.get_option(L.OPT_PERSISTENT))]
         # a pass of at most MIPT_OPT_TAIL_PATHS paths (a rank's shard at N >= 2) runs in the path kernel: closest-hit and
         # any-hit traversal, shading and accumulation of a wave's 64 paths in ONE launch, timed under "trace_closest"
@@ -400,8 +400,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[3]: %d random triangles in the unit cube, %dx%d spp=%d, max depth %d "
-                                   "(primary + NEE shadow ray), BVH2 %d nodes depth %d" % (
-                                       args.tris, w, h, SPP, args.max_depth, info["num_nodes"], info["depth"]),
+                                   "(primary + NEE shadow ray), BVH2 %d nodes depth %d, node format %d (%d mirror nodes, stack %d)" % (
+                                       args.tris, w, h, SPP, args.max_depth, info["num_nodes"], info["depth"], info["node_format"], info["mirror_nodes"], info["stack_entries"]),
                        "rays_per_frame": rays_total, "closest_rays": counts["closest_rays"] if world == 1 else None,
                        "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather%s" % (
                            world, " (frame k's gather overlaps frame k+1's tracing)" if args.overlap else ""),

@@ -128,8 +128,11 @@ typedef struct MiptAccelInfo {
     uint32_t leaf_max;
     uint64_t device_bytes;
     double   build_seconds;
-    uint32_t node_format;      /* 1: the boxes are fp16 values and a packed 32-byte mirror exists (MiptBvhNode32); 0: fp32 boxes */
+    uint32_t node_format;      /* the format in effect (MIPT_OPT_NODE_FORMAT): 2 BVH4 mirror, 1 packed BVH2 mirror, 0 fp32 boxes only */
     uint32_t num_instances;    /* > 0: an instance (two-level) structure; num_nodes = its top level, num_triangles = all referenced */
+    uint32_t stack_entries;    /* entries a lane's traversal stack can need over the structure the tiled kernel walks (format 2: the
+                                  BVH4 mirror's worst case, <= 32; else = depth) */
+    uint32_t mirror_nodes;     /* nodes of the mirror (format 2: BVH4 nodes; format 1: = num_nodes; format 0: 0) */
 } MiptAccelInfo;
 
 /* one triangle build input == OptixBuildInputTriangleArray as the samples use it
@@ -201,10 +204,15 @@ typedef enum MiptOption {
                                   half the value when MAX_DEPTH caps the paths), one kernel runs each of them to its
                                   end, a wave per 64 paths, instead of five kernels per bounce; a pass that starts with at
                                   most this many paths (three quarters of it when capped) starts there.  Same pixels, same ray counts.  Default 1048576, 0 = off */
-    MIPT_OPT_NODE_FORMAT  = 14, /* set before mipt_accel_build.  1 (default): child boxes rounded outward to fp16 values + the packed
-                                  32-byte node mirror (MiptBvhNode32) for the entry-pool kernels; scenes that do not suit fp16
-                                  boxes (a coordinate beyond +-32768, or the largest extent below a quarter of the largest
-                                  coordinate) silently keep format 0.  0: fp32 boxes, 64-byte nodes only. */
+    MIPT_OPT_NODE_FORMAT  = 14, /* set before mipt_accel_build.  What the entry-pool traversal kernels walk:
+                                  2 (default): child boxes rounded outward to fp16 values + a BVH4 mirror of the tree (64-byte nodes
+                                     of four fp16 boxes, collapsed on the host so that a lane's stack never needs more than 32 entries);
+                                     the device LBVH builder (MIPT_OPT_BUILD = 1, the fast-build path) keeps format 1;
+                                  1: the rounded boxes + the packed 32-byte BVH2 mirror (MiptBvhNode32);
+                                  0: fp32 boxes, 64-byte nodes only.
+                                  Scenes that do not suit fp16 boxes (a coordinate beyond +-32768, or the largest extent below a
+                                  quarter of the largest coordinate) silently keep format 0.  The 64-byte BVH2 nodes stay the
+                                  canonical tree in every format (mipt_accel_export, counting launches, instance walk). */
     MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
                                   (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;

@@ -36,7 +36,7 @@ class MiptHitGroupData(C.Structure):
 class MiptAccelInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_uint32), ("num_triangles", C.c_uint32), ("depth", C.c_uint32),
                 ("leaf_max", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double),
-                ("node_format", C.c_uint32), ("num_instances", C.c_uint32)]
+                ("node_format", C.c_uint32), ("num_instances", C.c_uint32), ("stack_entries", C.c_uint32), ("mirror_nodes", C.c_uint32)]
 
 
 class MiptInstance(C.Structure):

@@ -44,8 +44,12 @@ struct DeviceBvh {
     const struct DeviceInstance* inst;      // null: an ordinary triangle BVH
     const uint32_t* inst_order;
     uint32_t n_inst;
-    uint32_t node32_off;       // byte offset, in the same allocation, of the packed 32-byte nodes (MiptBvhNode32: the boxes of
-                               // `nodes` as fp16 -- the two arrays hold the SAME values); 0 = this BVH has none
+    uint32_t node32_off;       // byte offset, in the same allocation, of the entry-pool kernels' node mirror; 0 = this BVH has none
+    uint32_t node4_off;        // byte offset of the BVH4 mirror (64-byte nodes of four fp16 boxes) behind the packed one; 0 = none
+    uint32_t stack4;           // the most entries a lane's stack can need over the BVH4 mirror
+    uint32_t node_fmt;         // 0: fp32 64-byte BVH2 nodes only; 1: + packed 32-byte BVH2 nodes at node32_off (MiptBvhNode32: the boxes of
+                               // `nodes` as fp16 -- the two arrays hold the SAME values), walked by every entry-pool kernel; 2: + the BVH4
+                               // mirror at node4_off, walked by the kernels that live on the pool alone (static chunks, path kernels)
 };
 
 // one instance of a two-level structure (built by mipt_accel_build_instances from an OptixInstance-compatible record)
@@ -93,6 +97,8 @@ struct TraceOpts {
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
     int  blocks_user, num_cus; // the grid was set with MIPT_OPT_TRACE_GRID; CUs of the device
+    const uint32_t* tile_order; uint32_t* tile_cost; uint32_t n_order;     // closest-hit launches in the tiled form: TraceArgs
+    int  tiled_bvh4;           // experiments: the tiled kernel walks the BVH4 mirror too (when a lane's stack over it fits 32 rows)
 };
 
 // ---- launches (all asynchronous on `st`) ----

@@ -104,13 +104,13 @@ __device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_b
 __device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
 struct SlabOut { float tn0, tf0, tn1, tf1; int c0, c1; };
 
-template <bool Q>
+template <int Q>
 __device__ __forceinline__ SlabOut slab_children(const u32x4 n0, const u32x4 n1, const u32x4 n2, const u32x4 n3, const float ix, const float iy,
                                                  const float iz, const float nx, const float ny, const float nz, const float tmn, const float tcur)
 {
     float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
     SlabOut o;
-    if (Q) {
+    if (Q == 1) {
         // (halves taken by shift / truncate of each dword: a bit_cast of the dword to a half2 vector miscompiles on ROCm 7.2 --
         // every v_fma_mix_f32 then reads element 0 of the loaded vector, whichever element the source names)
         ax0 = __builtin_fmaf(half_lo(n0.x), ix, nx); ax1 = __builtin_fmaf(half_hi(n0.x), ix, nx);
@@ -136,6 +136,49 @@ __device__ __forceinline__ SlabOut slab_children(const u32x4 n0, const u32x4 n1,
     return o;
 }
 
+// ---- node format 2: four children per node (BVH4 mirror of the BVH2, mipt_api.cpp Bvh4Builder) ------------------------------------
+// 64 bytes = four 16-byte pieces, piece c = child c: {lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16} as fp16, then its
+// reference (>= 0: BVH4 node, < 0: the BVH2's leaf descriptor, kNoChild: empty slot).  One step tests four boxes and orders the
+// hit children by entry distance: 0.63 x the steps of the BVH2 walk per primary ray, 0.58 x per shadow ray (1 M-triangle
+// scene).  Hit records cannot depend on the tree (closest: min t, tie -> lowest primitive; any: a boolean), so frames equal
+// those of the other formats bit for bit.
+constexpr int kNoChild = 0x7fffffff;
+struct Slab4 { float t[4]; int ref[4]; int n; };       // the hit children, nearest first; n of them
+
+__device__ __forceinline__ void slab_piece(const u32x4 q, const float ix, const float iy, const float iz, const float nx, const float ny, const float nz,
+                                           const float tmn, const float tcur, float& key, int& ref)
+{
+    const float x0 = __builtin_fmaf(half_lo(q.x), ix, nx), x1 = __builtin_fmaf(half_hi(q.x), ix, nx);
+    const float y0 = __builtin_fmaf(half_lo(q.y), iy, ny), y1 = __builtin_fmaf(half_hi(q.y), iy, ny);
+    const float z0 = __builtin_fmaf(half_lo(q.z), iz, nz), z1 = __builtin_fmaf(half_hi(q.z), iz, nz);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), tmn));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fminf(__builtin_fmaxf(z0, z1), tcur));
+    ref = (int)q.w;
+    key = (tn <= tf && ref != kNoChild) ? tn : __builtin_inff();
+}
+__device__ __forceinline__ void cmp_swap(float& ka, int& ra, float& kb, int& rb)
+{
+    const bool sw = kb < ka;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+__device__ __forceinline__ Slab4 slab_children4(const u32x4 q0, const u32x4 q1, const u32x4 q2, const u32x4 q3, const float ix, const float iy,
+                                                const float iz, const float nx, const float ny, const float nz, const float tmn, const float tcur)
+{
+    Slab4 o;
+    slab_piece(q0, ix, iy, iz, nx, ny, nz, tmn, tcur, o.t[0], o.ref[0]);
+    slab_piece(q1, ix, iy, iz, nx, ny, nz, tmn, tcur, o.t[1], o.ref[1]);
+    slab_piece(q2, ix, iy, iz, nx, ny, nz, tmn, tcur, o.t[2], o.ref[2]);
+    slab_piece(q3, ix, iy, iz, nx, ny, nz, tmn, tcur, o.t[3], o.ref[3]);
+    cmp_swap(o.t[0], o.ref[0], o.t[1], o.ref[1]); cmp_swap(o.t[2], o.ref[2], o.t[3], o.ref[3]);     // 5-comparator network
+    cmp_swap(o.t[0], o.ref[0], o.t[2], o.ref[2]); cmp_swap(o.t[1], o.ref[1], o.t[3], o.ref[3]);
+    cmp_swap(o.t[1], o.ref[1], o.t[2], o.ref[2]);
+    const float inf = __builtin_inff();
+    o.n = (o.t[0] < inf ? 1 : 0) + (o.t[1] < inf ? 1 : 0) + (o.t[2] < inf ? 1 : 0) + (o.t[3] < inf ? 1 : 0);
+    return o;
+}
+
 // this step's 64 (fp32 nodes) or 32 / 48 (packed nodes / triangles) bytes of a lane: inner lanes fetch their node, leaf
 // lanes their next triangle, idle lanes re-read node 0 (a broadcast).  The memory pipeline (TA / TD) spends 16 cycles per
 // dwordx4 wave instruction whatever the exec mask (profiles/r02_l1_*), so the packed form's third piece is fetched by leaf
@@ -155,6 +198,12 @@ __device__ __forceinline__ SlabOut slab_children(const u32x4 n0, const u32x4 n1,
 #ifndef MIPT_PROBE_STAMP
 #define MIPT_PROBE_STAMP 0
 #endif
+// MIPT_PROBE_WAVES: per wave of k_trace_pool {lifetime, cycles in the bulk phase, bulk steps, pool rounds} and its start / end on
+// the device-wide 100 MHz counter, into the buffer whose device address the host put into DeviceCounters::dbg[0]
+// (mipt_trace_closest, env MIPT_PROBE_WAVES; tools/probe_waves.py): five SMEM stamps per wave
+#ifndef MIPT_PROBE_WAVES
+#define MIPT_PROBE_WAVES 0
+#endif
 #if MIPT_PROBE_STAMP
 #define PROBE_PARAM , unsigned long long& pw_wait
 #define PROBE_ARG , pw_wait
@@ -173,20 +222,24 @@ __device__ __forceinline__ float probe_valu(float seed)
     return (a0 + a1) + (a2 + a3);
 }
 
-template <bool Q>
+template <int Q>
 __device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, const bool inner, const bool tri,
                                           const uint32_t node, const uint32_t lfirst, u32x4& n0, u32x4& n1, u32x4& n2, u32x4& n3 PROBE_PARAM)
 {
 #if MIPT_PROBE_STAMP
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
-    uint32_t off = Q ? bvh.node32_off : 0u;
-    if (inner) off = Q ? bvh.node32_off + (node << 5) : node << 6;
+    uint32_t off = Q == 2 ? bvh.node4_off : (Q == 1 ? bvh.node32_off : 0u);
+    if (inner) off = Q == 2 ? bvh.node4_off + (node << 6) : (Q == 1 ? bvh.node32_off + (node << 5) : node << 6);
     if (tri)   off = bvh.tri_byte_off + lfirst * 48u;
     n0 = ldq(blob, off); n1 = ldq(blob, off + 16u);
-    if (Q) {
+    if (Q == 1) {
         n2 = u32x4{ 0u, 0u, 0u, 0u }; n3 = n2;
         if (tri) n2 = ldq(blob, off + 32u);
+    } else if (Q == 2) {
+        n2 = ldq(blob, off + 32u);                          // third child, or the triangle's third piece
+        n3 = u32x4{ 0u, 0u, 0u, (uint32_t)kNoChild };
+        if (inner) n3 = ldq(blob, off + 48u);
     } else {
         n2 = ldq(blob, off + 32u); n3 = ldq(blob, off + 48u);
     }
@@ -215,7 +268,7 @@ __device__ __forceinline__ uint32_t shfl_u(uint32_t v, uint32_t src) { return (u
 // One step of the lane state machine (see k_trace_stream): every lane loads 64 bytes -- its node, or its next
 // triangle -- then inner lanes do a slab step and leaf lanes one branch-free triangle test.  `sb` is the bottom of
 // the lane's stack (entries below it were given away); shared by k_trace_stream and the bulk phase of k_trace_pool.
-template <int MODE, bool COUNT, bool Q = false>
+template <int MODE, bool COUNT, int Q = 0>
 __device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_buffer_rsrc_t blob, uint32_t* stk, int lane, bool has_ray, Trav& T,
                                             int sb, bool cull_back, uint32_t& n_visits, uint32_t& n_tests PROBE_PARAM)
 {
@@ -230,7 +283,19 @@ __device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_b
     if (probe_valu(T.tmin) == 12345.678f) T.tbest = 0.0f;                 // never true (tmin is 0.01 or a hit distance)
 #endif
     // ------------------------------------------------------------ one inner-node step
-    if (inner) {
+    if (Q == 2 && inner) {
+        const Slab4 b = slab_children4(q0, q1, q2, q3, T.idir.x, T.idir.y, T.idir.z, T.nood.x, T.nood.y, T.nood.z, T.tmin, T.tbest);
+        if (b.n == 0) {
+            if (T.sp == sb) T.node = kSentinel;
+            else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
+        } else {
+            if (b.n > 3) { stk[T.sp * 64 + lane] = (uint32_t)b.ref[3]; ++T.sp; }          // farthest first, the nearest is walked next
+            if (b.n > 2) { stk[T.sp * 64 + lane] = (uint32_t)b.ref[2]; ++T.sp; }
+            if (b.n > 1) { stk[T.sp * 64 + lane] = (uint32_t)b.ref[1]; ++T.sp; }
+            T.node = b.ref[0];
+        }
+    }
+    if (Q != 2 && inner) {
         if (COUNT) ++n_visits;
         const SlabOut b = slab_children<Q>(q0, q1, q2, q3, T.idir.x, T.idir.y, T.idir.z, T.nood.x, T.nood.y, T.nood.z, T.tmin, T.tbest);
         const bool h0 = b.tn0 <= b.tf0, h1 = b.tn1 <= b.tf1;
@@ -535,7 +600,7 @@ __device__ __forceinline__ bool range_grab(const TraceArgs& a, RayRange& r, uint
 // each lane processes one -- an inner node: slab-test both children against the ray's current best t and push the
 // survivors, nearer on top; a leaf reference: test its first triangle and push the rest of the leaf.  The ray of slot s is
 // read from the registers of lane s; its best hit is merged in LDS (min t, tie -> lowest primitive).
-template <int MODE, int CAP, bool Q>
+template <int MODE, int CAP, int Q>
 __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, int& psize, const bool cull_back PROBE_PARAM)
@@ -543,8 +608,9 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
     constexpr int kPoolCap = CAP;
     // ------------------------------------------------------------ pop up to 64 entries (each lane adds at most one net entry)
     int k = psize < 64 ? psize : 64;
-    const int room = kPoolCap - 104 - psize;                  // 64 for ray starts, 40 for a single-lane descent
-    if (k > room) k = room > 1 ? room : 1;
+    const int room = kPoolCap - (Q == 2 ? 120 : 104) - psize;  // 64 for ray starts, 40 (BVH4: 56) for a single-lane descent
+    if (Q == 2) { if (3 * k > room) k = room > 3 ? room / 3 : 1; }      // a popped BVH4 node may push four entries
+    else        { if (k > room) k = room > 1 ? room : 1; }
     const bool have = lane < k;
     uint32_t ent = 0u;
     if (have) ent = stk[psize - 1 - lane];
@@ -572,9 +638,17 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
 #endif
     const float4 n0 = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), n1 = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
                  n2 = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
-    uint32_t push0 = 0u, push1 = 0u;
+    uint32_t push0 = 0u, push1 = 0u, push2 = 0u, push3 = 0u;
     int npush = 0;
-    if (do_inner) {
+    if (Q == 2 && do_inner) {
+        const Slab4 b = slab_children4(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
+        npush = b.n;                                          // push1 = the nearest (ends on top), push0 the next, then push2, push3
+        if (b.n > 0) push1 = pool_pack(b.ref[0], slot);
+        if (b.n > 1) push0 = pool_pack(b.ref[1], slot);
+        if (b.n > 2) push2 = pool_pack(b.ref[2], slot);
+        if (b.n > 3) push3 = pool_pack(b.ref[3], slot);
+    }
+    if (Q != 2 && do_inner) {
         const SlabOut b = slab_children<Q>(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
         const bool h0 = b.tn0 <= b.tf0, h1 = b.tn1 <= b.tf1;
         const int c0 = b.c0, c1 = b.c1;
@@ -617,9 +691,21 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
         }
     }
     {
-        const unsigned long long m2 = __ballot(npush == 2);
+        if (Q == 2) {                                         // the farthest children of all lanes first
+            const unsigned long long m4 = __ballot(npush >= 4);
+            if (m4 != 0ull) {
+                if (npush >= 4) stk[psize + (int)lane_rank(m4)] = push3;
+                psize += __popcll(m4);
+            }
+            const unsigned long long m3 = __ballot(npush >= 3);
+            if (m3 != 0ull) {
+                if (npush >= 3) stk[psize + (int)lane_rank(m3)] = push2;
+                psize += __popcll(m3);
+            }
+        }
+        const unsigned long long m2 = __ballot(npush >= 2);
         if (m2 != 0ull) {
-            if (npush == 2) stk[psize + (int)lane_rank(m2)] = push0;
+            if (npush >= 2) stk[psize + (int)lane_rank(m2)] = push0;
             psize += __popcll(m2);
         }
         const unsigned long long m1 = __ballot(npush >= 1);
@@ -633,7 +719,7 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
 
 // ROWS: entries of a lane's stack = rows of the LDS block (24 when the tree is at most 24 deep -- 7.5 KB of LDS per
 // wave and <= 96 VGPRs let 20 waves share a CU instead of 16 -- else 32)
-template <int MODE, int ROWS, bool Q>
+template <int MODE, int ROWS, int Q>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? 6 : 5, ROWS == 24 ? 6 : 5)))
 void k_trace_pool(TraceArgs a)
 {
@@ -663,6 +749,12 @@ void k_trace_pool(TraceArgs a)
     unsigned long long pw_wait = 0ull, pw_bulk = 0ull, pw_pool = 0ull, pw_steps = 0ull, pw_rounds = 0ull;
     const unsigned long long pw_t0 = __builtin_amdgcn_s_memtime();
 #endif
+#if MIPT_PROBE_WAVES
+    const unsigned long long wv_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long wv_r0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz, one counter for the whole device
+    unsigned long long wv_t1 = wv_t0;
+    uint32_t wv_steps = 0u, wv_rounds = 0u;
+#endif
 
     for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
         // ============================================================ bulk: one ray per lane, one tile at a time
@@ -677,6 +769,11 @@ void k_trace_pool(TraceArgs a)
             tile = (gq * kNumSegments + xcd) * a.tile_group + r;
         } else if (k >= tiles_seg) break;
         if (tile >= tiles) break;
+        // the slot's tile: by last launch's costs, heaviest first -- a tile's life varies 1 : 5 (median to worst), and with the
+        // launch order of the image the kernel ends in a drain of a third of its duration during which the long tiles that
+        // started late run alone (tools/probe_waves.py); results do not depend on which wave walks which tile
+        if (a.tile_order != nullptr && a.n_order == tiles) tile = a.tile_order[tile];
+        uint32_t cost = 0u;
         const uint32_t ray = tile * 64u + (uint32_t)lane;
         bool has_ray = false;
         if (ray < n) {
@@ -695,6 +792,10 @@ void k_trace_pool(TraceArgs a)
 #if MIPT_PROBE_STAMP
                 ++pw_steps;
 #endif
+#if MIPT_PROBE_WAVES
+                ++wv_steps;
+#endif
+                ++cost;
             }
             const bool done = has_ray && T.node == kSentinel;
             if (done) { finish_ray<MODE>(a, T, ray, T.prim != 0xffffffffu); has_ray = false; }
@@ -703,7 +804,13 @@ void k_trace_pool(TraceArgs a)
         const unsigned long long pw_b1 = __builtin_amdgcn_s_memtime();
         pw_bulk += pw_b1 - pw_b0;
 #endif
-        if (__ballot(has_ray) == 0ull) continue;                     // the whole tile is finished
+#if MIPT_PROBE_WAVES
+        wv_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        if (__ballot(has_ray) == 0ull) {                             // the whole tile is finished
+            if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) a.tile_cost[tile] = cost;
+            continue;
+        }
 
         // ============================================================ tail: one entry pool per wave
         // move the per-lane stacks into the pool, row by row and in place: row e is read before at most
@@ -734,7 +841,12 @@ void k_trace_pool(TraceArgs a)
 #if MIPT_PROBE_STAMP
             ++pw_rounds;
 #endif
+#if MIPT_PROBE_WAVES
+            ++wv_rounds;
+#endif
+            ++cost;
         }
+        if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) a.tile_cost[tile] = cost;
 #if MIPT_PROBE_STAMP
         pw_pool += __builtin_amdgcn_s_memtime() - pw_b1;
 #endif
@@ -745,6 +857,15 @@ void k_trace_pool(TraceArgs a)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the next tile's stacks overwrite the merge slots
     }
+#if MIPT_PROBE_WAVES
+    if (lane == 0 && a.ctr->dbg[0] != 0ull) {
+        uint4* rec = reinterpret_cast<uint4*>(a.ctr->dbg[0]);
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();
+        rec[blockIdx.x] = make_uint4((uint32_t)(t2 - wv_t0), (uint32_t)(wv_t1 - wv_t0), wv_steps, wv_rounds);
+        rec[gridDim.x + blockIdx.x] = make_uint4((uint32_t)wv_r0, (uint32_t)(wv_r0 >> 32), (uint32_t)r2, (uint32_t)(r2 >> 32));
+    }
+#endif
 #if MIPT_PROBE_STAMP
     if (lane == 0) {
         atomicAdd(&a.ctr->dbg[0], __builtin_amdgcn_s_memtime() - pw_t0);     // wave lifetime
@@ -1134,7 +1255,7 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
 // argument).  Measured and dropped: one ray per lane first (stream_step) and the pool only for the tail of the tile, as in
 // k_trace_pool's tiled form -- 164 VGPRs, and capped at 128 or 96 it is slower than this (Cornell 512x512 0.41 / 0.53 vs
 // 0.38 ms; the headline frame run this way 1.05 / 1.08 vs 0.95 ms).
-template <int MODE, bool Q>
+template <int MODE, int Q>
 __device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, const bool has_ray, const bool cull_back = false)
@@ -1154,7 +1275,7 @@ __device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, co
         pool_round<MODE, kPoolCap, Q>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back PROBE_ARG);
 }
 
-template <bool Q>
+template <int Q>
 __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
 {
     constexpr int kPoolCap = 24 * 64 - 384;
@@ -1222,14 +1343,15 @@ __device__ __forceinline__ uint32_t pool_pack2(int ref, uint32_t slot7)
     return 0x80000000u | ((desc >> 4) << 9) | (((desc - 1u) & 3u) << 7) | slot7;
 }
 
-template <int CAP, bool Q>
+template <int CAP, int Q>
 __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                             unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done, const float* sray,
                                             const int lane, const Trav& T, int& psize)
 {
     int k = psize < 64 ? psize : 64;
-    const int room = CAP - 104 - psize;
-    if (k > room) k = room > 1 ? room : 1;
+    const int room = CAP - (Q == 2 ? 120 : 104) - psize;
+    if (Q == 2) { if (3 * k > room) k = room > 3 ? room / 3 : 1; }
+    else        { if (k > room) k = room > 1 ? room : 1; }
     const bool have = lane < k;
     uint32_t ent = 0u;
     if (have) ent = stk[psize - 1 - lane];
@@ -1268,9 +1390,17 @@ __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, c
     load_step<Q>(blob, bvh, do_inner, do_tri, payload, lfirst, q0, q1, q2, q3 PROBE_ARG);
     const float4 n0 = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), n1 = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
                  n2 = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
-    uint32_t push0 = 0u, push1 = 0u;
+    uint32_t push0 = 0u, push1 = 0u, push2 = 0u, push3 = 0u;
     int npush = 0;
-    if (do_inner) {
+    if (Q == 2 && do_inner) {
+        const Slab4 b = slab_children4(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
+        npush = b.n;
+        if (b.n > 0) push1 = pool_pack2(b.ref[0], slot7);
+        if (b.n > 1) push0 = pool_pack2(b.ref[1], slot7);
+        if (b.n > 2) push2 = pool_pack2(b.ref[2], slot7);
+        if (b.n > 3) push3 = pool_pack2(b.ref[3], slot7);
+    }
+    if (Q != 2 && do_inner) {
         const SlabOut b = slab_children<Q>(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
         const bool h0 = b.tn0 <= b.tf0, h1 = b.tn1 <= b.tf1;
         const int c0 = b.c0, c1 = b.c1;
@@ -1313,9 +1443,21 @@ __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, c
         }
     }
     {
-        const unsigned long long m2 = __ballot(npush == 2);
+        if (Q == 2) {
+            const unsigned long long m4 = __ballot(npush >= 4);
+            if (m4 != 0ull) {
+                if (npush >= 4) stk[psize + (int)lane_rank(m4)] = push3;
+                psize += __popcll(m4);
+            }
+            const unsigned long long m3 = __ballot(npush >= 3);
+            if (m3 != 0ull) {
+                if (npush >= 3) stk[psize + (int)lane_rank(m3)] = push2;
+                psize += __popcll(m3);
+            }
+        }
+        const unsigned long long m2 = __ballot(npush >= 2);
         if (m2 != 0ull) {
-            if (npush == 2) stk[psize + (int)lane_rank(m2)] = push0;
+            if (npush >= 2) stk[psize + (int)lane_rank(m2)] = push0;
             psize += __popcll(m2);
         }
         const unsigned long long m1 = __ballot(npush >= 1);
@@ -1327,7 +1469,7 @@ __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, c
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
-template <bool Q>
+template <int Q>
 __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
 {
     constexpr int kCap = 1152;
@@ -1413,7 +1555,7 @@ __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
 // buys nothing for them: 421 k shadow rays of the headline frame 0.265 -> 0.228 ms with 32 rays per wave, 8.3 M occlusion rays
 // of the MeshViewer frame at 4K 6.64 -> 6.07 ms with 64 (big closest-hit launches: 0.512 -> 0.529 ms, they keep the tiled form).
 // A launch with few rays lasts as long as ONE wave needs for its rays, so there a wave gets 8 .. 32 and all 64 lanes serve them.
-template <int MODE, bool Q>
+template <int MODE, int Q>
 __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
 {
     constexpr int kPoolCap = 24 * 64 - 384;
@@ -1551,8 +1693,9 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
                 want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
                 if (o.blocks_user) want = (unsigned long long)blocks;
                 const uint32_t g = (uint32_t)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
-                if (a.bvh.node32_off) hipLaunchKernelGGL((k_trace_static<MODE, true>), dim3(g), dim3(64), 0, st, a, ppw);
-                else                  hipLaunchKernelGGL((k_trace_static<MODE, false>), dim3(g), dim3(64), 0, st, a, ppw);
+                if (a.bvh.node_fmt == 2)      hipLaunchKernelGGL((k_trace_static<MODE, 2>), dim3(g), dim3(64), 0, st, a, ppw);
+                else if (a.bvh.node_fmt == 1) hipLaunchKernelGGL((k_trace_static<MODE, 1>), dim3(g), dim3(64), 0, st, a, ppw);
+                else                          hipLaunchKernelGGL((k_trace_static<MODE, 0>), dim3(g), dim3(64), 0, st, a, ppw);
             } else if constexpr (MODE == 0) {
                 // tiled form: one wave per tile of 64 rays, at most 128 waves per CU (beyond that a wave takes several tiles);
                 // the ray count may be smaller on the device (n_ptr), surplus waves leave at once
@@ -1561,12 +1704,18 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
                     want = want < cus * 16ull ? cus * 16ull : (want > cus * 128ull ? cus * 128ull : want);
                     blocks = (int)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
                 }
-                if (a.bvh.node32_off) {
-                    if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, true>), dim3(blocks), dim3(64), 0, st, a);
-                    else                    hipLaunchKernelGGL((k_trace_pool<0, 32, true>), dim3(blocks), dim3(64), 0, st, a);
+                // (the tiled kernel keeps the BVH2 when a BVH4 mirror exists too: a lane's stack over the BVH4 can need 32 rows -- 8 KB
+                //  per wave, 20 waves per CU instead of 24 -- which gives back what the shorter walk gains: 0.404 against 0.406 ms on
+                //  the headline frame; MIPT_TILED_BVH4=1 selects it for experiments when the stack fits)
+                if (a.bvh.node_fmt == 2 && o.tiled_bvh4 && a.bvh.stack4 <= 32u) {
+                    if (a.bvh.stack4 <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, 2>), dim3(blocks), dim3(64), 0, st, a);
+                    else                     hipLaunchKernelGGL((k_trace_pool<0, 32, 2>), dim3(blocks), dim3(64), 0, st, a);
+                } else if (a.bvh.node_fmt >= 1) {
+                    if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, 1>), dim3(blocks), dim3(64), 0, st, a);
+                    else                    hipLaunchKernelGGL((k_trace_pool<0, 32, 1>), dim3(blocks), dim3(64), 0, st, a);
                 } else {
-                    if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, false>), dim3(blocks), dim3(64), 0, st, a);
-                    else                    hipLaunchKernelGGL((k_trace_pool<0, 32, false>), dim3(blocks), dim3(64), 0, st, a);
+                    if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, 0>), dim3(blocks), dim3(64), 0, st, a);
+                    else                    hipLaunchKernelGGL((k_trace_pool<0, 32, 0>), dim3(blocks), dim3(64), 0, st, a);
                 }
             }
         }
@@ -1585,6 +1734,7 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr;
     a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
+    a.tile_order = o.tile_order; a.tile_cost = o.tile_cost; a.n_order = o.n_order;
     launch_trace<0>(st, a, o);
 }
 
@@ -1641,11 +1791,13 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
         }
         if (fc.max_depth != 1u && bvh.pool2_ok != 0u)
         {                                                                                                    // more than one bounce: two rays per pass
-            if (bvh.node32_off) hipLaunchKernelGGL(k_tail_pool2<true>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
-            else                hipLaunchKernelGGL(k_tail_pool2<false>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+            if (bvh.node_fmt == 2)      hipLaunchKernelGGL(k_tail_pool2<2>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+            else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool2<1>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+            else                        hipLaunchKernelGGL(k_tail_pool2<0>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
         }
-        else if (bvh.node32_off) hipLaunchKernelGGL(k_tail_pool<true>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
-        else                     hipLaunchKernelGGL(k_tail_pool<false>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+        else if (bvh.node_fmt == 2) hipLaunchKernelGGL(k_tail_pool<2>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+        else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool<1>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+        else                        hipLaunchKernelGGL(k_tail_pool<0>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
     }
     else
         hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);

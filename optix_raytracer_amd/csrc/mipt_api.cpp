@@ -53,7 +53,11 @@ struct Accel {
     float4*   d_tris  = nullptr;   // = d_nodes + num_nodes * 4
     uint32_t  tri_byte_off = 0;    // 0 when the blob does not fit 32-bit offsets (then no streaming kernel)
     uint32_t  blob_bytes = 0;
-    uint32_t  node32_off = 0;      // byte offset of the packed 32-byte nodes behind the triangles (node format 1); 0 = none
+    uint32_t  node32_off = 0;      // byte offset of the packed 32-byte BVH2 mirror behind the triangles (node formats 1 and 2); 0 = none
+    uint32_t  node4_off = 0;       // ... and of the BVH4 mirror behind that (format 2)
+    uint32_t  node_fmt = 0;        // the format in effect: 0 fp32 only, 1 + packed BVH2 mirror, 2 + BVH4 mirror
+    uint32_t  stack_need = 0;      // format 2: the most entries a lane's stack can hold while walking the BVH4 (<= 32 by construction)
+    uint32_t  num_nodes4 = 0;
     uint32_t* d_mat   = nullptr;
     uint32_t  n_prims = 0;
     uint64_t  bytes   = 0;
@@ -95,7 +99,8 @@ struct MiptContext {
     int      batch_samples = 0;
     int      persistent = 3;
     int      build_mode = 0;              // MIPT_OPT_BUILD: 0 host binned SAH, 1 device LBVH
-    int      node_format = 1;             // MIPT_OPT_NODE_FORMAT: 1 fp16 boxes + packed 32-byte nodes (where the scene suits them), 0 fp32
+    int      node_format = 2;             // MIPT_OPT_NODE_FORMAT: 2 fp16 boxes + BVH4 mirror, 1 fp16 boxes + packed 32-byte BVH2 mirror (where the
+                                          // scene suits fp16 boxes), 0 fp32 boxes only
     uint32_t tail_paths = 1048576;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
     bool     bounces_on_device = false;   // launch statistics: iterations counted by k_advance / k_tail
     int      tile_group = 256;
@@ -120,6 +125,13 @@ struct MiptContext {
     uint32_t*   im_flags = nullptr;
     size_t      im_cap = 0;
     int      refill_min = 16, steal_min = 24, burst_bulk = 12, burst_dry = 8;   // tools/tune.py sweeps, profiles/r01_tuning*.txt
+    // cost-ordered tiles of the primary closest-hit launch (k_trace_pool's tile_order / tile_cost)
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_order = nullptr;
+    uint32_t  tile_n = 0;                // tiles both arrays cover
+    bool      tile_order_valid = false;  // d_tile_order holds a permutation made from a launch of the same tile count
+    int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
+    int       tile_order_mode = 0;       // MIPT_OPT_TILE_ORDER: 0 off, 1 device sort after every launch, 2 host sort (experiments)
     int      profile = 0;
 
     // launch buffers
@@ -272,6 +284,7 @@ TraceOpts trace_opts(const MiptContext* c)
     o.blocks_user = c->blocks_per_cu > 0 ? 1 : 0; o.num_cus = c->num_cus;
     o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.burst_bulk = c->burst_bulk; o.burst_dry = c->burst_dry;
     o.tile_group = c->tile_group;
+    o.tiled_bvh4 = c->tiled_bvh4;
     return o;
 }
 
@@ -281,22 +294,141 @@ int default_build_threads()
     return threads < 1 ? 1 : (threads > 32 ? 32 : threads);
 }
 
-// Byte layout of the one BVH allocation: nodes (64 B each) | triangles (48 B each) | 64 B pad | packed nodes (32 B each).
-// Sets the 32-bit offsets the streaming kernels use (0 when the allocation does not fit them) and, for node format 1, rounds the
-// boxes to fp16 and writes the packed mirror (pack_nodes32); a scene that does not suit fp16 boxes keeps its fp32 nodes.
+// ---- node format 2: the BVH4 mirror -------------------------------------------------------------------------------------------
+// Collapses the (already fp16-rounded) BVH2 into four-child nodes: a node takes its grandchildren in place of its inner
+// children, one child at a time, as long as the walk's per-lane stack stays within `budget` entries in the worst case -- a
+// node with n children costs n - 1 entries while its deepest subtree is walked, a BVH2 level costs 1, so a subtree of BVH2
+// height h always fits h entries and an expansion is taken when what is left after it still covers the heights below.
+// 64-byte node = 4 pieces {lo.x|hi.x, lo.y|hi.y, lo.z|hi.z (fp16 pairs), reference}; reference >= 0: BVH4 node, < 0: the BVH2's
+// leaf descriptor, 0x7fffffff: empty slot.
+struct Bvh4Builder {
+    const MiptBvhNode* n2;
+    std::vector<uint8_t> height;          // BVH2 height of every inner node (a leaf child counts 0)
+    std::vector<uint32_t> out;            // 16 words per BVH4 node
+    uint32_t stack_need = 0;
+
+    static uint32_t half_bits(float f)    // f is an fp16 value (pack_nodes32 rounded it): exact
+    {
+        uint32_t u; std::memcpy(&u, &f, 4);
+        const uint32_t sign = (u >> 16) & 0x8000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+        if (e == 0xffu) return sign | 0x7c00u | (m ? 0x200u : 0u);
+        if (e == 0u) return sign;                                          // +-0 (subnormal halves were flushed)
+        const int he = (int)e - 127 + 15;
+        if (he <= 0) return sign;                                          // cannot happen for a rounded box
+        if (he >= 31) return sign | 0x7c00u;
+        return sign | ((uint32_t)he << 10) | (m >> 13);
+    }
+    void child(const MiptBvhNode& n, int k, float lo[3], float hi[3], int32_t& ref) const
+    {
+        if (k == 0) { lo[0] = n.c0x[0]; hi[0] = n.c0x[1]; lo[1] = n.c0y[0]; hi[1] = n.c0y[1]; lo[2] = n.c0z[0]; hi[2] = n.c0z[1]; ref = n.c0; }
+        else        { lo[0] = n.c1x[0]; hi[0] = n.c1x[1]; lo[1] = n.c1y[0]; hi[1] = n.c1y[1]; lo[2] = n.c1z[0]; hi[2] = n.c1z[1]; ref = n.c1; }
+    }
+    uint32_t h_of(int32_t ref) const { return ref >= 0 ? height[(size_t)ref] : 0u; }
+    void heights(uint32_t n_nodes)
+    {
+        height.assign(n_nodes, 0);
+        // children come after their parent in both builders' node orders only for the host builder; do it with an explicit post-order
+        std::vector<std::pair<uint32_t, int>> st;
+        st.push_back({ 0u, 0 });
+        while (!st.empty()) {
+            auto& [x, phase] = st.back();
+            const MiptBvhNode& n = n2[x];
+            if (phase == 0) { phase = 1; if (n.c0 >= 0) st.push_back({ (uint32_t)n.c0, 0 }); }
+            else if (phase == 1) { phase = 2; if (n.c1 >= 0) st.push_back({ (uint32_t)n.c1, 0 }); }
+            else { height[x] = (uint8_t)(1u + std::max(h_of(n.c0), h_of(n.c1))); st.pop_back(); }
+        }
+    }
+    // returns the BVH4 index of BVH2 node x; `budget` stack entries are available below, `used` are held above
+    uint32_t collapse(uint32_t x, uint32_t budget, uint32_t used)
+    {
+        const uint32_t me = (uint32_t)(out.size() / 16);
+        out.resize(out.size() + 16, 0u);
+        float lo[4][3], hi[4][3]; int32_t ref[4]; int n = 2;
+        child(n2[x], 0, lo[0], hi[0], ref[0]); child(n2[x], 1, lo[1], hi[1], ref[1]);
+        for (;;) {
+            // expand the inner child with the largest box whose expansion still leaves room for everything below
+            int best = -1; float best_area = -1.0f;
+            if (n < 4) for (int i = 0; i < n; ++i) if (ref[i] >= 0) {
+                const float dx = hi[i][0] - lo[i][0], dy = hi[i][1] - lo[i][1], dz = hi[i][2] - lo[i][2];
+                const float area = dx * dy + dy * dz + dz * dx;
+                if (area > best_area) { best_area = area; best = i; }
+            }
+            if (best < 0) break;
+            // after the expansion this node holds n + 1 children: n entries pushed while the deepest subtree (height hmax) is walked
+            uint32_t hmax = 0;
+            for (int i = 0; i < n; ++i) if (i != best) hmax = std::max(hmax, h_of(ref[i]));
+            const MiptBvhNode& c = n2[(size_t)ref[best]];
+            hmax = std::max(hmax, std::max(h_of(c.c0), h_of(c.c1)));
+            if ((uint32_t)n + hmax > budget) {
+                // not this one; another child may still fit (a shallower subtree): mark and retry without it
+                bool other = false;
+                for (int i = 0; i < n && !other; ++i) if (i != best && ref[i] >= 0) {
+                    uint32_t hm = 0;
+                    for (int j = 0; j < n; ++j) if (j != i) hm = std::max(hm, h_of(ref[j]));
+                    const MiptBvhNode& d = n2[(size_t)ref[i]];
+                    hm = std::max(hm, std::max(h_of(d.c0), h_of(d.c1)));
+                    if ((uint32_t)n + hm <= budget) { best = i; other = true; }
+                }
+                if (!other) break;
+            }
+            const MiptBvhNode cc = n2[(size_t)ref[best]];
+            child(cc, 0, lo[best], hi[best], ref[best]);
+            child(cc, 1, lo[n], hi[n], ref[n]);
+            ++n;
+        }
+        stack_need = std::max(stack_need, used + (uint32_t)(n - 1));
+        int32_t fin[4];
+        for (int i = 0; i < n; ++i) fin[i] = ref[i] >= 0 ? (int32_t)collapse((uint32_t)ref[i], budget - (uint32_t)(n - 1), used + (uint32_t)(n - 1)) : ref[i];
+        uint32_t* w = &out[(size_t)me * 16];
+        for (int i = 0; i < 4; ++i) {
+            if (i < n) {
+                for (int k = 0; k < 3; ++k) w[4 * i + k] = half_bits(lo[i][k]) | (half_bits(hi[i][k]) << 16);
+                w[4 * i + 3] = (uint32_t)fin[i];
+            } else {
+                w[4 * i] = w[4 * i + 1] = w[4 * i + 2] = 0u; w[4 * i + 3] = 0x7fffffffu;
+            }
+        }
+        return me;
+    }
+};
+
+// Byte layout of the one BVH allocation: nodes (64 B each) | triangles (48 B each) | 64 B pad | node mirror (up to 64 B per node).
+// Sets the 32-bit offsets the streaming kernels use (0 when the allocation does not fit them).  Node formats 1 and 2 round the
+// boxes to fp16 in place and write the packed 32-byte mirror (pack_nodes32); format 2 then replaces the mirror by the BVH4
+// collapse of the rounded tree (host side: the nodes are read back once).  A scene that does not suit fp16 boxes keeps fp32 nodes.
 hipError_t finish_blob(const MiptContext* c, Accel* a)
 {
     const size_t nb = (size_t)a->num_nodes * sizeof(MiptBvhNode), tb = (size_t)std::max<uint32_t>(a->num_tris, 1u) * sizeof(MiptBvhTri);
-    const size_t n32 = (nb + tb + 64 + 127) & ~(size_t)127;                     // a packed node never straddles a 128-byte line
-    const size_t total = n32 + (size_t)a->num_nodes * 32u;
+    const size_t n32 = (nb + tb + 64 + 127) & ~(size_t)127;                     // a mirror node never straddles a 128-byte line
+    const size_t n4 = (n32 + (size_t)a->num_nodes * 32u + 127) & ~(size_t)127;   // the BVH4 mirror behind the packed BVH2 one
+    const size_t total = n4 + (size_t)a->num_nodes * 64u;
     a->tri_byte_off = total < (1ull << 31) ? (uint32_t)nb : 0u;
     a->blob_bytes = a->tri_byte_off ? (uint32_t)total : 0u;
-    a->node32_off = 0u;
-    if (c->node_format == 1 && a->tri_byte_off != 0u && a->num_tris >= 2u) {
+    a->node32_off = 0u; a->node4_off = 0u; a->node_fmt = 0u; a->stack_need = 0u; a->num_nodes4 = 0u;
+    if (c->node_format != 0 && a->tri_byte_off != 0u && a->num_tris >= 2u) {
         bool ok = false;
-        const hipError_t e = pack_nodes32(nullptr, a->d_nodes, a->num_nodes, (char*)a->d_nodes + n32, &ok);
+        hipError_t e = pack_nodes32(nullptr, a->d_nodes, a->num_nodes, (char*)a->d_nodes + n32, &ok);
         if (e != hipSuccess) return e;
-        if (ok) a->node32_off = (uint32_t)n32;
+        if (!ok) return hipSuccess;
+        a->node32_off = (uint32_t)n32; a->node_fmt = 1u;
+        // the device LBVH is the fast-build path (a few ms): it keeps the packed BVH2 mirror, the collapse costs tens of ms of host time
+        if (c->node_format == 2 && a->builder == 0 && a->num_nodes < (1u << 24)) {
+            std::vector<MiptBvhNode> host(a->num_nodes);
+            e = hipMemcpy(host.data(), a->d_nodes, nb, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return e;
+            Bvh4Builder B;
+            B.n2 = host.data();
+            B.heights(a->num_nodes);
+            if (B.height[0] <= 32u) {
+                B.collapse(0u, 32u, 0u);
+                const size_t cnt4 = B.out.size() / 16;
+                if (cnt4 <= a->num_nodes && B.stack_need <= 32u) {
+                    e = hipMemcpy((char*)a->d_nodes + n4, B.out.data(), cnt4 * 64u, hipMemcpyHostToDevice);
+                    if (e != hipSuccess) return e;
+                    a->node_fmt = 2u; a->node4_off = (uint32_t)n4; a->stack_need = B.stack_need; a->num_nodes4 = (uint32_t)cnt4;
+                }
+            }
+        }
     }
     return hipSuccess;
 }
@@ -313,7 +445,8 @@ DeviceBvh device_bvh(const Accel* a)
     b.nodes = a->d_nodes; b.tris = a->d_tris; b.mat_index = a->d_mat; b.tri_byte_off = a->tri_byte_off; b.blob_bytes = a->blob_bytes; b.depth = a->depth;
     b.pool_ok = (a->num_nodes < (1u << 25) && a->num_tris >= 2u && a->num_tris < (1u << 23) && a->leaf_max <= 4u) ? 1u : 0u;
     b.pool2_ok = (b.pool_ok && a->num_nodes < (1u << 24) && a->num_tris < (1u << 22)) ? 1u : 0u;
-    b.node32_off = a->node32_off;
+    b.node32_off = a->node32_off; b.node_fmt = a->node32_off ? a->node_fmt : 0u;
+    b.node4_off = b.node_fmt == 2u ? a->node4_off : 0u; b.stack4 = a->stack_need;
     if (a->is_ias) { b.inst = a->d_inst; b.inst_order = a->d_order; b.n_inst = (uint32_t)a->gas.size(); b.pool_ok = b.pool2_ok = 0u; b.tri_byte_off = 0u; b.node32_off = 0u; }
     return b;
 }
@@ -406,7 +539,22 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         uint32_t bound = n_paths;      // upper bound of the live-path count (it only falls): the latest count the host has seen
         for (uint32_t bounce = 0;; ++bounce) {
             { TimedScope t(ctx, st, T_CLOSEST);
-              launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, bound, ctx->hits, ctx->d_ctr, opts); }
+              TraceOpts o2 = opts;
+              if (bounce == 0u && fc.world == 0u && ctx->tile_order_mode != 0 && !batch) {
+                  // the primary rays of a full frame: tiles in the order of their cost in the previous launch, costs recorded for the next
+                  const uint32_t tiles = n_paths / 64u;
+                  if (ctx->tile_n != tiles) {
+                      if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+                      if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+                      ctx->d_tile_cost = ctx->d_tile_order = nullptr; ctx->tile_n = 0; ctx->tile_order_valid = false;
+                      HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_cost, (size_t)tiles * 4u));
+                      HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_order, (size_t)tiles * 4u));
+                      ctx->tile_n = tiles;
+                  }
+                  o2.tile_cost = ctx->d_tile_cost; o2.n_order = tiles;
+                  o2.tile_order = ctx->tile_order_valid ? ctx->d_tile_order : nullptr;
+              }
+              launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, bound, ctx->hits, ctx->d_ctr, o2); }
             { TimedScope t(ctx, st, T_SHADE);
               launch_shade(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->hits, ctx->q[cur ^ 1], ctx->sq,
                            ctx->result, ctx->d_ctr, bound, ctx->common_vertices); }
@@ -442,6 +590,16 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         }
     }
     { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots, advance_in_resolve ? ctx->d_ctr : nullptr); }
+    if (fc.world == 0u && ctx->tile_order_mode == 2 && ctx->tile_n != 0u && !batch && n_paths / 64u == ctx->tile_n) {
+        // experiment: the next launch's order from this launch's costs, sorted on the host (drains the stream)
+        std::vector<uint32_t> cost(ctx->tile_n), order(ctx->tile_n);
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost, (size_t)ctx->tile_n * 4u, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < ctx->tile_n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+        HIPCHK(ctx, hipMemcpy(ctx->d_tile_order, order.data(), (size_t)ctx->tile_n * 4u, hipMemcpyHostToDevice));
+        ctx->tile_order_valid = true;
+    }
     ctx->bounces_on_device = true;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
@@ -496,7 +654,9 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
-    if (const char* e = std::getenv("MIPT_NODE_FORMAT")) { const int v = std::atoi(e); if (v == 0 || v == 1) c->node_format = v; }
+    if (const char* e = std::getenv("MIPT_NODE_FORMAT")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->node_format = v; }
+    if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
     if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
     if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 30)) c->tail_paths = (uint32_t)v; }
@@ -514,6 +674,8 @@ int mipt_context_destroy(MiptContext* c)
     free_launch_buffers(c);
     if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
     if (c->im_sq.ray_o) (void)hipFree(c->im_sq.ray_o);
     if (c->im_sq.contrib) (void)hipFree(c->im_sq.contrib);
     if (c->im_flags) (void)hipFree(c->im_flags);
@@ -555,7 +717,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH) or 1 (device LBVH)");
         c->build_mode = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_NODE_FORMAT:
-        if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "node format must be 0 (fp32 boxes) or 1 (fp16 boxes, packed 32-byte nodes)");
+        if (value > 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "node format must be 0 (fp32 boxes), 1 (fp16 boxes, packed 32-byte BVH2 nodes) or 2 (fp16 boxes, BVH4 nodes)");
         c->node_format = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_BURST:
         if ((value & 0xffu) < 1 || (value & 0xffu) > 64 || ((value >> 8) & 0xffu) < 1 || ((value >> 8) & 0xffu) > 64)
@@ -787,7 +949,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         for (MiptBvhTri& t : a->host.tris) t.pad1 = gflags[t.prim];
         nb = a->host.nodes.size() * sizeof(MiptBvhNode);
         tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
-        e = hipMalloc((void**)&a->d_nodes, nb + tb + 64 + 128 + a->host.nodes.size() * 32u);      // + room for the packed nodes (finish_blob)
+        e = hipMalloc((void**)&a->d_nodes, nb + tb + 64 + 256 + a->host.nodes.size() * 96u);      // + room for the node mirrors (finish_blob)
         if (e == hipSuccess) {
             a->d_tris = a->d_nodes + nb / sizeof(float4);
             e = hipMemset((char*)a->d_nodes + nb + tb, 0, 64);
@@ -1012,7 +1174,9 @@ int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccel
     info->leaf_max = a->leaf_max;
     info->device_bytes = a->bytes;
     info->build_seconds = a->seconds;
-    info->node_format = a->node32_off ? 1u : 0u; info->num_instances = a->is_ias ? (uint32_t)a->gas.size() : 0u;
+    info->node_format = a->node32_off ? a->node_fmt : 0u; info->num_instances = a->is_ias ? (uint32_t)a->gas.size() : 0u;
+    info->stack_entries = info->node_format == 2u ? a->stack_need : a->depth;
+    info->mirror_nodes = info->node_format == 2u ? a->num_nodes4 : (info->node_format == 1u ? a->num_nodes : 0u);
     return MIPT_SUCCESS;
 }
 
@@ -1051,7 +1215,7 @@ int mipt_host_bvh_info(const MiptHostBvh* h, MiptAccelInfo* info)
     info->leaf_max = h->bvh.leaf_max;
     info->device_bytes = 0;
     info->build_seconds = h->bvh.seconds;
-    info->node_format = 0u; info->num_instances = 0u;
+    info->node_format = 0u; info->num_instances = 0u; info->stack_entries = h->bvh.depth; info->mirror_nodes = 0u;
     return MIPT_SUCCESS;
 }
 
@@ -1401,6 +1565,10 @@ int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle
     ctx->last_stream = st;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, n);
+    if (const char* e = std::getenv("MIPT_PROBE_WAVES")) {          // probe builds: address of a caller-allocated device buffer for per-wave records
+        const unsigned long long addr = std::strtoull(e, nullptr, 0);
+        HIPCHK(ctx, hipMemcpyAsync(&ctx->d_ctr->dbg[0], &addr, 8, hipMemcpyHostToDevice, st));
+    }
     const float4* r = (const float4*)rays;
     { TimedScope t(ctx, st, T_CLOSEST);
       launch_trace_closest(st, device_bvh(a), r, r + 1, 2, nullptr, n, (float4*)hits, ctx->d_ctr, trace_opts(ctx)); }

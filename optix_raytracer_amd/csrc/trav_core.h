@@ -111,6 +111,9 @@ struct TraceArgs {
     int             burst_dry;    // ... and once the ray range is exhausted
     uint32_t        ray_flags;    // MiptRayFlags of every ray of the launch (closest hit: back-face culling)
     uint32_t        tile_group;   // k_trace_pool, tiled: consecutive tiles dealt to one XCD at a time (0: a contiguous eighth each)
+    const uint32_t* tile_order;   // k_trace_pool, tiled: slot -> tile (a permutation of the launch's tiles, heaviest first); null: identity
+    uint32_t*       tile_cost;    // ... and where each tile's cost (bulk steps + pool rounds) of THIS launch is recorded; null: not recorded
+    uint32_t        n_order;      // tiles the two arrays cover (they are used only when the launch has exactly that many)
 };
 
 template <int MODE>

@@ -730,7 +730,8 @@ def test_device_build_reads_every_input_form():
 
 def test_packed_fp16_nodes_give_the_same_hits(monkeypatch):
     """MIPT_OPT_NODE_FORMAT: format 1 rounds every child box outward to fp16 values and gives the entry-pool kernels a packed
-    32-byte node (two 16-byte loads per visit instead of four).  Wider boxes only weaken pruning: frames, ray counters and hit
+    32-byte node (two 16-byte loads per visit instead of four); format 2 (the default) gives them a BVH4 collapse of that tree
+    (four fp16 boxes per 64-byte node, about 0.6 x the steps per ray).  Wider boxes only weaken pruning: frames, ray counters and hit
     records equal those over the fp32 boxes bit for bit; the exported nodes ARE the fp16 values (the oracle walks the same
     boxes, so visit counters agree too); a scene that does not suit fp16 boxes keeps format 0."""
     torch = _torch()
@@ -740,7 +741,7 @@ def test_packed_fp16_nodes_give_the_same_hits(monkeypatch):
     w, h = 320, 180
     launch = scenes.launch_desc(scene, w, h, 2)
     got = {}
-    for fmt in (0, 1):
+    for fmt in (0, 1, 2):
         monkeypatch.setenv("MIPT_NODE_FORMAT", str(fmt))
         PT, st = _state(scene, w, h, spp=2)
         info = st.context.accel_info(st.gas_handle)
@@ -768,9 +769,13 @@ def test_packed_fp16_nodes_give_the_same_hits(monkeypatch):
         st.context.sync()
         got[fmt] = (acc, nodes, d_hits.cpu().numpy(), stats, stats2)
         PT.cleanupState(st)
-    assert np.array_equal(got[0][0].view(np.uint32), got[1][0].view(np.uint32))
-    assert np.array_equal(got[0][2].view(np.uint32), got[1][2].view(np.uint32))
-    assert got[0][3]["closest_rays"] == got[1][3]["closest_rays"] and got[0][3]["shadow_rays"] == got[1][3]["shadow_rays"]
+    for fmt in (1, 2):
+        assert np.array_equal(got[0][0].view(np.uint32), got[fmt][0].view(np.uint32)), fmt
+        assert np.array_equal(got[0][2].view(np.uint32), got[fmt][2].view(np.uint32)), fmt
+        assert got[0][3]["closest_rays"] == got[fmt][3]["closest_rays"] and got[0][3]["shadow_rays"] == got[fmt][3]["shadow_rays"]
+    # format 2 (the BVH4 mirror) is a collapse of format 1's tree: the exported BVH2 is the same, node for node
+    assert np.array_equal(got[1][1].view(np.uint32), got[2][1].view(np.uint32))
+    assert got[1][4] == got[2][4]
     n0, n1 = got[0][1], got[1][1]
     assert np.array_equal(n0[:, 12:].view(np.uint32), n1[:, 12:].view(np.uint32))          # same tree
     box1 = n1[:, :12]
@@ -781,7 +786,7 @@ def test_packed_fp16_nodes_give_the_same_hits(monkeypatch):
     assert got[1][4]["node_visits"] >= got[0][4]["node_visits"]
     assert got[1][4]["node_visits"] <= 1.1 * got[0][4]["node_visits"]
     # a scene 5000 units from the origin, 1 unit across: fp16 steps of 4 units would make the boxes useless -> fp32 kept
-    monkeypatch.setenv("MIPT_NODE_FORMAT", "1")
+    monkeypatch.setenv("MIPT_NODE_FORMAT", "2")
     far = dict(scene)
     v = np.array(scene["vertices"], np.float32, copy=True)
     v[:, :3] += np.float32(5000.0)
