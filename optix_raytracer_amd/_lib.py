@@ -142,7 +142,7 @@ GEOMETRY_FLAG_NONE, GEOMETRY_FLAG_DISABLE_ANYHIT, GEOMETRY_FLAG_REQUIRE_SINGLE_A
 GEOMETRY_FLAG_DISABLE_TRIANGLE_FACE_CULLING = 4
 RAY_FLAG_NONE, RAY_FLAG_CULL_BACK_FACING_TRIANGLES = 0, 16
 OPT_MAX_DEPTH, OPT_COUNT_VISITS, OPT_TRACE_GRID, OPT_PERSISTENT, OPT_PROFILE = 1, 2, 3, 4, 5
-OPT_REFILL_MIN, OPT_STEAL_MIN, OPT_BURST, OPT_BATCH_SAMPLES, OPT_BUILD, OPT_TAIL_PATHS, OPT_NODE_FORMAT = 7, 8, 9, 10, 12, 13, 14
+OPT_REFILL_MIN, OPT_STEAL_MIN, OPT_BURST, OPT_BATCH_SAMPLES, OPT_BUILD, OPT_TAIL_PATHS, OPT_NODE_FORMAT, OPT_TILE_ORDER = 7, 8, 9, 10, 12, 13, 14, 15
 
 # every symbol include/mipt.h declares: (name, restype, argtypes)
 _vp, _u32, _u64 = C.c_void_p, C.c_uint32, C.c_uint64

@@ -101,6 +101,10 @@ struct TraceOpts {
     int  tiled_bvh4;           // experiments: the tiled kernel walks the BVH4 mirror too (when a lane's stack over it fits 32 rows)
 };
 
+// what one workgroup of the raygen launch does for the coming primary closest-hit launch: out[slot] = tile, from the previous launch's
+// costs (out == null: nothing)
+struct TileOrderJob { const uint32_t* cost; uint32_t* out; uint32_t n; uint32_t width; };
+
 // ---- launches (all asynchronous on `st`) ----
 void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, uint32_t n_valid);
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
@@ -108,7 +112,7 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
 void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = nullptr);   // host_live: pinned word that receives the new live count
 // ctr != null: the kernel also does launch_begin_sample's work for the pass (and clears the launch statistics when zero_stats)
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
-                   DeviceCounters* ctr = nullptr, uint32_t n_valid = 0, bool zero_stats = false);
+                   DeviceCounters* ctr = nullptr, uint32_t n_valid = 0, bool zero_stats = false, TileOrderJob order = TileOrderJob{});
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                           const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o,
                           uint32_t ray_flags = 0u /* MiptRayFlags */);

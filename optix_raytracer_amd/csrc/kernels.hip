@@ -772,7 +772,7 @@ void k_trace_pool(TraceArgs a)
         // the slot's tile: by last launch's costs, heaviest first -- a tile's life varies 1 : 5 (median to worst), and with the
         // launch order of the image the kernel ends in a drain of a third of its duration during which the long tiles that
         // started late run alone (tools/probe_waves.py); results do not depend on which wave walks which tile
-        if (a.tile_order != nullptr && a.n_order == tiles) tile = a.tile_order[tile];
+        if (a.tile_order != nullptr && a.n_order == tiles) { const uint32_t t2 = a.tile_order[tile]; tile = t2 < tiles ? t2 : tile; }
         uint32_t cost = 0u;
         const uint32_t ray = tile * 64u + (uint32_t)lane;
         bool has_ray = false;
@@ -953,14 +953,65 @@ __global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
 // frames, or by the StaticWorkDistribution map for a rank's shard.  The raygen-local seed advances
 // by the two jitter draws only (the path's own stream is discarded, :260-278), so it is kept per slot.
 // ------------------------------------------------------------------------------------------------
+// The tile order of the coming primary launch (TraceArgs::tile_order), made by ONE workgroup of the raygen launch while the others
+// write rays: a stable counting sort of the previous launch's tile costs into 16 classes of `width` cost units, heaviest class first,
+// image order inside a class -- each of the 256 threads owns a contiguous stripe of tiles, counts its stripe per class, the
+// (class, thread) counts are scanned in LDS, and the stripe is written out.  Deterministic; a few microseconds beside a raygen
+// launch of 25.
+__device__ __forceinline__ void build_tile_order(const TileOrderJob j)
+{
+    constexpr uint32_t kClasses = 16u;
+    __shared__ uint32_t cnt[kClasses * 256u];                       // [class][thread]
+    __shared__ uint32_t class_base[kClasses];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (j.n + 255u) / 256u, lo = t * per, hi = lo + per < j.n ? lo + per : j.n;
+    uint32_t mine[kClasses];
+#pragma unroll
+    for (uint32_t c = 0; c < kClasses; ++c) mine[c] = 0u;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t q = j.cost[i] / j.width;
+        const uint32_t cls = kClasses - 1u - (q < kClasses - 1u ? q : kClasses - 1u);      // class 0 = heaviest
+#pragma unroll
+        for (uint32_t c = 0; c < kClasses; ++c) mine[c] += cls == c ? 1u : 0u;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < kClasses; ++c) cnt[c * 256u + t] = mine[c];
+    __syncthreads();
+    // exclusive scan over (class-major, thread-minor): thread t scans class t / 16's ... simpler: 16 threads scan one class each, then
+    // the class bases by thread 0 (256 + 16 sequential steps; this block has nothing else to do)
+    if (t < kClasses) {
+        uint32_t run = 0u;
+        for (uint32_t k = 0; k < 256u; ++k) { const uint32_t v = cnt[t * 256u + k]; cnt[t * 256u + k] = run; run += v; }
+        class_base[t] = run;                                        // the class total, turned into a base below
+    }
+    __syncthreads();
+    if (t == 0u) {
+        uint32_t run = 0u;
+        for (uint32_t c = 0; c < kClasses; ++c) { const uint32_t v = class_base[c]; class_base[c] = run; run += v; }
+    }
+    __syncthreads();
+    uint32_t pos[kClasses];
+#pragma unroll
+    for (uint32_t c = 0; c < kClasses; ++c) pos[c] = class_base[c] + cnt[c * 256u + t];
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t q = j.cost[i] / j.width;
+        const uint32_t cls = kClasses - 1u - (q < kClasses - 1u ? q : kClasses - 1u);
+        uint32_t p = 0u;
+#pragma unroll
+        for (uint32_t c = 0; c < kClasses; ++c) { if (cls == c) { p = pos[c]; pos[c] = p + 1u; } }
+        j.out[p] = i;
+    }
+}
+
 // With fc.batch_spp != 0 every sample of the launch is a path of its own (path i -> sample i / paths_per_sample)
 // with its own accumulator slot `sample * n_slots + slot`; the raygen seed of sample s is reached by 2*s LCG
 // steps from the pixel's tea<4> seed, exactly the state the sequential loop would have.
 // The first workgroup also does the pass's queue bookkeeping (begin_sample: a launch of its own costs ~8 us with its gap).
 __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
-                                                DeviceCounters* ctr, uint32_t n_valid, uint32_t zero_stats)
+                                                DeviceCounters* ctr, uint32_t n_valid, uint32_t zero_stats, TileOrderJob order)
 {
     if (ctr && blockIdx.x == 0u) begin_sample(ctr, threadIdx.x, fc.n_paths, n_valid, zero_stats);
+    if (order.out != nullptr && blockIdx.x == 1u) build_tile_order(order);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= fc.n_paths) return;
     uint32_t i0 = i;
@@ -1647,10 +1698,11 @@ void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live)
 }
 
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
-                   DeviceCounters* ctr, uint32_t n_valid, bool zero_stats)
+                   DeviceCounters* ctr, uint32_t n_valid, bool zero_stats, TileOrderJob order)
 {
     const uint32_t blocks = (fc.n_paths + 255u) / 256u;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, fc, sample, q, rg_seed, result, ctr, n_valid, zero_stats ? 1u : 0u);
+    if (blocks < 2u) order.out = nullptr;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, fc, sample, q, rg_seed, result, ctr, n_valid, zero_stats ? 1u : 0u, order);
 }
 
 template <int MODE>

@@ -125,13 +125,14 @@ struct MiptContext {
     uint32_t*   im_flags = nullptr;
     size_t      im_cap = 0;
     int      refill_min = 16, steal_min = 24, burst_bulk = 12, burst_dry = 8;   // tools/tune.py sweeps, profiles/r01_tuning*.txt
-    // cost-ordered tiles of the primary closest-hit launch (k_trace_pool's tile_order / tile_cost)
-    uint32_t* d_tile_cost = nullptr;
-    uint32_t* d_tile_order = nullptr;
+    // cost-ordered tiles of the primary closest-hit launch (TraceArgs::tile_order / tile_cost)
+    uint32_t* d_tile_cost = nullptr;     // every tile's cost in the last primary launch that ran the tiled kernel
+    uint32_t* d_tile_order = nullptr;    // slot -> tile of the coming one (built by the raygen launch)
     uint32_t  tile_n = 0;                // tiles both arrays cover
-    bool      tile_order_valid = false;  // d_tile_order holds a permutation made from a launch of the same tile count
+    bool      tile_cost_valid = false;   // d_tile_cost was written completely by a launch of the same tile count
+    uint32_t  tile_class_width = 16;     // env MIPT_TILE_CLASS: cost units per class of the order (16 classes)
     int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
-    int       tile_order_mode = 0;       // MIPT_OPT_TILE_ORDER: 0 off, 1 device sort after every launch, 2 host sort (experiments)
+    int       tile_order_mode = 1;       // MIPT_OPT_TILE_ORDER: 0 image order, 1 (default) by the previous launch's costs
     int      profile = 0;
 
     // launch buffers
@@ -517,9 +518,6 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
     const TraceOpts opts = trace_opts(ctx);
     bool advance_in_resolve = false;
     for (uint32_t s = 0; s < passes; ++s) {
-        // raygen's first workgroup resets the queue counters (and, for the first pass, the launch statistics)
-        { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result, ctx->d_ctr, pass_valid, s == 0u); }
-        int cur = 0;
         // MIPT_OPT_TAIL_PATHS is meant for the pool form of the tail kernel; the plain loop (BVHs that do not fit the pool's
         // packed entries, other kernel variants) pays off at a quarter of it, and not at all for depth-capped passes from
         // the start.  Depth-capped paths have few bounces left, so a switch inside the loop pays later: at half the count
@@ -530,6 +528,30 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         const uint32_t tail_limit = fc.max_depth != 0u ? tail_paths / 2u : tail_paths;
         // (a capped pass of a million paths is as fast in the wavefront kernels: half the headline frame 0.54 vs 0.56 ms)
         const uint32_t first_limit = fc.max_depth == 0u ? tail_paths : (pool_tail ? tail_paths / 4u * 3u : 0u);
+        // raygen's first workgroup resets the queue counters (and, for the first pass, the launch statistics)
+        // the primary rays of a full frame walk their tiles in the order of the previous launch's costs (MIPT_OPT_TILE_ORDER) when this
+        // pass runs the tiled kernel (launch_trace's choice: the pool form over a one-level BVH that fits it, more than 2560 rays
+        // per CU, not a counting launch): the raygen launch clears the class counters this pass fills
+        const bool tiled_primary = fc.world == 0u && ctx->tile_order_mode != 0 && !batch && opts.persistent == 3 && !opts.count_visits &&
+                                   bvh.pool_ok != 0u && bvh.tri_byte_off != 0u && bvh.depth <= 32u && bvh.inst == nullptr &&
+                                   n_paths > (uint32_t)ctx->num_cus * 2560u && n_paths > first_limit;
+        TileOrderJob job{};
+        if (tiled_primary) {
+            const uint32_t tiles = n_paths / 64u;
+            if (ctx->tile_n != tiles) {
+                if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+                if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+                ctx->d_tile_cost = ctx->d_tile_order = nullptr; ctx->tile_n = 0; ctx->tile_cost_valid = false;
+                HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_cost, (size_t)tiles * 4u));
+                HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_order, (size_t)tiles * 4u));
+                ctx->tile_n = tiles;
+            }
+            if (ctx->tile_cost_valid) job = TileOrderJob{ ctx->d_tile_cost, ctx->d_tile_order, tiles, ctx->tile_class_width };
+        } else {
+            ctx->tile_cost_valid = false;
+        }
+        { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result, ctx->d_ctr, pass_valid, s == 0u, job); }
+        int cur = 0;
         if (n_paths <= first_limit) {
             // a pass this small runs in the tail kernel from the first bounce on (Cornell 512x512: 0.73 -> 0.37 ms)
             TimedScope t(ctx, st, T_CLOSEST);
@@ -540,19 +562,9 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         for (uint32_t bounce = 0;; ++bounce) {
             { TimedScope t(ctx, st, T_CLOSEST);
               TraceOpts o2 = opts;
-              if (bounce == 0u && fc.world == 0u && ctx->tile_order_mode != 0 && !batch) {
-                  // the primary rays of a full frame: tiles in the order of their cost in the previous launch, costs recorded for the next
-                  const uint32_t tiles = n_paths / 64u;
-                  if (ctx->tile_n != tiles) {
-                      if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
-                      if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
-                      ctx->d_tile_cost = ctx->d_tile_order = nullptr; ctx->tile_n = 0; ctx->tile_order_valid = false;
-                      HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_cost, (size_t)tiles * 4u));
-                      HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_order, (size_t)tiles * 4u));
-                      ctx->tile_n = tiles;
-                  }
-                  o2.tile_cost = ctx->d_tile_cost; o2.n_order = tiles;
-                  o2.tile_order = ctx->tile_order_valid ? ctx->d_tile_order : nullptr;
+              if (bounce == 0u && tiled_primary) {
+                  o2.tile_cost = ctx->d_tile_cost; o2.tile_order = job.out; o2.n_order = n_paths / 64u;
+                  ctx->tile_cost_valid = true;                                    // the next pass orders its tiles by what this one records
               }
               launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, bound, ctx->hits, ctx->d_ctr, o2); }
             { TimedScope t(ctx, st, T_SHADE);
@@ -590,16 +602,6 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         }
     }
     { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots, advance_in_resolve ? ctx->d_ctr : nullptr); }
-    if (fc.world == 0u && ctx->tile_order_mode == 2 && ctx->tile_n != 0u && !batch && n_paths / 64u == ctx->tile_n) {
-        // experiment: the next launch's order from this launch's costs, sorted on the host (drains the stream)
-        std::vector<uint32_t> cost(ctx->tile_n), order(ctx->tile_n);
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        HIPCHK(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost, (size_t)ctx->tile_n * 4u, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < ctx->tile_n; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
-        HIPCHK(ctx, hipMemcpy(ctx->d_tile_order, order.data(), (size_t)ctx->tile_n * 4u, hipMemcpyHostToDevice));
-        ctx->tile_order_valid = true;
-    }
     ctx->bounces_on_device = true;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
@@ -655,8 +657,9 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
     if (const char* e = std::getenv("MIPT_NODE_FORMAT")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->node_format = v; }
+    if (const char* e = std::getenv("MIPT_TILE_CLASS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
+    if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 1) c->tile_order_mode = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
     if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
     if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 30)) c->tail_paths = (uint32_t)v; }
@@ -716,6 +719,9 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
     case MIPT_OPT_BUILD:
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH) or 1 (device LBVH)");
         c->build_mode = (int)value; return MIPT_SUCCESS;
+    case MIPT_OPT_TILE_ORDER:
+        if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "tile order must be 0 (image order) or 1 (by the previous launch's costs)");
+        c->tile_order_mode = (int)value; c->tile_cost_valid = false; return MIPT_SUCCESS;
     case MIPT_OPT_NODE_FORMAT:
         if (value > 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "node format must be 0 (fp32 boxes), 1 (fp16 boxes, packed 32-byte BVH2 nodes) or 2 (fp16 boxes, BVH4 nodes)");
         c->node_format = (int)value; return MIPT_SUCCESS;
@@ -747,6 +753,7 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
     case MIPT_OPT_BATCH_SAMPLES: *value = (uint64_t)c->batch_samples; return MIPT_SUCCESS;
     case MIPT_OPT_BUILD: *value = (uint64_t)c->build_mode; return MIPT_SUCCESS;
     case MIPT_OPT_NODE_FORMAT: *value = (uint64_t)c->node_format; return MIPT_SUCCESS;
+    case MIPT_OPT_TILE_ORDER: *value = (uint64_t)c->tile_order_mode; return MIPT_SUCCESS;
     case MIPT_OPT_TAIL_PATHS: *value = (uint64_t)c->tail_paths; return MIPT_SUCCESS;
     case MIPT_OPT_BURST: *value = (uint64_t)c->burst_bulk | ((uint64_t)c->burst_dry << 8); return MIPT_SUCCESS;
     default: return MIPT_ERROR_INVALID_VALUE;

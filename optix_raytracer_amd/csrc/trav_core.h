@@ -111,9 +111,12 @@ struct TraceArgs {
     int             burst_dry;    // ... and once the ray range is exhausted
     uint32_t        ray_flags;    // MiptRayFlags of every ray of the launch (closest hit: back-face culling)
     uint32_t        tile_group;   // k_trace_pool, tiled: consecutive tiles dealt to one XCD at a time (0: a contiguous eighth each)
-    const uint32_t* tile_order;   // k_trace_pool, tiled: slot -> tile (a permutation of the launch's tiles, heaviest first); null: identity
-    uint32_t*       tile_cost;    // ... and where each tile's cost (bulk steps + pool rounds) of THIS launch is recorded; null: not recorded
-    uint32_t        n_order;      // tiles the two arrays cover (they are used only when the launch has exactly that many)
+    // k_trace_pool, tiled: the launch walks its tiles in the order `tile_order` gives (slot -> tile: a permutation made by the raygen
+    // launch from the previous launch's costs, heaviest class first, image order inside a class; null or another tile count: image
+    // order) and records every tile's cost (bulk steps + pool rounds) in `tile_cost` (null: not recorded)
+    const uint32_t* tile_order;
+    uint32_t*       tile_cost;
+    uint32_t        n_order;      // tiles the tables are laid out for (they are used only when the launch has exactly that many)
 };
 
 template <int MODE>
