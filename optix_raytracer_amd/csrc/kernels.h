@@ -97,13 +97,20 @@ struct TraceOpts {
     int  count_visits;
     int  blocks;               // persistent grid size (workgroups of 64)
     int  blocks_user, num_cus; // the grid was set with MIPT_OPT_TRACE_GRID; CUs of the device
-    const uint32_t* tile_order; uint32_t* tile_cost; uint32_t n_order;     // closest-hit launches in the tiled form: TraceArgs
+    const uint32_t* tile_order; uint8_t* tile_cost; uint32_t* tile_hist; uint32_t n_order, class_width;   // tiled closest-hit launches: TraceArgs
     int  tiled_bvh4;           // experiments: the tiled kernel walks the BVH4 mirror too (when a lane's stack over it fits 32 rows)
 };
 
-// what one workgroup of the raygen launch does for the coming primary closest-hit launch: out[slot] = tile, from the previous launch's
-// costs (out == null: nothing)
-struct TileOrderJob { const uint32_t* cost; uint32_t* out; uint32_t n; uint32_t width; };
+// The next primary launch's tile order, made inside the launches the pass has anyway: the tiled kernel leaves a class byte per
+// tile and per-chunk class histograms (TraceArgs), the first `n_chunks` workgroups of the shade launch turn them into the order
+// (stable counting sort: heaviest class first, image order inside a class), the raygen launch zeroes the histograms.
+constexpr uint32_t kOrderChunk = 512, kOrderClasses = 16;
+struct TileOrderJob {
+    const uint8_t*  cls;      // [n_tiles]
+    const uint32_t* hist;     // [n_chunks][kOrderClasses]
+    uint32_t*       order;    // [n_tiles] out: slot -> tile
+    uint32_t        n_tiles, n_chunks;
+};
 
 // ---- launches (all asynchronous on `st`) ----
 void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, uint32_t n_valid);
@@ -112,7 +119,8 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
 void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = nullptr);   // host_live: pinned word that receives the new live count
 // ctr != null: the kernel also does launch_begin_sample's work for the pass (and clears the launch statistics when zero_stats)
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
-                   DeviceCounters* ctr = nullptr, uint32_t n_valid = 0, bool zero_stats = false, TileOrderJob order = TileOrderJob{});
+                   DeviceCounters* ctr = nullptr, uint32_t n_valid = 0, bool zero_stats = false,
+                   uint32_t* zero_words = nullptr, uint32_t n_zero = 0);     // words the launch clears (TileOrderJob::hist)
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                           const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o,
                           uint32_t ray_flags = 0u /* MiptRayFlags */);
@@ -122,7 +130,7 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
                       DeviceCounters* ctr, const TraceOpts& o);
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
-                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices);
+                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order = TileOrderJob{});
 void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots,
                     DeviceCounters* advance_ctr = nullptr);   // advance_ctr: also do the last bounce's launch_advance
 // SDK/imgui_test pipeline (imgui_kernels.hip)

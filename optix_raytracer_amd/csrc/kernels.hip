@@ -719,6 +719,19 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
 
 // ROWS: entries of a lane's stack = rows of the LDS block (24 when the tree is at most 24 deep -- 7.5 KB of LDS per
 // wave and <= 96 VGPRs let 20 waves share a CU instead of 16 -- else 32)
+// a tile's sort key for the next launch's order: 0 = heaviest, 255 = lightest; classes of `width` cost units (bulk steps + pool rounds)
+__device__ __forceinline__ uint32_t tile_class(uint32_t cost, uint32_t width)
+{
+    const uint32_t q = cost / width;
+    return (kOrderClasses - 1u) - (q < kOrderClasses - 1u ? q : kOrderClasses - 1u);
+}
+__device__ __forceinline__ void record_tile_cost(const TraceArgs& a, uint32_t tile, uint32_t cost)
+{
+    const uint32_t c = tile_class(cost, a.class_width);
+    a.tile_cost[tile] = (uint8_t)c;
+    atomicAdd(&a.tile_hist[(tile / kOrderChunk) * kOrderClasses + c], 1u);
+}
+
 template <int MODE, int ROWS, int Q>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? 6 : 5, ROWS == 24 ? 6 : 5)))
 void k_trace_pool(TraceArgs a)
@@ -808,7 +821,7 @@ void k_trace_pool(TraceArgs a)
         wv_t1 = __builtin_amdgcn_s_memtime();
 #endif
         if (__ballot(has_ray) == 0ull) {                             // the whole tile is finished
-            if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) a.tile_cost[tile] = cost;
+            if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) record_tile_cost(a, tile, cost);
             continue;
         }
 
@@ -846,7 +859,7 @@ void k_trace_pool(TraceArgs a)
 #endif
             ++cost;
         }
-        if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) a.tile_cost[tile] = cost;
+        if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) record_tile_cost(a, tile, cost);
 #if MIPT_PROBE_STAMP
         pw_pool += __builtin_amdgcn_s_memtime() - pw_b1;
 #endif
@@ -953,66 +966,16 @@ __global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
 // frames, or by the StaticWorkDistribution map for a rank's shard.  The raygen-local seed advances
 // by the two jitter draws only (the path's own stream is discarded, :260-278), so it is kept per slot.
 // ------------------------------------------------------------------------------------------------
-// The tile order of the coming primary launch (TraceArgs::tile_order), made by ONE workgroup of the raygen launch while the others
-// write rays: a stable counting sort of the previous launch's tile costs into 16 classes of `width` cost units, heaviest class first,
-// image order inside a class -- each of the 256 threads owns a contiguous stripe of tiles, counts its stripe per class, the
-// (class, thread) counts are scanned in LDS, and the stripe is written out.  Deterministic; a few microseconds beside a raygen
-// launch of 25.
-__device__ __forceinline__ void build_tile_order(const TileOrderJob j)
-{
-    constexpr uint32_t kClasses = 16u;
-    __shared__ uint32_t cnt[kClasses * 256u];                       // [class][thread]
-    __shared__ uint32_t class_base[kClasses];
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (j.n + 255u) / 256u, lo = t * per, hi = lo + per < j.n ? lo + per : j.n;
-    uint32_t mine[kClasses];
-#pragma unroll
-    for (uint32_t c = 0; c < kClasses; ++c) mine[c] = 0u;
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t q = j.cost[i] / j.width;
-        const uint32_t cls = kClasses - 1u - (q < kClasses - 1u ? q : kClasses - 1u);      // class 0 = heaviest
-#pragma unroll
-        for (uint32_t c = 0; c < kClasses; ++c) mine[c] += cls == c ? 1u : 0u;
-    }
-#pragma unroll
-    for (uint32_t c = 0; c < kClasses; ++c) cnt[c * 256u + t] = mine[c];
-    __syncthreads();
-    // exclusive scan over (class-major, thread-minor): thread t scans class t / 16's ... simpler: 16 threads scan one class each, then
-    // the class bases by thread 0 (256 + 16 sequential steps; this block has nothing else to do)
-    if (t < kClasses) {
-        uint32_t run = 0u;
-        for (uint32_t k = 0; k < 256u; ++k) { const uint32_t v = cnt[t * 256u + k]; cnt[t * 256u + k] = run; run += v; }
-        class_base[t] = run;                                        // the class total, turned into a base below
-    }
-    __syncthreads();
-    if (t == 0u) {
-        uint32_t run = 0u;
-        for (uint32_t c = 0; c < kClasses; ++c) { const uint32_t v = class_base[c]; class_base[c] = run; run += v; }
-    }
-    __syncthreads();
-    uint32_t pos[kClasses];
-#pragma unroll
-    for (uint32_t c = 0; c < kClasses; ++c) pos[c] = class_base[c] + cnt[c * 256u + t];
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t q = j.cost[i] / j.width;
-        const uint32_t cls = kClasses - 1u - (q < kClasses - 1u ? q : kClasses - 1u);
-        uint32_t p = 0u;
-#pragma unroll
-        for (uint32_t c = 0; c < kClasses; ++c) { if (cls == c) { p = pos[c]; pos[c] = p + 1u; } }
-        j.out[p] = i;
-    }
-}
-
 // With fc.batch_spp != 0 every sample of the launch is a path of its own (path i -> sample i / paths_per_sample)
 // with its own accumulator slot `sample * n_slots + slot`; the raygen seed of sample s is reached by 2*s LCG
 // steps from the pixel's tea<4> seed, exactly the state the sequential loop would have.
 // The first workgroup also does the pass's queue bookkeeping (begin_sample: a launch of its own costs ~8 us with its gap).
 __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
-                                                DeviceCounters* ctr, uint32_t n_valid, uint32_t zero_stats, TileOrderJob order)
+                                                DeviceCounters* ctr, uint32_t n_valid, uint32_t zero_stats, uint32_t* zero_words, uint32_t n_zero)
 {
     if (ctr && blockIdx.x == 0u) begin_sample(ctr, threadIdx.x, fc.n_paths, n_valid, zero_stats);
-    if (order.out != nullptr && blockIdx.x == 1u) build_tile_order(order);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_zero) zero_words[i] = 0u;                              // the tile-class histograms of the coming closest-hit launch
     if (i >= fc.n_paths) return;
     uint32_t i0 = i;
     if (fc.batch_spp != 0u) { sample = i / fc.paths_per_sample; i0 = i - sample * fc.paths_per_sample; }
@@ -1101,6 +1064,7 @@ struct ShadeArgs {
     DeviceCounters*         ctr;
     uint32_t                n_max;
     const void*             common_vertices;   // non-null when every hit-group record points at the same vertex buffer
+    TileOrderJob            order;             // n_chunks != 0: the first n_chunks workgroups make the next launch's tile order
 };
 
 struct ShadeOut {
@@ -1192,14 +1156,66 @@ __device__ __forceinline__ void shade_path(const ShadeArgs& a, float4 hit, float
 // One global atomic per 512-path tile and queue (not per wave): the queue-length words are single
 // addresses, and ~32 k returning atomics on one word serialise at ~88 per microsecond (measured: the
 // per-wave version spent 0.37 of its 0.44 ms there).
+// The order of the next primary launch's tiles, one chunk of kOrderChunk tiles per workgroup: slot of a tile = tiles of heavier
+// classes (all chunks) + tiles of its class in earlier chunks + tiles of its class before it in this chunk.
+__device__ void tile_order_job(const TileOrderJob& j, uint32_t chunk)
+{
+    constexpr uint32_t kSegs = kOrderChunk / 64u;
+    __shared__ uint32_t s_tot[kOrderClasses], s_pre[kOrderClasses], s_first[kOrderClasses], s_seg[kSegs][kOrderClasses];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
+    if (tid < kOrderClasses) { s_tot[tid] = 0u; s_pre[tid] = 0u; }
+    __syncthreads();
+    {   // class totals over all chunks / over the chunks before this one
+        const uint32_t k = tid % kOrderClasses, stripe = tid / kOrderClasses, stripes = blockDim.x / kOrderClasses;
+        uint32_t tot = 0u, pre = 0u;
+        for (uint32_t c = stripe; c < j.n_chunks; c += stripes) {
+            const uint32_t h = j.hist[c * kOrderClasses + k];
+            tot += h; pre += c < chunk ? h : 0u;
+        }
+        if (tot) atomicAdd(&s_tot[k], tot);
+        if (pre) atomicAdd(&s_pre[k], pre);
+    }
+    // tiles of every class in every 64-tile segment of the chunk
+    for (uint32_t g = wave; g < kSegs; g += waves) {
+        const uint32_t tile = chunk * kOrderChunk + g * 64u + lane;
+        const uint32_t cl = tile < j.n_tiles ? j.cls[tile] : 0xffu;
+        uint32_t mine = 0u;
+        for (uint32_t k = 0; k < kOrderClasses; ++k) { const uint32_t c = (uint32_t)__popcll(__ballot(cl == k)); if (lane == k) mine = c; }
+        if (lane < kOrderClasses) s_seg[g][lane] = mine;
+    }
+    __syncthreads();
+    if (tid < kOrderClasses) {
+        uint32_t first = s_pre[tid];
+        for (uint32_t k = 0; k < tid; ++k) first += s_tot[k];
+        s_first[tid] = first;
+    }
+    __syncthreads();
+    for (uint32_t g = wave; g < kSegs; g += waves) {
+        const uint32_t tile = chunk * kOrderChunk + g * 64u + lane;
+        const uint32_t cl = tile < j.n_tiles ? j.cls[tile] : 0xffu;
+        uint32_t rank = 0u;
+        for (uint32_t k = 0; k < kOrderClasses; ++k) {
+            const unsigned long long m = __ballot(cl == k);
+            if (cl == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        if (cl < kOrderClasses) {
+            uint32_t slot = s_first[cl] + rank;
+            for (uint32_t g2 = 0; g2 < g; ++g2) slot += s_seg[g2][cl];
+            if (slot < j.n_tiles) j.order[slot] = tile;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a)
 {
     __shared__ uint32_t s_cnt[2], s_base[2];
+    if (blockIdx.x < a.order.n_chunks) { tile_order_job(a.order, blockIdx.x); return; }
+    const uint32_t first_block = a.order.n_chunks, stride = gridDim.x - a.order.n_chunks;
     uint32_t n = a.ctr->n_cur;
     n = n < a.n_max ? n : a.n_max;
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t tile = blockIdx.x; tile * kShadeBlock < n; tile += gridDim.x) {
+    for (uint32_t tile = blockIdx.x - first_block; tile * kShadeBlock < n; tile += stride) {
         const uint32_t i = tile * kShadeBlock + threadIdx.x;
         ShadeOut o;
         o.push_next = false; o.push_shadow = false;
@@ -1698,11 +1714,12 @@ void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live)
 }
 
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
-                   DeviceCounters* ctr, uint32_t n_valid, bool zero_stats, TileOrderJob order)
+                   DeviceCounters* ctr, uint32_t n_valid, bool zero_stats, uint32_t* zero_words, uint32_t n_zero)
 {
     const uint32_t blocks = (fc.n_paths + 255u) / 256u;
-    if (blocks < 2u) order.out = nullptr;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, fc, sample, q, rg_seed, result, ctr, n_valid, zero_stats ? 1u : 0u, order);
+    if (n_zero > fc.n_paths) n_zero = 0u;                             // never: 16 words per 32768 paths
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, st, fc, sample, q, rg_seed, result, ctr, n_valid, zero_stats ? 1u : 0u,
+                       zero_words, n_zero);
 }
 
 template <int MODE>
@@ -1786,7 +1803,7 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr;
     a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
-    a.tile_order = o.tile_order; a.tile_cost = o.tile_cost; a.n_order = o.n_order;
+    a.tile_order = o.tile_order; a.tile_cost = o.tile_cost; a.tile_hist = o.tile_hist; a.n_order = o.n_order; a.class_width = o.class_width ? o.class_width : 6u;
     launch_trace<0>(st, a, o);
 }
 
@@ -1804,14 +1821,16 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
 
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
-                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices)
+                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order)
 {
     ShadeArgs a{};
+    a.order = order;
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur; a.hits = hits;
     a.next = next; a.shadow = shadow; a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
     uint32_t blocks = (n_max + kShadeBlock - 1u) / kShadeBlock;
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0u) blocks = 1u;
+    blocks += order.n_chunks;
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, st, a);
 }
 

@@ -125,12 +125,14 @@ struct MiptContext {
     uint32_t*   im_flags = nullptr;
     size_t      im_cap = 0;
     int      refill_min = 16, steal_min = 24, burst_bulk = 12, burst_dry = 8;   // tools/tune.py sweeps, profiles/r01_tuning*.txt
-    // cost-ordered tiles of the primary closest-hit launch (TraceArgs::tile_order / tile_cost)
-    uint32_t* d_tile_cost = nullptr;     // every tile's cost in the last primary launch that ran the tiled kernel
-    uint32_t* d_tile_order = nullptr;    // slot -> tile of the coming one (built by the raygen launch)
-    uint32_t  tile_n = 0;                // tiles both arrays cover
-    bool      tile_cost_valid = false;   // d_tile_cost was written completely by a launch of the same tile count
-    uint32_t  tile_class_width = 16;     // env MIPT_TILE_CLASS: cost units per class of the order (16 classes)
+    // cost-ordered tiles of the primary closest-hit launch (TraceArgs::tile_order / tile_cost / tile_hist; TileOrderJob): the tiled
+    // kernel records a cost class per tile, the first workgroups of the shade launch turn them into the next launch's order
+    uint8_t*    d_tile_class = nullptr;  // written by the last primary launch that ran the tiled kernel
+    uint32_t*   d_tile_hist = nullptr;   // [chunks][kOrderClasses], cleared by the raygen launch
+    uint32_t*   d_tile_order = nullptr;  // slot -> tile for the coming launch
+    uint32_t    tile_n = 0;              // tiles the arrays cover
+    bool        tile_order_valid = false;    // d_tile_order was made by a launch of the same tile count
+    uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
     int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
     int       tile_order_mode = 1;       // MIPT_OPT_TILE_ORDER: 0 image order, 1 (default) by the previous launch's costs
     int      profile = 0;
@@ -537,20 +539,22 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                                    n_paths > (uint32_t)ctx->num_cus * 2560u && n_paths > first_limit;
         TileOrderJob job{};
         if (tiled_primary) {
-            const uint32_t tiles = n_paths / 64u;
+            const uint32_t tiles = n_paths / 64u, chunks = (tiles + kOrderChunk - 1u) / kOrderChunk;
             if (ctx->tile_n != tiles) {
-                if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
-                if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
-                ctx->d_tile_cost = ctx->d_tile_order = nullptr; ctx->tile_n = 0; ctx->tile_cost_valid = false;
-                HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_cost, (size_t)tiles * 4u));
+                HIPCHK(ctx, hipDeviceSynchronize());
+                for (void* p : { (void*)ctx->d_tile_class, (void*)ctx->d_tile_hist, (void*)ctx->d_tile_order }) if (p) (void)hipFree(p);
+                ctx->d_tile_class = nullptr; ctx->d_tile_hist = ctx->d_tile_order = nullptr; ctx->tile_n = 0; ctx->tile_order_valid = false;
+                HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_class, tiles));
+                HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_hist, (size_t)chunks * kOrderClasses * 4u));
                 HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_order, (size_t)tiles * 4u));
                 ctx->tile_n = tiles;
             }
-            if (ctx->tile_cost_valid) job = TileOrderJob{ ctx->d_tile_cost, ctx->d_tile_order, tiles, ctx->tile_class_width };
+            job.cls = ctx->d_tile_class; job.hist = ctx->d_tile_hist; job.order = ctx->d_tile_order; job.n_tiles = tiles; job.n_chunks = chunks;
         } else {
-            ctx->tile_cost_valid = false;
+            ctx->tile_order_valid = false;
         }
-        { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result, ctx->d_ctr, pass_valid, s == 0u, job); }
+        { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result, ctx->d_ctr, pass_valid, s == 0u,
+                                                         ctx->d_tile_hist, job.n_chunks * kOrderClasses); }
         int cur = 0;
         if (n_paths <= first_limit) {
             // a pass this small runs in the tail kernel from the first bounce on (Cornell 512x512: 0.73 -> 0.37 ms)
@@ -563,13 +567,17 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             { TimedScope t(ctx, st, T_CLOSEST);
               TraceOpts o2 = opts;
               if (bounce == 0u && tiled_primary) {
-                  o2.tile_cost = ctx->d_tile_cost; o2.tile_order = job.out; o2.n_order = n_paths / 64u;
-                  ctx->tile_cost_valid = true;                                    // the next pass orders its tiles by what this one records
+                  // this pass walks the order the previous pass's shade launch made and records its own cost classes for the next
+                  // (MIPT_TILE_ORDER=2, a diagnostic: the first order is kept)
+                  o2.tile_cost = ctx->d_tile_class; o2.tile_hist = ctx->d_tile_hist; o2.tile_order = ctx->tile_order_valid ? ctx->d_tile_order : nullptr;
+                  o2.n_order = job.n_tiles; o2.class_width = ctx->tile_class_width;
+                  if (ctx->tile_order_mode == 2 && ctx->tile_order_valid) { o2.tile_cost = nullptr; job = TileOrderJob{}; }
               }
               launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, bound, ctx->hits, ctx->d_ctr, o2); }
             { TimedScope t(ctx, st, T_SHADE);
               launch_shade(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->hits, ctx->q[cur ^ 1], ctx->sq,
-                           ctx->result, ctx->d_ctr, bound, ctx->common_vertices); }
+                           ctx->result, ctx->d_ctr, bound, ctx->common_vertices, bounce == 0u ? job : TileOrderJob{}); }
+            if (bounce == 0u && job.n_chunks != 0u) ctx->tile_order_valid = true;
             { TimedScope t(ctx, st, T_ANY);
               launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, bound, nullptr, ctx->sq.contrib,
                                ctx->result, ctx->d_ctr, opts); }
@@ -659,7 +667,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_NODE_FORMAT")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->node_format = v; }
     if (const char* e = std::getenv("MIPT_TILE_CLASS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 1) c->tile_order_mode = v; }
+    if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
     if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
     if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 30)) c->tail_paths = (uint32_t)v; }
@@ -677,8 +685,7 @@ int mipt_context_destroy(MiptContext* c)
     free_launch_buffers(c);
     if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
-    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
-    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+    for (void* p : { (void*)c->d_tile_class, (void*)c->d_tile_hist, (void*)c->d_tile_order }) if (p) (void)hipFree(p);
     if (c->im_sq.ray_o) (void)hipFree(c->im_sq.ray_o);
     if (c->im_sq.contrib) (void)hipFree(c->im_sq.contrib);
     if (c->im_flags) (void)hipFree(c->im_flags);
@@ -721,7 +728,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         c->build_mode = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_TILE_ORDER:
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "tile order must be 0 (image order) or 1 (by the previous launch's costs)");
-        c->tile_order_mode = (int)value; c->tile_cost_valid = false; return MIPT_SUCCESS;
+        c->tile_order_mode = (int)value; c->tile_order_valid = false; return MIPT_SUCCESS;
     case MIPT_OPT_NODE_FORMAT:
         if (value > 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "node format must be 0 (fp32 boxes), 1 (fp16 boxes, packed 32-byte BVH2 nodes) or 2 (fp16 boxes, BVH4 nodes)");
         c->node_format = (int)value; return MIPT_SUCCESS;

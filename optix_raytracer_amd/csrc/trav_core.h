@@ -111,11 +111,14 @@ struct TraceArgs {
     int             burst_dry;    // ... and once the ray range is exhausted
     uint32_t        ray_flags;    // MiptRayFlags of every ray of the launch (closest hit: back-face culling)
     uint32_t        tile_group;   // k_trace_pool, tiled: consecutive tiles dealt to one XCD at a time (0: a contiguous eighth each)
-    // k_trace_pool, tiled: the launch walks its tiles in the order `tile_order` gives (slot -> tile: a permutation made by the raygen
-    // launch from the previous launch's costs, heaviest class first, image order inside a class; null or another tile count: image
-    // order) and records every tile's cost (bulk steps + pool rounds) in `tile_cost` (null: not recorded)
+    // k_trace_pool, tiled: the launch walks its tiles in the order `tile_order` gives (slot -> tile: a permutation made from the
+    // previous launch's costs by a stable counting sort, heaviest class first, image order inside a class: tile_order_job();
+    // null or another tile count: image order) and records every tile's cost class in `tile_cost` and the class histogram of
+    // every chunk of kOrderChunk tiles in `tile_hist` (null: not recorded)
     const uint32_t* tile_order;
-    uint32_t*       tile_cost;
+    uint8_t*        tile_cost;    // one byte per tile: its cost CLASS (0 = heaviest .. kOrderClasses-1; tile_class())
+    uint32_t*       tile_hist;    // [chunk][class] counts, zero when the launch starts
+    uint32_t        class_width;  // cost units per class
     uint32_t        n_order;      // tiles the tables are laid out for (they are used only when the launch has exactly that many)
 };
 
