@@ -99,6 +99,54 @@ def test_headline_depth8_spot_check(big):
     assert stats["closest_rays"] > 1920 * 1080
 
 
+def test_cost_ordered_tiles_change_nothing_but_the_order():
+    """MIPT_OPT_TILE_ORDER: from the second launch on the primary closest-hit launch walks its 64-ray tiles heaviest first, in
+    an order made inside the previous launch (class bytes + per-chunk histograms -> counting sort in the shade launch).  A wrong
+    order (a tile twice, a tile missing) shows as wrong pixels: every launch is compared with the same launch in image order,
+    with the camera moving between launches (so the order is stale), a tile count that does not fill the last sort chunk
+    (1280x720: 14400 tiles = 28.125 chunks), a change of size in between, and the oracle on random pixels at the end."""
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    from optix_raytracer_amd.camera import Camera
+    scene = scenes.random_soup(300_000, seed_tag=5)
+    cam = scene["camera"]
+    frames = {}
+    for mode in (1, 0):
+        st = PT.make_state(scene, 1280, 720, 1, 0, max_depth=1)
+        st.context.set_option(L.OPT_TILE_ORDER, mode)
+        assert st.context.get_option(L.OPT_TILE_ORDER) == mode
+        ob = PT.OutputBuffer(1280, 720, st.device)
+        out = []
+        for k in range(5):
+            eye = (cam["eye"][0] + 0.15 * k, cam["eye"][1] - 0.1 * k, cam["eye"][2])
+            PT.handleCameraUpdate(st, Camera(eye, cam["lookat"], cam["up"], cam["fovY"], 1280 / 720))
+            if k == 3:                            # another tile count: the tables are laid out again, the first launch is in image order
+                PT.initLaunchParams(st, 1600, 900, 1)
+                ob = PT.OutputBuffer(1600, 900, st.device)
+                PT.handleCameraUpdate(st, Camera(eye, cam["lookat"], cam["up"], cam["fovY"], 1600 / 900))
+            st.params.subframe_index = k
+            PT.launchSubframe(ob, st)
+            out.append((st.accum.cpu().numpy().copy(), st.context.launch_stats()))
+        frames[mode] = out
+        if mode == 1:
+            nodes, tris = st.context.accel_export(st.gas_handle)
+        PT.cleanupState(st)
+    for (a1, s1), (a0, s0) in zip(frames[1], frames[0]):
+        assert a1.shape == a0.shape and np.array_equal(a1.view(np.uint32), a0.view(np.uint32)) and s1 == s0
+    assert not np.array_equal(frames[1][1][0], frames[1][2][0])          # the camera did move
+    # the accumulation of subframes 3 and 4 at 1600x900 against the oracle
+    osc = O.Scene(scene).set_bvh(nodes, tris)
+    idx = np.random.default_rng(3).integers(0, 1600 * 900, 20000).astype(np.uint32)
+    acc = np.zeros((idx.shape[0], 4), np.float32)
+    for k in (3, 4):
+        eye = (cam["eye"][0] + 0.15 * k, cam["eye"][1] - 0.1 * k, cam["eye"][2])
+        sc2 = dict(scene); sc2["camera"] = dict(cam, eye=eye)
+        launch = scenes.launch_desc(sc2, 1600, 900, 1, subframe=k)
+        acc, _ = osc.render_pixels(launch, idx, max_depth=1, prev=acc)
+    assert np.array_equal(frames[1][4][0].reshape(-1, 4)[idx].view(np.uint32), acc.view(np.uint32))
+
+
 def test_config2_cornell_1080p_spp16():
     """BASELINE config 2: Cornell box 1920x1080 spp 16, one launch, unbounded (Russian roulette) depth.
     33 M paths: the oracle checks 30 k random pixels bit for bit and the ray counters of the whole frame
