@@ -213,11 +213,12 @@ typedef enum MiptOption {
                                   Scenes that do not suit fp16 boxes (a coordinate beyond +-32768, or the largest extent below a
                                   quarter of the largest coordinate) silently keep format 0.  The 64-byte BVH2 nodes stay the
                                   canonical tree in every format (mipt_accel_export, counting launches, instance walk). */
-    MIPT_OPT_TILE_ORDER   = 15, /* the primary closest-hit launch of a full frame walks its 64-ray tiles 1 (default): in the order of their
-                                  cost (traversal steps) in the previous launch, heaviest first -- a tile's cost varies 1 : 5 and in image
-                                  order the kernel ends in a long drain while late, heavy tiles run alone; the order is rebuilt on the
-                                  device at the end of every launch (k_tile_order) and only schedules, it cannot change a result;
-                                  0: image order; 2: as 1 but sorted on the host (experiments: drains the stream) */
+    MIPT_OPT_TILE_ORDER   = 15, /* the primary closest-hit launch of a full frame walks its 64-ray tiles 1 (default): heaviest first,
+                                  by their cost (bulk steps + pool rounds) in the PREVIOUS launch -- a tile's cost varies 1 : 5, and in
+                                  image order the kernel ends in a long drain while late, heavy tiles run alone.  The order is made
+                                  on the device inside the launches a frame has anyway (16 cost classes, stable counting sort:
+                                  image order inside a class keeps the L2 locality) and only schedules: it cannot change a result.
+                                  0: image order.  Launches of another size, shards and batched samples are not ordered. */
     MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
                                   (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;

@@ -90,6 +90,16 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
     uint32_t tile_shift;             // full frames: a tile of 64 paths covers (1 << tile_shift) x (64 >> tile_shift) pixels
 };
 
+struct RaygenJob {             // the arguments of k_raygen
+    FrameConsts     fc;
+    uint32_t        sample;
+    PathQueue       q;
+    uint32_t*       rg_seed;
+    float4*         result;
+    DeviceCounters* ctr;
+    uint32_t        n_valid, zero_stats;
+};
+
 struct TraceOpts {
     int  persistent;           // 3: tiles + entry pool (default), 2: streaming waves, 0: one thread per ray
     int  refill_min, steal_min, burst_bulk, burst_dry; // k_trace_stream knobs
@@ -103,11 +113,12 @@ struct TraceOpts {
 
 // The next primary launch's tile order, made inside the launches the pass has anyway: the tiled kernel leaves a class byte per
 // tile and per-chunk class histograms (TraceArgs), the first `n_chunks` workgroups of the shade launch turn them into the order
-// (stable counting sort: heaviest class first, image order inside a class), the raygen launch zeroes the histograms.
+// (stable counting sort: heaviest class first, image order inside a class) and clear the histograms of the launch after.
 constexpr uint32_t kOrderChunk = 512, kOrderClasses = 16;
 struct TileOrderJob {
     const uint8_t*  cls;      // [n_tiles]
     const uint32_t* hist;     // [n_chunks][kOrderClasses]
+    uint32_t*       zero;     // [n_chunks][kOrderClasses] the histograms of the NEXT tiled launch, cleared here (the two sets alternate)
     uint32_t*       order;    // [n_tiles] out: slot -> tile
     uint32_t        n_tiles, n_chunks;
 };
@@ -120,10 +131,14 @@ void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = n
 // ctr != null: the kernel also does launch_begin_sample's work for the pass (and clears the launch statistics when zero_stats)
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
                    DeviceCounters* ctr = nullptr, uint32_t n_valid = 0, bool zero_stats = false,
-                   uint32_t* zero_words = nullptr, uint32_t n_zero = 0);     // words the launch clears (TileOrderJob::hist)
+                   uint32_t* zero_words = nullptr, uint32_t n_zero = 0);     // words the launch clears
+// rg != null (only where closest_launch_is_tiled()): the launch makes its rays itself -- k_raygen's work for the pass, folded into
+// the kernel that traces them (no launch of its own, the rays are not read back)
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                           const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o,
-                          uint32_t ray_flags = 0u /* MiptRayFlags */);
+                          uint32_t ray_flags = 0u /* MiptRayFlags */, const struct RaygenJob* rg = nullptr);
+// the closest-hit launch of n_max rays takes the tiled form (k_trace_pool), not k_trace_static / k_trace_stream / k_trace_simple
+bool closest_launch_is_tiled(const DeviceBvh& bvh, uint32_t n_max, const TraceOpts& o);
 // mode 1: occluded flags (uint32 per ray); mode 2: accumulate contrib into result when unoccluded
 void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                       const uint32_t* n_ptr, uint32_t n_max, uint32_t* occluded, const float4* contrib, float4* result,

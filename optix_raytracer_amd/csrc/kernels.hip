@@ -732,9 +732,16 @@ __device__ __forceinline__ void record_tile_cost(const TraceArgs& a, uint32_t ti
     atomicAdd(&a.tile_hist[(tile / kOrderChunk) * kOrderClasses + c], 1u);
 }
 
-template <int MODE, int ROWS, int Q>
+__device__ __forceinline__ void begin_sample(DeviceCounters* c, uint32_t i, uint32_t n_paths, uint32_t n_valid, uint32_t zero_stats);
+__device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t sample, const PathQueue& q, uint32_t* rg_seed, float4* result,
+                                            uint32_t i, float4& ro, float4& rd);
+
+// RG: the launch makes the rays it traces (the pass's primary rays: raygen_path, k_raygen's body) and does the pass's queue
+// bookkeeping -- a raygen launch of its own is 25 us of stores plus a launch gap in front of this kernel, which has the store
+// bandwidth to spare, and the rays need not be read back.
+template <int MODE, int ROWS, int Q, bool RG = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? 6 : 5, ROWS == 24 ? 6 : 5)))
-void k_trace_pool(TraceArgs a)
+void k_trace_pool(TraceArgs a, RaygenJob rg)
 {
     // ONE LDS block per wave: in the bulk phase ROWS rows of 64 lanes (the lanes' stacks), in the tail phase the entry
     // pool in its first kPoolCap words and the per-slot merge state in the last 384 (written only after the stacks
@@ -748,7 +755,9 @@ void k_trace_pool(TraceArgs a)
     const int lane = (int)threadIdx.x;
     const bool cull_back = MODE == 0 && (a.ray_flags & 16u) != 0u;   // MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES: det < 0 is a back face
     uint32_t n = a.n_max;
-    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    if (!RG && a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    if (RG && blockIdx.x == 0u) begin_sample(rg.ctr, threadIdx.x, rg.fc.n_paths, rg.n_valid, rg.zero_stats);     // nothing in this launch reads them
+    static_assert(alignof(RaygenJob) == 8 && alignof(TraceArgs) == 8, "RaygenJob follows TraceArgs in the kernel-argument segment at the next multiple of 8");
     // the stacks of the still busy lanes must fit the pool: at most (kPoolCap - 168) / ROWS busy lanes at the switch
     const int steal_floor = 64 - (kPoolCap - 168) / ROWS;
     const int steal_min = a.steal_min < 64 ? (a.steal_min > steal_floor ? a.steal_min : steal_floor) : 64;   // 64: switch when the wave is empty
@@ -785,12 +794,33 @@ void k_trace_pool(TraceArgs a)
         // the slot's tile: by last launch's costs, heaviest first -- a tile's life varies 1 : 5 (median to worst), and with the
         // launch order of the image the kernel ends in a drain of a third of its duration during which the long tiles that
         // started late run alone (tools/probe_waves.py); results do not depend on which wave walks which tile
-        if (a.tile_order != nullptr && a.n_order == tiles) { const uint32_t t2 = a.tile_order[tile]; tile = t2 < tiles ? t2 : tile; }
+        if (a.tile_order != nullptr && a.n_order == tiles) {
+            const uint32_t t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[tile]);      // the same word in every lane: keep it scalar
+            tile = t2 < tiles ? t2 : tile;
+        }
         uint32_t cost = 0u;
         const uint32_t ray = tile * 64u + (uint32_t)lane;
         bool has_ray = false;
         if (ray < n) {
-            trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+            if (RG) {
+                // the job is read from the kernel-argument segment HERE, once per tile: as plain kernel arguments its ~50 words stay
+                // in SGPRs across the traversal loop, which then spills (106 SGPRs, 17 of them into VGPR lanes, 18 VGPRs to scratch)
+#if defined(__HIP_DEVICE_COMPILE__)
+                typedef const __attribute__((address_space(4))) RaygenJob* JobPtr;
+                JobPtr rp = (JobPtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                     ((sizeof(TraceArgs) + 7u) & ~size_t(7)));
+                asm volatile("" : "+s"(rp));
+#else
+                const RaygenJob* rp = &rg;            // (the host pass only parses this)
+#endif
+                const FrameConsts fc = rp->fc;
+                const PathQueue q = rp->q;
+                float4 ro, rd;
+                raygen_path(fc, rp->sample, q, rp->rg_seed, rp->result, ray, ro, rd);
+                trav_init(T, ro, rd);
+            } else {
+                trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+            }
             has_ray = T.node != kSentinel;
             if (!has_ray) finish_ray<MODE>(a, T, ray, false);      // empty interval: a miss, no BVH access
         }
@@ -970,13 +1000,10 @@ __global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
 // with its own accumulator slot `sample * n_slots + slot`; the raygen seed of sample s is reached by 2*s LCG
 // steps from the pixel's tea<4> seed, exactly the state the sequential loop would have.
 // The first workgroup also does the pass's queue bookkeeping (begin_sample: a launch of its own costs ~8 us with its gap).
-__global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
-                                                DeviceCounters* ctr, uint32_t n_valid, uint32_t zero_stats, uint32_t* zero_words, uint32_t n_zero)
+// one path of the pass: writes its queue entry, the raygen seed and (first sample) the cleared accumulator; returns the ray
+__device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t sample, const PathQueue& q, uint32_t* rg_seed, float4* result,
+                                            uint32_t i, float4& ro, float4& rd)
 {
-    if (ctr && blockIdx.x == 0u) begin_sample(ctr, threadIdx.x, fc.n_paths, n_valid, zero_stats);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_zero) zero_words[i] = 0u;                              // the tile-class histograms of the coming closest-hit launch
-    if (i >= fc.n_paths) return;
     uint32_t i0 = i;
     if (fc.batch_spp != 0u) { sample = i / fc.paths_per_sample; i0 = i - sample * fc.paths_per_sample; }
     int px, py; uint32_t slot; bool valid;
@@ -997,12 +1024,14 @@ __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample,
     if (fc.batch_spp != 0u) slot += sample * fc.n_slots;
     if (!valid) {
         // padding lane: a ray with an empty interval, killed by shade
-        q.ray_o[i]   = make_float4(0.f, 0.f, 0.f, 1.0f);
-        q.ray_d[i]   = make_float4(0.f, 0.f, 1.f, 0.0f);
+        ro = make_float4(0.f, 0.f, 0.f, 1.0f);
+        rd = make_float4(0.f, 0.f, 1.f, 0.0f);
+        q.ray_o[i]   = ro;
+        q.ray_d[i]   = rd;
         q.state_a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         q.state_b[i] = make_uint2(kInvalidSlot, 0u);
         if (fc.world != 0u && (sample == 0u || fc.batch_spp != 0u)) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
+        return false;
     }
     uint32_t seed;
     if (fc.batch_spp != 0u) {
@@ -1018,11 +1047,25 @@ __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample,
     const float dy = 2.0f * (((float)py + jy) / (float)fc.height) - 1.0f;
     const f3 U = mk3(fc.U[0], fc.U[1], fc.U[2]), V = mk3(fc.V[0], fc.V[1], fc.V[2]), W = mk3(fc.W[0], fc.W[1], fc.W[2]);
     const f3 dir = normalize(dx * U + dy * V + W);
-    q.ray_o[i]   = make_float4(fc.eye[0], fc.eye[1], fc.eye[2], 0.01f);
-    q.ray_d[i]   = make_float4(dir.x, dir.y, dir.z, 1e16f);
+    ro = make_float4(fc.eye[0], fc.eye[1], fc.eye[2], 0.01f);
+    rd = make_float4(dir.x, dir.y, dir.z, 1e16f);
+    q.ray_o[i]   = ro;
+    q.ray_d[i]   = rd;
     q.state_a[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
     q.state_b[i] = make_uint2(slot, 0u);
     if (sample == 0u || fc.batch_spp != 0u) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
+                                                DeviceCounters* ctr, uint32_t n_valid, uint32_t zero_stats, uint32_t* zero_words, uint32_t n_zero)
+{
+    if (ctr && blockIdx.x == 0u) begin_sample(ctr, threadIdx.x, fc.n_paths, n_valid, zero_stats);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_zero) zero_words[i] = 0u;
+    if (i >= fc.n_paths) return;
+    float4 ro, rd;
+    raygen_path(fc, sample, q, rg_seed, result, i, ro, rd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1164,6 +1207,7 @@ __device__ void tile_order_job(const TileOrderJob& j, uint32_t chunk)
     __shared__ uint32_t s_tot[kOrderClasses], s_pre[kOrderClasses], s_first[kOrderClasses], s_seg[kSegs][kOrderClasses];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
     if (tid < kOrderClasses) { s_tot[tid] = 0u; s_pre[tid] = 0u; }
+    if (j.zero != nullptr && tid < kOrderClasses) j.zero[chunk * kOrderClasses + tid] = 0u;
     __syncthreads();
     {   // class totals over all chunks / over the chunks before this one
         const uint32_t k = tid % kOrderClasses, stripe = tid / kOrderClasses, stripes = blockDim.x / kOrderClasses;
@@ -1323,7 +1367,7 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
 // k_trace_pool's tiled form -- 164 VGPRs, and capped at 128 or 96 it is slower than this (Cornell 512x512 0.41 / 0.53 vs
 // 0.38 ms; the headline frame run this way 1.05 / 1.08 vs 0.95 ms).
 template <int MODE, int Q>
-__device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
+__device__ __forceinline__ uint2 tail_trace(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, const bool has_ray, const bool cull_back = false)
 {
@@ -1338,8 +1382,12 @@ __device__ __forceinline__ void tail_trace(const __amdgpu_buffer_rsrc_t blob, co
 #if MIPT_PROBE_STAMP
     unsigned long long pw_wait = 0ull;
 #endif
-    while (psize > 0)
+    uint2 work = make_uint2(0u, 0u);          // rounds, entries offered to them (probe builds read it)
+    while (psize > 0) {
+        work.x += 1u; work.y += (uint32_t)(psize < 64 ? psize : 64);
         pool_round<MODE, kPoolCap, Q>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back PROBE_ARG);
+    }
+    return work;
 }
 
 template <int Q>
@@ -1636,6 +1684,10 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
     uint32_t n = a.n_max;
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     const uint32_t chunks = (n + ppw - 1u) / ppw;
+#if MIPT_PROBE_WAVES
+    const unsigned long long wv_t0 = __builtin_amdgcn_s_memtime(), wv_r0 = __builtin_amdgcn_s_memrealtime();
+    uint2 wv_work = make_uint2(0u, 0u); uint32_t wv_rays = 0u;
+#endif
     // consecutive chunks go to different XCDs: occlusion rays of neighbouring image regions cost very different amounts, and
     // a contiguous band of the queue per XCD (as the tiled closest-hit kernel has it) leaves XCDs idle (MeshViewer 4K: 6.73 vs 6.07 ms)
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
@@ -1645,8 +1697,12 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
-        tail_trace<MODE, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel,
-                         MODE == 0 && (a.ray_flags & 16u) != 0u);
+        const uint2 work = tail_trace<MODE, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel,
+                                               MODE == 0 && (a.ray_flags & 16u) != 0u);
+        (void)work;
+#if MIPT_PROBE_WAVES
+        wv_work.x += work.x; wv_work.y += work.y; wv_rays += (uint32_t)__popcll(__ballot(mine));
+#endif
         if (mine) {
             if (MODE == 0) {
                 const unsigned long long key = sh_best[lane];
@@ -1655,6 +1711,14 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
             finish_ray<MODE>(a, T, ray, MODE == 0 ? T.prim != 0xffffffffu : sh_done[lane] != 0u);
         }
     }
+#if MIPT_PROBE_WAVES
+    if (lane == 0 && a.ctr->dbg[1] != 0ull && blockIdx.x < 40000u) {      // env MIPT_PROBE_WAVES_ANY
+        uint4* rec = reinterpret_cast<uint4*>(a.ctr->dbg[1]);
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+        rec[blockIdx.x] = make_uint4((uint32_t)(t2 - wv_t0), wv_rays, wv_work.y, wv_work.x);
+        rec[40000u + blockIdx.x] = make_uint4((uint32_t)wv_r0, (uint32_t)(wv_r0 >> 32), (uint32_t)r2, (uint32_t)(r2 >> 32));
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1731,10 +1795,18 @@ static void launch_simple(hipStream_t st, const TraceArgs& a, const TraceOpts& o
     else                hipLaunchKernelGGL((k_trace_simple<MODE, false>), dim3(blocks), dim3(64), 0, st, a);
 }
 
+bool closest_launch_is_tiled(const DeviceBvh& bvh, uint32_t n_max, const TraceOpts& o)
+{
+    if (n_max == 0u || bvh.inst) return false;
+    if (!(o.persistent == 3 && !o.count_visits && bvh.pool_ok && bvh.tri_byte_off != 0u && bvh.depth <= (uint32_t)kStreamStack)) return false;
+    return n_max > (uint32_t)(o.num_cus > 0 ? o.num_cus : 256) * 2560u;       // below: static chunks on the pool (launch_trace)
+}
+
 template <int MODE>
-static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
+static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o, const RaygenJob* rgp = nullptr)
 {
     if (a.n_max == 0) return;
+    const RaygenJob rg = rgp ? *rgp : RaygenJob{};
     if (a.bvh.inst) { launch_trace_inst(st, a, MODE, o.count_visits != 0); return; }       // two-level structure: instances.hip
     if (o.persistent >= 2 && a.bvh.tri_byte_off != 0u && a.bvh.depth <= (uint32_t)kStreamStack) {
         int blocks = ((o.blocks > 0 ? o.blocks : 4096) + kNumSegments - 1) / kNumSegments * kNumSegments;
@@ -1752,11 +1824,12 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
             //   closest hit: 32 from 1536 rays per CU on (518 k rays: 16 / 32 / 64 take 0.236 / 0.226 / 0.256 ms, the tiled form
             //   0.248; 1.04 M rays: 0.438 / 0.344 / 0.327 against 0.300 tiled), 16 below (259 k: 0.164 / 0.169 / 0.247, the
             //   cursor-fed pool this replaces 0.215; 130 k: 0.115 against 0.149), 8 below 192 per CU (32 k: 0.067 against 0.086)
-            const uint32_t n_est = MODE != 0 ? a.n_max / 4u : a.n_max;
+            const uint32_t n_est = MODE != 0 && a.n_ptr != nullptr ? a.n_max / 4u : a.n_max;     // no device-side count: n_max is exact
             const uint32_t q = n_est / (cus * 16u);
             uint32_t ppw = 0u;
             if (MODE != 0)                    ppw = n_est > cus * 2048u ? 64u : (q >= 24u ? 32u : (q >= 12u ? 16u : 8u));
-            else if (n_est <= cus * 2560u)    ppw = q >= 96u ? 32u : (q >= 12u ? 16u : 8u);
+            else if (!closest_launch_is_tiled(a.bvh, a.n_max, o)) ppw = q >= 96u ? 32u : (q >= 12u ? 16u : 8u);
+            if (MODE != 0) { static const int e_ppw = [] { const char* e = std::getenv("MIPT_ANY_PPW"); return e ? std::atoi(e) : 0; }(); if (e_ppw >= 1 && e_ppw <= 64) ppw = (uint32_t)e_ppw; }
             if (ppw != 0u) {
                 unsigned long long want = ((unsigned long long)n_est + ppw - 1u) / ppw;
                 want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
@@ -1776,16 +1849,17 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
                 // (the tiled kernel keeps the BVH2 when a BVH4 mirror exists too: a lane's stack over the BVH4 can need 32 rows -- 8 KB
                 //  per wave, 20 waves per CU instead of 24 -- which gives back what the shorter walk gains: 0.404 against 0.406 ms on
                 //  the headline frame; MIPT_TILED_BVH4=1 selects it for experiments when the stack fits)
+#define MIPT_LAUNCH_TILED(ROWS, Q) do { \
+                    if (rgp) hipLaunchKernelGGL((k_trace_pool<0, ROWS, Q, true>), dim3(blocks), dim3(64), 0, st, a, rg); \
+                    else     hipLaunchKernelGGL((k_trace_pool<0, ROWS, Q, false>), dim3(blocks), dim3(64), 0, st, a, rg); } while (0)
                 if (a.bvh.node_fmt == 2 && o.tiled_bvh4 && a.bvh.stack4 <= 32u) {
-                    if (a.bvh.stack4 <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, 2>), dim3(blocks), dim3(64), 0, st, a);
-                    else                     hipLaunchKernelGGL((k_trace_pool<0, 32, 2>), dim3(blocks), dim3(64), 0, st, a);
+                    if (a.bvh.stack4 <= 24u) MIPT_LAUNCH_TILED(24, 2); else MIPT_LAUNCH_TILED(32, 2);
                 } else if (a.bvh.node_fmt >= 1) {
-                    if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, 1>), dim3(blocks), dim3(64), 0, st, a);
-                    else                    hipLaunchKernelGGL((k_trace_pool<0, 32, 1>), dim3(blocks), dim3(64), 0, st, a);
+                    if (a.bvh.depth <= 24u) MIPT_LAUNCH_TILED(24, 1); else MIPT_LAUNCH_TILED(32, 1);
                 } else {
-                    if (a.bvh.depth <= 24u) hipLaunchKernelGGL((k_trace_pool<0, 24, 0>), dim3(blocks), dim3(64), 0, st, a);
-                    else                    hipLaunchKernelGGL((k_trace_pool<0, 32, 0>), dim3(blocks), dim3(64), 0, st, a);
+                    if (a.bvh.depth <= 24u) MIPT_LAUNCH_TILED(24, 0); else MIPT_LAUNCH_TILED(32, 0);
                 }
+#undef MIPT_LAUNCH_TILED
             }
         }
         else if (o.count_visits) hipLaunchKernelGGL((k_trace_stream<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
@@ -1796,7 +1870,8 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o)
 }
 
 void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
-                          const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o, uint32_t ray_flags)
+                          const uint32_t* n_ptr, uint32_t n_max, float4* hits, DeviceCounters* ctr, const TraceOpts& o, uint32_t ray_flags,
+                          const RaygenJob* rg)
 {
     TraceArgs a{};
     a.ray_flags = ray_flags;
@@ -1804,7 +1879,7 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
     a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr;
     a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
     a.tile_order = o.tile_order; a.tile_cost = o.tile_cost; a.tile_hist = o.tile_hist; a.n_order = o.n_order; a.class_width = o.class_width ? o.class_width : 6u;
-    launch_trace<0>(st, a, o);
+    launch_trace<0>(st, a, o, rg && closest_launch_is_tiled(bvh, n_max, o) ? rg : nullptr);
 }
 
 void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,

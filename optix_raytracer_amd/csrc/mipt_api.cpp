@@ -128,11 +128,13 @@ struct MiptContext {
     // cost-ordered tiles of the primary closest-hit launch (TraceArgs::tile_order / tile_cost / tile_hist; TileOrderJob): the tiled
     // kernel records a cost class per tile, the first workgroups of the shade launch turn them into the next launch's order
     uint8_t*    d_tile_class = nullptr;  // written by the last primary launch that ran the tiled kernel
-    uint32_t*   d_tile_hist = nullptr;   // [chunks][kOrderClasses], cleared by the raygen launch
+    uint32_t*   d_tile_hist = nullptr;   // 2 x [chunks][kOrderClasses]: the set a launch fills was cleared by the shade launch before it
+    uint32_t    tile_hist_set = 0;       // the set the coming tiled launch fills
     uint32_t*   d_tile_order = nullptr;  // slot -> tile for the coming launch
     uint32_t    tile_n = 0;              // tiles the arrays cover
     bool        tile_order_valid = false;    // d_tile_order was made by a launch of the same tile count
     uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
+    int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
     int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
     int       tile_order_mode = 1;       // MIPT_OPT_TILE_ORDER: 0 image order, 1 (default) by the previous launch's costs
     int      profile = 0;
@@ -545,16 +547,25 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                 for (void* p : { (void*)ctx->d_tile_class, (void*)ctx->d_tile_hist, (void*)ctx->d_tile_order }) if (p) (void)hipFree(p);
                 ctx->d_tile_class = nullptr; ctx->d_tile_hist = ctx->d_tile_order = nullptr; ctx->tile_n = 0; ctx->tile_order_valid = false;
                 HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_class, tiles));
-                HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_hist, (size_t)chunks * kOrderClasses * 4u));
+                HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_hist, (size_t)chunks * kOrderClasses * 8u));
+                HIPCHK(ctx, hipMemset(ctx->d_tile_hist, 0, (size_t)chunks * kOrderClasses * 8u));
+                ctx->tile_hist_set = 0;
                 HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_order, (size_t)tiles * 4u));
                 ctx->tile_n = tiles;
             }
-            job.cls = ctx->d_tile_class; job.hist = ctx->d_tile_hist; job.order = ctx->d_tile_order; job.n_tiles = tiles; job.n_chunks = chunks;
+            job.cls = ctx->d_tile_class; job.order = ctx->d_tile_order; job.n_tiles = tiles; job.n_chunks = chunks;
+            job.hist = ctx->d_tile_hist + (size_t)ctx->tile_hist_set * chunks * kOrderClasses;
+            job.zero = ctx->d_tile_hist + (size_t)(ctx->tile_hist_set ^ 1u) * chunks * kOrderClasses;
+            ctx->tile_hist_set ^= 1u;
         } else {
             ctx->tile_order_valid = false;
         }
-        { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result, ctx->d_ctr, pass_valid, s == 0u,
-                                                         ctx->d_tile_hist, job.n_chunks * kOrderClasses); }
+        // the pass's primary rays: made by the closest-hit launch itself where that takes the tiled form (RaygenJob), else by k_raygen
+        RaygenJob rg{};
+        rg.fc = fc; rg.sample = s; rg.q = ctx->q[0]; rg.rg_seed = ctx->rg_seed; rg.result = ctx->result; rg.ctr = ctx->d_ctr;
+        rg.n_valid = pass_valid; rg.zero_stats = s == 0u ? 1u : 0u;
+        const bool fused_raygen = ctx->fuse_raygen && n_paths > first_limit && closest_launch_is_tiled(bvh, n_paths, opts);
+        if (!fused_raygen) { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result, ctx->d_ctr, pass_valid, s == 0u); }
         int cur = 0;
         if (n_paths <= first_limit) {
             // a pass this small runs in the tail kernel from the first bounce on (Cornell 512x512: 0.73 -> 0.37 ms)
@@ -569,11 +580,22 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
               if (bounce == 0u && tiled_primary) {
                   // this pass walks the order the previous pass's shade launch made and records its own cost classes for the next
                   // (MIPT_TILE_ORDER=2, a diagnostic: the first order is kept)
-                  o2.tile_cost = ctx->d_tile_class; o2.tile_hist = ctx->d_tile_hist; o2.tile_order = ctx->tile_order_valid ? ctx->d_tile_order : nullptr;
+                  o2.tile_cost = ctx->d_tile_class; o2.tile_hist = const_cast<uint32_t*>(job.hist); o2.tile_order = ctx->tile_order_valid ? ctx->d_tile_order : nullptr;
                   o2.n_order = job.n_tiles; o2.class_width = ctx->tile_class_width;
                   if (ctx->tile_order_mode == 2 && ctx->tile_order_valid) { o2.tile_cost = nullptr; job = TileOrderJob{}; }
               }
-              launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, bound, ctx->hits, ctx->d_ctr, o2); }
+              if (bounce == 0u) {     // probe builds, as in mipt_trace_closest (MIPT_PROBE_WAVES_ANY: the any-hit kernel's records)
+                  if (const char* e = std::getenv("MIPT_PROBE_WAVES")) {
+                      const unsigned long long addr = std::strtoull(e, nullptr, 0);
+                      HIPCHK(ctx, hipMemcpyAsync(&ctx->d_ctr->dbg[0], &addr, 8, hipMemcpyHostToDevice, st));
+                  }
+                  if (const char* e = std::getenv("MIPT_PROBE_WAVES_ANY")) {
+                      const unsigned long long addr = std::strtoull(e, nullptr, 0);
+                      HIPCHK(ctx, hipMemcpyAsync(&ctx->d_ctr->dbg[1], &addr, 8, hipMemcpyHostToDevice, st));
+                  }
+              }
+              launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, bound, ctx->hits, ctx->d_ctr, o2, 0u,
+                                   bounce == 0u && fused_raygen ? &rg : nullptr); }
             { TimedScope t(ctx, st, T_SHADE);
               launch_shade(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->hits, ctx->q[cur ^ 1], ctx->sq,
                            ctx->result, ctx->d_ctr, bound, ctx->common_vertices, bounce == 0u ? job : TileOrderJob{}); }
@@ -667,6 +689,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_NODE_FORMAT")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->node_format = v; }
     if (const char* e = std::getenv("MIPT_TILE_CLASS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_FUSE_RAYGEN")) c->fuse_raygen = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
     if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
@@ -1602,6 +1625,10 @@ int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, co
     ctx->last_stream = st;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, 0);
+    if (const char* e = std::getenv("MIPT_PROBE_WAVES_ANY")) {      // probe builds: per-wave records of k_trace_static (tools/probe_shadow_order.py)
+        const unsigned long long addr = std::strtoull(e, nullptr, 0);
+        HIPCHK(ctx, hipMemcpyAsync(&ctx->d_ctr->dbg[1], &addr, 8, hipMemcpyHostToDevice, st));
+    }
     const float4* r = (const float4*)rays;
     { TimedScope t(ctx, st, T_ANY);
       launch_trace_any(st, device_bvh(a), r, r + 1, 2, nullptr, n, (uint32_t*)occluded, nullptr, nullptr, ctx->d_ctr, trace_opts(ctx)); }

@@ -78,6 +78,44 @@ for name, o in orders.items():
         ref = back
     print("%-30s %d rays  %.4f ms  occluded %.3f  same flags %s" % (name, n, tm["ms_trace_any"] / 20, occ.mean(), bool(np.array_equal(back, ref))), flush=True)
 
+# ---- what would the IDEAL order be worth?  (probe build: make -C optix_raytracer_amd/csrc probe-waves PROBE_FLAGS=-DMIPT_PROBE_WAVES=1,
+# MIPT_LIBRARY=.../probe_waves.so)  Pool rounds of every 32-ray chunk in path order, then the chunks heaviest first.
+if "probe_waves" in os.environ.get("MIPT_LIBRARY", ""):
+    rec = torch.zeros((2 * 40000, 4), dtype=torch.int32, device="cuda")
+    dr = torch.from_numpy(np.ascontiguousarray(sh)).cuda()
+    os.environ["MIPT_PROBE_WAVES_ANY"] = str(rec.data_ptr())
+    ctx.trace_any(st.gas_handle, dr.data_ptr(), n, d_occ.data_ptr())
+    ctx.sync()
+    del os.environ["MIPT_PROBE_WAVES_ANY"]
+    q = rec.cpu().numpy().view(np.uint32)
+    nch = (n + 31) // 32
+    life, nr, ent, rnd = (q[:nch, k].astype(np.float64) for k in range(4))
+    occ0 = d_occ.cpu().numpy()
+    occ_frac = np.add.reduceat(occ0.astype(np.float64), np.arange(0, n, 32)) / np.maximum(nr, 1)
+    print("chunks %d; rounds per chunk mean %.1f p90 %.0f max %d; corr(rounds, unoccluded fraction) = %.2f; corr(rounds, lifetime) = %.2f" % (
+        nch, rnd.mean(), np.quantile(rnd, 0.9), rnd.max(), np.corrcoef(rnd, 1 - occ_frac)[0, 1], np.corrcoef(rnd, life)[0, 1]))
+    lag = np.corrcoef(rnd[:-1], rnd[1:])[0, 1]
+    print("corr(rounds of chunk i, chunk i+1) = %.2f, (i, i+4) = %.2f, (i, i+30: one tile row of 1920 px further) = %.2f" % (
+        lag, np.corrcoef(rnd[:-4], rnd[4:])[0, 1], np.corrcoef(rnd[:-30], rnd[30:])[0, 1]))
+    def chunk_order(key):
+        o = np.argsort(-key, kind="stable")
+        return np.concatenate([np.arange(c * 32, min(c * 32 + 32, n)) for c in o])
+    cls16 = np.minimum(rnd // 4, 15)
+    trial = {"chunks by rounds, heaviest first": chunk_order(rnd), "chunks by 16 classes of 4 rounds, stable": chunk_order(cls16),
+             "chunks by unoccluded fraction": chunk_order(1 - occ_frac), "chunks lightest first": chunk_order(-rnd)}
+    for name, o in trial.items():
+        dr = torch.from_numpy(np.ascontiguousarray(sh[o])).cuda()
+        for _ in range(3):
+            ctx.trace_any(st.gas_handle, dr.data_ptr(), n, d_occ.data_ptr())
+        ctx.sync()
+        ctx.set_option(L.OPT_PROFILE, 2)
+        for _ in range(20):
+            ctx.trace_any(st.gas_handle, dr.data_ptr(), n, d_occ.data_ptr())
+        tm = ctx.launch_timings()
+        ctx.set_option(L.OPT_PROFILE, 0)
+        print("%-45s %.4f ms" % (name, tm["ms_trace_any"] / 20), flush=True)
+    sys.exit(0)
+
 # ---- occluder sharing: how often does the triangle that occludes ray i-k also occlude ray i?  (closest occluders from
 # mipt_trace_closest on the shadow segments, path order; the any-hit kernel would find SOME occluder, this is an estimate)
 d_sh = torch.from_numpy(np.ascontiguousarray(sh)).cuda()

@@ -31,12 +31,24 @@ d_rays = torch.from_numpy(rays).cuda()
 d_hits = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
 waves = (n + 63) // 64
 rec = torch.zeros((2 * 40000, 4), dtype=torch.int32, device="cuda")
-for _ in range(3):
+FRAME = "--frame" in sys.argv        # the primary launch of whole frames (with the cost-ordered tiles of MIPT_OPT_TILE_ORDER) instead
+if FRAME:
+    ob = PT.OutputBuffer(w, h, st.device)
+    for _ in range(4):
+        PT.launchSubframe(ob, st)
+    os.environ["MIPT_PROBE_WAVES"] = str(rec.data_ptr())
+    rec_any = torch.zeros((2 * 40000, 4), dtype=torch.int32, device="cuda")
+    os.environ["MIPT_PROBE_WAVES_ANY"] = str(rec_any.data_ptr())
+    ctx.set_option(L.OPT_PROFILE, 2)
+    PT.launchSubframe(ob, st)
+    print("whole frame, MIPT_OPT_TILE_ORDER = %d" % ctx.get_option(L.OPT_TILE_ORDER))
+else:
+    for _ in range(3):
+        ctx.trace_closest(st.gas_handle, d_rays.data_ptr(), n, d_hits.data_ptr())
+    ctx.sync()
+    os.environ["MIPT_PROBE_WAVES"] = str(rec.data_ptr())
+    ctx.set_option(L.OPT_PROFILE, 2)
     ctx.trace_closest(st.gas_handle, d_rays.data_ptr(), n, d_hits.data_ptr())
-ctx.sync()
-os.environ["MIPT_PROBE_WAVES"] = str(rec.data_ptr())
-ctx.set_option(L.OPT_PROFILE, 2)
-ctx.trace_closest(st.gas_handle, d_rays.data_ptr(), n, d_hits.data_ptr())
 tm = ctx.launch_timings()
 r = rec.cpu().numpy().view(np.uint32)
 info = ctx.accel_info(st.gas_handle)
@@ -74,6 +86,28 @@ print("waves started per slice:", " ".join("%d" % x for x in started))
 heavy = life[ok] > np.quantile(life[ok], 0.99)
 print("the heaviest 1 %% of the waves: start at %.2f +- %.2f of the span, end at %.2f +- %.2f; the last 5 %% of the span holds the ends of %d waves, their mean lifetime %.0f k cycles" % (
     (a0[heavy] / span).mean(), (a0[heavy] / span).std(), (a1[heavy] / span).mean(), (a1[heavy] / span).std(), (a1 > 0.95 * span).sum(), life[ok][a1 > 0.95 * span].mean() / 1e3))
+if FRAME:
+    # ---- the any-hit kernel (k_trace_static<2>): a record per wave = chunk of rays
+    q = rec_any.cpu().numpy().view(np.uint32)
+    lifeA, raysA, entA, rndA = (q[:40000, k].astype(np.float64) for k in range(4))
+    okA = lifeA > 0
+    b0 = q[40000:, 0].astype(np.uint64) | (q[40000:, 1].astype(np.uint64) << np.uint64(32))
+    b1 = q[40000:, 2].astype(np.uint64) | (q[40000:, 3].astype(np.uint64) << np.uint64(32))
+    kc = tm["ms_trace_any"] * 1e-3 * 2.4e9
+    print("\nany-hit kernel %.4f ms = %.0f k cycles; %d waves with %d rays" % (tm["ms_trace_any"], kc / 1e3, okA.sum(), raysA[okA].sum()))
+    print("wave lifetime [k cycles]: mean %.1f, median %.1f, p90 %.1f, p99 %.1f, max %.1f; %.1f waves resident per CU on average" % (
+        lifeA[okA].mean() / 1e3, np.median(lifeA[okA]) / 1e3, np.quantile(lifeA[okA], 0.9) / 1e3, np.quantile(lifeA[okA], 0.99) / 1e3,
+        lifeA[okA].max() / 1e3, lifeA[okA].sum() / kc / 256))
+    print("pool rounds per wave: mean %.1f, p90 %.0f, max %d; entries per round %.1f of 64; entries per ray %.1f; cycles per round %.0f" % (
+        rndA[okA].mean(), np.quantile(rndA[okA], 0.9), rndA[okA].max(), entA[okA].sum() / rndA[okA].sum(), entA[okA].sum() / raysA[okA].sum(),
+        lifeA[okA].sum() / rndA[okA].sum()))
+    s0 = float(b0[okA].min()); spanA = float(b1[okA].max()) - s0
+    c0, c1 = b0[okA].astype(np.float64) - s0, b1[okA].astype(np.float64) - s0
+    edges = np.linspace(0.0, spanA, 21)
+    print("first start -> last end: %.1f us" % (spanA / 100.0))
+    print("waves resident per CU in 20 time slices:", " ".join("%.1f" % ((np.clip(np.minimum(c1, b) - np.maximum(c0, a), 0, None).sum() / (b - a)) / 256.0) for a, b in zip(edges[:-1], edges[1:])))
+    print("waves started per slice:", " ".join("%d" % ((c0 >= a) & (c0 < b)).sum() for a, b in zip(edges[:-1], edges[1:])))
+    sys.exit(0)                      # the slot -> tile map of an ordered launch is not the static one below
 tile_of_block = np.arange(waves)
 k, xcd = tile_of_block // 8, tile_of_block % 8
 tile = (k // 256 * 8 + xcd) * 256 + k % 256
