@@ -62,7 +62,12 @@ def pmc_counters(kernel):
     None when no profile of this kernel is on file."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_kernels.json")))
-        return d["kernels"][kernel], {"file": "profiles/pmc_kernels.json", "commit": d.get("commit"), "source": d.get("source")}
+        key = kernel
+        if key not in d["kernels"]:      # the same kernel under a template argument list that grew or shrank since the profile was taken
+            stem = kernel.rstrip(">")
+            cand = [k for k in d["kernels"] if "<" in k and (k.rstrip(">").startswith(stem + ",") or stem.startswith(k.rstrip(">") + ","))]
+            key = cand[0]
+        return d["kernels"][key], {"file": "profiles/pmc_kernels.json", "kernel": key, "commit": d.get("commit"), "source": d.get("source")}
     except Exception:
         return None, None
 
@@ -367,7 +372,9 @@ def main():
         bytes_closest = 64 * nv_c + 48 * tt_c + (32 + 16) * counts["closest_rays"]
         bytes_any = 64 * counts["shadow_node_visits"] + 48 * counts["shadow_tri_tests"] + (32 + 16 + 32) * counts["shadow_rays"]
         q = str(int(info.get("node_format", 0)))
-        variant = {3: "k_trace_pool<%%d, %d, %s>" % (24 if info["depth"] <= 24 else 32, "1" if q != "0" else "0"), 2: "k_trace_stream<%d, false>",
+        # (the tiled kernel makes the primary rays itself -- its last template argument -- unless MIPT_FUSE_RAYGEN=0)
+        rg = "true" if os.environ.get("MIPT_FUSE_RAYGEN", "1") != "0" else "false"
+        variant = {3: "k_trace_pool<%%d, %d, %s, %s>" % (24 if info["depth"] <= 24 else 32, "1" if q != "0" else "0", rg), 2: "k_trace_stream<%d, false>",
                    0: "k_trace_simple<%d, false>"}[int(st.context.get_option(L.OPT_PERSISTENT))]
         # a pass of at most MIPT_OPT_TAIL_PATHS paths (a rank's shard at N >= 2) runs in the path kernel: closest-hit and
         # any-hit traversal, shading and accumulation of a wave's 64 paths in ONE launch, timed under "trace_closest"

@@ -145,7 +145,8 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
                       DeviceCounters* ctr, const TraceOpts& o);
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
-                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order = TileOrderJob{});
+                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order = TileOrderJob{},
+                  uint32_t primary = 0u);    // ShadeArgs::primary: the pass's rays were made by the closest-hit launch (RaygenJob)
 void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots,
                     DeviceCounters* advance_ctr = nullptr);   // advance_ctr: also do the last bounce's launch_advance
 // SDK/imgui_test pipeline (imgui_kernels.hip)

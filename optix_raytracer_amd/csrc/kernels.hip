@@ -733,6 +733,7 @@ __device__ __forceinline__ void record_tile_cost(const TraceArgs& a, uint32_t ti
 }
 
 __device__ __forceinline__ void begin_sample(DeviceCounters* c, uint32_t i, uint32_t n_paths, uint32_t n_valid, uint32_t zero_stats);
+template <bool COMPACT>
 __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t sample, const PathQueue& q, uint32_t* rg_seed, float4* result,
                                             uint32_t i, float4& ro, float4& rd);
 
@@ -816,7 +817,7 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
                 const FrameConsts fc = rp->fc;
                 const PathQueue q = rp->q;
                 float4 ro, rd;
-                raygen_path(fc, rp->sample, q, rp->rg_seed, rp->result, ray, ro, rd);
+                raygen_path<true>(fc, rp->sample, q, rp->rg_seed, rp->result, ray, ro, rd);
                 trav_init(T, ro, rd);
             } else {
                 trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
@@ -1000,7 +1001,11 @@ __global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
 // with its own accumulator slot `sample * n_slots + slot`; the raygen seed of sample s is reached by 2*s LCG
 // steps from the pixel's tea<4> seed, exactly the state the sequential loop would have.
 // The first workgroup also does the pass's queue bookkeeping (begin_sample: a launch of its own costs ~8 us with its gap).
-// one path of the pass: writes its queue entry, the raygen seed and (first sample) the cleared accumulator; returns the ray
+// one path of the pass: writes its queue entry, the raygen seed and (first sample) the cleared accumulator; returns the ray.
+// COMPACT (the tiled kernel's own raygen; read by the first shade launch of the pass only, ShadeArgs::primary): the entry is
+// direction + (slot, seed) -- 24 bytes instead of 56 -- because origin, interval, attenuation and depth of a primary path are
+// constants, and the accumulator is not cleared: the shade launch starts from zero instead of reading it.
+template <bool COMPACT>
 __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t sample, const PathQueue& q, uint32_t* rg_seed, float4* result,
                                             uint32_t i, float4& ro, float4& rd)
 {
@@ -1026,9 +1031,7 @@ __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t samp
         // padding lane: a ray with an empty interval, killed by shade
         ro = make_float4(0.f, 0.f, 0.f, 1.0f);
         rd = make_float4(0.f, 0.f, 1.f, 0.0f);
-        q.ray_o[i]   = ro;
-        q.ray_d[i]   = rd;
-        q.state_a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!COMPACT) { q.ray_o[i] = ro; q.ray_d[i] = rd; q.state_a[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
         q.state_b[i] = make_uint2(kInvalidSlot, 0u);
         if (fc.world != 0u && (sample == 0u || fc.batch_spp != 0u)) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         return false;
@@ -1049,11 +1052,15 @@ __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t samp
     const f3 dir = normalize(dx * U + dy * V + W);
     ro = make_float4(fc.eye[0], fc.eye[1], fc.eye[2], 0.01f);
     rd = make_float4(dir.x, dir.y, dir.z, 1e16f);
-    q.ray_o[i]   = ro;
     q.ray_d[i]   = rd;
-    q.state_a[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
-    q.state_b[i] = make_uint2(slot, 0u);
-    if (sample == 0u || fc.batch_spp != 0u) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (COMPACT) {
+        q.state_b[i] = make_uint2(slot, seed);
+    } else {
+        q.ray_o[i]   = ro;
+        q.state_a[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
+        q.state_b[i] = make_uint2(slot, 0u);
+        if (sample == 0u || fc.batch_spp != 0u) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     return true;
 }
 
@@ -1065,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample,
     if (i < n_zero) zero_words[i] = 0u;
     if (i >= fc.n_paths) return;
     float4 ro, rd;
-    raygen_path(fc, sample, q, rg_seed, result, i, ro, rd);
+    raygen_path<false>(fc, sample, q, rg_seed, result, i, ro, rd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1108,6 +1115,8 @@ struct ShadeArgs {
     uint32_t                n_max;
     const void*             common_vertices;   // non-null when every hit-group record points at the same vertex buffer
     TileOrderJob            order;             // n_chunks != 0: the first n_chunks workgroups make the next launch's tile order
+    uint32_t                primary;           // k_shade: bit 0: the entries are raygen_path<true>'s (state_b = slot, seed; depth 0, attenuation 1,
+                                               // origin = the eye); bit 1: the accumulators start at zero (first sample of a launch)
 };
 
 struct ShadeOut {
@@ -1265,12 +1274,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a)
         o.push_next = false; o.push_shadow = false;
         if (i < n) {
             const uint2 sb = a.cur.state_b[i];
-            const uint32_t slot = sb.x, depth = sb.y;
+            const bool compact = (a.primary & 1u) != 0u;
+            const uint32_t slot = sb.x, depth = compact ? 0u : sb.y;
             if (slot != kInvalidSlot) {
                 const float4 hit = a.hits[i];
-                const float4 sa = a.cur.state_a[i];
-                float4 res = a.result[slot];
-                shade_path(a, hit, sa, slot, depth, res, o, [&](float4& ro4, float4& rd4) { ro4 = a.cur.ray_o[i]; rd4 = a.cur.ray_d[i]; });
+                const float4 sa = compact ? make_float4(1.0f, 1.0f, 1.0f, u2f(sb.y)) : a.cur.state_a[i];
+                float4 res = (a.primary & 2u) != 0u ? make_float4(0.f, 0.f, 0.f, 0.f) : a.result[slot];
+                shade_path(a, hit, sa, slot, depth, res, o, [&](float4& ro4, float4& rd4) {
+                    ro4 = compact ? make_float4(a.fc.eye[0], a.fc.eye[1], a.fc.eye[2], 0.01f) : a.cur.ray_o[i];
+                    rd4 = a.cur.ray_d[i];
+                });
                 a.result[slot] = res;
             }
         }
@@ -1896,10 +1909,10 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
 
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
-                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order)
+                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order, uint32_t primary)
 {
     ShadeArgs a{};
-    a.order = order;
+    a.order = order; a.primary = primary;
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur; a.hits = hits;
     a.next = next; a.shadow = shadow; a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
     uint32_t blocks = (n_max + kShadeBlock - 1u) / kShadeBlock;

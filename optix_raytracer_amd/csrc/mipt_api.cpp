@@ -598,7 +598,8 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                                    bounce == 0u && fused_raygen ? &rg : nullptr); }
             { TimedScope t(ctx, st, T_SHADE);
               launch_shade(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->hits, ctx->q[cur ^ 1], ctx->sq,
-                           ctx->result, ctx->d_ctr, bound, ctx->common_vertices, bounce == 0u ? job : TileOrderJob{}); }
+                           ctx->result, ctx->d_ctr, bound, ctx->common_vertices, bounce == 0u ? job : TileOrderJob{},
+                           bounce == 0u && fused_raygen ? (1u | ((s == 0u || batch) ? 2u : 0u)) : 0u); }
             if (bounce == 0u && job.n_chunks != 0u) ctx->tile_order_valid = true;
             { TimedScope t(ctx, st, T_ANY);
               launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, bound, nullptr, ctx->sq.contrib,

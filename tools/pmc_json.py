@@ -20,7 +20,8 @@ for line in open(src):
     m = re.match(r"== (.*)", line)
     if m:
         cur = m.group(1).strip()
-        out["kernels"][cur] = {}
+        if cur:
+            out["kernels"][cur] = {}
         continue
     m = re.match(r"\s+(\S+)\s+([\d.]+)\s+\(n=", line)
     if m and cur:
