@@ -963,7 +963,7 @@ __device__ __forceinline__ void begin_sample(DeviceCounters* c, uint32_t i, uint
     if (i == 0) {
         if (zero_stats) {
             unsigned long long* w = &c->closest_rays;
-            for (int k = 0; k < 14; ++k) w[k] = 0ull;
+            for (int k = 0; k < (MIPT_PROBE_STAMP ? 14 : 8); ++k) w[k] = 0ull;     // (dbg[]: only the stamp probe's sums are per launch)
         }
         c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0;
         c->iterations += c->tail_max; c->tail_max = 0;       // the previous pass's tail (iterations is zeroed per launch)

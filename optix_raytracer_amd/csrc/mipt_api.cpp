@@ -103,7 +103,8 @@ struct MiptContext {
                                           // scene suits fp16 boxes), 0 fp32 boxes only
     uint32_t tail_paths = 1048576;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
     bool     bounces_on_device = false;   // launch statistics: iterations counted by k_advance / k_tail
-    int      tile_group = 256;
+    int      tile_group = 256;           // consecutive tiles dealt to one XCD at a time (env MIPT_TILE_GROUP)
+    bool     tile_group_set = false;     // ... chosen by the environment: also for the cost-ordered launches, which default to 96
     int      tile_shift = 4;              // path tracer, full frames: 64 paths cover 16 x 4 pixels (8 x 8: closest-hit kernel of the
                                           // headline frame 0.440 instead of 0.413 ms; the Whitted and imgui_test raygens keep 8 x 8,
                                           // which is 1-3 % faster on their scenes)
@@ -132,6 +133,7 @@ struct MiptContext {
     uint32_t    tile_hist_set = 0;       // the set the coming tiled launch fills
     uint32_t*   d_tile_order = nullptr;  // slot -> tile for the coming launch
     uint32_t    tile_n = 0;              // tiles the arrays cover
+    uint32_t    tile_map = 0;            // world << 16 | rank of the launch the order was made by (another path -> pixel map: start over)
     bool        tile_order_valid = false;    // d_tile_order was made by a launch of the same tile count
     uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
     int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
@@ -533,10 +535,10 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         // (a capped pass of a million paths is as fast in the wavefront kernels: half the headline frame 0.54 vs 0.56 ms)
         const uint32_t first_limit = fc.max_depth == 0u ? tail_paths : (pool_tail ? tail_paths / 4u * 3u : 0u);
         // raygen's first workgroup resets the queue counters (and, for the first pass, the launch statistics)
-        // the primary rays of a full frame walk their tiles in the order of the previous launch's costs (MIPT_OPT_TILE_ORDER) when this
+        // the primary rays of a frame (or of a rank's shard of it) walk their tiles in the order of the previous launch's costs (MIPT_OPT_TILE_ORDER) when this
         // pass runs the tiled kernel (launch_trace's choice: the pool form over a one-level BVH that fits it, more than 2560 rays
         // per CU, not a counting launch): the raygen launch clears the class counters this pass fills
-        const bool tiled_primary = fc.world == 0u && ctx->tile_order_mode != 0 && !batch && opts.persistent == 3 && !opts.count_visits &&
+        const bool tiled_primary = ctx->tile_order_mode != 0 && !batch && opts.persistent == 3 && !opts.count_visits &&
                                    bvh.pool_ok != 0u && bvh.tri_byte_off != 0u && bvh.depth <= 32u && bvh.inst == nullptr &&
                                    n_paths > (uint32_t)ctx->num_cus * 2560u && n_paths > first_limit;
         TileOrderJob job{};
@@ -553,6 +555,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                 HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_order, (size_t)tiles * 4u));
                 ctx->tile_n = tiles;
             }
+            if (ctx->tile_map != ((fc.world << 16) | fc.rank)) { ctx->tile_map = (fc.world << 16) | fc.rank; ctx->tile_order_valid = false; }
             job.cls = ctx->d_tile_class; job.order = ctx->d_tile_order; job.n_tiles = tiles; job.n_chunks = chunks;
             job.hist = ctx->d_tile_hist + (size_t)ctx->tile_hist_set * chunks * kOrderClasses;
             job.zero = ctx->d_tile_hist + (size_t)(ctx->tile_hist_set ^ 1u) * chunks * kOrderClasses;
@@ -582,6 +585,10 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                   // (MIPT_TILE_ORDER=2, a diagnostic: the first order is kept)
                   o2.tile_cost = ctx->d_tile_class; o2.tile_hist = const_cast<uint32_t*>(job.hist); o2.tile_order = ctx->tile_order_valid ? ctx->d_tile_order : nullptr;
                   o2.n_order = job.n_tiles; o2.class_width = ctx->tile_class_width;
+                  // in cost order a group of consecutive slots is a group of equally heavy tiles: smaller groups spread them over the
+                  // XCDs better (32 / 48 / 64 / 96 / 128 / 256 / 512: closest-hit kernel 0.335 / 0.333 / 0.339 / 0.334 / 0.342 / 0.345 / 0.363 ms;
+                  // at 32 the any-hit kernel that follows loses 25 us -- it inherits the L2 contents)
+                  if (!ctx->tile_group_set && o2.tile_order != nullptr) o2.tile_group = 96;
                   if (ctx->tile_order_mode == 2 && ctx->tile_order_valid) { o2.tile_cost = nullptr; job = TileOrderJob{}; }
               }
               if (bounce == 0u) {     // probe builds, as in mipt_trace_closest (MIPT_PROBE_WAVES_ANY: the any-hit kernel's records)
@@ -693,7 +700,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_FUSE_RAYGEN")) c->fuse_raygen = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
-    if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) c->tile_group = v; }
+    if (const char* e = std::getenv("MIPT_TILE_GROUP")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 24)) { c->tile_group = v; c->tile_group_set = true; } }
     if (const char* e = std::getenv("MIPT_TAIL_PATHS")) { const int v = std::atoi(e); if (v >= 0 && v <= (1 << 30)) c->tail_paths = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_STEAL_MIN")) { const int v = std::atoi(e); if (v >= 1 && v <= 65) c->steal_min = v; }
     *out = c;

@@ -147,6 +147,31 @@ def test_cost_ordered_tiles_change_nothing_but_the_order():
     assert np.array_equal(frames[1][4][0].reshape(-1, 4)[idx].view(np.uint32), acc.view(np.uint32))
 
 
+def test_cost_ordered_tiles_of_a_shard(big):
+    """a rank's half of the headline frame (world 2: 1.04 M paths, the tiled kernel) walks its tiles in cost order from the
+    second launch on, like a full frame; the compact shard buffer must not depend on it"""
+    import torch
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import api
+    PT, st, ob, scene = big
+    ns = api.shard_num_samples(1920, 1080, 2)
+    out = {}
+    for mode in (1, 0):
+        st.context.set_option(L.OPT_TILE_ORDER, mode)
+        bufs = []
+        for k in range(4):
+            rank = 1 if k == 2 else 0                   # a change of rank in between: the order of rank 0's map is dropped
+            shard = torch.zeros((ns, 4), dtype=torch.float32, device="cuda")
+            st.context.launch_shard(st.params, 1920, 1080, rank, 2, shard.data_ptr(), stream=st.stream.cuda_stream)
+            st.context.sync()
+            bufs.append(shard.cpu().numpy())
+        out[mode] = bufs
+    st.context.set_option(L.OPT_TILE_ORDER, 1)
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(out[1][0], out[1][1]) and not np.array_equal(out[1][0], out[1][2])
+
+
 def test_config2_cornell_1080p_spp16():
     """BASELINE config 2: Cornell box 1920x1080 spp 16, one launch, unbounded (Russian roulette) depth.
     33 M paths: the oracle checks 30 k random pixels bit for bit and the ray counters of the whole frame

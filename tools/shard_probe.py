@@ -11,11 +11,12 @@ scene = scenes.random_soup(1_000_000)
 st = PT.make_state(scene, W, H, 1, 0, max_depth=1)
 stream = torch.cuda.current_stream()
 frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=st.device)
-steals = [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['32'])]
-drains = [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['0'])]
-for steal, drain, world in [(s_, d_, w_) for s_ in steals for d_ in drains for w_ in [int(x) for x in os.environ.get('PROBE_WORLDS', '1,8').split(',')]]:
+# optional arguments: comma lists of MIPT_OPT_STEAL_MIN and MIPT_OPT_BURST values to sweep (default: the library's defaults)
+steals = [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else [str(st.context.get_option(L.OPT_STEAL_MIN))])]
+drains = [int(x, 0) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else [str(st.context.get_option(L.OPT_BURST))])]
+for steal, drain, world in [(s_, d_, w_) for s_ in steals for d_ in drains for w_ in [int(x) for x in os.environ.get('PROBE_WORLDS', '1,2,4,8').split(',')]]:
     st.context.set_option(L.OPT_STEAL_MIN, steal)
-    st.context.set_option(L.OPT_BURST, (drain & 0xff) | ((drain >> 8) << 8))
+    st.context.set_option(L.OPT_BURST, drain)
     ns = api.shard_num_samples(W, H, world)
     compact = torch.zeros((ns, 4), dtype=torch.float32, device=st.device)
     gathered = torch.zeros((world * ns, 4), dtype=torch.float32, device=st.device)
