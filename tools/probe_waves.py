@@ -89,7 +89,8 @@ print("the heaviest 1 %% of the waves: start at %.2f +- %.2f of the span, end at
 if FRAME:
     # ---- the any-hit kernel (k_trace_static<2>): a record per wave = chunk of rays
     q = rec_any.cpu().numpy().view(np.uint32)
-    lifeA, raysA, entA, rndA = (q[:40000, k].astype(np.float64) for k in range(4))
+    lifeA, raysA, entA = (q[:40000, k].astype(np.float64) for k in range(3))
+    rndA, deadA = (q[:40000, 3] & 0xffff).astype(np.float64), (q[:40000, 3] >> 16).astype(np.float64)
     okA = lifeA > 0
     b0 = q[40000:, 0].astype(np.uint64) | (q[40000:, 1].astype(np.uint64) << np.uint64(32))
     b1 = q[40000:, 2].astype(np.uint64) | (q[40000:, 3].astype(np.uint64) << np.uint64(32))
@@ -101,6 +102,7 @@ if FRAME:
     print("pool rounds per wave: mean %.1f, p90 %.0f, max %d; entries per round %.1f of 64; entries per ray %.1f; cycles per round %.0f" % (
         rndA[okA].mean(), np.quantile(rndA[okA], 0.9), rndA[okA].max(), entA[okA].sum() / rndA[okA].sum(), entA[okA].sum() / raysA[okA].sum(),
         lifeA[okA].sum() / rndA[okA].sum()))
+    print("popped entries whose ray was already found occluded: %.1f %% of all popped entries" % (100.0 * deadA[okA].sum() / entA[okA].sum()))
     s0 = float(b0[okA].min()); spanA = float(b1[okA].max()) - s0
     c0, c1 = b0[okA].astype(np.float64) - s0, b1[okA].astype(np.float64) - s0
     edges = np.linspace(0.0, spanA, 21)
