@@ -1398,6 +1398,13 @@ __device__ __forceinline__ uint2 tail_trace(const __amdgpu_buffer_rsrc_t blob, c
     uint2 work = make_uint2(0u, 0u);          // rounds, entries offered to them (probe builds read it)
     while (psize > 0) {
         work.x += 1u; work.y += (uint32_t)(psize < 64 ? psize : 64);
+#if MIPT_PROBE_WAVES
+        if (MODE != 0) {                      // upper 16 bits of .x: popped entries whose ray has been found occluded already
+            const int k = psize < 64 ? psize : 64;
+            const bool dead = lane < k && sh_done[stk[psize - 1 - lane] & 63u] != 0u;
+            work.x += (uint32_t)__popcll(__ballot(dead)) << 16;
+        }
+#endif
         pool_round<MODE, kPoolCap, Q>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back PROBE_ARG);
     }
     return work;
