@@ -65,17 +65,20 @@ def test_headline_determinism_and_kernel_variants(big):
         st.context.set_option(o, v)
 
 
-def test_headline_shards_equal_full_frame(big):
+@pytest.mark.parametrize("world", [8, 2, 3])
+def test_headline_shards_equal_full_frame(big, world):
+    """world 8: every shard is a pass of 259 k paths (the path kernel from the first bounce); world 2 and 3: tiled launches that
+    make their own primary rays (RaygenJob) and, launched twice, walk their tiles in cost order the second time"""
     import torch
     from optix_raytracer_amd import api
     PT, st, ob, scene = big
     full, full_frame, _ = _render(PT, st, ob)
-    world = 8
     ns = api.shard_num_samples(1920, 1080, world)
-    assert ns * world == 1920 * 1080
+    assert ns * world >= 1920 * 1080
     gathered = torch.zeros((world, ns, 4), dtype=torch.float32, device="cuda")
     for r in range(world):
-        st.context.launch_shard(st.params, 1920, 1080, r, world, gathered[r].data_ptr(), stream=st.stream.cuda_stream)
+        for _ in range(2):
+            st.context.launch_shard(st.params, 1920, 1080, r, world, gathered[r].data_ptr(), stream=st.stream.cuda_stream)
     acc = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda")
     frame = torch.zeros((1080, 1920, 4), dtype=torch.uint8, device="cuda")
     st.context.unpermute(gathered.data_ptr(), world, 1920, 1080, acc.data_ptr(), frame.data_ptr(), stream=st.stream.cuda_stream)
