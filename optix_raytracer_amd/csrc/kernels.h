@@ -108,6 +108,7 @@ struct TraceOpts {
     int  blocks;               // persistent grid size (workgroups of 64)
     int  blocks_user, num_cus; // the grid was set with MIPT_OPT_TRACE_GRID; CUs of the device
     const uint32_t* tile_order; uint8_t* tile_cost; uint32_t* tile_hist; uint32_t n_order, class_width;   // tiled closest-hit launches: TraceArgs
+    const uint32_t* class_width_dev;
     int  tiled_bvh4;           // experiments: the tiled kernel walks the BVH4 mirror too (when a lane's stack over it fits 32 rows)
 };
 
@@ -119,6 +120,7 @@ struct TileOrderJob {
     const uint8_t*  cls;      // [n_tiles]
     const uint32_t* hist;     // [n_chunks][kOrderClasses]
     uint32_t*       zero;     // [n_chunks][kOrderClasses] the histograms of the NEXT tiled launch, cleared here (the two sets alternate)
+    uint32_t*       width;    // null, or the device word the tiled kernel takes its class width from: adapted here to the frame's costs
     uint32_t*       order;    // [n_tiles] out: slot -> tile
     uint32_t        n_tiles, n_chunks;
 };

@@ -727,7 +727,7 @@ __device__ __forceinline__ uint32_t tile_class(uint32_t cost, uint32_t width)
 }
 __device__ __forceinline__ void record_tile_cost(const TraceArgs& a, uint32_t tile, uint32_t cost)
 {
-    const uint32_t c = tile_class(cost, a.class_width);
+    const uint32_t c = tile_class(cost, a.class_width_dev != nullptr ? *a.class_width_dev : a.class_width);
     a.tile_cost[tile] = (uint8_t)c;
     atomicAdd(&a.tile_hist[(tile / kOrderChunk) * kOrderClasses + c], 1u);
 }
@@ -1241,6 +1241,19 @@ __device__ void tile_order_job(const TileOrderJob& j, uint32_t chunk)
         uint32_t first = s_pre[tid];
         for (uint32_t k = 0; k < tid; ++k) first += s_tot[k];
         s_first[tid] = first;
+    }
+    // The class width follows the frame: the heaviest class (it is open-ended, its tiles stay in image order) should hold about a
+    // third of the tiles that cost anything -- on the headline frame that is 6 units (0.36 of them; 5 / 6 / 7 units: 0.355 /
+    // 0.344 / 0.349 ms), and a fixed unit would mean nothing on a scene whose tiles cost a tenth or ten times as much.  One step
+    // per launch, with a dead band, so a steady frame keeps its width.
+    if (j.width != nullptr && chunk == 0u && tid == 0u) {
+        const uint32_t busy = j.n_tiles - s_tot[kOrderClasses - 1u];            // tiles above the lightest class
+        uint32_t w = *j.width;
+        if (busy >= 64u) {
+            if (s_tot[0] * 100u > busy * 42u && w < 4096u) ++w;
+            else if (s_tot[0] * 100u < busy * 30u && w > 1u) --w;
+        }
+        *j.width = w;
     }
     __syncthreads();
     for (uint32_t g = wave; g < kSegs; g += waves) {
@@ -1898,7 +1911,7 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.hits = hits; a.cursors = ctr->cursor_closest; a.ctr = ctr;
     a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
-    a.tile_order = o.tile_order; a.tile_cost = o.tile_cost; a.tile_hist = o.tile_hist; a.n_order = o.n_order; a.class_width = o.class_width ? o.class_width : 6u;
+    a.tile_order = o.tile_order; a.tile_cost = o.tile_cost; a.tile_hist = o.tile_hist; a.n_order = o.n_order; a.class_width_dev = o.class_width_dev; a.class_width = o.class_width ? o.class_width : 6u;
     launch_trace<0>(st, a, o, rg && closest_launch_is_tiled(bvh, n_max, o) ? rg : nullptr);
 }
 

@@ -135,6 +135,8 @@ struct MiptContext {
     uint32_t    tile_n = 0;              // tiles the arrays cover
     uint32_t    tile_map = 0;            // world << 16 | rank of the launch the order was made by (another path -> pixel map: start over)
     bool        tile_order_valid = false;    // d_tile_order was made by a launch of the same tile count
+    uint32_t*   d_tile_width = nullptr;  // the class width the tiled kernel uses, adapted by the order job (starts at tile_class_width)
+    bool        tile_class_fixed = false;    // MIPT_TILE_CLASS given: that width, not adapted
     uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
     int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
     int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
@@ -553,6 +555,10 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                 HIPCHK(ctx, hipMemset(ctx->d_tile_hist, 0, (size_t)chunks * kOrderClasses * 8u));
                 ctx->tile_hist_set = 0;
                 HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_order, (size_t)tiles * 4u));
+                if (!ctx->d_tile_width) {
+                    HIPCHK(ctx, hipMalloc((void**)&ctx->d_tile_width, 4u));
+                    HIPCHK(ctx, hipMemcpy(ctx->d_tile_width, &ctx->tile_class_width, 4u, hipMemcpyHostToDevice));
+                }
                 ctx->tile_n = tiles;
             }
             if (ctx->tile_map != ((fc.world << 16) | fc.rank)) { ctx->tile_map = (fc.world << 16) | fc.rank; ctx->tile_order_valid = false; }
@@ -560,6 +566,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             job.hist = ctx->d_tile_hist + (size_t)ctx->tile_hist_set * chunks * kOrderClasses;
             job.zero = ctx->d_tile_hist + (size_t)(ctx->tile_hist_set ^ 1u) * chunks * kOrderClasses;
             ctx->tile_hist_set ^= 1u;
+            job.width = ctx->tile_class_fixed ? nullptr : ctx->d_tile_width;
         } else {
             ctx->tile_order_valid = false;
         }
@@ -584,7 +591,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                   // this pass walks the order the previous pass's shade launch made and records its own cost classes for the next
                   // (MIPT_TILE_ORDER=2, a diagnostic: the first order is kept)
                   o2.tile_cost = ctx->d_tile_class; o2.tile_hist = const_cast<uint32_t*>(job.hist); o2.tile_order = ctx->tile_order_valid ? ctx->d_tile_order : nullptr;
-                  o2.n_order = job.n_tiles; o2.class_width = ctx->tile_class_width;
+                  o2.n_order = job.n_tiles; o2.class_width = ctx->tile_class_width; o2.class_width_dev = job.width;
                   // in cost order a group of consecutive slots is a group of equally heavy tiles: smaller groups spread them over the
                   // XCDs better (32 / 48 / 64 / 96 / 128 / 256 / 512: closest-hit kernel 0.335 / 0.333 / 0.339 / 0.334 / 0.342 / 0.345 / 0.363 ms;
                   // at 32 the any-hit kernel that follows loses 25 us -- it inherits the L2 contents)
@@ -695,7 +702,8 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
     if (const char* e = std::getenv("MIPT_NODE_FORMAT")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->node_format = v; }
-    if (const char* e = std::getenv("MIPT_TILE_CLASS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }
+    if (const char* e = std::getenv("MIPT_TILE_CLASS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) { c->tile_class_width = (uint32_t)v; c->tile_class_fixed = true; } }
+    if (const char* e = std::getenv("MIPT_TILE_CLASS_INIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }   // adapted from there
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_FUSE_RAYGEN")) c->fuse_raygen = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
@@ -716,7 +724,7 @@ int mipt_context_destroy(MiptContext* c)
     free_launch_buffers(c);
     if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
-    for (void* p : { (void*)c->d_tile_class, (void*)c->d_tile_hist, (void*)c->d_tile_order }) if (p) (void)hipFree(p);
+    for (void* p : { (void*)c->d_tile_class, (void*)c->d_tile_hist, (void*)c->d_tile_order, (void*)c->d_tile_width }) if (p) (void)hipFree(p);
     if (c->im_sq.ray_o) (void)hipFree(c->im_sq.ray_o);
     if (c->im_sq.contrib) (void)hipFree(c->im_sq.contrib);
     if (c->im_flags) (void)hipFree(c->im_flags);

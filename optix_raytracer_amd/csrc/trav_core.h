@@ -118,7 +118,8 @@ struct TraceArgs {
     const uint32_t* tile_order;
     uint8_t*        tile_cost;    // one byte per tile: its cost CLASS (0 = heaviest .. kOrderClasses-1; tile_class())
     uint32_t*       tile_hist;    // [chunk][class] counts, zero when the launch starts
-    uint32_t        class_width;  // cost units per class
+    uint32_t        class_width;  // cost units per class ...
+    const uint32_t* class_width_dev;   // ... or, when not null, read from here (the shade launch's order job adapts it: TileOrderJob::width)
     uint32_t        n_order;      // tiles the tables are laid out for (they are used only when the launch has exactly that many)
 };
 

@@ -67,6 +67,10 @@ print("wave lifetime [k cycles]: mean %.1f, median %.1f, p90 %.1f, p99 %.1f, max
     life[ok].sum() / kernel_cycles / 256))
 print("bulk share of the lifetime %.2f; bulk steps per wave mean %.1f max %d; pool rounds mean %.1f max %d" % (
     bulk[ok].sum() / life[ok].sum(), steps[ok].mean(), steps[ok].max(), rounds[ok].mean(), rounds[ok].max()))
+cost = steps[ok] + rounds[ok]
+print("tile cost (bulk steps + pool rounds): mean %.1f, median %.0f, p75 %.0f, p90 %.0f, p99 %.0f; share of the tiles per class of 6 units, heaviest (>= 90) first: %s" % (
+    cost.mean(), np.median(cost), np.quantile(cost, 0.75), np.quantile(cost, 0.9), np.quantile(cost, 0.99),
+    " ".join("%.3f" % ((np.minimum(cost // 6, 15) == k).mean()) for k in range(15, -1, -1))))
 A = np.stack([np.ones(ok.sum()), steps[ok], rounds[ok]], 1)
 coef, *_ = np.linalg.lstsq(A, life[ok], rcond=None)
 print("least squares: lifetime = %.0f cycles + %.0f per bulk step + %.0f per pool round" % (coef[0], coef[1], coef[2]))
