@@ -1392,12 +1392,12 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
 // argument).  Measured and dropped: one ray per lane first (stream_step) and the pool only for the tail of the tile, as in
 // k_trace_pool's tiled form -- 164 VGPRs, and capped at 128 or 96 it is slower than this (Cornell 512x512 0.41 / 0.53 vs
 // 0.38 ms; the headline frame run this way 1.05 / 1.08 vs 0.95 ms).
-template <int MODE, int Q>
+template <int MODE, int Q, int CAP = 24 * 64 - 384>
 __device__ __forceinline__ uint2 tail_trace(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, const bool has_ray, const bool cull_back = false)
 {
-    constexpr int kPoolCap = 24 * 64 - 384;
+    constexpr int kPoolCap = CAP;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
     sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u;
@@ -1703,11 +1703,21 @@ __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
 // buys nothing for them: 421 k shadow rays of the headline frame 0.265 -> 0.228 ms with 32 rays per wave, 8.3 M occlusion rays
 // of the MeshViewer frame at 4K 6.64 -> 6.07 ms with 64 (big closest-hit launches: 0.512 -> 0.529 ms, they keep the tiled form).
 // A launch with few rays lasts as long as ONE wave needs for its rays, so there a wave gets 8 .. 32 and all 64 lanes serve them.
+// LDS rows and waves per SIMD of k_trace_static: 20 rows (5 KB: a pool of 896 entries -- pool_round pops fewer when it runs full) and
+// <= 72 VGPRs give 28 waves per CU instead of 25 with the 24 rows of the other pool kernels: any-hit kernel of the headline frame
+// 0.1937 -> 0.1877 ms, MeshViewer at 4K 5.59 -> 5.51 ms; 22 rows change nothing, 8 waves per SIMD (64 VGPRs, spilling) 0.216 / 0.226 ms
+#ifndef MIPT_STATIC_ROWS
+#define MIPT_STATIC_ROWS 20
+#endif
+#ifndef MIPT_STATIC_WAVES
+#define MIPT_STATIC_WAVES 7
+#endif
+#define MIPT_STATIC_ATTR __attribute__((amdgpu_waves_per_eu(MIPT_STATIC_WAVES, MIPT_STATIC_WAVES)))
 template <int MODE, int Q>
-__global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
+__global__ __launch_bounds__(64) MIPT_STATIC_ATTR void k_trace_static(TraceArgs a, uint32_t ppw)
 {
-    constexpr int kPoolCap = 24 * 64 - 384;
-    __shared__ uint32_t stk[24 * 64];
+    constexpr int kPoolCap = MIPT_STATIC_ROWS * 64 - 384;
+    __shared__ uint32_t stk[MIPT_STATIC_ROWS * 64];
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
@@ -1730,7 +1740,7 @@ __global__ __launch_bounds__(64) void k_trace_static(TraceArgs a, uint32_t ppw)
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
-        const uint2 work = tail_trace<MODE, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel,
+        const uint2 work = tail_trace<MODE, Q, kPoolCap>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel,
                                                MODE == 0 && (a.ray_flags & 16u) != 0u);
         (void)work;
 #if MIPT_PROBE_WAVES
