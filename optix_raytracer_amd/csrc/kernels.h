@@ -90,6 +90,17 @@ struct FrameConsts {           // the by-value part of Params (optixPathTracer.h
     uint32_t tile_shift;             // full frames: a tile of 64 paths covers (1 << tile_shift) x (64 >> tile_shift) pixels
 };
 
+// on != 0: the launch that ENDS a path writes its pixel (k_resolve's arithmetic for one slot: resolve_pixel) -- launches of one sample
+// per pixel over a full frame, where every pixel has exactly one path; k_resolve is then not launched.  A path ends in the shade
+// launch (no continuation ray; if it casts a last occlusion ray, that ray's queue entry carries bit 31 of the slot and the any-hit
+// launch writes the pixel) or in a path kernel.
+struct ResolveJob {
+    float4*   accum;
+    uint32_t* frame;           // may be null
+    uint32_t  subframe_index;
+    uint32_t  on;
+};
+
 struct RaygenJob {             // the arguments of k_raygen
     FrameConsts     fc;
     uint32_t        sample;
@@ -128,7 +139,8 @@ struct TileOrderJob {
 // ---- launches (all asynchronous on `st`) ----
 void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, uint32_t n_valid);
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
-                 PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const struct TraceOpts& o);
+                 PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const struct TraceOpts& o,
+                 const struct ResolveJob& resolve);
 void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = nullptr);   // host_live: pinned word that receives the new live count
 // ctr != null: the kernel also does launch_begin_sample's work for the pass (and clears the launch statistics when zero_stats)
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,
@@ -144,11 +156,12 @@ bool closest_launch_is_tiled(const DeviceBvh& bvh, uint32_t n_max, const TraceOp
 // mode 1: occluded flags (uint32 per ray); mode 2: accumulate contrib into result when unoccluded
 void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                       const uint32_t* n_ptr, uint32_t n_max, uint32_t* occluded, const float4* contrib, float4* result,
-                      DeviceCounters* ctr, const TraceOpts& o);
+                      DeviceCounters* ctr, const TraceOpts& o, const ResolveJob& resolve = ResolveJob{});
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
                   float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order = TileOrderJob{},
-                  uint32_t primary = 0u);    // ShadeArgs::primary: the pass's rays were made by the closest-hit launch (RaygenJob)
+                  uint32_t primary = 0u,     // ShadeArgs::primary: the pass's rays were made by the closest-hit launch (RaygenJob)
+                  const ResolveJob& resolve = ResolveJob{});
 void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots,
                     DeviceCounters* advance_ctr = nullptr);   // advance_ctr: also do the last bounce's launch_advance
 // SDK/imgui_test pipeline (imgui_kernels.hip)

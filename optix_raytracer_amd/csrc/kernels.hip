@@ -1115,6 +1115,7 @@ struct ShadeArgs {
     uint32_t                n_max;
     const void*             common_vertices;   // non-null when every hit-group record points at the same vertex buffer
     TileOrderJob            order;             // n_chunks != 0: the first n_chunks workgroups make the next launch's tile order
+    ResolveJob              resolve;           // on: a path that ends in this launch gets its pixel written (ResolveJob)
     uint32_t                primary;           // k_shade: bit 0: the entries are raygen_path<true>'s (state_b = slot, seed; depth 0, attenuation 1,
                                                // origin = the eye); bit 1: the accumulators start at zero (first sample of a launch)
 };
@@ -1297,7 +1298,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a)
                     ro4 = compact ? make_float4(a.fc.eye[0], a.fc.eye[1], a.fc.eye[2], 0.01f) : a.cur.ray_o[i];
                     rd4 = a.cur.ray_d[i];
                 });
-                a.result[slot] = res;
+                if (a.resolve.on && !o.push_next) {
+                    // the path ends here: with a last occlusion ray pending the any-hit launch finishes the pixel, else it is finished
+                    if (o.push_shadow) { o.sc.w = u2f(f2u(o.sc.w) | 0x80000000u); a.result[slot] = res; }
+                    else resolve_pixel(a.resolve, slot, res);
+                } else {
+                    a.result[slot] = res;
+                }
             }
         }
         const bool push_shadow = o.push_shadow, push_next = o.push_next;
@@ -1377,7 +1384,7 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
             ++n_closest;
             ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y;
         }
-        a.result[slot] = res;
+        if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res;
     }
     wave_add64(&a.ctr->closest_rays, n_closest);
     wave_add64(&a.ctr->shadow_rays, n_shadow);
@@ -1470,7 +1477,7 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
         active = active && o.push_next;
         if (active) { ++n_closest; ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y; }
     }
-    if (slot != kInvalidSlot) a.result[slot] = res;
+    if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
     wave_add64(&a.ctr->closest_rays, n_closest);
     wave_add64(&a.ctr->shadow_rays, n_shadow);
 #pragma unroll
@@ -1689,7 +1696,7 @@ __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
             if (active) { ++n_closest; ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y; }
         }
     }
-    if (slot != kInvalidSlot) a.result[slot] = res;
+    if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
     wave_add64(&a.ctr->closest_rays, n_closest);
     wave_add64(&a.ctr->shadow_rays, n_shadow);
 #pragma unroll
@@ -1927,9 +1934,10 @@ void launch_trace_closest(hipStream_t st, const DeviceBvh& bvh, const float4* ra
 
 void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, uint32_t stride,
                       const uint32_t* n_ptr, uint32_t n_max, uint32_t* occluded, const float4* contrib, float4* result,
-                      DeviceCounters* ctr, const TraceOpts& o)
+                      DeviceCounters* ctr, const TraceOpts& o, const ResolveJob& resolve)
 {
     TraceArgs a{};
+    a.resolve = resolve;
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.stride = stride; a.n_ptr = n_ptr; a.n_max = n_max;
     a.occluded = occluded; a.contrib = contrib; a.result = result; a.cursors = ctr->cursor_shadow; a.ctr = ctr;
     a.refill_min = o.refill_min; a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
@@ -1939,10 +1947,11 @@ void launch_trace_any(hipStream_t st, const DeviceBvh& bvh, const float4* ray_o,
 
 void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups,
                   uint32_t n_hitgroups, PathQueue cur, const float4* hits, PathQueue next, ShadowQueue shadow,
-                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order, uint32_t primary)
+                  float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TileOrderJob& order, uint32_t primary,
+                  const ResolveJob& resolve)
 {
     ShadeArgs a{};
-    a.order = order; a.primary = primary;
+    a.order = order; a.primary = primary; a.resolve = resolve;
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur; a.hits = hits;
     a.next = next; a.shadow = shadow; a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
     uint32_t blocks = (n_max + kShadeBlock - 1u) / kShadeBlock;
@@ -1953,10 +1962,12 @@ void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, c
 }
 
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
-                 PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TraceOpts& o)
+                 PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TraceOpts& o,
+                 const ResolveJob& resolve)
 {
     if (n_max == 0u) return;
     ShadeArgs a{};
+    a.resolve = resolve;
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur;
     a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
     // the pool variant needs a BVH that fits k_trace_pool's packed entries; MIPT_OPT_PERSISTENT != 3 selects the plain loop

@@ -138,6 +138,8 @@ struct MiptContext {
     uint32_t*   d_tile_width = nullptr;  // the class width the tiled kernel uses, adapted by the order job (starts at tile_class_width)
     bool        tile_class_fixed = false;    // MIPT_TILE_CLASS given: that width, not adapted
     uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
+    int       direct_resolve = 1;        // env MIPT_DIRECT_RESOLVE=0: always a k_resolve launch (A/B)
+    bool      advance_pending = false;   // the last launch ended without its final k_advance step (mipt_get_launch_stats applies it)
     int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
     int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
     int       tile_order_mode = 1;       // MIPT_OPT_TILE_ORDER: 0 image order, 1 (default) by the previous launch's costs
@@ -517,6 +519,11 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
     fc.batch_spp = batch ? fc.samples_per_launch : 0u;
     const uint32_t passes = batch ? 1u : fc.samples_per_launch;
     const uint32_t pass_valid = batch ? n_valid * fc.samples_per_launch : n_valid;
+    // one sample per pixel over a full frame: whichever launch ends a path writes its pixel, and k_resolve (13 us + a launch gap)
+    // is not launched (ResolveJob; env MIPT_DIRECT_RESOLVE=0 for the A/B)
+    ResolveJob rj{};
+    rj.accum = accum_out; rj.frame = frame_out; rj.subframe_index = fc.subframe_index;
+    rj.on = (ctx->direct_resolve && passes == 1u && !batch && fc.world == 0u && !ctx->count_visits) ? 1u : 0u;
     if (batch) fc.n_paths *= fc.samples_per_launch;
     const uint32_t n_paths = fc.n_paths;
     int rc = ensure_capacity(ctx, n_paths, batch ? n_slots * fc.samples_per_launch : n_slots);
@@ -580,7 +587,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         if (n_paths <= first_limit) {
             // a pass this small runs in the tail kernel from the first bounce on (Cornell 512x512: 0.73 -> 0.37 ms)
             TimedScope t(ctx, st, T_CLOSEST);
-            launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[0], ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, opts);
+            launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[0], ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, opts, rj);
             continue;
         }
         uint32_t bound = n_paths;      // upper bound of the live-path count (it only falls): the latest count the host has seen
@@ -613,11 +620,11 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             { TimedScope t(ctx, st, T_SHADE);
               launch_shade(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->hits, ctx->q[cur ^ 1], ctx->sq,
                            ctx->result, ctx->d_ctr, bound, ctx->common_vertices, bounce == 0u ? job : TileOrderJob{},
-                           bounce == 0u && fused_raygen ? (1u | ((s == 0u || batch) ? 2u : 0u)) : 0u); }
+                           bounce == 0u && fused_raygen ? (1u | ((s == 0u || batch) ? 2u : 0u)) : 0u, rj); }
             if (bounce == 0u && job.n_chunks != 0u) ctx->tile_order_valid = true;
             { TimedScope t(ctx, st, T_ANY);
               launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, bound, nullptr, ctx->sq.contrib,
-                               ctx->result, ctx->d_ctr, opts); }
+                               ctx->result, ctx->d_ctr, opts, rj); }
             if (fc.max_depth != 0u && bounce + 1u >= fc.max_depth && s + 1u == passes) { advance_in_resolve = true; break; }   // k_resolve does it
             launch_advance(st, ctx->d_ctr, ctx->h_pinned + bounce % kRing);
             cur ^= 1;
@@ -639,14 +646,17 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                     // few paths left: one launch runs them to their ends instead of five per bounce
                     TimedScope t(ctx, st, T_CLOSEST);
                     launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[cur], ctx->result, ctx->d_ctr, live,
-                                ctx->common_vertices, opts);
+                                ctx->common_vertices, opts, rj);
                     break;
                 }
             }
             if (bounce > 100000u) return ctx->fail(MIPT_ERROR_INTERNAL, "path length runaway");
         }
     }
-    { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots, advance_in_resolve ? ctx->d_ctr : nullptr); }
+    // (with ResolveJob the pixels are written already; the last bounce's queue bookkeeping, which rides on k_resolve, only feeds the
+    //  statistics then and is applied to their copy when they are read: advance_pending)
+    ctx->advance_pending = rj.on != 0u && advance_in_resolve;
+    if (!rj.on) { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots, advance_in_resolve ? ctx->d_ctr : nullptr); }
     ctx->bounces_on_device = true;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
@@ -705,6 +715,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_TILE_CLASS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) { c->tile_class_width = (uint32_t)v; c->tile_class_fixed = true; } }
     if (const char* e = std::getenv("MIPT_TILE_CLASS_INIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }   // adapted from there
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_DIRECT_RESOLVE")) c->direct_resolve = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_FUSE_RAYGEN")) c->fuse_raygen = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
@@ -1389,6 +1400,10 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
     DeviceCounters h;
     HIPCHK(ctx, hipMemcpy(&h, ctx->d_ctr, sizeof h, hipMemcpyDeviceToHost));
+    if (ctx->advance_pending) {            // advance() of the launch's last bounce (kernels.hip), on the copy
+        if (h.n_cur) h.iterations += 1;
+        h.closest_rays += h.n_next; h.shadow_rays += h.n_shadow;
+    }
     stats->closest_rays = h.closest_rays; stats->shadow_rays = h.shadow_rays;
     stats->node_visits = h.node_visits[0] + h.node_visits[1]; stats->tri_tests = h.tri_tests[0] + h.tri_tests[1];
     stats->shadow_node_visits = h.node_visits[1]; stats->shadow_tri_tests = h.tri_tests[1];
@@ -1449,6 +1464,7 @@ int mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* p, 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
+    ctx->advance_pending = false;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     imgui_run(st, *p, n_paths, device_bvh(acc), ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->rg_seed,
               ctx->d_ctr, trace_opts(ctx));
@@ -1571,6 +1587,7 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     }
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
+    ctx->advance_pending = false;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     WhBuffers B{};
     B.q[0] = ctx->q[0]; B.q[1] = ctx->q[1]; B.hits = ctx->hits; B.sh = ctx->im_sq; B.e1 = ctx->wh_e1; B.flags = ctx->im_flags;
@@ -1616,6 +1633,7 @@ int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
+    ctx->advance_pending = false;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, n);
     if (const char* e = std::getenv("MIPT_PROBE_WAVES")) {          // probe builds: address of a caller-allocated device buffer for per-wave records
@@ -1639,6 +1657,7 @@ int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, co
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
+    ctx->advance_pending = false;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, 0);
     if (const char* e = std::getenv("MIPT_PROBE_WAVES_ANY")) {      // probe builds: per-wave records of k_trace_static (tools/probe_shadow_order.py)

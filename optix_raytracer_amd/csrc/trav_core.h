@@ -120,8 +120,23 @@ struct TraceArgs {
     uint32_t*       tile_hist;    // [chunk][class] counts, zero when the launch starts
     uint32_t        class_width;  // cost units per class ...
     const uint32_t* class_width_dev;   // ... or, when not null, read from here (the shade launch's order job adapts it: TileOrderJob::width)
+    ResolveJob      resolve;      // MODE 2: an entry whose slot carries bit 31 is its path's last term -- write the pixel
     uint32_t        n_order;      // tiles the tables are laid out for (they are used only when the launch has exactly that many)
 };
+
+// k_resolve (optixPathTracer.cu:308-319) for one pixel of a launch with one sample per pixel: `r` is the finished accumulator
+__device__ __forceinline__ void resolve_pixel(const ResolveJob& rj, uint32_t slot, float4 r)
+{
+    const float inv_spp = 1.0f / 1.0f;
+    f3 c = mk3(r.x, r.y, r.z) * inv_spp;
+    if (rj.subframe_index > 0u) {
+        const float a = 1.0f / (float)(rj.subframe_index + 1u);
+        const float4 p = rj.accum[slot];
+        c = lerp3(mk3(p.x, p.y, p.z), c, a);
+    }
+    rj.accum[slot] = make_float4(c.x, c.y, c.z, 1.0f);
+    if (rj.frame) rj.frame[slot] = make_color(c);
+}
 
 template <int MODE>
 __device__ __forceinline__ void finish_ray(const TraceArgs& a, const Trav& T, uint32_t ray, bool hit)
@@ -131,7 +146,19 @@ __device__ __forceinline__ void finish_ray(const TraceArgs& a, const Trav& T, ui
     } else if (MODE == 1) {
         a.occluded[ray] = hit ? 1u : 0u;
     } else {
-        if (!hit) {
+        if (a.resolve.on) {
+            const float4 c = a.contrib[ray];
+            const uint32_t sw = f2u(c.w), slot = sw & 0x7fffffffu;
+            if ((sw >> 31) != 0u) {                      // the path's last term: its pixel is finished here
+                float4 r = a.result[slot];
+                if (!hit) { r.x += c.x; r.y += c.y; r.z += c.z; }
+                resolve_pixel(a.resolve, slot, r);
+            } else if (!hit) {
+                float4 r = a.result[slot];
+                r.x += c.x; r.y += c.y; r.z += c.z;
+                a.result[slot] = r;
+            }
+        } else if (!hit) {
             // result += radiance * attenuation (optixPathTracer.cu:292); one path per slot is in flight
             const float4 c = a.contrib[ray];
             const uint32_t slot = f2u(c.w);
