@@ -732,6 +732,12 @@ __device__ __forceinline__ void record_tile_cost(const TraceArgs& a, uint32_t ti
     atomicAdd(&a.tile_hist[(tile / kOrderChunk) * kOrderClasses + c], 1u);
 }
 
+#ifndef MIPT_TILED_ROWS        // experiments: LDS rows / waves per SIMD of the tiled kernel's small build (trees up to that many levels)
+#define MIPT_TILED_ROWS 24
+#endif
+#ifndef MIPT_TILED_WAVES
+#define MIPT_TILED_WAVES 6
+#endif
 __device__ __forceinline__ void begin_sample(DeviceCounters* c, uint32_t i, uint32_t n_paths, uint32_t n_valid, uint32_t zero_stats);
 template <bool COMPACT>
 __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t sample, const PathQueue& q, uint32_t* rg_seed, float4* result,
@@ -741,7 +747,7 @@ __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t samp
 // bookkeeping -- a raygen launch of its own is 25 us of stores plus a launch gap in front of this kernel, which has the store
 // bandwidth to spare, and the rays need not be read back.
 template <int MODE, int ROWS, int Q, bool RG = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS == 24 ? 6 : 5, ROWS == 24 ? 6 : 5)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS <= 24 ? MIPT_TILED_WAVES : 5, ROWS <= 24 ? MIPT_TILED_WAVES : 5)))
 void k_trace_pool(TraceArgs a, RaygenJob rg)
 {
     // ONE LDS block per wave: in the bulk phase ROWS rows of 64 lanes (the lanes' stacks), in the tail phase the entry
@@ -1905,7 +1911,7 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o, const 
                 if (a.bvh.node_fmt == 2 && o.tiled_bvh4 && a.bvh.stack4 <= 32u) {
                     if (a.bvh.stack4 <= 24u) MIPT_LAUNCH_TILED(24, 2); else MIPT_LAUNCH_TILED(32, 2);
                 } else if (a.bvh.node_fmt >= 1) {
-                    if (a.bvh.depth <= 24u) MIPT_LAUNCH_TILED(24, 1); else MIPT_LAUNCH_TILED(32, 1);
+                    if (a.bvh.depth <= (uint32_t)MIPT_TILED_ROWS) MIPT_LAUNCH_TILED(MIPT_TILED_ROWS, 1); else MIPT_LAUNCH_TILED(32, 1);
                 } else {
                     if (a.bvh.depth <= 24u) MIPT_LAUNCH_TILED(24, 0); else MIPT_LAUNCH_TILED(32, 0);
                 }
