@@ -120,6 +120,7 @@ struct TraceOpts {
     int  blocks_user, num_cus; // the grid was set with MIPT_OPT_TRACE_GRID; CUs of the device
     const uint32_t* tile_order; uint8_t* tile_cost; uint32_t* tile_hist; uint32_t n_order, class_width;   // tiled closest-hit launches: TraceArgs
     const uint32_t* class_width_dev;
+    int  tail_refill;          // k_tail_pool2 as one set of resident waves that refill ended paths from the queue: 0 never, 1 big trees, 2 always
     int  tiled_bvh4;           // experiments: the tiled kernel walks the BVH4 mirror too (when a lane's stack over it fits 32 rows)
 };
 

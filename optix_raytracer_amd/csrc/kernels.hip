@@ -1631,7 +1631,12 @@ __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, c
 }
 
 template <int Q>
-__global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
+// `refill` != 0: the launch has fewer waves than ppw-path chunks (one set of resident waves), and a wave whose paths have ended
+// takes new ones from the rest of the queue -- the survivors of a Russian-roulette pass thin out geometrically, and a wave that
+// walks its last two paths for forty bounces does so at the price of sixty-four.  Path ranges are dealt per XCD segment
+// (DeviceCounters::cursor_closest, zero at the start of a bounce): segment s = blockIdx % 8 holds the paths [s, s + 1) * seg_len,
+// its waves start on the first chunks and the cursor counts what has been taken beyond them.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tail_pool2(ShadeArgs a, uint32_t ppw, uint32_t refill)
 {
     constexpr int kCap = 1152;
     __shared__ uint32_t lds[kCap + 128 + 3 * 64 + 14 * 64];
@@ -1645,16 +1650,53 @@ __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
     uint32_t n = a.ctr->n_cur;
     n = n < a.n_max ? n : a.n_max;
-    const uint32_t i = blockIdx.x * ppw + threadIdx.x;
-    uint32_t n_closest = 0, n_shadow = 0, n_iter = 0;
+    // without refill: wave w owns the paths [w, w + 1) * ppw.  With: the segment's range and this wave's first chunk in it
+    const uint32_t seg = blockIdx.x & (kNumSegments - 1), waves_seg = gridDim.x / kNumSegments;
+    const uint32_t seg_len = refill ? (n + kNumSegments - 1) / kNumSegments : 0u;
+    const uint32_t seg_lo = seg * seg_len, seg_hi = seg_lo + seg_len < n ? seg_lo + seg_len : n;
+    uint32_t i = refill ? seg_lo + (blockIdx.x / kNumSegments) * ppw + threadIdx.x : blockIdx.x * ppw + threadIdx.x;
+    const uint32_t i_end = refill ? seg_hi : n;
+    uint32_t n_closest = 0, n_shadow = 0, n_iter = 0, n_iter_max = 0;
     uint32_t slot = kInvalidSlot, depth = 0;
-    if (i < n && threadIdx.x < ppw) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
+    if (i < i_end && threadIdx.x < ppw) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
     bool active = slot != kInvalidSlot;
     float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
     if (active) { ro4 = a.cur.ray_o[i]; rd4 = a.cur.ray_d[i]; sa = a.cur.state_a[i]; res = a.result[slot]; }
     bool has_s = false;                          // an occlusion ray of the previous bounce is waiting (in LDS)
     float cx = 0.f, cy = 0.f, cz = 0.f;          // what it adds when nothing is in its way
-    while (__ballot(active || has_s) != 0ull) {
+    uint32_t fslot = kInvalidSlot;               // refill: the waiting occlusion ray is the last term of the ENDED path of this slot
+                                                 // (its accumulator is parked in result[fslot]; the lane may carry a new path already)
+    bool dry = refill == 0u;                     // nothing left to take
+    uint32_t try_seg = seg;
+    while (__ballot(active || has_s) != 0ull || !dry) {
+        // ---- refill: lanes below ppw without a path take the next paths of the queue
+        if (!dry) {
+            const bool want = !active && (uint32_t)lane < ppw;
+            const unsigned long long mw = __ballot(want);
+            const uint32_t k = (uint32_t)__popcll(mw);
+            if (k >= refill) {                   // enough of the wave is free: one cursor atomic for all of them
+                uint32_t base = 0u, lo = 0u, hi = 0u;
+                for (;;) {
+                    lo = try_seg * seg_len + waves_seg * ppw; hi = (try_seg + 1u) * seg_len < n ? (try_seg + 1u) * seg_len : n;
+                    if (lane == 0) base = atomicAdd(&a.ctr->cursor_closest[try_seg * kCursorStride], k);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (lo + base < hi) break;                                   // at least one path for us
+                    try_seg = (try_seg + 1u) & (kNumSegments - 1);               // this segment is used up: the next one, round once
+                    if (try_seg == seg) { dry = true; break; }
+                }
+                if (!dry) {
+                    const uint32_t j = lo + base + lane_rank(mw);
+                    if (want && j < hi) {
+                        const uint2 sb = a.cur.state_b[j];
+                        if (sb.x != kInvalidSlot) {
+                            slot = sb.x; depth = sb.y; n_iter = 0u;
+                            ro4 = a.cur.ray_o[j]; rd4 = a.cur.ray_d[j]; sa = a.cur.state_a[j]; res = a.result[slot];
+                            active = true;
+                        }
+                    }
+                }
+            }
+        }
         Trav T;
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
@@ -1672,7 +1714,12 @@ __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
         while (psize > 0) pool_round2<kCap, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, sray, lane, T, psize);
         // the previous bounce's light term first: the accumulator gets its terms in the reference's order
         if (has_s) {
-            if (sh_done[lane] == 0u) { res.x += cx; res.y += cy; res.z += cz; }      // finish_ray<2>
+            if (fslot != kInvalidSlot) {          // ... of a path that has ended: finish its pixel
+                float4 r = a.result[fslot];
+                if (sh_done[lane] == 0u) { r.x += cx; r.y += cy; r.z += cz; }
+                if (a.resolve.on) resolve_pixel(a.resolve, fslot, r); else a.result[fslot] = r;
+                fslot = kInvalidSlot;
+            } else if (sh_done[lane] == 0u) { res.x += cx; res.y += cy; res.z += cz; }      // finish_ray<2>
             has_s = false;
         }
         if (active) {
@@ -1700,9 +1747,19 @@ __global__ __launch_bounds__(64) void k_tail_pool2(ShadeArgs a, uint32_t ppw)
             }
             active = o.push_next;
             if (active) { ++n_closest; ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y; }
+            else if (refill) {
+                // the path has ended and the lane may get another: its pixel is finished now, or -- with its last occlusion ray
+                // still to come -- its accumulator waits in result[] for that ray's pass
+                n_iter_max = n_iter > n_iter_max ? n_iter : n_iter_max;
+                if (has_s) { a.result[slot] = res; fslot = slot; }
+                else if (a.resolve.on) resolve_pixel(a.resolve, slot, res);
+                else a.result[slot] = res;
+                slot = kInvalidSlot;
+            }
         }
     }
     if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
+    n_iter = n_iter > n_iter_max ? n_iter : n_iter_max;
     wave_add64(&a.ctr->closest_rays, n_closest);
     wave_add64(&a.ctr->shadow_rays, n_shadow);
 #pragma unroll
@@ -1997,9 +2054,19 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
         }
         if (fc.max_depth != 1u && bvh.pool2_ok != 0u)
         {                                                                                                    // more than one bounce: two rays per pass
-            if (bvh.node_fmt == 2)      hipLaunchKernelGGL(k_tail_pool2<2>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
-            else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool2<1>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
-            else                        hipLaunchKernelGGL(k_tail_pool2<0>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+            // more chunks than ONE set of resident waves (16 per CU): that set, each wave refilling its ended paths from the rest
+            // of the queue (k_tail_pool2) -- where a pass is long enough to pay for the refill's own latency (a cursor atomic and two
+            // dependent loads inside the wave's loop): unbounded depth on the 1 M-triangle scene at 1080p 4.00 -> 3.59 ms (refill at
+            // 1/4 / 1/2 / 3/4 / all lanes free: 3.59 / 3.60 / 3.67 / 3.84), but Cornell 1080p spp 16 8.28 -> 8.78 ms, a 100 k-triangle
+            // scene 6.03 -> 6.20 ms, the 240 k-triangle hall unchanged -- hence only over big trees (>= 2^18 nodes)
+            const int e_refill = o.tail_refill;          // env MIPT_TAIL_REFILL at context creation: 0 never, 1 (default) as described, 2 whenever it can
+            const uint32_t resident = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256) * 16u / kNumSegments * kNumSegments;
+            uint32_t g = (n_max + ppw - 1u) / ppw, refill = 0u;
+            const bool long_paths = (fc.max_depth == 0u || fc.max_depth > 8u) && bvh.tri_byte_off / 64u >= (1u << 18);
+            if (g > resident && (e_refill == 2 || (e_refill == 1 && long_paths))) { g = resident; refill = ppw / 4u; }     // refill when a quarter is free
+            if (bvh.node_fmt == 2)      hipLaunchKernelGGL(k_tail_pool2<2>, dim3(g), dim3(64), 0, st, a, ppw, refill);
+            else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool2<1>, dim3(g), dim3(64), 0, st, a, ppw, refill);
+            else                        hipLaunchKernelGGL(k_tail_pool2<0>, dim3(g), dim3(64), 0, st, a, ppw, refill);
         }
         else if (bvh.node_fmt == 2) hipLaunchKernelGGL(k_tail_pool<2>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
         else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool<1>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);

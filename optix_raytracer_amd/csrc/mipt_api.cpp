@@ -138,6 +138,7 @@ struct MiptContext {
     uint32_t*   d_tile_width = nullptr;  // the class width the tiled kernel uses, adapted by the order job (starts at tile_class_width)
     bool        tile_class_fixed = false;    // MIPT_TILE_CLASS given: that width, not adapted
     uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
+    int       tail_refill = 1;           // env MIPT_TAIL_REFILL (TraceOpts::tail_refill)
     int       direct_resolve = 1;        // env MIPT_DIRECT_RESOLVE=0: always a k_resolve launch (A/B)
     bool      advance_pending = false;   // the last launch ended without its final k_advance step (mipt_get_launch_stats applies it)
     int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
@@ -295,6 +296,7 @@ TraceOpts trace_opts(const MiptContext* c)
     o.blocks_user = c->blocks_per_cu > 0 ? 1 : 0; o.num_cus = c->num_cus;
     o.refill_min = c->refill_min; o.steal_min = c->steal_min; o.burst_bulk = c->burst_bulk; o.burst_dry = c->burst_dry;
     o.tile_group = c->tile_group;
+    o.tail_refill = c->tail_refill;
     o.tiled_bvh4 = c->tiled_bvh4;
     return o;
 }
@@ -715,6 +717,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_TILE_CLASS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) { c->tile_class_width = (uint32_t)v; c->tile_class_fixed = true; } }
     if (const char* e = std::getenv("MIPT_TILE_CLASS_INIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }   // adapted from there
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_TAIL_REFILL")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tail_refill = v; }
     if (const char* e = std::getenv("MIPT_DIRECT_RESOLVE")) c->direct_resolve = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_FUSE_RAYGEN")) c->fuse_raygen = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }

@@ -175,6 +175,40 @@ def test_cost_ordered_tiles_of_a_shard(big):
     assert np.array_equal(out[1][0], out[1][1]) and not np.array_equal(out[1][0], out[1][2])
 
 
+@pytest.mark.parametrize("scene_kind,max_depth", [("soup", 0), ("cornell", 0), ("soup", 12)])
+def test_path_kernel_refilling_its_waves_changes_nothing(scene_kind, max_depth, monkeypatch):
+    """k_tail_pool2 as ONE set of resident waves whose lanes take new paths from the queue when theirs have ended (by default only
+    over big trees; MIPT_TAIL_REFILL=2 forces it wherever the queue is longer than the resident waves hold): 786 k paths from the
+    first bounce on, against the same launch without refill -- pixels, ray counters, reported depth -- and the oracle on pixels"""
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    scene = scenes.random_soup(60_000, seed_tag=9) if scene_kind == "soup" else scenes.cornell_box()
+    w, h = 1024, 768
+    out = {}
+    for refill in ("2", "0"):
+        monkeypatch.setenv("MIPT_TAIL_REFILL", refill)          # read when the context is created
+        st = PT.make_state(scene, w, h, 1, 0, max_depth=max_depth)
+        ob = PT.OutputBuffer(w, h, st.device)
+        frames = []
+        for k in range(2):
+            st.params.subframe_index = k
+            PT.launchSubframe(ob, st)
+            frames.append((st.accum.cpu().numpy().copy(), ob.getHostPointer().copy(), st.context.launch_stats()))
+        out[refill] = frames
+        if refill == "2":
+            nodes, tris = st.context.accel_export(st.gas_handle)
+        PT.cleanupState(st)
+    for (a2, f2, s2), (a0, f0, s0) in zip(out["2"], out["0"]):
+        assert np.array_equal(a2.view(np.uint32), a0.view(np.uint32)) and np.array_equal(f2, f0) and s2 == s0
+    osc = O.Scene(scene).set_bvh(nodes, tris)
+    idx = np.random.default_rng(4).integers(0, w * h, 20000).astype(np.uint32)
+    acc = np.zeros((idx.shape[0], 4), np.float32)
+    for k in range(2):
+        acc, _ = osc.render_pixels(scenes.launch_desc(scene, w, h, 1, subframe=k), idx, max_depth=max_depth, prev=acc)
+    assert np.array_equal(out["2"][1][0].reshape(-1, 4)[idx].view(np.uint32), acc.view(np.uint32))
+
+
 def test_config2_cornell_1080p_spp16():
     """BASELINE config 2: Cornell box 1920x1080 spp 16, one launch, unbounded (Russian roulette) depth.
     33 M paths: the oracle checks 30 k random pixels bit for bit and the ray counters of the whole frame
