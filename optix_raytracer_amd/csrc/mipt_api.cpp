@@ -521,11 +521,11 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
     fc.batch_spp = batch ? fc.samples_per_launch : 0u;
     const uint32_t passes = batch ? 1u : fc.samples_per_launch;
     const uint32_t pass_valid = batch ? n_valid * fc.samples_per_launch : n_valid;
-    // one sample per pixel over a full frame: whichever launch ends a path writes its pixel, and k_resolve (13 us + a launch gap)
+    // one sample per pixel over a frame or a rank's shard of it: whichever launch ends a path writes its pixel, and k_resolve (13 us + a launch gap)
     // is not launched (ResolveJob; env MIPT_DIRECT_RESOLVE=0 for the A/B)
     ResolveJob rj{};
     rj.accum = accum_out; rj.frame = frame_out; rj.subframe_index = fc.subframe_index;
-    rj.on = (ctx->direct_resolve && passes == 1u && !batch && fc.world == 0u && !ctx->count_visits) ? 1u : 0u;
+    rj.on = (ctx->direct_resolve && passes == 1u && !batch && !ctx->count_visits) ? 1u : 0u;       // (a rank's shard too: slot = its compact index)
     if (batch) fc.n_paths *= fc.samples_per_launch;
     const uint32_t n_paths = fc.n_paths;
     int rc = ensure_capacity(ctx, n_paths, batch ? n_slots * fc.samples_per_launch : n_slots);
