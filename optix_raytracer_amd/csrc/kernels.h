@@ -29,6 +29,7 @@ struct DeviceCounters {
     unsigned long long iterations;                      // wavefront bounces that had live paths (+ the tails of finished passes)
     unsigned long long tail_max;                        // deepest path of the current pass's k_tail launch (bounces it ran)
     unsigned long long dbg[6];
+    uint32_t epoch;            // path kernels that do their own begin_sample (TailArgs): the launch whose first workgroup is through it
 };
 
 struct DeviceBvh {
@@ -141,7 +142,9 @@ struct TileOrderJob {
 void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, uint32_t n_valid);
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
                  PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const struct TraceOpts& o,
-                 const struct ResolveJob& resolve);
+                 const struct ResolveJob& resolve, const struct RaygenJob* rg = nullptr, uint32_t epoch = 0u);
+// rg is allowed (the launch makes the pass's primary paths itself: no k_raygen in front of it) when the pool forms of the path kernel run
+bool tail_launch_makes_rays(const DeviceBvh& bvh, const struct TraceOpts& o);
 void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = nullptr);   // host_live: pinned word that receives the new live count
 // ctr != null: the kernel also does launch_begin_sample's work for the pass (and clears the launch statistics when zero_stats)
 void launch_raygen(hipStream_t st, const FrameConsts& fc, uint32_t sample, PathQueue q, uint32_t* rg_seed, float4* result,

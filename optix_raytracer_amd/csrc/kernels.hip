@@ -739,9 +739,17 @@ __device__ __forceinline__ void record_tile_cost(const TraceArgs& a, uint32_t ti
 #define MIPT_TILED_WAVES 6
 #endif
 __device__ __forceinline__ void begin_sample(DeviceCounters* c, uint32_t i, uint32_t n_paths, uint32_t n_valid, uint32_t zero_stats);
-template <bool COMPACT>
+template <int WR>
 __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t sample, const PathQueue& q, uint32_t* rg_seed, float4* result,
-                                            uint32_t i, float4& ro, float4& rd);
+                                            uint32_t i, float4& ro, float4& rd, uint32_t& slot_out, uint32_t& seed_out);
+// a RaygenJob that is the kernel's `Member` argument, read through the kernel-argument segment where it is used: as a plain
+// argument its ~50 words would stay in SGPRs across the traversal loops (k_trace_pool spilled 17 SGPRs and 18 VGPRs that way)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MIPT_RG_JOB_PTR(Type, member, fallback) \
+    ((const __attribute__((address_space(4))) RaygenJob*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Type, member)))
+#else
+#define MIPT_RG_JOB_PTR(Type, member, fallback) (&(fallback))          /* (the host pass only parses the kernels) */
+#endif
 
 // RG: the launch makes the rays it traces (the pass's primary rays: raygen_path, k_raygen's body) and does the pass's queue
 // bookkeeping -- a raygen launch of its own is 25 us of stores plus a launch gap in front of this kernel, which has the store
@@ -822,8 +830,8 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
 #endif
                 const FrameConsts fc = rp->fc;
                 const PathQueue q = rp->q;
-                float4 ro, rd;
-                raygen_path<true>(fc, rp->sample, q, rp->rg_seed, rp->result, ray, ro, rd);
+                float4 ro, rd; uint32_t slot_, seed_;
+                raygen_path<1>(fc, rp->sample, q, rp->rg_seed, rp->result, ray, ro, rd, slot_, seed_);
                 trav_init(T, ro, rd);
             } else {
                 trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
@@ -1008,13 +1016,16 @@ __global__ void k_advance(DeviceCounters* c, uint32_t* host_live)
 // steps from the pixel's tea<4> seed, exactly the state the sequential loop would have.
 // The first workgroup also does the pass's queue bookkeeping (begin_sample: a launch of its own costs ~8 us with its gap).
 // one path of the pass: writes its queue entry, the raygen seed and (first sample) the cleared accumulator; returns the ray.
-// COMPACT (the tiled kernel's own raygen; read by the first shade launch of the pass only, ShadeArgs::primary): the entry is
+// WR = 1 (the tiled kernel's own raygen; read by the first shade launch of the pass only, ShadeArgs::primary): the entry is
 // direction + (slot, seed) -- 24 bytes instead of 56 -- because origin, interval, attenuation and depth of a primary path are
 // constants, and the accumulator is not cleared: the shade launch starts from zero instead of reading it.
-template <bool COMPACT>
+// WR = 2 (the path kernels' own raygen): no entry at all, the path stays in the lane's registers (slot_out, seed_out).
+template <int WR>
 __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t sample, const PathQueue& q, uint32_t* rg_seed, float4* result,
-                                            uint32_t i, float4& ro, float4& rd)
+                                            uint32_t i, float4& ro, float4& rd, uint32_t& slot_out, uint32_t& seed_out)
 {
+    constexpr bool COMPACT = WR != 0;
+    slot_out = kInvalidSlot; seed_out = 0u;
     uint32_t i0 = i;
     if (fc.batch_spp != 0u) { sample = i / fc.paths_per_sample; i0 = i - sample * fc.paths_per_sample; }
     int px, py; uint32_t slot; bool valid;
@@ -1038,7 +1049,7 @@ __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t samp
         ro = make_float4(0.f, 0.f, 0.f, 1.0f);
         rd = make_float4(0.f, 0.f, 1.f, 0.0f);
         if (!COMPACT) { q.ray_o[i] = ro; q.ray_d[i] = rd; q.state_a[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        q.state_b[i] = make_uint2(kInvalidSlot, 0u);
+        if (WR != 2) q.state_b[i] = make_uint2(kInvalidSlot, 0u);
         if (fc.world != 0u && (sample == 0u || fc.batch_spp != 0u)) result[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         return false;
     }
@@ -1058,6 +1069,8 @@ __device__ __forceinline__ bool raygen_path(const FrameConsts& fc, uint32_t samp
     const f3 dir = normalize(dx * U + dy * V + W);
     ro = make_float4(fc.eye[0], fc.eye[1], fc.eye[2], 0.01f);
     rd = make_float4(dir.x, dir.y, dir.z, 1e16f);
+    slot_out = slot; seed_out = seed;
+    if (WR == 2) return true;
     q.ray_d[i]   = rd;
     if (COMPACT) {
         q.state_b[i] = make_uint2(slot, seed);
@@ -1077,8 +1090,8 @@ __global__ __launch_bounds__(256) void k_raygen(FrameConsts fc, uint32_t sample,
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_zero) zero_words[i] = 0u;
     if (i >= fc.n_paths) return;
-    float4 ro, rd;
-    raygen_path<false>(fc, sample, q, rg_seed, result, i, ro, rd);
+    float4 ro, rd; uint32_t slot, seed;
+    raygen_path<0>(fc, sample, q, rg_seed, result, i, ro, rd, slot, seed);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1436,9 +1449,71 @@ __device__ __forceinline__ uint2 tail_trace(const __amdgpu_buffer_rsrc_t blob, c
     return work;
 }
 
-template <int Q>
-__global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
+// The path kernels' arguments.  rg.ctr != null: the pass starts in this launch, which then makes the primary paths itself
+// (raygen_path<2>: path i of the pass instead of queue entry i, nothing written but the raygen seed) and does the pass's queue
+// bookkeeping in its first workgroup, instead of a k_raygen launch in front of it.  That bookkeeping reads, clears and adds to the
+// launch statistics, to which every wave adds at its end -- on a small scene a wave can be through its paths before the first
+// workgroup is through eight dependent global accesses (seen: one continuation ray missing from closest_rays on Cornell 96x64).
+// So the first workgroup publishes `epoch` (a number the host counts up per such launch) in DeviceCounters when it is done, and a
+// wave looks for it before its own additions: the first workgroup is dispatched first and waits for nobody, so the wait ends
+// (and is bounded anyway); it is almost never entered.
+struct TailArgs {
+    ShadeArgs a;
+    uint32_t  ppw, refill;
+    RaygenJob rg;
+    uint32_t  epoch;
+};
+
+__device__ __forceinline__ void tail_publish_epoch(DeviceCounters* c, uint32_t epoch)
 {
+    if (threadIdx.x == 0u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&c->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void tail_await_epoch(DeviceCounters* c, uint32_t epoch)
+{
+    if (threadIdx.x == 0u) {
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+            if (__hip_atomic_load(&c->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
+// one path of a path kernel: from the queue, or made here
+__device__ __forceinline__ void tail_load_path(const TailArgs& k, const bool use_rg, const uint32_t j, uint32_t& slot, uint32_t& depth,
+                                               float4& ro4, float4& rd4, float4& sa, float4& res)
+{
+    const ShadeArgs& a = k.a;
+    if (use_rg) {
+        auto rp = MIPT_RG_JOB_PTR(TailArgs, rg, k.rg);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(rp));
+#endif
+        const FrameConsts fc = rp->fc;
+        const uint32_t sample = rp->sample;
+        uint32_t seed = 0u;
+        const bool valid = raygen_path<2>(fc, sample, PathQueue{}, rp->rg_seed, rp->result, j, ro4, rd4, slot, seed);
+        depth = 0u;
+        sa = make_float4(1.0f, 1.0f, 1.0f, u2f(seed));
+        res = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && !(sample == 0u || fc.batch_spp != 0u)) res = rp->result[slot];       // later samples add to the accumulator
+    } else {
+        const uint2 sb = a.cur.state_b[j];
+        slot = sb.x; depth = sb.y;
+        if (slot != kInvalidSlot) { ro4 = a.cur.ray_o[j]; rd4 = a.cur.ray_d[j]; sa = a.cur.state_a[j]; res = a.result[slot]; }
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(64) void k_tail_pool(TailArgs k)
+{
+    const ShadeArgs& a = k.a;
+    const uint32_t ppw = k.ppw;
+    const bool use_rg = k.rg.ctr != nullptr;
+    if (use_rg && blockIdx.x == 0u) { begin_sample(k.rg.ctr, threadIdx.x, k.rg.fc.n_paths, k.rg.n_valid, k.rg.zero_stats); tail_publish_epoch(k.rg.ctr, k.epoch); }
     constexpr int kPoolCap = 24 * 64 - 384;
     __shared__ uint32_t stk[24 * 64];
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
@@ -1447,15 +1522,14 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
     uint32_t* const sh_done = stk + kPoolCap + 320;
     const int lane = (int)threadIdx.x;
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
-    uint32_t n = a.ctr->n_cur;
-    n = n < a.n_max ? n : a.n_max;
+    uint32_t n = a.n_max;
+    if (!use_rg) { const uint32_t m = a.ctr->n_cur; n = m < n ? m : n; }
     const uint32_t i = blockIdx.x * ppw + threadIdx.x;
     uint32_t n_closest = 0, n_shadow = 0, n_iter = 0;
     uint32_t slot = kInvalidSlot, depth = 0;
-    if (i < n && threadIdx.x < ppw) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
-    bool active = slot != kInvalidSlot;
     float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
-    if (active) { ro4 = a.cur.ray_o[i]; rd4 = a.cur.ray_d[i]; sa = a.cur.state_a[i]; res = a.result[slot]; }
+    if (i < n && threadIdx.x < ppw) tail_load_path(k, use_rg, i, slot, depth, ro4, rd4, sa, res);
+    bool active = slot != kInvalidSlot;
     while (__ballot(active) != 0ull) {
         Trav T;
         trav_init(T, ro4, rd4);
@@ -1484,6 +1558,7 @@ __global__ __launch_bounds__(64) void k_tail_pool(ShadeArgs a, uint32_t ppw)
         if (active) { ++n_closest; ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y; }
     }
     if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
+    if (use_rg) tail_await_epoch(a.ctr, k.epoch);
     wave_add64(&a.ctr->closest_rays, n_closest);
     wave_add64(&a.ctr->shadow_rays, n_shadow);
 #pragma unroll
@@ -1636,8 +1711,12 @@ template <int Q>
 // walks its last two paths for forty bounces does so at the price of sixty-four.  Path ranges are dealt per XCD segment
 // (DeviceCounters::cursor_closest, zero at the start of a bounce): segment s = blockIdx % 8 holds the paths [s, s + 1) * seg_len,
 // its waves start on the first chunks and the cursor counts what has been taken beyond them.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tail_pool2(ShadeArgs a, uint32_t ppw, uint32_t refill)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tail_pool2(TailArgs k)
 {
+    const ShadeArgs& a = k.a;
+    const uint32_t ppw = k.ppw, refill = k.refill;
+    const bool use_rg = k.rg.ctr != nullptr;
+    if (use_rg && blockIdx.x == 0u) { begin_sample(k.rg.ctr, threadIdx.x, k.rg.fc.n_paths, k.rg.n_valid, k.rg.zero_stats); tail_publish_epoch(k.rg.ctr, k.epoch); }
     constexpr int kCap = 1152;
     __shared__ uint32_t lds[kCap + 128 + 3 * 64 + 14 * 64];
     uint32_t* const stk = lds;
@@ -1648,8 +1727,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     float* const sray = reinterpret_cast<float*>(lds + kCap + 320);
     const int lane = (int)threadIdx.x;
     const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
-    uint32_t n = a.ctr->n_cur;
-    n = n < a.n_max ? n : a.n_max;
+    uint32_t n = a.n_max;
+    if (!use_rg) { const uint32_t m = a.ctr->n_cur; n = m < n ? m : n; }
     // without refill: wave w owns the paths [w, w + 1) * ppw.  With: the segment's range and this wave's first chunk in it
     const uint32_t seg = blockIdx.x & (kNumSegments - 1), waves_seg = gridDim.x / kNumSegments;
     const uint32_t seg_len = refill ? (n + kNumSegments - 1) / kNumSegments : 0u;
@@ -1658,27 +1737,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint32_t i_end = refill ? seg_hi : n;
     uint32_t n_closest = 0, n_shadow = 0, n_iter = 0, n_iter_max = 0;
     uint32_t slot = kInvalidSlot, depth = 0;
-    if (i < i_end && threadIdx.x < ppw) { const uint2 sb = a.cur.state_b[i]; slot = sb.x; depth = sb.y; }
-    bool active = slot != kInvalidSlot;
     float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
-    if (active) { ro4 = a.cur.ray_o[i]; rd4 = a.cur.ray_d[i]; sa = a.cur.state_a[i]; res = a.result[slot]; }
+    if (i < i_end && threadIdx.x < ppw) tail_load_path(k, use_rg, i, slot, depth, ro4, rd4, sa, res);
+    bool active = slot != kInvalidSlot;
     bool has_s = false;                          // an occlusion ray of the previous bounce is waiting (in LDS)
     float cx = 0.f, cy = 0.f, cz = 0.f;          // what it adds when nothing is in its way
     uint32_t fslot = kInvalidSlot;               // refill: the waiting occlusion ray is the last term of the ENDED path of this slot
                                                  // (its accumulator is parked in result[fslot]; the lane may carry a new path already)
     bool dry = refill == 0u;                     // nothing left to take
+    bool synced = false;                         // (own raygen) the first workgroup's bookkeeping has been seen
     uint32_t try_seg = seg;
     while (__ballot(active || has_s) != 0ull || !dry) {
         // ---- refill: lanes below ppw without a path take the next paths of the queue
         if (!dry) {
             const bool want = !active && (uint32_t)lane < ppw;
             const unsigned long long mw = __ballot(want);
-            const uint32_t k = (uint32_t)__popcll(mw);
-            if (k >= refill) {                   // enough of the wave is free: one cursor atomic for all of them
+            const uint32_t kfree = (uint32_t)__popcll(mw);
+            if (kfree >= refill) {
+                if (use_rg && !synced) { tail_await_epoch(a.ctr, k.epoch); synced = true; }      // the cursors are cleared by the first workgroup                   // enough of the wave is free: one cursor atomic for all of them
                 uint32_t base = 0u, lo = 0u, hi = 0u;
                 for (;;) {
                     lo = try_seg * seg_len + waves_seg * ppw; hi = (try_seg + 1u) * seg_len < n ? (try_seg + 1u) * seg_len : n;
-                    if (lane == 0) base = atomicAdd(&a.ctr->cursor_closest[try_seg * kCursorStride], k);
+                    if (lane == 0) base = atomicAdd(&a.ctr->cursor_closest[try_seg * kCursorStride], kfree);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                     if (lo + base < hi) break;                                   // at least one path for us
                     try_seg = (try_seg + 1u) & (kNumSegments - 1);               // this segment is used up: the next one, round once
@@ -1687,12 +1767,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (!dry) {
                     const uint32_t j = lo + base + lane_rank(mw);
                     if (want && j < hi) {
-                        const uint2 sb = a.cur.state_b[j];
-                        if (sb.x != kInvalidSlot) {
-                            slot = sb.x; depth = sb.y; n_iter = 0u;
-                            ro4 = a.cur.ray_o[j]; rd4 = a.cur.ray_d[j]; sa = a.cur.state_a[j]; res = a.result[slot];
-                            active = true;
-                        }
+                        tail_load_path(k, use_rg, j, slot, depth, ro4, rd4, sa, res);
+                        if (slot != kInvalidSlot) { n_iter = 0u; active = true; }
                     }
                 }
             }
@@ -1760,6 +1836,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
     n_iter = n_iter > n_iter_max ? n_iter : n_iter_max;
+    if (use_rg && !synced) tail_await_epoch(a.ctr, k.epoch);
     wave_add64(&a.ctr->closest_rays, n_closest);
     wave_add64(&a.ctr->shadow_rays, n_shadow);
 #pragma unroll
@@ -2026,10 +2103,12 @@ void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, c
 
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
                  PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const TraceOpts& o,
-                 const ResolveJob& resolve)
+                 const ResolveJob& resolve, const RaygenJob* rg, uint32_t epoch)
 {
     if (n_max == 0u) return;
-    ShadeArgs a{};
+    TailArgs k{};
+    if (rg) { k.rg = *rg; k.epoch = epoch; }
+    ShadeArgs& a = k.a;
     a.resolve = resolve;
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur;
     a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
@@ -2064,16 +2143,24 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
             uint32_t g = (n_max + ppw - 1u) / ppw, refill = 0u;
             const bool long_paths = (fc.max_depth == 0u || fc.max_depth > 8u) && bvh.tri_byte_off / 64u >= (1u << 18);
             if (g > resident && (e_refill == 2 || (e_refill == 1 && long_paths))) { g = resident; refill = ppw / 4u; }     // refill when a quarter is free
-            if (bvh.node_fmt == 2)      hipLaunchKernelGGL(k_tail_pool2<2>, dim3(g), dim3(64), 0, st, a, ppw, refill);
-            else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool2<1>, dim3(g), dim3(64), 0, st, a, ppw, refill);
-            else                        hipLaunchKernelGGL(k_tail_pool2<0>, dim3(g), dim3(64), 0, st, a, ppw, refill);
+            k.ppw = ppw; k.refill = refill;
+            if (bvh.node_fmt == 2)      hipLaunchKernelGGL(k_tail_pool2<2>, dim3(g), dim3(64), 0, st, k);
+            else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool2<1>, dim3(g), dim3(64), 0, st, k);
+            else                        hipLaunchKernelGGL(k_tail_pool2<0>, dim3(g), dim3(64), 0, st, k);
+            return;
         }
-        else if (bvh.node_fmt == 2) hipLaunchKernelGGL(k_tail_pool<2>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
-        else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool<1>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
-        else                        hipLaunchKernelGGL(k_tail_pool<0>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, a, ppw);
+        k.ppw = ppw;
+        if (bvh.node_fmt == 2)      hipLaunchKernelGGL(k_tail_pool<2>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
+        else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool<1>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
+        else                        hipLaunchKernelGGL(k_tail_pool<0>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
     }
     else
-        hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);          // (never with rg: tail_launch_makes_rays)
+}
+
+bool tail_launch_makes_rays(const DeviceBvh& bvh, const TraceOpts& o)
+{
+    return o.persistent == 3 && bvh.pool_ok && bvh.tri_byte_off != 0u && bvh.depth <= 32u;      // the pool forms of launch_tail
 }
 
 void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result, float4* accum, uint32_t* frame, uint32_t n_slots,

@@ -138,6 +138,7 @@ struct MiptContext {
     uint32_t*   d_tile_width = nullptr;  // the class width the tiled kernel uses, adapted by the order job (starts at tile_class_width)
     bool        tile_class_fixed = false;    // MIPT_TILE_CLASS given: that width, not adapted
     uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
+    uint32_t  tail_epoch = 0;            // TailArgs::epoch of the last path-kernel launch that made its own rays
     int       tail_refill = 1;           // env MIPT_TAIL_REFILL (TraceOpts::tail_refill)
     int       direct_resolve = 1;        // env MIPT_DIRECT_RESOLVE=0: always a k_resolve launch (A/B)
     bool      advance_pending = false;   // the last launch ended without its final k_advance step (mipt_get_launch_stats applies it)
@@ -583,13 +584,15 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         RaygenJob rg{};
         rg.fc = fc; rg.sample = s; rg.q = ctx->q[0]; rg.rg_seed = ctx->rg_seed; rg.result = ctx->result; rg.ctr = ctx->d_ctr;
         rg.n_valid = pass_valid; rg.zero_stats = s == 0u ? 1u : 0u;
-        const bool fused_raygen = ctx->fuse_raygen && n_paths > first_limit && closest_launch_is_tiled(bvh, n_paths, opts);
+        const bool tail_first = n_paths <= first_limit;                   // the pass runs in the path kernel from its first bounce
+        const bool fused_raygen = ctx->fuse_raygen && (tail_first ? tail_launch_makes_rays(bvh, opts) : closest_launch_is_tiled(bvh, n_paths, opts));
         if (!fused_raygen) { TimedScope t(ctx, st, T_RAYGEN); launch_raygen(st, fc, s, ctx->q[0], ctx->rg_seed, ctx->result, ctx->d_ctr, pass_valid, s == 0u); }
         int cur = 0;
         if (n_paths <= first_limit) {
             // a pass this small runs in the tail kernel from the first bounce on (Cornell 512x512: 0.73 -> 0.37 ms)
             TimedScope t(ctx, st, T_CLOSEST);
-            launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[0], ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, opts, rj);
+            launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[0], ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, opts, rj,
+                        fused_raygen ? &rg : nullptr, ++ctx->tail_epoch);
             continue;
         }
         uint32_t bound = n_paths;      // upper bound of the live-path count (it only falls): the latest count the host has seen

@@ -189,6 +189,12 @@ def test_cornell_multi_sample_and_ragged_sizes(w, h, spp, max_depth):
     _assert_pixels(acc, a)
     assert np.array_equal(frame, f)
     assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"]
+    # these passes run in the path kernel from their first bounce, which then also does the pass's queue bookkeeping in its first
+    # workgroup while the other waves run (TailArgs::epoch orders it before their additions to the statistics): the counters of
+    # 30 more launches, whose waves finish within microseconds on this scene
+    for _ in range(30):
+        _, _, again = _render_gpu(PT, st)
+        assert again == stats
     PT.cleanupState(st)
 
 
