@@ -3,7 +3,8 @@
 
 Workload (configs[3], SURVEY.md 8d "C4"): 1,000,000 random triangles in the unit cube, 1920x1080,
 spp = 1, subframe 0, max depth 1 (the primary ray and its next-event-estimation shadow ray).
-A "step" is one frame: raygen -> trace_closest -> shade -> trace_any -> resolve.  With N > 1 ranks
+A "step" is one frame = one mipt_launch: raygen + closest hit (one kernel), shade (+ the pixels of the paths that end there),
+any hit (+ the pixels whose last term it adds) -- three launches, DESIGN.md 3.1 / 3.3.  With N > 1 ranks
 (one process per GPU, launched by torch.distributed.run) every rank renders its interleaved 8x4-tile
 shard of the SAME frame, the compact float4 shards are all-gathered over RCCL and un-permuted
 (strong scaling: the total work is the frame).
