@@ -218,7 +218,8 @@ typedef enum MiptOption {
                                   image order the kernel ends in a long drain while late, heavy tiles run alone.  The order is made
                                   on the device inside the launches a frame has anyway (16 cost classes, stable counting sort:
                                   image order inside a class keeps the L2 locality) and only schedules: it cannot change a result.
-                                  0: image order.  Launches of another size, shards and batched samples are not ordered. */
+                                  0: image order.  The first launch after a change of size (or of a shard's rank) and launches with
+                                  batched samples run in image order. */
     MIPT_OPT_BURST        = 9  /* streaming waves: traversal steps per bookkeeping round, value = bulk | dry << 8
                                   (bulk: while fresh rays remain; dry: once the ray range is exhausted) */
 } MiptOption;
