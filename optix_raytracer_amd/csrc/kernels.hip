@@ -615,7 +615,23 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
     uint32_t ent = 0u;
     if (have) ent = stk[psize - 1 - lane];
     psize -= k;
-    const uint32_t slot = ent & 63u;
+    uint32_t slot = ent & 63u;
+#ifndef MIPT_ANY_SECOND_POP
+#define MIPT_ANY_SECOND_POP 1       // 0: the A/B (any-hit kernel of the headline frame 0.1905 -> 0.1838 ms with it)
+#endif
+    bool dead = false;
+    if (MODE != 0 && MIPT_ANY_SECOND_POP) {
+        // an entry of a ray that has been found occluded in the meantime costs its lane the round (18 % of the popped entries on the
+        // headline frame's shadow rays): such a lane takes one more entry from the top
+        dead = have && sh_done[slot] != 0u;
+        const unsigned long long dm = __ballot(dead);
+        if (dm != 0ull && psize > 0) {
+            const int nd = __popcll(dm), k2 = nd < psize ? nd : psize;
+            const int r = (int)lane_rank(dm);
+            if (dead && r < k2) { ent = stk[psize - 1 - r]; slot = ent & 63u; dead = sh_done[slot] != 0u; }
+            psize -= k2;
+        }
+    }
     // the ray of that slot, from its owner's registers
     const float ox = shfl_f(T.o.x, slot), oy = shfl_f(T.o.y, slot), oz = shfl_f(T.o.z, slot);
     const float dx = shfl_f(T.d.x, slot), dy = shfl_f(T.d.y, slot), dz = shfl_f(T.d.z, slot);
@@ -625,6 +641,7 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
     float tcur = tmx;
     bool live = have;
     if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[slot] >> 32)); }
+    else if (MIPT_ANY_SECOND_POP) { if (dead) live = false; }
     else           { if (have && sh_done[slot] != 0u) live = false; }
     const bool leaf = (ent >> 31) != 0u;
     const uint32_t payload = (ent >> 6) & 0x1ffffffu;
