@@ -189,7 +189,9 @@ typedef enum MiptOption {
                                   launches); 0 one thread per ray (tight while-while loop; also the
                                   fallback for trees deeper than 32). */
     MIPT_OPT_PROFILE      = 5, /* 1 = bracket every kernel of a launch with HIP events (mipt_get_launch_timings),
-                                  2 = only the two traversal kernels (10 -> 4 event records per frame) */
+                                  2 = only the two traversal kernels (10 -> 4 event records per frame),
+                                  3 = those of every 8th launch only (a record costs ~4 us of stream time: mode 2 is 2.6 % of
+                                  the headline frame, mode 3 0.3 %) */
     MIPT_OPT_REFILL_MIN   = 7, /* variant 2: idle lanes that trigger a swap-in/prefetch round (default 16) */
     MIPT_OPT_STEAL_MIN    = 8, /* finished lanes of a tile that make the wave go over to its entry pool (variant 3) / idle
                                   lanes that trigger a round in which they take stack entries of busy rays once the ray

@@ -140,6 +140,7 @@ struct MiptContext {
     uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
     uint32_t  tail_epoch = 0;            // TailArgs::epoch of the last path-kernel launch that made its own rays
     int       tail_refill = 1;           // env MIPT_TAIL_REFILL (TraceOpts::tail_refill)
+    uint32_t  profile_launch = 0;        // launches since MIPT_OPT_PROFILE was set (mode 3 brackets every 8th)
     int       direct_resolve = 1;        // env MIPT_DIRECT_RESOLVE=0: always a k_resolve launch (A/B)
     bool      advance_pending = false;   // the last launch ended without its final k_advance step (mipt_get_launch_stats applies it)
     int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
@@ -207,7 +208,7 @@ struct TimedScope {
     MiptContext* c; hipStream_t st; int kind; bool on = false; hipEvent_t a = nullptr, b = nullptr;
     TimedScope(MiptContext* c_, hipStream_t st_, int kind_) : c(c_), st(st_), kind(kind_)
     {
-        on = c->profile == 1 || (c->profile == 2 && (kind_ == T_CLOSEST || kind_ == T_ANY));
+        on = c->profile == 1 || ((c->profile == 2 || (c->profile == 3 && c->profile_launch % 8u == 0u)) && (kind_ == T_CLOSEST || kind_ == T_ANY));
         if (on) { a = c->get_event(); b = c->get_event(); if (a) (void)hipEventRecord(a, st); }
     }
     ~TimedScope()
@@ -663,6 +664,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
     ctx->advance_pending = rj.on != 0u && advance_in_resolve;
     if (!rj.on) { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots, advance_in_resolve ? ctx->d_ctr : nullptr); }
     ctx->bounces_on_device = true;
+    ++ctx->profile_launch;
     HIPCHK(ctx, hipGetLastError());
     return MIPT_SUCCESS;
 }
@@ -797,7 +799,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         c->steal_min = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_PROFILE:
         if (c->last_stream || c->timed.size()) (void)hipStreamSynchronize(c->last_stream);
-        c->profile = value == 2 ? 2 : (value ? 1 : 0); c->timed.clear(); c->events_used = 0; return MIPT_SUCCESS;
+        c->profile = value == 2 || value == 3 ? (int)value : (value ? 1 : 0); c->timed.clear(); c->events_used = 0; c->profile_launch = 0; return MIPT_SUCCESS;
     default: return c->fail(MIPT_ERROR_INVALID_VALUE, "unknown option %d", option);
     }
 }
