@@ -177,7 +177,8 @@ def test_cornell_config1_512_spp1():
     PT.cleanupState(st)
 
 
-@pytest.mark.parametrize("w,h,spp,max_depth", [(96, 64, 4, 0), (100, 37, 3, 0), (64, 64, 16, 8), (33, 9, 1, 1)])
+@pytest.mark.parametrize("w,h,spp,max_depth", [(96, 64, 4, 0), (100, 37, 3, 0), (64, 64, 16, 8), (33, 9, 1, 1),
+                                               (1, 1, 1, 0), (7, 1, 2, 0), (1, 65, 1, 3), (65, 3, 1, 1)])
 def test_cornell_multi_sample_and_ragged_sizes(w, h, spp, max_depth):
     _torch()
     from optix_raytracer_amd import scenes
