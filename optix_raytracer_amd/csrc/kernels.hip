@@ -2111,8 +2111,10 @@ void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, c
     a.order = order; a.primary = primary; a.resolve = resolve;
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur; a.hits = hits;
     a.next = next; a.shadow = shadow; a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
+    // one workgroup per 512 paths, in path order, up to 65536 (beyond that they stride): with 2048 striding workgroups the shadow
+    // queue interleaved tiles 2048 apart, and the any-hit launch that follows was 8 us slower on the headline frame (0.556 -> 0.548 ms)
     uint32_t blocks = (n_max + kShadeBlock - 1u) / kShadeBlock;
-    if (blocks > 2048u) blocks = 2048u;
+    if (blocks > 65536u) blocks = 65536u;
     if (blocks == 0u) blocks = 1u;
     blocks += order.n_chunks;
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, st, a);
