@@ -170,6 +170,7 @@ def initLaunchParams(state, width=None, height=None, lights=None):
     p.miss_color = (C.c_float * 3)(0.1, 0.1, 0.1)
     p.handle = state.handle
     state.stream = torch.cuda.Stream(device=state.device)
+    state.stream.wait_stream(torch.cuda.current_stream(state.device))      # the buffers above were cleared on torch's current stream
 
 
 def handleCameraUpdate(state):

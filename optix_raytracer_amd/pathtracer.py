@@ -94,6 +94,8 @@ def initLaunchParams(state, width, height, samples_per_launch):
         setattr(p.light, k, (C.c_float * 3)(*[float(x) for x in lt[k]]))
     p.handle = state.gas_handle
     state.stream = torch.cuda.Stream(device=state.device)
+    # (the accumulation buffer was cleared on torch's current stream; a launch writes pixels as soon as their paths end)
+    state.stream.wait_stream(torch.cuda.current_stream(state.device))
 
 
 def handleCameraUpdate(state, camera):

@@ -32,6 +32,7 @@ def main():
         ns = api.shard_num_samples(w, h, world)
         assert ns == idx.shape[0]
         d_compact = torch.zeros((ns, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         pst.context.launch_shard(pst.params, w, h, rank, world, d_compact.data_ptr(), stream=pst.stream.cuda_stream)
         pst.context.sync()
         stats = pst.context.launch_stats()
@@ -43,6 +44,7 @@ def main():
         gathered = D.all_gather_shards(d_compact.cpu(), world).cuda()            # gloo: staged through the host
         d_acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
         d_frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         pst.context.unpermute(gathered.data_ptr(), world, w, h, d_acc.data_ptr(), d_frame.data_ptr(), stream=pst.stream.cuda_stream)
         pst.context.sync()
         frame = d_acc.cpu().numpy()

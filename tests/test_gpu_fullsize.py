@@ -76,11 +76,12 @@ def test_headline_shards_equal_full_frame(big, world):
     ns = api.shard_num_samples(1920, 1080, world)
     assert ns * world >= 1920 * 1080
     gathered = torch.zeros((world, ns, 4), dtype=torch.float32, device="cuda")
+    acc = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda")
+    frame = torch.zeros((1080, 1920, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()          # cleared on torch's stream, written by launches on the state's stream (as soon as a path ends)
     for r in range(world):
         for _ in range(2):
             st.context.launch_shard(st.params, 1920, 1080, r, world, gathered[r].data_ptr(), stream=st.stream.cuda_stream)
-    acc = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda")
-    frame = torch.zeros((1080, 1920, 4), dtype=torch.uint8, device="cuda")
     st.context.unpermute(gathered.data_ptr(), world, 1920, 1080, acc.data_ptr(), frame.data_ptr(), stream=st.stream.cuda_stream)
     st.context.sync()
     assert np.array_equal(acc.cpu().numpy().view(np.uint32), full.view(np.uint32))
@@ -165,6 +166,7 @@ def test_cost_ordered_tiles_of_a_shard(big):
         for k in range(4):
             rank = 1 if k == 2 else 0                   # a change of rank in between: the order of rank 0's map is dropped
             shard = torch.zeros((ns, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
             st.context.launch_shard(st.params, 1920, 1080, rank, 2, shard.data_ptr(), stream=st.stream.cuda_stream)
             st.context.sync()
             bufs.append(shard.cpu().numpy())

@@ -276,10 +276,11 @@ def test_shards_reassemble_to_the_full_frame():
     for world in (1, 2, 3, 8):
         ns = api.shard_num_samples(w, h, world)
         gathered = torch.zeros((world, ns, 4), dtype=torch.float32, device="cuda")
-        for r in range(world):
-            st.context.launch_shard(st.params, w, h, r, world, gathered[r].data_ptr(), stream=st.stream.cuda_stream)
         acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
         frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()      # cleared on torch's stream, written on the state's stream
+        for r in range(world):
+            st.context.launch_shard(st.params, w, h, r, world, gathered[r].data_ptr(), stream=st.stream.cuda_stream)
         st.context.unpermute(gathered.data_ptr(), world, w, h, acc.data_ptr(), frame.data_ptr(), stream=st.stream.cuda_stream)
         st.context.sync()
         assert np.array_equal(acc.cpu().numpy().view(np.uint32), full.view(np.uint32)), world

@@ -25,7 +25,8 @@ def soak(name, scene, w, h, spp, max_depth, shard_world=0):
             torch.cuda.synchronize()
             key, buf = r % shard_world, compact
         else:
-            st.accum.zero_()
+            with torch.cuda.stream(st.stream):           # on the launch's stream: a launch writes pixels as soon as their paths end
+                st.accum.zero_()
             PT.launchSubframe(ob, st)
             key, buf = 0, st.accum
         c = zlib.crc32(buf.cpu().numpy().tobytes())
