@@ -273,7 +273,7 @@ int mipt_accel_export(const MiptContext* ctx, unsigned long long handle,
  * i.e. the order of mipt_scene_flatten*, so hit-group records, the Whitted geometry arrays and the launch functions are used
  * exactly as with one flattened BVH.  instanceId / sbtOffset / visibilityMask / flags are stored but not interpreted (the samples
  * use mask 1 and no flags).  mipt_accel_update_instances takes the same instances with new transforms (an instance moved).
- * Alpha-tested / blended materials (any-hit programs) are not supported over an instance structure yet.
+ * Alpha-tested / blended materials (the Whitted any-hit programs) work over an instance structure too (k_wh_trace_inst).
  * ------------------------------------------------------------------------- */
 typedef struct MiptInstance {
     float              transform[12];

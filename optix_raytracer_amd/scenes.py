@@ -236,11 +236,13 @@ def write_duck_like_gltf(path, seed=3):
     return path
 
 
-def write_instanced_gltf(path, n_instances=150, seed=9):
+def write_instanced_gltf(path, n_instances=150, seed=9, alpha_textures=None):
     """An instanced scene for the two-level (instance) acceleration structure: TWO meshes -- a bumpy blob of 960 triangles
     (u16 indices) and a box of 12 -- placed `n_instances` times by nodes with random translation / rotation / NON-uniform
     scale (some nested under a scaled parent, so matrices are general affine), over a floor quad; three opaque materials, a
-    camera node.  Every node with a mesh becomes one sutil::Scene instance (Scene.cpp:192-205).  Returns the path."""
+    camera node.  Every node with a mesh becomes one sutil::Scene instance (Scene.cpp:192-205).  Returns the path.
+    alpha_textures = (png bytes, png bytes): the blob becomes a BLEND material and the box a double-sided MASK material over
+    those RGBA images (both meshes get TEXCOORD_0), so the Whitted any-hit programs run inside the instances."""
     import base64
     import json
     rng = np.random.default_rng(seed)
@@ -276,8 +278,14 @@ def write_instanced_gltf(path, n_instances=150, seed=9):
         accs.append(a)
         blob += arr.tobytes()
         return len(accs) - 1
-    meshes = [{"primitives": [{"attributes": {"POSITION": add(pts, "VEC3", 5126)}, "indices": add(idx_blob, "SCALAR", 5123), "material": 0}]},
-              {"primitives": [{"attributes": {"POSITION": add(box, "VEC3", 5126)}, "indices": add(idx_box, "SCALAR", 5123), "material": 1}]},
+    a_blob, a_box = {"POSITION": add(pts, "VEC3", 5126)}, {"POSITION": add(box, "VEC3", 5126)}
+    if alpha_textures is not None:
+        uv_blob = np.stack([np.arctan2(pts[:, 2], pts[:, 0]) / (2 * np.pi) + 0.5, np.clip(pts[:, 1] / 0.9 + 0.5, 0, 1)], -1).astype(np.float32)
+        uv_box = ((box[:, :2] + box[:, 2:3] * 0.5) / 0.6 + 0.5).astype(np.float32)
+        a_blob["TEXCOORD_0"] = add(uv_blob, "VEC2", 5126)
+        a_box["TEXCOORD_0"] = add(uv_box, "VEC2", 5126)
+    meshes = [{"primitives": [{"attributes": a_blob, "indices": add(idx_blob, "SCALAR", 5123), "material": 0}]},
+              {"primitives": [{"attributes": a_box, "indices": add(idx_box, "SCALAR", 5123), "material": 1}]},
               {"primitives": [{"attributes": {"POSITION": add(floor, "VEC3", 5126)}, "indices": add(idx_floor, "SCALAR", 5123), "material": 2}]}]
     nodes = [{"mesh": 2}]
     parents = []
@@ -304,6 +312,15 @@ def write_instanced_gltf(path, n_instances=150, seed=9):
                          {"pbrMetallicRoughness": {"baseColorFactor": [0.7, 0.7, 0.7, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.9}}],
            "meshes": meshes, "cameras": [{"type": "perspective", "perspective": {"yfov": 0.75, "aspectRatio": 16 / 9, "znear": 0.05}}],
            "nodes": nodes, "scenes": [{"nodes": roots}], "scene": 0}
+    if alpha_textures is not None:
+        uri = lambda b: "data:image/png;base64," + base64.b64encode(b).decode()
+        doc["images"] = [{"uri": uri(alpha_textures[0])}, {"uri": uri(alpha_textures[1])}]
+        doc["samplers"] = [{"minFilter": 9728, "magFilter": 9728}, {}]
+        doc["textures"] = [{"source": 0, "sampler": 0}, {"source": 1, "sampler": 1}]
+        doc["materials"][0].update({"alphaMode": "BLEND", "doubleSided": True})
+        doc["materials"][0]["pbrMetallicRoughness"].update({"baseColorFactor": [0.85, 0.55, 0.2, 0.8], "baseColorTexture": {"index": 0}})
+        doc["materials"][1].update({"alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True})
+        doc["materials"][1]["pbrMetallicRoughness"].update({"baseColorTexture": {"index": 1}})
     path.write_text(json.dumps(doc))
     return path
 
