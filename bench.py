@@ -401,7 +401,11 @@ def main():
         if ceil:
             bound = max(ceil, key=lambda k: ceil[k]["frac"])
             top = ceil[bound]
-            assert top["frac"] <= 1.0 + 1e-9, "roofline fraction above 1: %s" % ceil
+            # (the counters are the committed profile's, the time is this run's: a run much faster than the profiled one could
+            #  push a busy-cycle ratio past 1 -- report that as stale counters, do not pass it off as a fraction)
+            if top["frac"] > 1.0:
+                counters_from = dict(counters_from or {}, stale="a ceiling computed from these counters exceeds 1 for this run's kernel time: re-profile")
+                top = dict(top, frac=None)
         else:
             bound, top = "hbm", {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
         out = {
