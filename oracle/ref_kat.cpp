@@ -8,6 +8,8 @@
 //   SDK/cuda/helpers.h         make_color / toSRGB / quantizeUnsigned8Bits
 //   SDK/sutil/Camera.{h,cpp}   Camera::UVWFrame
 //   SDK/sutil/WorkDistribution.h  StaticWorkDistribution
+//   SDK/optixPathTracer/optixPathTracer.h, SDK/cuda/whitted.h, BufferView.h, Light.h, MaterialData.h,
+//   include/optix_types.h      sizeof / offsetof of every struct whose layout the C ABI keeps ("layouts")
 // The CUDA vector types come from the cuda_runtime headers that the triton
 // wheel ships in this image.  Output -> tests/golden/ref_kat.json (committed),
 // which pins oracle/pt_oracle.c.  Built only where /root/reference exists
@@ -24,6 +26,12 @@
 #include <cuda/helpers.h>
 #include <sutil/Camera.h>
 #include <sutil/WorkDistribution.h>
+#include <cstddef>
+#include <optix_types.h>
+#include <cuda/whitted.h>
+namespace pt {                         // optixPathTracer.h and whitted.h both define Params-like names at file scope
+#include <optixPathTracer/optixPathTracer.h>
+}
 
 static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
@@ -167,6 +175,66 @@ int main()
             std::printf("}%s\n", i < n_pix - 1 ? "," : "");
         }
     }
-    std::printf("]\n}\n");
+    std::printf("],\n");
+
+    // ---- layouts the C ABI keeps: stated by the reference's own headers ---------------------------------------
+    // {"struct": {"sizeof": n, "alignof": a, "fields": {"name": [offset, size], ...}}, ...}
+#define LAY_BEGIN(name, T) std::printf("  \"%s\": {\"sizeof\": %zu, \"alignof\": %zu, \"fields\": {", name, sizeof(T), alignof(T))
+#define LAY_F(T, f, last) std::printf("\"%s\": [%zu, %zu]%s", #f, offsetof(T, f), sizeof(((T*)0)->f), last ? "" : ", ")
+#define LAY_END(last) std::printf("}}%s\n", last ? "" : ",")
+    std::printf("\"layouts\": {\n");
+    LAY_BEGIN("Params", pt::Params);
+    LAY_F(pt::Params, subframe_index, 0); LAY_F(pt::Params, accum_buffer, 0); LAY_F(pt::Params, frame_buffer, 0);
+    LAY_F(pt::Params, width, 0); LAY_F(pt::Params, height, 0); LAY_F(pt::Params, samples_per_launch, 0);
+    LAY_F(pt::Params, eye, 0); LAY_F(pt::Params, U, 0); LAY_F(pt::Params, V, 0); LAY_F(pt::Params, W, 0);
+    LAY_F(pt::Params, light, 0); LAY_F(pt::Params, handle, 1);
+    LAY_END(0);
+    LAY_BEGIN("ParallelogramLight", pt::ParallelogramLight);
+    LAY_F(pt::ParallelogramLight, corner, 0); LAY_F(pt::ParallelogramLight, v1, 0); LAY_F(pt::ParallelogramLight, v2, 0);
+    LAY_F(pt::ParallelogramLight, normal, 0); LAY_F(pt::ParallelogramLight, emission, 1);
+    LAY_END(0);
+    LAY_BEGIN("HitGroupData", pt::HitGroupData);
+    LAY_F(pt::HitGroupData, emission_color, 0); LAY_F(pt::HitGroupData, diffuse_color, 0); LAY_F(pt::HitGroupData, vertices, 1);
+    LAY_END(0);
+    LAY_BEGIN("MissData", pt::MissData);
+    LAY_F(pt::MissData, bg_color, 1);
+    LAY_END(0);
+    LAY_BEGIN("RadiancePRD", pt::RadiancePRD);
+    LAY_F(pt::RadiancePRD, attenuation, 0); LAY_F(pt::RadiancePRD, seed, 0); LAY_F(pt::RadiancePRD, depth, 0);
+    LAY_F(pt::RadiancePRD, emitted, 0); LAY_F(pt::RadiancePRD, radiance, 0); LAY_F(pt::RadiancePRD, origin, 0);
+    LAY_F(pt::RadiancePRD, direction, 0); LAY_F(pt::RadiancePRD, done, 1);
+    LAY_END(0);
+    typedef whitted::LaunchParams WLP;
+    LAY_BEGIN("whitted::LaunchParams", WLP);
+    LAY_F(WLP, width, 0); LAY_F(WLP, height, 0); LAY_F(WLP, subframe_index, 0); LAY_F(WLP, accum_buffer, 0); LAY_F(WLP, frame_buffer, 0);
+    LAY_F(WLP, max_depth, 0); LAY_F(WLP, scene_epsilon, 0); LAY_F(WLP, eye, 0); LAY_F(WLP, U, 0); LAY_F(WLP, V, 0); LAY_F(WLP, W, 0);
+    LAY_F(WLP, lights, 0); LAY_F(WLP, miss_color, 0); LAY_F(WLP, handle, 1);
+    LAY_END(0);
+    typedef BufferView<Light> BVL;
+    LAY_BEGIN("BufferView", BVL);
+    LAY_F(BVL, data, 0); LAY_F(BVL, count, 0); LAY_F(BVL, byte_stride, 0); LAY_F(BVL, elmt_byte_size, 1);
+    LAY_END(0);
+    LAY_BEGIN("Light", Light);
+    LAY_F(Light, type, 0); LAY_F(Light, point, 0); LAY_F(Light, point.color, 0); LAY_F(Light, point.intensity, 0);
+    LAY_F(Light, point.position, 0); LAY_F(Light, point.falloff, 0); LAY_F(Light, ambient, 0); LAY_F(Light, ambient.color, 1);
+    LAY_END(0);
+    typedef MaterialData::Texture MTex;
+    LAY_BEGIN("MaterialData::Texture", MTex);
+    LAY_F(MTex, texcoord, 0); LAY_F(MTex, tex, 0); LAY_F(MTex, texcoord_offset, 0); LAY_F(MTex, texcoord_rotation, 0); LAY_F(MTex, texcoord_scale, 1);
+    LAY_END(0);
+    LAY_BEGIN("MaterialData", MaterialData);
+    LAY_F(MaterialData, type, 0); LAY_F(MaterialData, normal_tex, 0); LAY_F(MaterialData, alpha_mode, 0); LAY_F(MaterialData, alpha_cutoff, 0);
+    LAY_F(MaterialData, emissive_factor, 0); LAY_F(MaterialData, emissive_tex, 0); LAY_F(MaterialData, doubleSided, 0);
+    LAY_F(MaterialData, pbr, 0); LAY_F(MaterialData, pbr.base_color, 0); LAY_F(MaterialData, pbr.metallic, 0); LAY_F(MaterialData, pbr.roughness, 0);
+    LAY_F(MaterialData, pbr.base_color_tex, 0); LAY_F(MaterialData, pbr.metallic_roughness_tex, 1);
+    LAY_END(0);
+    LAY_BEGIN("whitted::HitGroupData", whitted::HitGroupData);
+    LAY_F(whitted::HitGroupData, geometry_data, 0); LAY_F(whitted::HitGroupData, material_data, 1);
+    LAY_END(0);
+    LAY_BEGIN("OptixInstance", OptixInstance);
+    LAY_F(OptixInstance, transform, 0); LAY_F(OptixInstance, instanceId, 0); LAY_F(OptixInstance, sbtOffset, 0);
+    LAY_F(OptixInstance, visibilityMask, 0); LAY_F(OptixInstance, flags, 0); LAY_F(OptixInstance, traversableHandle, 0); LAY_F(OptixInstance, pad, 1);
+    LAY_END(1);
+    std::printf("}\n}\n");
     return 0;
 }

@@ -38,16 +38,73 @@ def test_library_exports_every_declared_symbol():
     assert lib.mipt_abi_version() == 2
 
 
+# kept struct -> (the reference struct of tests/golden/ref_kat.json "layouts", {reference field: our field})
+# The layouts come from the reference's OWN headers (oracle/ref_kat.cpp prints sizeof / alignof / offsetof of
+# optixPathTracer.h:82-126, cuda/whitted.h:59-77, cuda/BufferView.h:33-49, cuda/Light.h:33-71, include/optix_types.h
+# OptixInstance), not from numbers typed into this file.
+KEPT_LAYOUTS = {
+    "MiptParams": ("Params", None),
+    "MiptParallelogramLight": ("ParallelogramLight", None),
+    "MiptHitGroupData": ("HitGroupData", None),
+    "MiptMissData": ("MissData", None),
+    "MiptWhittedLaunchParams": ("whitted::LaunchParams", None),
+    "MiptBufferView": ("BufferView", None),
+    "MiptLight": ("Light", {"type": "type", "point.color": "color", "point.intensity": "intensity", "point.position": "position",
+                            "point.falloff": "falloff", "ambient.color": "color"}),
+    "MiptInstance": ("OptixInstance", None),
+}
+
+
 def test_struct_layouts_match_reference_offsets():
-    # Params 152 B, offsets probed from the reference build
-    P = L.MiptParams
-    assert C.sizeof(P) == 152
-    exp = {"subframe_index": 0, "accum_buffer": 8, "frame_buffer": 16, "width": 24, "height": 28,
-           "samples_per_launch": 32, "eye": 36, "U": 48, "V": 60, "W": 72, "light": 84, "handle": 144}
-    for k, off in exp.items():
-        assert getattr(P, k).offset == off, k
-    assert C.sizeof(L.MiptParallelogramLight) == 60 and C.sizeof(L.MiptHitGroupData) == 32
-    assert C.sizeof(L.MiptMissData) == 16
+    """ctypes mirrors (optix_raytracer_amd/_lib.py) against the layouts the reference's headers state."""
+    lay = json.load(open(GOLD))["layouts"]
+    for ours, (ref, fmap) in KEPT_LAYOUTS.items():
+        T, R = getattr(L, ours), lay[ref]
+        assert C.sizeof(T) == R["sizeof"], (ours, C.sizeof(T), R["sizeof"])
+        fmap = fmap or {k: k for k in R["fields"]}
+        for rf, of in fmap.items():
+            off, size = R["fields"][rf]
+            d = getattr(T, of)
+            assert (d.offset, d.size) == (off, size), (ours, of, (d.offset, d.size), (off, size))
+        assert len(fmap) >= len([k for k in R["fields"] if "." not in k]) - (1 if ref == "Light" else 0)
+
+
+def test_c_header_layouts_match_reference_offsets(tmp_path):
+    """include/mipt.h itself, compiled as C99: sizeof / offsetof of the kept structs against the same reference layouts."""
+    import subprocess
+    lay = json.load(open(GOLD))["layouts"]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "mipt.h"', "int main(void) {"]
+    want = []
+    for ours, (ref, fmap) in KEPT_LAYOUTS.items():
+        R = lay[ref]
+        lines.append('printf("%%zu\\n", sizeof(%s));' % ours)
+        want.append(R["sizeof"])
+        for rf, of in (fmap or {k: k for k in R["fields"]}).items():
+            lines.append('printf("%%zu\\n", offsetof(%s, %s));' % (ours, of))
+            want.append(R["fields"][rf][0])
+    lines += ["return 0; }"]
+    src = tmp_path / "lay.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "lay"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == want
+
+
+def test_reference_material_record_is_reshaped_not_kept():
+    """MaterialData (cuda/MaterialData.h) holds cudaTextureObject_t handles and a Pbr / Glass / Phong union: 240 bytes inside a
+    352-byte whitted::HitGroupData SBT record.  The ABI does not keep that layout (there are no texture objects on this side):
+    MiptMaterialData carries the PBR branch's fields by name, MiptTextureInfo the Texture's (index instead of handle).  This test
+    pins what the reference's are, so that a change of either side is seen."""
+    lay = json.load(open(GOLD))["layouts"]
+    assert lay["MaterialData"]["sizeof"] == 240 and lay["MaterialData::Texture"]["sizeof"] == 40
+    assert lay["whitted::HitGroupData"]["sizeof"] == 352
+    ref_pbr = {k.split(".", 1)[1] for k in lay["MaterialData"]["fields"] if k.startswith("pbr.")}
+    ours = {n for n, _ in L.MiptMaterialData._fields_}
+    assert ref_pbr <= ours, ref_pbr - ours
+    assert {"alpha_mode", "alpha_cutoff", "emissive_factor", "emissive_tex", "normal_tex"} <= ours
+    tex = {n for n, _ in L.MiptTextureInfo._fields_}
+    assert {"texcoord", "offset", "rotation", "scale"} <= tex
 
 
 def test_no_device_is_an_error_not_a_fallback():
