@@ -318,6 +318,14 @@ def test_config3_duck_like_gltf_1080p_spp64_depth8(tmp_path):
     _gltf_config(tmp_path, lambda d: scenes.write_duck_like_gltf(d / "duck_like.gltf"), 1920, 1080, 64, 8, 24000, 2, (4212, 4212))
 
 
+def test_config3_duck_gltf_1080p_spp64_depth8(tmp_path):
+    """BASELINE config 3 on the asset it names: SDK/data/Duck/Duck.gltf (4 212 triangles, u16 indices, root scale 0.01, camera node,
+    base-colour texture) -- here as the data fixture tests/golden/duck/ -- at 1920x1080 spp 64, depth cap 8, NEE shadow rays."""
+    import os
+    duck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "duck", "Duck.gltf")
+    _gltf_config(tmp_path, lambda d: duck, 1920, 1080, 64, 8, 24000, 2, (4212, 4212))
+
+
 def test_config5_rooms_gltf_4k_spp256_rr_depth16(tmp_path):
     """BASELINE config 5 (its one-GPU share): a Sponza-class glTF (~250 k triangles) through the sutil::Scene-compatible loader,
     3840x2160 spp 256, Russian roulette at every bounce as the reference's loop has it, depth cap 16.  The tree holds no such

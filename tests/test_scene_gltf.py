@@ -10,7 +10,7 @@ import _gltf_fixture as F
 import _oracle as O
 from optix_raytracer_amd import api, scenes
 
-DUCK = "/root/reference/SDK/data/Duck/Duck.gltf"
+DUCK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "duck", "Duck.gltf")     # data fixture: tests/golden/duck/README.md
 
 
 def test_synthetic_scene_flattening_is_exact(tmp_path):
@@ -123,7 +123,6 @@ def test_malformed_accessors_are_refused(tmp_path):
     assert sc.info()["num_triangles"] == 0
 
 
-@pytest.mark.skipif(not os.path.exists(DUCK), reason="reference assets are only present in the build container")
 def test_duck_kats_from_the_reference_loader():
     """values printed by the reference's own Scene/Matrix/Aabb/Camera code for Duck.gltf"""
     sc = api.Scene(DUCK)
