@@ -56,21 +56,32 @@ def parse():
     return ap.parse_args()
 
 
+def kernels_blob_sha():
+    """git's blob id of the traversal kernels' source as it is in THIS tree (sha1 of "blob <len>\\0" + content): the GPU box has no
+    .git, so the profile carries the id it was measured on (tools/pmc_json.py) and the two are compared here."""
+    import hashlib
+    data = open(os.path.join(ROOT, "optix_raytracer_amd", "csrc", "kernels.hip"), "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def pmc_counters(kernel):
     """Per-launch PMC counters of `kernel` from the COMMITTED rocprofv3 passes (profiles/pmc_kernels.json, written by
-    tools/prof_l1.sh + tools/pmc_json.py; the file names the commit it was measured on).  They are properties of the
-    kernel on this workload, not of this run: bench.py cannot collect them itself (that takes ~20 rocprofv3 passes).
-    None when no profile of this kernel is on file."""
+    tools/prof_l1.sh + tools/pmc_json.py).  They are properties of the kernel on this workload, not of this run: bench.py
+    cannot collect them itself (that takes ~20 rocprofv3 passes).  The profile is used only when it was measured on the
+    kernels.hip of this tree (blob id recorded in the file) and names exactly this kernel: a profile of other kernel source is
+    refused, not matched by name.  -> (counters or None, provenance)."""
+    src = {"file": "profiles/pmc_kernels.json"}
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_kernels.json")))
-        key = kernel
-        if key not in d["kernels"]:      # the same kernel under a template argument list that grew or shrank since the profile was taken
-            stem = kernel.rstrip(">")
-            cand = [k for k in d["kernels"] if "<" in k and (k.rstrip(">").startswith(stem + ",") or stem.startswith(k.rstrip(">") + ","))]
-            key = cand[0]
-        return d["kernels"][key], {"file": "profiles/pmc_kernels.json", "kernel": key, "commit": d.get("commit"), "source": d.get("source")}
     except Exception:
-        return None, None
+        return None, dict(src, refused="no profile on file")
+    src.update(commit=d.get("commit"), source=d.get("source"), kernels_hip_blob=d.get("kernels_hip_blob"))
+    if d.get("kernels_hip_blob") != kernels_blob_sha():
+        return None, dict(src, refused="the profile was measured on another kernels.hip (blob %s, this tree %s): re-run tools/prof_l1.sh" % (
+            str(d.get("kernels_hip_blob"))[:12], kernels_blob_sha()[:12]))
+    if kernel not in d["kernels"]:
+        return None, dict(src, refused="the profile holds no kernel named %s" % kernel)
+    return d["kernels"][kernel], dict(src, kernel=kernel)
 
 
 def ceilings(counters, t_s, alg_bytes):
@@ -78,7 +89,8 @@ def ceilings(counters, t_s, alg_bytes):
     hbm   fabric bytes (2 * FETCH_SIZE + WRITE_SIZE: FETCH_SIZE doubled as the guide prescribes for gfx950) / t / 8 TB/s
     l2    TCC_REQ * 128 B / t / 34.5 TB/s
     l1    vector-L1 cache-line lookups per CU-cycle, TCP_TOTAL_CACHE_ACCESSES / (256 CUs * t * 2.4 GHz), peak 1
-    ta/td busy cycles of the texture addresser / data-return unit per CU-cycle (TA_TA_BUSY, TD_TD_BUSY)
+    ta    busy cycles of the texture addresser per CU-cycle (TA_TA_BUSY)
+    td    TRANSFER cycles of the data-return unit per CU-cycle (TD_TD_BUSY - TD_TC_STALL; the stall share is reported beside it)
     valu  wave64 VALU instructions * 2 cycles / (1024 SIMDs * t * 2.4 GHz)
     Counter values come from the committed profile, the duration t from THIS run's HIP events."""
     c = {}
@@ -102,8 +114,13 @@ def ceilings(counters, t_s, alg_bytes):
         a = counters["TA_TA_BUSY_sum"] / (N_CUS * cyc)
         c["ta"] = {"achieved": round(a, 4), "peak": 1.0, "unit": "TA busy cycles per CU-cycle", "frac": round(a, 4)}
     if "TD_TD_BUSY_sum" in counters:
-        a = counters["TD_TD_BUSY_sum"] / (N_CUS * cyc)
-        c["td"] = {"achieved": round(a, 4), "peak": 1.0, "unit": "TD busy cycles per CU-cycle (transfers + stalls on L1 misses)", "frac": round(a, 4)}
+        # a THROUGHPUT ceiling counts the cycles the unit moves data, not the ones in which the load at the head of its in-order
+        # queue waits for an L1 miss (TD_TC_STALL): a counter that calls waiting "busy" reads high on any latency-bound kernel
+        stall = counters.get("TD_TC_STALL_sum", 0.0)
+        a = (counters["TD_TD_BUSY_sum"] - stall) / (N_CUS * cyc)
+        c["td"] = {"achieved": round(a, 4), "peak": 1.0, "unit": "TD transfer cycles per CU-cycle (TD_TD_BUSY - TD_TC_STALL)", "frac": round(a, 4),
+                   "busy_incl_stall": round(counters["TD_TD_BUSY_sum"] / (N_CUS * cyc), 4),
+                   "stall_share_of_busy": round(stall / counters["TD_TD_BUSY_sum"], 4) if counters["TD_TD_BUSY_sum"] else None}
     if "SQ_INSTS_VALU" in counters:
         a = counters["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMDS * cyc)
         c["valu"] = {"achieved": round(a, 4), "peak": 1.0, "unit": "SIMD issue cycles per cycle", "frac": round(a, 4)}
@@ -345,6 +362,53 @@ def main():
     k_other = (tb["ms_raygen"] + tb["ms_resolve"]) / nb
     st.context.set_option(L.OPT_PROFILE, 0)
 
+    # ---- the first frame after a change (camera size, rank, option): no cost order of the tiles exists yet and the primary launch
+    # walks them in image order.  The timed region above is the steady state of a progressive renderer (identical frames, perfect
+    # order); this is the other end.  Setting MIPT_OPT_TILE_ORDER discards the order; median of 5 such frames, each fenced.
+    first_ms = []
+    for _ in range(5):
+        st.context.set_option(L.OPT_TILE_ORDER, int(st.context.get_option(L.OPT_TILE_ORDER)))
+        fence()
+        t1 = time.perf_counter()
+        step()
+        fence()
+        first_ms.append((time.perf_counter() - t1) * 1e3)
+    first_frame_ms = sorted(first_ms)[len(first_ms) // 2]
+    for _ in range(2):
+        step()                               # leave the context in its steady state again
+    fence()
+
+    # ---- N > 1 (or --force-shard-path): what a rank's step consists of -- render (mipt_launch_shard on the launch stream), gather (the
+    # all-gather on the exchange stream), scatter (mipt_unpermute) -- from events in a few extra, untimed steps; max over ranks below
+    per_rank = None
+    if sharded:
+        ne = 8
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(ne)]
+        for i in range(ne):
+            b = state["k"] & 1
+            state["k"] += 1
+            stream.wait_event(consumed[b])
+            ev[i][0].record(stream)
+            st.context.launch_shard(st.params, w, h, rank, world, compact[b].data_ptr(), stream=stream.cuda_stream)
+            ev[i][1].record(stream)
+            rendered[b].record(stream)
+            with torch.cuda.stream(xstream):
+                xstream.wait_event(rendered[b])
+                ev[i][2].record(xstream)
+                if world == 1:
+                    gathered[b].copy_(compact[b])
+                elif args.backend == "nccl":
+                    dist.all_gather_into_tensor(gathered[b], compact[b])
+                else:
+                    gathered[b].copy_(D.all_gather_shards(compact[b].cpu(), world))
+                ev[i][3].record(xstream)
+                consumed[b].record(xstream)
+                ev[i][4].record(xstream)
+                st.context.unpermute(gathered[b].data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=xstream.cuda_stream)
+                ev[i][5].record(xstream)
+        fence()
+        per_rank = [sum(e[2 * j].elapsed_time(e[2 * j + 1]) for e in ev) / ne for j in range(3)]
+
     if args.verify and sharded:
         got = st.accum.clone()
         st.context.launch(st.params, w, h, 1, stream=stream.cuda_stream)
@@ -365,6 +429,9 @@ def main():
         rr = torch.tensor([rays_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays_total = int(rr.item())
+        pr = torch.tensor(per_rank, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(pr, op=dist.ReduceOp.MAX)
+        per_rank = [float(x) for x in pr.tolist()]
 
     if rank == 0:
         ms_per_step = t_max / args.steps * 1e3
@@ -396,18 +463,23 @@ def main():
         alg_gbs = kbytes_launch / (kms_avg * 1e-3) / 1e9 if kms_avg > 0 else 0.0
         # ---- the ceilings that can bind: HBM (counter bytes), L2, vector L1, VALU issue.  The BVH (~115 MB) is resident in L2 /
         # Infinity Cache, so algorithmic bytes / t exceeds what HBM could deliver and is reported as information only.
-        counters, counters_from = pmc_counters(kname) if world == 1 else (None, None)
+        counters, counters_from = pmc_counters(kname) if world == 1 else (None, {"refused": "N > 1: the profile is of the one-GPU kernels"})
         ceil = ceilings(counters, kms_avg * 1e-3, kbytes_launch)
-        if ceil:
-            bound = max(ceil, key=lambda k: ceil[k]["frac"])
-            top = ceil[bound]
-            # (the counters are the committed profile's, the time is this run's: a run much faster than the profiled one could
-            #  push a busy-cycle ratio past 1 -- report that as stale counters, do not pass it off as a fraction)
-            if top["frac"] > 1.0:
+        # SURVEY.md 8(d)'s number: HBM bytes (PMC counters, per launch) / the kernel's live duration / 8 TB/s.  `bound` says what the
+        # kernel is limited by: the largest THROUGHPUT ceiling when one exceeds 0.7, else "latency" -- no pipe is saturated and the
+        # waves wait for dependent fetches; the stall share of the data-return unit's busy time is reported with it.
+        hbm = ceil.get("hbm", {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "bytes_per_launch": None})
+        thr = {k: v["frac"] for k, v in ceil.items()}
+        bound, limiter = "hbm", None
+        if thr:
+            top = max(thr, key=lambda k: thr[k])
+            if thr[top] > 1.0:
                 counters_from = dict(counters_from or {}, stale="a ceiling computed from these counters exceeds 1 for this run's kernel time: re-profile")
-                top = dict(top, frac=None)
-        else:
-            bound, top = "hbm", {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
+            bound = top if thr[top] >= 0.7 else "latency"
+            limiter = {"largest_throughput_ceiling": top, "its_frac": thr[top],
+                       "td_stall_share_of_busy": ceil.get("td", {}).get("stall_share_of_busy"),
+                       "reading": "no pipe above 0.7 busy: the kernel waits for dependent L1-miss fetches behind the CU's in-order data return"
+                                  if bound == "latency" else "bound by the %s ceiling" % top}
         out = {
             "metric": "Mray/s (primary+shadow), 1920x1080 spp=1, 1M-tri scene",
             "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -419,16 +491,25 @@ def main():
                        "rays_per_frame": rays_total, "closest_rays": counts["closest_rays"] if world == 1 else None,
                        "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather%s" % (
                            world, " (frame k's gather overlaps frame k+1's tracing)" if args.overlap else ""),
-                       "bvh_build_s": round(info["build_seconds"], 3), "setup_s": round(build_s, 3)},
-            "roofline": {"bound": bound, "kernel": kname, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
-                         "frac": top["frac"],
-                         "traffic": ceil["hbm"]["bytes_per_launch"] if "hbm" in ceil else None,
-                         "ceilings": ceil, "counters_from": counters_from,
+                       "bvh_build_s": round(info["build_seconds"], 3), "setup_s": round(build_s, 3),
+                       "first_frame_ms": round(first_frame_ms, 4),
+                       "first_frame_is": "median of 5 fenced frames launched with no tile cost order (image order), as after any change of "
+                                         "camera size, rank or option; ms_per_step is the steady state of identical progressive frames"},
+            "roofline": {"bound": bound, "kernel": kname, "achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"],
+                         "frac": hbm["frac"], "frac_is": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s",
+                         "traffic": hbm.get("bytes_per_launch"),
+                         "limiter": limiter, "ceilings": ceil, "counters_from": counters_from,
                          "algorithmic_bytes_per_launch": int(kbytes_launch), "algorithmic_GBps_informational": round(alg_gbs, 1),
                          "kernel_ms_avg": round(kms_avg, 4), "kernel_ms_from": "HIP events around the kernel in every 8th timed step (%d launches)" % klaunches,
                          "per_frame_ms": {"trace_closest": round(k_closest, 4), "trace_any": round(k_any, 4),
                                           "shade": round(k_shade, 4), "raygen+resolve": round(k_other, 4)}},
         }
+        if sharded:
+            out["per_rank_ms"] = {"render": round(per_rank[0], 4), "gather": round(per_rank[1], 4), "scatter": round(per_rank[2], 4),
+                                  "is": "max over ranks of the mean over 8 extra untimed steps (events on the launch / exchange streams); "
+                                        "gather and scatter of frame k run beside the render of frame k+1%s" % ("" if args.overlap else " (not in this run: --no-overlap)"),
+                                  "ranks": world, "backend": ("rccl (torch.distributed nccl), %d ranks" % dist.get_world_size()) if world > 1 and args.backend == "nccl"
+                                  else (args.backend if world > 1 else "none (one rank: device copy)")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(st, scene, w, h, args.max_depth, args.cpu_seconds)
         print(json.dumps(out), flush=True)

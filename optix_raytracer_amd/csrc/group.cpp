@@ -163,6 +163,10 @@ int mipt_group_launch(MiptGroup* g, const MiptParams* params, unsigned int width
             mb.compact = mb.gathered = nullptr; mb.cap = 0;
             if (hipMalloc(&mb.compact, (size_t)ns * 16u) != hipSuccess || hipMalloc(&mb.gathered, (size_t)ns * 16u * n) != hipSuccess)
                 return g->fail(MIPT_ERROR_OUT_OF_MEMORY, "shard buffers");
+            // the padding slots of a shard (tiles beyond the image edge) are never written by the launch: gather zeros, not whatever
+            // hipMalloc returned
+            if (hipMemsetAsync(mb.compact, 0, (size_t)ns * 16u, mb.stream) != hipSuccess || hipMemsetAsync(mb.gathered, 0, (size_t)ns * 16u * n, mb.stream) != hipSuccess)
+                return g->fail(MIPT_ERROR_HIP, "clearing the shard buffers failed");
             mb.cap = ns;
         }
         rc = mipt_launch_shard(mb.ctx, (void*)mb.stream, &params[i], width, height, i, n, mb.compact);

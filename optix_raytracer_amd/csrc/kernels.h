@@ -30,7 +30,12 @@ struct DeviceCounters {
     unsigned long long tail_max;                        // deepest path of the current pass's k_tail launch (bounces it ran)
     unsigned long long dbg[6];
     uint32_t epoch;            // path kernels that do their own begin_sample (TailArgs): the launch whose first workgroup is through it
+    uint32_t pad_;
+    uint32_t* fault_host;      // pinned host word (MiptContext::h_pinned + kFaultWord): a kernel that gave up on a bounded wait ORs its
+                               // kFault* bit into it; mipt_sync / mipt_get_launch_stats / the next launch turn it into an error
 };
+constexpr uint32_t kFaultWord = 8;              // index into MiptContext::h_pinned (words 0 .. 3: run_wavefront's ring of live counts)
+constexpr uint32_t kFaultEpochTimeout = 1u;     // tail_await_epoch ran out: the statistics race it guards against may have happened
 
 struct DeviceBvh {
     const float4* nodes;       // 4 x float4 per MiptBvhNode

@@ -1250,7 +1250,7 @@ __device__ __forceinline__ void shade_path(const ShadeArgs& a, float4 hit, float
 __device__ void tile_order_job(const TileOrderJob& j, uint32_t chunk)
 {
     constexpr uint32_t kSegs = kOrderChunk / 64u;
-    __shared__ uint32_t s_tot[kOrderClasses], s_pre[kOrderClasses], s_first[kOrderClasses], s_seg[kSegs][kOrderClasses];
+    __shared__ uint32_t s_tot[kOrderClasses], s_pre[kOrderClasses], s_first[kOrderClasses], s_seg[kSegs][kOrderClasses], s_ok;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, waves = blockDim.x >> 6;
     if (tid < kOrderClasses) { s_tot[tid] = 0u; s_pre[tid] = 0u; }
     if (j.zero != nullptr && tid < kOrderClasses) j.zero[chunk * kOrderClasses + tid] = 0u;
@@ -1279,6 +1279,14 @@ __device__ void tile_order_job(const TileOrderJob& j, uint32_t chunk)
         for (uint32_t k = 0; k < tid; ++k) first += s_tot[k];
         s_first[tid] = first;
     }
+    // The ranks below are a permutation only if the launch before this one recorded EVERY tile (the histograms then sum to the tile
+    // count).  If it did not -- another kernel form ran than the host assumed -- the class bytes are stale: emit image order rather
+    // than an order with duplicate and missing tiles, which would leave pixels untraced.
+    if (tid == 0u) {
+        uint32_t total = 0u;
+        for (uint32_t k = 0; k < kOrderClasses; ++k) total += s_tot[k];
+        s_ok = total == j.n_tiles ? 1u : 0u;
+    }
     // The class width follows the frame: the heaviest class (it is open-ended, its tiles stay in image order) should hold about a
     // third of the tiles that cost anything -- on the headline frame that is 6 units (0.36 of them; 5 / 6 / 7 units: 0.355 /
     // 0.344 / 0.349 ms), and a fixed unit would mean nothing on a scene whose tiles cost a tenth or ten times as much.  One step
@@ -1293,6 +1301,10 @@ __device__ void tile_order_job(const TileOrderJob& j, uint32_t chunk)
         *j.width = w;
     }
     __syncthreads();
+    if (s_ok == 0u) {
+        for (uint32_t t = chunk * kOrderChunk + tid; t < (chunk + 1u) * kOrderChunk && t < j.n_tiles; t += blockDim.x) j.order[t] = t;
+        return;
+    }
     for (uint32_t g = wave; g < kSegs; g += waves) {
         const uint32_t tile = chunk * kOrderChunk + g * 64u + lane;
         const uint32_t cl = tile < j.n_tiles ? j.cls[tile] : 0xffu;
@@ -1481,19 +1493,28 @@ struct TailArgs {
     uint32_t  epoch;
 };
 
+// (bit 31 of `epoch` is the host's fault injection, env MIPT_DEBUG_EPOCH_FAULT at context creation: the first workgroup then
+//  publishes nothing and every wave runs into the time-out below -- tests/test_gpu_parity.py checks that this is reported)
 __device__ __forceinline__ void tail_publish_epoch(DeviceCounters* c, uint32_t epoch)
 {
-    if (threadIdx.x == 0u) {
+    if (threadIdx.x == 0u && (epoch >> 31) == 0u) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(&c->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// The wait is bounded (a wave must never hang the device): ~2^17 polls of 512 cycles, tens of milliseconds.  Running out of it is
+// NOT silent: the wave raises kFaultEpochTimeout in the context's pinned fault word, and the host's next synchronising call fails.
 __device__ __forceinline__ void tail_await_epoch(DeviceCounters* c, uint32_t epoch)
 {
     if (threadIdx.x == 0u) {
-        for (int spin = 0; spin < (1 << 20); ++spin) {
-            if (__hip_atomic_load(&c->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) break;
+        bool seen = false;
+        for (int spin = 0; spin < (1 << 17); ++spin) {
+            if (__hip_atomic_load(&c->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { seen = true; break; }
             __builtin_amdgcn_s_sleep(8);
+        }
+        if (!seen) {
+            uint32_t* f = __hip_atomic_load(&c->fault_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f) __hip_atomic_fetch_or(f, kFaultEpochTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }

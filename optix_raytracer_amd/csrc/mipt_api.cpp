@@ -26,6 +26,15 @@
 
 using namespace mipt;
 
+// per-wave probe builds (make probe-waves PROBE_FLAGS=-DMIPT_PROBE_WAVES=1: this file and kernels.hip are compiled with the flag):
+// only they read a record buffer's device address from the environment -- the shipped library has no such hook
+#ifndef MIPT_PROBE_WAVES
+#define MIPT_PROBE_WAVES 0
+#endif
+
+// the kept layouts: each figure below is what the reference's own headers state (oracle/ref_kat.cpp prints sizeof / offsetof from
+// optixPathTracer.h, cuda/whitted.h, BufferView.h, Light.h, optix_types.h into tests/golden/ref_kat.json "layouts";
+// tests/test_host_abi.py compares include/mipt.h, compiled as C, and the ctypes mirrors against that file)
 static_assert(sizeof(MiptParams) == 152, "Params layout must match optixPathTracer.h:91-107");
 static_assert(offsetof(MiptParams, accum_buffer) == 8 && offsetof(MiptParams, frame_buffer) == 16, "Params layout");
 static_assert(offsetof(MiptParams, width) == 24 && offsetof(MiptParams, samples_per_launch) == 32, "Params layout");
@@ -139,6 +148,7 @@ struct MiptContext {
     bool        tile_class_fixed = false;    // MIPT_TILE_CLASS given: that width, not adapted
     uint32_t    tile_class_width = 6;    // env MIPT_TILE_CLASS: cost units per class (headline frame, 16 classes: 6 / 8 / 12 -> 0.349 / 0.354 / 0.381 ms)
     uint32_t  tail_epoch = 0;            // TailArgs::epoch of the last path-kernel launch that made its own rays
+    bool      debug_epoch_fault = false; // env MIPT_DEBUG_EPOCH_FAULT: the next such launches publish no epoch (tests the fault report)
     int       tail_refill = 1;           // env MIPT_TAIL_REFILL (TraceOpts::tail_refill)
     uint32_t  profile_launch = 0;        // launches since MIPT_OPT_PROFILE was set (mode 3 brackets every 8th)
     int       direct_resolve = 1;        // env MIPT_DIRECT_RESOLVE=0: always a k_resolve launch (A/B)
@@ -509,6 +519,25 @@ uint32_t shard_valid_pixels(uint32_t w, uint32_t h, uint32_t world, uint32_t ran
     return valid;
 }
 
+uint32_t next_epoch(MiptContext* ctx)
+{
+    ctx->tail_epoch = (ctx->tail_epoch + 1u) & 0x7fffffffu;
+    if (ctx->tail_epoch == 0u) ctx->tail_epoch = 1u;
+    return ctx->tail_epoch | (ctx->debug_epoch_fault ? 0x80000000u : 0u);
+}
+
+// A kernel that gave up on a bounded wait has said so in the pinned fault word: after a synchronisation that is an error, once.
+int check_device_faults(MiptContext* ctx)
+{
+    uint32_t* fw = ctx->h_pinned + kFaultWord;
+    const uint32_t f = __atomic_exchange_n(fw, 0u, __ATOMIC_RELAXED);
+    if (f & kFaultEpochTimeout)
+        return ctx->fail(MIPT_ERROR_INTERNAL, "a path-kernel wave timed out waiting for the launch's first workgroup (epoch handshake): "
+                                              "the ray counters of that launch may miss additions; pixels are not affected");
+    if (f) return ctx->fail(MIPT_ERROR_INTERNAL, "device fault word 0x%x", f);
+    return MIPT_SUCCESS;
+}
+
 int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, const Accel* acc, size_t n_slots,
                   float4* accum_out, uint32_t* frame_out)
 {
@@ -551,9 +580,8 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         // the primary rays of a frame (or of a rank's shard of it) walk their tiles in the order of the previous launch's costs (MIPT_OPT_TILE_ORDER) when this
         // pass runs the tiled kernel (launch_trace's choice: the pool form over a one-level BVH that fits it, more than 2560 rays
         // per CU, not a counting launch): the raygen launch clears the class counters this pass fills
-        const bool tiled_primary = ctx->tile_order_mode != 0 && !batch && opts.persistent == 3 && !opts.count_visits &&
-                                   bvh.pool_ok != 0u && bvh.tri_byte_off != 0u && bvh.depth <= 32u && bvh.inst == nullptr &&
-                                   n_paths > (uint32_t)ctx->num_cus * 2560u && n_paths > first_limit;
+        // (ONE predicate decides the kernel form: closest_launch_is_tiled() -- launch_trace consults the same function)
+        const bool tiled_primary = ctx->tile_order_mode != 0 && !batch && closest_launch_is_tiled(bvh, n_paths, opts) && n_paths > first_limit;
         TileOrderJob job{};
         if (tiled_primary) {
             const uint32_t tiles = n_paths / 64u, chunks = (tiles + kOrderChunk - 1u) / kOrderChunk;
@@ -593,7 +621,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             // a pass this small runs in the tail kernel from the first bounce on (Cornell 512x512: 0.73 -> 0.37 ms)
             TimedScope t(ctx, st, T_CLOSEST);
             launch_tail(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->q[0], ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, opts, rj,
-                        fused_raygen ? &rg : nullptr, ++ctx->tail_epoch);
+                        fused_raygen ? &rg : nullptr, next_epoch(ctx));
             continue;
         }
         uint32_t bound = n_paths;      // upper bound of the live-path count (it only falls): the latest count the host has seen
@@ -611,7 +639,8 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                   if (!ctx->tile_group_set && o2.tile_order != nullptr) o2.tile_group = 96;
                   if (ctx->tile_order_mode == 2 && ctx->tile_order_valid) { o2.tile_cost = nullptr; job = TileOrderJob{}; }
               }
-              if (bounce == 0u) {     // probe builds, as in mipt_trace_closest (MIPT_PROBE_WAVES_ANY: the any-hit kernel's records)
+#if MIPT_PROBE_WAVES
+              if (bounce == 0u) {     // probe builds only, as in mipt_trace_closest (MIPT_PROBE_WAVES_ANY: the any-hit kernel's records)
                   if (const char* e = std::getenv("MIPT_PROBE_WAVES")) {
                       const unsigned long long addr = std::strtoull(e, nullptr, 0);
                       HIPCHK(ctx, hipMemcpyAsync(&ctx->d_ctr->dbg[0], &addr, 8, hipMemcpyHostToDevice, st));
@@ -621,6 +650,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                       HIPCHK(ctx, hipMemcpyAsync(&ctx->d_ctr->dbg[1], &addr, 8, hipMemcpyHostToDevice, st));
                   }
               }
+#endif
               launch_trace_closest(st, bvh, ctx->q[cur].ray_o, ctx->q[cur].ray_d, 1, &ctx->d_ctr->n_cur, bound, ctx->hits, ctx->d_ctr, o2, 0u,
                                    bounce == 0u && fused_raygen ? &rg : nullptr); }
             { TimedScope t(ctx, st, T_SHADE);
@@ -714,8 +744,14 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
         delete c;
         return MIPT_ERROR_OUT_OF_MEMORY;
     }
+    std::memset(c->h_pinned, 0, 64);
+    {   // kernels report a bounded wait that ran out through this pinned word (DeviceCounters::fault_host)
+        uint32_t* fw = c->h_pinned + kFaultWord;
+        if (hipMemcpy(&c->d_ctr->fault_host, &fw, sizeof fw, hipMemcpyHostToDevice) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
+    }
     for (hipEvent_t& e : c->ring_ev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess) { delete c; return MIPT_ERROR_HIP; }
+    if (const char* e = std::getenv("MIPT_DEBUG_EPOCH_FAULT")) c->debug_epoch_fault = std::atoi(e) != 0;      // fault injection for the test of the report path
     // experiment hooks (tools/, CI matrix): initial values of MIPT_OPT_PERSISTENT / MIPT_OPT_STEAL_MIN
     if (const char* e = std::getenv("MIPT_PERSISTENT")) { const int v = std::atoi(e); if (v == 0 || v == 2 || v == 3) c->persistent = v; }
     if (const char* e = std::getenv("MIPT_NODE_FORMAT")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->node_format = v; }
@@ -931,7 +967,7 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
     a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = 1;
     if ((e = finish_blob(ctx, a)) != hipSuccess) { free_accel(a); return ctx->fail(MIPT_ERROR_HIP, "device BVH build: %s", hipGetErrorString(e)); }
-    a->bytes = nb + tb + (size_t)nn * 32u + (size_t)n * 4u;
+    a->bytes = nb + tb + 64 + 256 + (size_t)nn * 96u + (size_t)n * 4u;         // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
@@ -1039,7 +1075,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         free_accel(a);
         return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "accel upload failed: %s", hipGetErrorString(e));
     }
-    a->bytes = nb + tb + (size_t)a->num_nodes * 32u + mb;
+    a->bytes = nb + tb + 64 + 256 + (size_t)a->num_nodes * 96u + mb;             // the whole allocation: nodes | triangles | pad | room for both node mirrors, + the SBT index table
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
     *handle_out = h;
@@ -1073,18 +1109,28 @@ bool invert3x4(const float* m, float* out)
     return true;
 }
 
-// fills `a` (fresh or being rebuilt) from the instance records; on failure leaves a message in ctx
+// Fills `a` (fresh or being rebuilt) from the instance records.  Transactional: everything is validated and built into local
+// tables and FRESH device allocations first; `a` is touched -- the new tables swapped in, the old device copies released -- only
+// after the last step has succeeded.  On failure `a` is exactly what it was (a failed mipt_accel_update_instances leaves the
+// structure, its mesh references and its export tables intact) and ctx holds the message.
+struct IasScratch {
+    float4* d_nodes = nullptr; DeviceInstance* d_inst = nullptr; uint32_t* d_order = nullptr; uint32_t* d_mat = nullptr;
+    ~IasScratch() { for (void* p : { (void*)d_nodes, (void*)d_inst, (void*)d_order, (void*)d_mat }) if (p) (void)hipFree(p); }
+};
+
 int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
 {
     std::vector<float> boxes((size_t)n * 9);                       // lo, hi, lo per instance
     std::vector<DeviceInstance> recs(n);
-    a->h_inv.assign((size_t)n * 12, 0.0f); a->h_base.assign(n, 0u); a->gas.assign(n, 0ull);
+    std::vector<float> h_inv((size_t)n * 12, 0.0f);
+    std::vector<uint32_t> h_base(n, 0u);
+    std::vector<unsigned long long> gas(n, 0ull);
     uint64_t total_tris = 0; uint32_t max_depth = 0;
     for (uint32_t k = 0; k < n; ++k) {
         Accel* g = find_accel(ctx, inst[k].traversableHandle);
         if (!g || g->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "instance %u: traversableHandle 0x%llx is not a triangle acceleration structure of this context",
                                               k, inst[k].traversableHandle);
-        if (!invert3x4(inst[k].transform, &a->h_inv[(size_t)k * 12])) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance %u: singular transform", k);
+        if (!invert3x4(inst[k].transform, &h_inv[(size_t)k * 12])) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance %u: singular transform", k);
         // the mesh's object-space box = the union of its root's two child boxes, read back from the device
         MiptBvhNode root;
         HIPCHK(ctx, hipMemcpy(&root, g->d_nodes, sizeof root, hipMemcpyDeviceToHost));
@@ -1107,36 +1153,34 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
         const float pad = mag * 1.9073486e-6f + 1e-30f;              // 2^-19 of the largest coordinate
         for (int r = 0; r < 3; ++r) { bx[r] -= pad; bx[3 + r] += pad; bx[6 + r] = bx[r]; }
         DeviceInstance& d = recs[k];
-        std::memcpy(d.inv, &a->h_inv[(size_t)k * 12], 48);
+        std::memcpy(d.inv, &h_inv[(size_t)k * 12], 48);
         d.nodes = g->d_nodes; d.tris = g->d_tris; d.prim_base = (uint32_t)total_tris;
-        a->h_base[k] = (uint32_t)total_tris; a->gas[k] = inst[k].traversableHandle;
+        h_base[k] = (uint32_t)total_tris; gas[k] = inst[k].traversableHandle;
         total_tris += g->n_prims;
         max_depth = std::max(max_depth, g->depth);
         if (total_tris >= (1ull << 31)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instances reference more than 2^31 triangles");
     }
     HostBvh top;
     if (!build_bvh(boxes.data(), n, 1, kStackEntries, 1, top)) return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "instance BVH over %u instances is too deep", n);
-    a->h_order.resize(top.tris.size());
-    for (size_t k = 0; k < top.tris.size(); ++k) a->h_order[k] = top.tris[k].prim;
-    a->h_tlas = top.nodes;
-    // device copies (the previous ones, on a rebuild, are released first)
-    if (a->d_nodes) (void)hipFree(a->d_nodes);
-    if (a->d_inst) (void)hipFree(a->d_inst);
-    if (a->d_order) (void)hipFree(a->d_order);
-    if (a->d_mat) (void)hipFree(a->d_mat);
-    a->d_nodes = nullptr; a->d_inst = nullptr; a->d_order = nullptr; a->d_mat = nullptr;
-    HIPCHK(ctx, hipMalloc((void**)&a->d_nodes, top.nodes.size() * sizeof(MiptBvhNode)));
-    HIPCHK(ctx, hipMemcpy(a->d_nodes, top.nodes.data(), top.nodes.size() * sizeof(MiptBvhNode), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMalloc((void**)&a->d_inst, (size_t)n * sizeof(DeviceInstance)));
-    HIPCHK(ctx, hipMemcpy(a->d_inst, recs.data(), (size_t)n * sizeof(DeviceInstance), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMalloc((void**)&a->d_order, std::max<size_t>(a->h_order.size(), 1) * 4u));
-    if (!a->h_order.empty()) HIPCHK(ctx, hipMemcpy(a->d_order, a->h_order.data(), a->h_order.size() * 4u, hipMemcpyHostToDevice));
+    std::vector<uint32_t> h_order(top.tris.size());
+    for (size_t k = 0; k < top.tris.size(); ++k) h_order[k] = top.tris[k].prim;
+    // fresh device copies; the structure's current ones stay in place (and in use by nothing: the callers synchronise) until all exist
+    IasScratch S;
+    HIPCHK(ctx, hipMalloc((void**)&S.d_nodes, top.nodes.size() * sizeof(MiptBvhNode)));
+    HIPCHK(ctx, hipMemcpy(S.d_nodes, top.nodes.data(), top.nodes.size() * sizeof(MiptBvhNode), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void**)&S.d_inst, (size_t)n * sizeof(DeviceInstance)));
+    HIPCHK(ctx, hipMemcpy(S.d_inst, recs.data(), (size_t)n * sizeof(DeviceInstance), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void**)&S.d_order, std::max<size_t>(h_order.size(), 1) * 4u));
+    if (!h_order.empty()) HIPCHK(ctx, hipMemcpy(S.d_order, h_order.data(), h_order.size() * 4u, hipMemcpyHostToDevice));
     // hit-group record index per FLATTENED primitive: the meshes' own tables, one after the other
-    HIPCHK(ctx, hipMalloc((void**)&a->d_mat, std::max<uint64_t>(total_tris, 1) * 4u));
+    HIPCHK(ctx, hipMalloc((void**)&S.d_mat, std::max<uint64_t>(total_tris, 1) * 4u));
     for (uint32_t k = 0; k < n; ++k) {
         const Accel* g = find_accel(ctx, inst[k].traversableHandle);
-        if (g->n_prims) HIPCHK(ctx, hipMemcpy(a->d_mat + a->h_base[k], g->d_mat, (size_t)g->n_prims * 4u, hipMemcpyDeviceToDevice));
+        if (g->n_prims) HIPCHK(ctx, hipMemcpy(S.d_mat + h_base[k], g->d_mat, (size_t)g->n_prims * 4u, hipMemcpyDeviceToDevice));
     }
+    // ---- commit: nothing below can fail
+    std::swap(a->d_nodes, S.d_nodes); std::swap(a->d_inst, S.d_inst); std::swap(a->d_order, S.d_order); std::swap(a->d_mat, S.d_mat);   // ~IasScratch frees the old ones
+    a->h_inv.swap(h_inv); a->h_base.swap(h_base); a->gas.swap(gas); a->h_order.swap(h_order); a->h_tlas = top.nodes;
     a->d_tris = nullptr; a->tri_byte_off = 0; a->blob_bytes = 0; a->node32_off = 0;
     a->num_nodes = (uint32_t)top.nodes.size(); a->num_tris = (uint32_t)total_tris; a->n_prims = (uint32_t)total_tris;
     a->depth = top.depth + max_depth; a->leaf_max = 1; a->is_ias = true;
@@ -1398,7 +1442,7 @@ int mipt_sync(MiptContext* ctx)
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
-    return MIPT_SUCCESS;
+    return check_device_faults(ctx);
 }
 
 int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
@@ -1406,6 +1450,7 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     if (!ctx || !stats) return MIPT_ERROR_INVALID_VALUE;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->last_stream));
+    if (const int frc = check_device_faults(ctx)) return frc;
     DeviceCounters h;
     HIPCHK(ctx, hipMemcpy(&h, ctx->d_ctr, sizeof h, hipMemcpyDeviceToHost));
     if (ctx->advance_pending) {            // advance() of the launch's last bounce (kernels.hip), on the copy
@@ -1641,10 +1686,12 @@ int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle
     ctx->advance_pending = false;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, n);
-    if (const char* e = std::getenv("MIPT_PROBE_WAVES")) {          // probe builds: address of a caller-allocated device buffer for per-wave records
+#if MIPT_PROBE_WAVES
+    if (const char* e = std::getenv("MIPT_PROBE_WAVES")) {          // probe builds only: address of a caller-allocated device buffer for per-wave records
         const unsigned long long addr = std::strtoull(e, nullptr, 0);
         HIPCHK(ctx, hipMemcpyAsync(&ctx->d_ctr->dbg[0], &addr, 8, hipMemcpyHostToDevice, st));
     }
+#endif
     const float4* r = (const float4*)rays;
     { TimedScope t(ctx, st, T_CLOSEST);
       launch_trace_closest(st, device_bvh(a), r, r + 1, 2, nullptr, n, (float4*)hits, ctx->d_ctr, trace_opts(ctx)); }
@@ -1665,10 +1712,12 @@ int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, co
     ctx->advance_pending = false;
     HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, 0);
-    if (const char* e = std::getenv("MIPT_PROBE_WAVES_ANY")) {      // probe builds: per-wave records of k_trace_static (tools/probe_shadow_order.py)
+#if MIPT_PROBE_WAVES
+    if (const char* e = std::getenv("MIPT_PROBE_WAVES_ANY")) {      // probe builds only: per-wave records of k_trace_static (tools/probe_shadow_order.py)
         const unsigned long long addr = std::strtoull(e, nullptr, 0);
         HIPCHK(ctx, hipMemcpyAsync(&ctx->d_ctr->dbg[1], &addr, 8, hipMemcpyHostToDevice, st));
     }
+#endif
     const float4* r = (const float4*)rays;
     { TimedScope t(ctx, st, T_ANY);
       launch_trace_any(st, device_bvh(a), r, r + 1, 2, nullptr, n, (uint32_t*)occluded, nullptr, nullptr, ctx->d_ctr, trace_opts(ctx)); }

@@ -323,6 +323,35 @@ def test_error_behaviour():
     PT.cleanupState(st)
 
 
+def test_epoch_handshake_timeout_is_reported(monkeypatch):
+    """A path kernel that makes its own rays lets its waves wait (bounded) for the first workgroup's bookkeeping.  If that wait ever
+    runs out, the launch statistics may miss additions -- so it must not be silent: the wave raises a bit in the context's pinned
+    fault word and the next synchronising call returns MIPT_ERROR_INTERNAL, once.  MIPT_DEBUG_EPOCH_FAULT makes the first workgroup
+    publish nothing, so every wave runs into the time-out.  Pixels do not depend on the handshake: they still equal the oracle's."""
+    torch = _torch()
+    from optix_raytracer_amd import api, scenes
+    scene = scenes.cornell_box()
+    w, h = 96, 64
+    monkeypatch.setenv("MIPT_DEBUG_EPOCH_FAULT", "1")
+    PT, st = _state(scene, w, h, 1, 0)
+    monkeypatch.delenv("MIPT_DEBUG_EPOCH_FAULT")
+    ob = PT.OutputBuffer(w, h, st.device)
+    with pytest.raises(api.MiptError) as e:                    # a small pass: the path kernel from the first bounce, own raygen;
+        PT.launchSubframe(ob, st)                              # launchSubframe ends in mipt_sync (CUDA_SYNC_CHECK's place)
+    assert e.value.code == 8 and "epoch" in str(e.value)       # MIPT_ERROR_INTERNAL
+    st.context.sync()                                          # reported once
+    acc = st.accum.cpu().numpy()
+    a, f, ost = _oracle_scene(scene, st).render(scenes.launch_desc(scene, w, h, 1))
+    _assert_pixels(acc, a)
+    # a context without the injection never raises it
+    PT2, st2 = _state(scene, w, h, 1, 0)
+    acc2, _, stats2 = _render_gpu(PT2, st2)
+    st2.context.sync()
+    assert stats2["closest_rays"] == ost["closest_rays"] and stats2["shadow_rays"] == ost["shadow_rays"]
+    _assert_pixels(acc2, a)
+    PT.cleanupState(st); PT2.cleanupState(st2)
+
+
 def test_indexed_strided_and_transformed_inputs():
     """build inputs as sutil::Scene feeds them: u16/u32 indices, byte strides, a 3x4 instance transform"""
     torch = _torch()

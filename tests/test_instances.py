@@ -171,8 +171,24 @@ def test_two_level_structure_matches_the_oracle_and_the_flattened_scene(tmp_path
         ctx.accel_build_instances(bad)
     with pytest.raises(api.MiptError):
         ctx.accel_build_instances([(ias, np.eye(4, dtype=np.float32)[:3])])      # an instance structure as a child
+    # ---- a FAILED update changes nothing: a singular matrix at instance k is refused, the structure still gives the
+    # same hits, its export tables still describe the device copy, a later valid update works, and every structure can be destroyed
+    before = ctx.accel_export_instances(ias)
+    badu = list(moved)
+    badu[5] = (badu[5][0], np.zeros((3, 4), np.float32))
+    with pytest.raises(api.MiptError):
+        ctx.accel_update_instances(ias, badu)
+    after = ctx.accel_export_instances(ias)
+    for b_, a_ in zip(before, after):
+        assert np.array_equal(b_.view(np.uint8), a_.view(np.uint8))
+    ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+    assert np.array_equal(h_upd.view(np.uint32), d_hits.cpu().numpy().view(np.uint32))
+    ctx.accel_update_instances(ias, inst)                                         # back to the first placement
+    ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+    assert np.array_equal(hits2.view(np.uint32), d_hits.cpu().numpy().view(np.uint32))
     ctx.accel_destroy(fresh); ctx.accel_destroy(ias)
-    ctx.accel_destroy(gas[0])
+    for g in sorted(set(gas)):
+        ctx.accel_destroy(g)                                                      # no reference is left behind
     ctx.destroy()
 
 

@@ -11,7 +11,11 @@ import sys
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 commit = sys.argv[4] if len(sys.argv) > 4 else subprocess.run(
     ["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-out = {"source": tag, "commit": commit,
+import hashlib
+import os
+_k = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "optix_raytracer_amd", "csrc", "kernels.hip"), "rb").read()
+blob = hashlib.sha1(b"blob %d\0" % len(_k) + _k).hexdigest()      # git's blob id of the kernel source the profile was taken on (bench.py checks it)
+out = {"source": tag, "commit": commit, "kernels_hip_blob": blob,
        "note": "rocprofv3 --pmc, separate passes (tools/prof_l1.sh); per-launch means of the timed dispatches; FETCH_SIZE / "
                "WRITE_SIZE in KB as rocprofv3 reports them (FETCH_SIZE counts 64 B per 128-B request on gfx950: double it)",
        "kernels": {}}
