@@ -190,6 +190,8 @@ void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, ui
 // place, and writes the packed 32-byte mirror (MiptBvhNode32) the entry-pool kernels fetch.  *ok = false (nothing changed)
 // when the scene does not suit fp16 boxes: a coordinate beyond +-32768, or an extent below a quarter of the largest one.
 hipError_t pack_nodes32(hipStream_t st, float4* d_nodes, uint32_t nn, void* d_nodes32, bool* ok);
+// Node format 2: the BVH4 mirror (64-byte nodes of four fp16 boxes) of the packed BVH2 mirror, made on the device (lbvh_build.hip)
+hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4, uint32_t* stack_need, bool* ok);
 hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris);
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok);

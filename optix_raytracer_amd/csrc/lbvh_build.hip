@@ -343,6 +343,133 @@ __global__ __launch_bounds__(256) void k_pack_nodes32(MiptBvhNode* nodes, uint32
     out[2u * i + 1u] = make_uint4(w[1][0], w[1][1], w[1][2], (uint32_t)nd.c1);
 }
 
+
+// ---- node format 2 on the device: the BVH4 mirror -------------------------------------------------------------------------------
+// The collapse of the (fp16-rounded) BVH2 into four-child nodes that optixAccelBuild's counterpart here used to do on one host core
+// (round 2: a D2H copy of every node, tens of ms of host time, an H2D copy -- on every build AND every refit).  Same rule as there:
+// a node takes the two children of one of its inner children in place of that child, largest box first, while the worst-case
+// per-lane stack of the walk stays within the budget (a node with n children holds n - 1 entries while its deepest subtree is
+// walked; a BVH2 subtree of height h always fits h entries).  Level by level, top down: pass L turns the BVH2 nodes that became
+// the BVH4 nodes of level L into 64-byte nodes and allots the indices of level L + 1 (one atomic per workgroup; siblings get
+// consecutive indices, so the four children of a node share two 128-byte lines).  The boxes are read from the PACKED BVH2 mirror
+// (they are the fp16 values already), so the mirror holds the same boxes bit for bit and nothing is converted.
+// Heights (bottom-up, no thread waits: the last reporter of a node carries on to its parent) come first.
+__global__ __launch_bounds__(256) void k_b4_parents(const uint4* n32, uint32_t nn, int* parent)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    const int c0 = (int)n32[2u * i].w, c1 = (int)n32[2u * i + 1u].w;
+    if (c0 >= 0 && (uint32_t)c0 < nn) parent[c0] = (int)i;
+    if (c1 >= 0 && (uint32_t)c1 < nn) parent[c1] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void k_b4_heights(const uint4* n32, uint32_t nn, const int* parent, uint32_t* arrived, uint32_t* height)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    for (;;) {
+        const int c0 = (int)n32[2u * i].w, c1 = (int)n32[2u * i + 1u].w;
+        const bool in0 = c0 >= 0 && (uint32_t)c0 < nn, in1 = c1 >= 0 && (uint32_t)c1 < nn;
+        const uint32_t need = 1u + (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
+        __threadfence();
+        if (atomicAdd(&arrived[i], 1u) + 1u < need) return;
+        __threadfence();
+        const uint32_t h0 = in0 ? __hip_atomic_load(&height[c0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t h1 = in1 ? __hip_atomic_load(&height[c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        __hip_atomic_store(&height[i], 1u + (h0 > h1 ? h0 : h1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int pr = parent[i];
+        if (pr < 0) return;
+        i = (uint32_t)pr;
+    }
+}
+
+struct B4Work { uint32_t x, budget, used, pad; };      // BVH2 node x is BVH4 node <its position in the work array>
+
+__device__ __forceinline__ float b4_area(const uint4 q)
+{
+    const float dx = half_bits_to_float(q.x >> 16) - half_bits_to_float(q.x & 0xffffu);
+    const float dy = half_bits_to_float(q.y >> 16) - half_bits_to_float(q.y & 0xffffu);
+    const float dz = half_bits_to_float(q.z >> 16) - half_bits_to_float(q.z & 0xffffu);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// cnt[k]: BVH4 nodes of level k (cnt[0] = 1, the rest zero at the start); misc[0]: the most stack entries a lane can need
+__global__ __launch_bounds__(256) void k_b4_level(const uint4* __restrict__ n32, uint32_t nn, const uint32_t* __restrict__ height, uint32_t level,
+                                                  uint32_t* cnt, B4Work* work, uint32_t cap, uint4* out, uint32_t* misc)
+{
+    __shared__ uint32_t s_wave[4], s_base;
+    uint32_t begin = 0u;
+    for (uint32_t k = 0; k < level; ++k) begin += cnt[k];
+    const uint32_t end = begin + cnt[level];
+    for (uint32_t i0 = begin + blockIdx.x * blockDim.x; i0 < end; i0 += gridDim.x * blockDim.x) {      // (uniform per workgroup)
+        const uint32_t me = i0 + threadIdx.x;
+        uint4 q[4];
+        int n = 0;
+        uint32_t budget = 0u, used = 0u, n_inner = 0u;
+        if (me < end) {
+            const B4Work w = work[me];
+            budget = w.budget; used = w.used;
+            q[0] = n32[2u * w.x]; q[1] = n32[2u * w.x + 1u];
+            q[2] = q[3] = make_uint4(0u, 0u, 0u, 0x7fffffffu);
+            n = 2;
+            auto h_of = [&](uint32_t ref) { return (int)ref >= 0 && ref < nn ? height[ref] : 0u; };
+            for (;;) {
+                int best = -1; float best_area = -1.0f;
+                if (n < 4) for (int i = 0; i < n; ++i) if ((int)q[i].w >= 0) {
+                    const float a = b4_area(q[i]);
+                    if (a > best_area) { best_area = a; best = i; }
+                }
+                if (best < 0) break;
+                // expanding child c leaves n + 1 children: n entries are held while the deepest remaining subtree is walked
+                auto fits = [&](int c) {
+                    uint32_t hm = 0u;
+                    for (int j = 0; j < n; ++j) if (j != c) { const uint32_t h = h_of(q[j].w); hm = h > hm ? h : hm; }
+                    const uint32_t g0 = h_of(n32[2u * q[c].w].w), g1 = h_of(n32[2u * q[c].w + 1u].w);
+                    hm = g0 > hm ? g0 : hm; hm = g1 > hm ? g1 : hm;
+                    return (uint32_t)n + hm <= budget;
+                };
+                if (!fits(best)) {
+                    int other = -1;
+                    for (int i = 0; i < n && other < 0; ++i) if (i != best && (int)q[i].w >= 0 && fits(i)) other = i;
+                    if (other < 0) break;
+                    best = other;
+                }
+                const uint32_t c = q[best].w;
+                q[best] = n32[2u * c]; q[n] = n32[2u * c + 1u];
+                ++n;
+            }
+            for (int i = 0; i < n; ++i) n_inner += (int)q[i].w >= 0 ? 1u : 0u;
+            atomicMax(&misc[0], used + (uint32_t)(n - 1));
+        }
+        // indices of this workgroup's children in the next level: wave scan, workgroup scan, one atomic
+        uint32_t incl = n_inner;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64); if ((int)(threadIdx.x & 63u) >= off) incl += v; }
+        if ((threadIdx.x & 63u) == 63u) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            s_base = tot ? atomicAdd(&cnt[level + 1u], tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t at = end + s_base + (incl - n_inner);
+        for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) at += s_wave[wv];
+        __syncthreads();                                                     // s_wave / s_base are reused by the next round
+        if (me < end) {
+            const uint32_t nb = budget - (uint32_t)(n - 1), nu = used + (uint32_t)(n - 1);
+            for (int i = 0; i < 4; ++i) {
+                uint4 o = q[i];
+                if (i >= n) o = make_uint4(0u, 0u, 0u, 0x7fffffffu);
+                else if ((int)o.w >= 0) {
+                    if (at < cap) work[at] = B4Work{ o.w, nb, nu, 0u };
+                    else atomicMax(&misc[1], 1u);                            // cannot happen (a BVH4 has fewer nodes than its BVH2): reported
+                    o.w = at++;
+                }
+                if (me < cap) out[4u * me + (uint32_t)i] = o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t pack_nodes32(hipStream_t st, float4* d_nodes, uint32_t nn, void* d_nodes32, bool* ok)
@@ -371,6 +498,47 @@ hipError_t pack_nodes32(hipStream_t st, float4* d_nodes, uint32_t nn, void* d_no
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) *ok = true;
     return e;
+}
+
+// The BVH4 mirror of the packed BVH2 at d_nodes32, written to d_nodes4 (room for nn nodes of 64 B).  *ok = false (and nothing to
+// use) when the tree is higher than 32 or the mirror would not fit; *n4 nodes, *stack_need entries per lane at most.
+hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4, uint32_t* stack_need, bool* ok)
+{
+    *ok = false; *n4 = 0u; *stack_need = 0u;
+    if (nn == 0u || depth == 0u || depth > 32u) return hipSuccess;
+    char* tmp = nullptr;
+    const size_t o_parent = 0, o_arr = o_parent + (((size_t)nn * 4u + 255) & ~(size_t)255), o_h = o_arr + (((size_t)nn * 4u + 255) & ~(size_t)255),
+                 o_work = o_h + (((size_t)nn * 4u + 255) & ~(size_t)255), o_cnt = o_work + (((size_t)nn * sizeof(B4Work) + 255) & ~(size_t)255), total = o_cnt + 512;
+    hipError_t e = hipMalloc((void**)&tmp, total);
+    if (e != hipSuccess) return e;
+    int* parent = (int*)(tmp + o_parent); uint32_t* arrived = (uint32_t*)(tmp + o_arr); uint32_t* height = (uint32_t*)(tmp + o_h);
+    B4Work* work = (B4Work*)(tmp + o_work); uint32_t* cnt = (uint32_t*)(tmp + o_cnt); uint32_t* misc = cnt + 64;
+    auto fail = [&](hipError_t err) { (void)hipFree(tmp); return err; };
+    if ((e = hipMemsetAsync(parent, 0xff, (size_t)nn * 4u, st)) != hipSuccess) return fail(e);
+    if ((e = hipMemsetAsync(arrived, 0, (size_t)nn * 4u, st)) != hipSuccess) return fail(e);
+    if ((e = hipMemsetAsync(cnt, 0, 512, st)) != hipSuccess) return fail(e);
+    const uint32_t one = 1u;
+    const B4Work root{ 0u, 32u, 0u, 0u };
+    if ((e = hipMemcpyAsync(cnt, &one, 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(work, &root, sizeof root, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
+    const uint4* n32 = reinterpret_cast<const uint4*>(d_nodes32);
+    const uint32_t blocks = (nn + 255u) / 256u;
+    hipLaunchKernelGGL(k_b4_parents, dim3(blocks), dim3(256), 0, st, n32, nn, parent);
+    hipLaunchKernelGGL(k_b4_heights, dim3(blocks), dim3(256), 0, st, n32, nn, parent, arrived, height);
+    // a BVH4 level is at most a BVH2 level deep, so `depth` passes reach every node; a pass whose level is empty returns at once
+    const uint32_t grid = blocks < 2048u ? blocks : 2048u;
+    for (uint32_t level = 0; level < depth; ++level)
+        hipLaunchKernelGGL(k_b4_level, dim3(grid), dim3(256), 0, st, n32, nn, height, level, cnt, work, nn, reinterpret_cast<uint4*>(d_nodes4), misc);
+    uint32_t h_cnt[66];
+    if ((e = hipMemcpyAsync(h_cnt, cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+    (void)hipFree(tmp);
+    uint64_t tot = 0;
+    for (uint32_t k = 0; k <= depth && k < 64u; ++k) tot += h_cnt[k];
+    if (h_cnt[65] != 0u || tot > nn || h_cnt[depth < 64u ? depth : 63u] != 0u || h_cnt[64] > 32u) return hipSuccess;      // (none of these can happen)
+    *n4 = (uint32_t)tot; *stack_need = h_cnt[64]; *ok = true;
+    return hipSuccess;
 }
 
 hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris)

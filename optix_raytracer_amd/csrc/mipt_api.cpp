@@ -319,108 +319,11 @@ int default_build_threads()
     return threads < 1 ? 1 : (threads > 32 ? 32 : threads);
 }
 
-// ---- node format 2: the BVH4 mirror -------------------------------------------------------------------------------------------
-// Collapses the (already fp16-rounded) BVH2 into four-child nodes: a node takes its grandchildren in place of its inner
-// children, one child at a time, as long as the walk's per-lane stack stays within `budget` entries in the worst case -- a
-// node with n children costs n - 1 entries while its deepest subtree is walked, a BVH2 level costs 1, so a subtree of BVH2
-// height h always fits h entries and an expansion is taken when what is left after it still covers the heights below.
-// 64-byte node = 4 pieces {lo.x|hi.x, lo.y|hi.y, lo.z|hi.z (fp16 pairs), reference}; reference >= 0: BVH4 node, < 0: the BVH2's
-// leaf descriptor, 0x7fffffff: empty slot.
-struct Bvh4Builder {
-    const MiptBvhNode* n2;
-    std::vector<uint8_t> height;          // BVH2 height of every inner node (a leaf child counts 0)
-    std::vector<uint32_t> out;            // 16 words per BVH4 node
-    uint32_t stack_need = 0;
-
-    static uint32_t half_bits(float f)    // f is an fp16 value (pack_nodes32 rounded it): exact
-    {
-        uint32_t u; std::memcpy(&u, &f, 4);
-        const uint32_t sign = (u >> 16) & 0x8000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
-        if (e == 0xffu) return sign | 0x7c00u | (m ? 0x200u : 0u);
-        if (e == 0u) return sign;                                          // +-0 (subnormal halves were flushed)
-        const int he = (int)e - 127 + 15;
-        if (he <= 0) return sign;                                          // cannot happen for a rounded box
-        if (he >= 31) return sign | 0x7c00u;
-        return sign | ((uint32_t)he << 10) | (m >> 13);
-    }
-    void child(const MiptBvhNode& n, int k, float lo[3], float hi[3], int32_t& ref) const
-    {
-        if (k == 0) { lo[0] = n.c0x[0]; hi[0] = n.c0x[1]; lo[1] = n.c0y[0]; hi[1] = n.c0y[1]; lo[2] = n.c0z[0]; hi[2] = n.c0z[1]; ref = n.c0; }
-        else        { lo[0] = n.c1x[0]; hi[0] = n.c1x[1]; lo[1] = n.c1y[0]; hi[1] = n.c1y[1]; lo[2] = n.c1z[0]; hi[2] = n.c1z[1]; ref = n.c1; }
-    }
-    uint32_t h_of(int32_t ref) const { return ref >= 0 ? height[(size_t)ref] : 0u; }
-    void heights(uint32_t n_nodes)
-    {
-        height.assign(n_nodes, 0);
-        // children come after their parent in both builders' node orders only for the host builder; do it with an explicit post-order
-        std::vector<std::pair<uint32_t, int>> st;
-        st.push_back({ 0u, 0 });
-        while (!st.empty()) {
-            auto& [x, phase] = st.back();
-            const MiptBvhNode& n = n2[x];
-            if (phase == 0) { phase = 1; if (n.c0 >= 0) st.push_back({ (uint32_t)n.c0, 0 }); }
-            else if (phase == 1) { phase = 2; if (n.c1 >= 0) st.push_back({ (uint32_t)n.c1, 0 }); }
-            else { height[x] = (uint8_t)(1u + std::max(h_of(n.c0), h_of(n.c1))); st.pop_back(); }
-        }
-    }
-    // returns the BVH4 index of BVH2 node x; `budget` stack entries are available below, `used` are held above
-    uint32_t collapse(uint32_t x, uint32_t budget, uint32_t used)
-    {
-        const uint32_t me = (uint32_t)(out.size() / 16);
-        out.resize(out.size() + 16, 0u);
-        float lo[4][3], hi[4][3]; int32_t ref[4]; int n = 2;
-        child(n2[x], 0, lo[0], hi[0], ref[0]); child(n2[x], 1, lo[1], hi[1], ref[1]);
-        for (;;) {
-            // expand the inner child with the largest box whose expansion still leaves room for everything below
-            int best = -1; float best_area = -1.0f;
-            if (n < 4) for (int i = 0; i < n; ++i) if (ref[i] >= 0) {
-                const float dx = hi[i][0] - lo[i][0], dy = hi[i][1] - lo[i][1], dz = hi[i][2] - lo[i][2];
-                const float area = dx * dy + dy * dz + dz * dx;
-                if (area > best_area) { best_area = area; best = i; }
-            }
-            if (best < 0) break;
-            // after the expansion this node holds n + 1 children: n entries pushed while the deepest subtree (height hmax) is walked
-            uint32_t hmax = 0;
-            for (int i = 0; i < n; ++i) if (i != best) hmax = std::max(hmax, h_of(ref[i]));
-            const MiptBvhNode& c = n2[(size_t)ref[best]];
-            hmax = std::max(hmax, std::max(h_of(c.c0), h_of(c.c1)));
-            if ((uint32_t)n + hmax > budget) {
-                // not this one; another child may still fit (a shallower subtree): mark and retry without it
-                bool other = false;
-                for (int i = 0; i < n && !other; ++i) if (i != best && ref[i] >= 0) {
-                    uint32_t hm = 0;
-                    for (int j = 0; j < n; ++j) if (j != i) hm = std::max(hm, h_of(ref[j]));
-                    const MiptBvhNode& d = n2[(size_t)ref[i]];
-                    hm = std::max(hm, std::max(h_of(d.c0), h_of(d.c1)));
-                    if ((uint32_t)n + hm <= budget) { best = i; other = true; }
-                }
-                if (!other) break;
-            }
-            const MiptBvhNode cc = n2[(size_t)ref[best]];
-            child(cc, 0, lo[best], hi[best], ref[best]);
-            child(cc, 1, lo[n], hi[n], ref[n]);
-            ++n;
-        }
-        stack_need = std::max(stack_need, used + (uint32_t)(n - 1));
-        int32_t fin[4];
-        for (int i = 0; i < n; ++i) fin[i] = ref[i] >= 0 ? (int32_t)collapse((uint32_t)ref[i], budget - (uint32_t)(n - 1), used + (uint32_t)(n - 1)) : ref[i];
-        uint32_t* w = &out[(size_t)me * 16];
-        for (int i = 0; i < 4; ++i) {
-            if (i < n) {
-                for (int k = 0; k < 3; ++k) w[4 * i + k] = half_bits(lo[i][k]) | (half_bits(hi[i][k]) << 16);
-                w[4 * i + 3] = (uint32_t)fin[i];
-            } else {
-                w[4 * i] = w[4 * i + 1] = w[4 * i + 2] = 0u; w[4 * i + 3] = 0x7fffffffu;
-            }
-        }
-        return me;
-    }
-};
-
 // Byte layout of the one BVH allocation: nodes (64 B each) | triangles (48 B each) | 64 B pad | node mirror (up to 64 B per node).
 // Sets the 32-bit offsets the streaming kernels use (0 when the allocation does not fit them).  Node formats 1 and 2 round the
 // boxes to fp16 in place and write the packed 32-byte mirror (pack_nodes32); format 2 then replaces the mirror by the BVH4
-// collapse of the rounded tree (host side: the nodes are read back once).  A scene that does not suit fp16 boxes keeps fp32 nodes.
+// collapse of the rounded tree, also on the device: a build or a refit ends without a host copy of the nodes (the one word the host
+// reads is the root box, for the fp16 suitability test).  A scene that does not suit fp16 boxes keeps fp32 nodes.
 hipError_t finish_blob(const MiptContext* c, Accel* a)
 {
     const size_t nb = (size_t)a->num_nodes * sizeof(MiptBvhNode), tb = (size_t)std::max<uint32_t>(a->num_tris, 1u) * sizeof(MiptBvhTri);
@@ -436,23 +339,12 @@ hipError_t finish_blob(const MiptContext* c, Accel* a)
         if (e != hipSuccess) return e;
         if (!ok) return hipSuccess;
         a->node32_off = (uint32_t)n32; a->node_fmt = 1u;
-        // the device LBVH is the fast-build path (a few ms): it keeps the packed BVH2 mirror, the collapse costs tens of ms of host time
-        if (c->node_format == 2 && a->builder == 0 && a->num_nodes < (1u << 24)) {
-            std::vector<MiptBvhNode> host(a->num_nodes);
-            e = hipMemcpy(host.data(), a->d_nodes, nb, hipMemcpyDeviceToHost);
+        // the BVH4 mirror, made on the device from the packed mirror (collapse_bvh4, lbvh_build.hip) for either builder's tree
+        if (c->node_format == 2 && a->num_nodes < (1u << 24)) {
+            uint32_t cnt4 = 0u, need = 0u;
+            e = collapse_bvh4(nullptr, (const char*)a->d_nodes + n32, a->num_nodes, a->depth, (char*)a->d_nodes + n4, &cnt4, &need, &ok);
             if (e != hipSuccess) return e;
-            Bvh4Builder B;
-            B.n2 = host.data();
-            B.heights(a->num_nodes);
-            if (B.height[0] <= 32u) {
-                B.collapse(0u, 32u, 0u);
-                const size_t cnt4 = B.out.size() / 16;
-                if (cnt4 <= a->num_nodes && B.stack_need <= 32u) {
-                    e = hipMemcpy((char*)a->d_nodes + n4, B.out.data(), cnt4 * 64u, hipMemcpyHostToDevice);
-                    if (e != hipSuccess) return e;
-                    a->node_fmt = 2u; a->node4_off = (uint32_t)n4; a->stack_need = B.stack_need; a->num_nodes4 = (uint32_t)cnt4;
-                }
-            }
+            if (ok) { a->node_fmt = 2u; a->node4_off = (uint32_t)n4; a->stack_need = need; a->num_nodes4 = cnt4; }
         }
     }
     return hipSuccess;
