@@ -191,8 +191,15 @@ void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, ui
 // when the scene does not suit fp16 boxes: a coordinate beyond +-32768, or an extent below a quarter of the largest one.
 hipError_t pack_nodes32(hipStream_t st, float4* d_nodes, uint32_t nn, void* d_nodes32, bool* ok);
 // Node format 2: the BVH4 mirror (64-byte nodes of four fp16 boxes) of the packed BVH2 mirror, made on the device (lbvh_build.hip)
-hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4, uint32_t* stack_need, bool* ok);
-hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris);
+// (scratch: device memory of at least *_scratch_bytes() for the call's temporaries -- the context's arena, so that a refit allocates
+//  nothing in its steady state; null: the function allocates and frees its own)
+// height of every node (1 = both children are leaves; the root's = the tree's depth): topology only, computed once per build
+size_t topo_heights_scratch_bytes(uint32_t nn);
+hipError_t topo_heights(hipStream_t st, const float4* d_nodes, uint32_t nn, uint8_t* d_height, void* scratch = nullptr, size_t scratch_bytes = 0);
+size_t collapse_bvh4_scratch_bytes(uint32_t nn);
+hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d_height, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4,
+                         uint32_t* stack_need, bool* ok, void* scratch = nullptr, size_t scratch_bytes = 0);
+hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth);
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok);
 

@@ -113,30 +113,47 @@ __device__ __forceinline__ Box6 box_union(const Box6& a, const Box6& b)
     return r;
 }
 
-// bottom-up: the second thread to arrive at a node computes its box (its children's are final by then)
-__global__ __launch_bounds__(256) void k_lbvh_fit(const Box6* prim_boxes, const uint32_t* sorted_prims, int n, const int* left, const int* right,
-                                                 const int* parent_inner, const int* parent_leaf, Box6* node_boxes, uint32_t* arrived)
+// ---- bottom-up passes without fences ---------------------------------------------------------------------------------------------
+// Round 2 fitted boxes with "the second thread to arrive at a node computes it and climbs on": every step of the climb needs an
+// agent-scope release / acquire pair (__threadfence = L2 write-back + invalidate, microseconds each on a chip of eight L2s), and
+// 3.7 ms of a 6 ms LBVH build and 3.3 ms of a refit went there.  Now: (1) the HEIGHT of every inner node (1 + the larger height of
+// its inner children) by a climb that exchanges everything through ONE returning atomic per step -- a child adds its height into
+// its slot's byte of the parent's word together with an arrival count, and whoever completes the count has both heights in the
+// value the atomic returned: no fence, no second access; (2) the boxes level by level, one launch per height: a node reads what
+// the launch before wrote.  Heights depend on the topology only, so a refit reuses them.
+// word: bits 0-7 / 8-15 = height of the inner child in slot 0 / 1, bits 24+ = inner children that have reported
+__global__ __launch_bounds__(256) void k_lbvh_heights(const int* left, const int* right, const int* parent_inner, int n_inner, uint32_t* word, uint8_t* height)
 {
-    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (k >= n) return;
-    int node = parent_leaf[k];
-    while (node >= 0) {
-        __threadfence();
-        if (atomicAdd(&arrived[node], 1u) == 0u) return;
-        const int lc = left[node], rc = right[node];
-        // the sibling's box was written before its __threadfence + atomicAdd: read it past the L1 (agent-scope loads)
-        Box6 a, b;
-        for (int c = 0; c < 2; ++c) {
-            const int ch = c == 0 ? lc : rc;
-            Box6& dst = c == 0 ? a : b;
-            if (ch >= 0) {
-                const float* src = &node_boxes[ch].lo[0];
-                for (int k = 0; k < 6; ++k) (&dst.lo[0])[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else dst = prim_boxes[sorted_prims[~ch]];
-        }
-        node_boxes[node] = box_union(a, b);
-        node = parent_inner[node];
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner) return;
+    if (left[i] >= 0 || right[i] >= 0) return;                      // not a bottom node: its last child to report carries on from here
+    uint32_t h = 1u;
+    int node = i;
+    height[node] = 1u;
+    for (;;) {
+        const int p = parent_inner[node];
+        if (p < 0) return;
+        const int lc = left[p], rc = right[p];
+        const uint32_t slot = lc == node ? 0u : 1u, need = (lc >= 0 ? 1u : 0u) + (rc >= 0 ? 1u : 0u);
+        const uint32_t old = atomicAdd(&word[p], (h << (8u * slot)) + (1u << 24));
+        if ((old >> 24) + 1u < need) return;
+        const uint32_t other = (old >> (8u * (1u - slot))) & 0xffu;
+        h = 1u + (h > other ? h : other);
+        h = h < 255u ? h : 255u;
+        height[p] = (uint8_t)h;
+        node = p;
     }
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_fit_level(const Box6* prim_boxes, const uint32_t* sorted_prims, int n_inner, const int* left, const int* right,
+                                                       const uint8_t* height, uint32_t level, Box6* node_boxes)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner || height[i] != level) return;
+    const int lc = left[i], rc = right[i];
+    const Box6 a = lc >= 0 ? node_boxes[lc] : prim_boxes[sorted_prims[~lc]];
+    const Box6 b = rc >= 0 ? node_boxes[rc] : prim_boxes[sorted_prims[~rc]];
+    node_boxes[i] = box_union(a, b);
 }
 
 __global__ __launch_bounds__(256) void k_lbvh_flags(const int* range_lo, const int* range_hi, int n_inner, int leaf_max, uint32_t* emit)
@@ -226,47 +243,64 @@ __device__ __forceinline__ void refit_store_slot(MiptBvhNode* nd, int slot, cons
     x[0] = lo[0]; x[1] = hi[0]; y[0] = lo[1]; y[1] = hi[1]; z[0] = lo[2]; z[1] = hi[2];
 }
 
-// Every thread fits the leaf children of its node from the new vertices and then reports the node "done"; a node is complete
-// when its own thread and every inner child have reported, and whoever reports last carries the node's box (the union of
-// its two child boxes) into the parent's slot and reports there.  No thread ever waits for another.
-__global__ __launch_bounds__(256) void k_refit_nodes(MiptBvhNode* nodes, uint32_t nn, const MiptBvhTri* tris, uint32_t nt,
-                                                     const float* __restrict__ world, const int* parent, uint32_t* arrived)
+// heights of the traversal-layout tree (same scheme as k_lbvh_heights; parent[c] = node * 2 + slot)
+__global__ __launch_bounds__(256) void k_topo_heights(const MiptBvhNode* nodes, uint32_t nn, const int* parent, uint32_t* word, uint8_t* height)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nn) return;
-    {
-        MiptBvhNode* nd = &nodes[i];
-        for (int slot = 0; slot < 2; ++slot) {
-            const int ref = slot == 0 ? nd->c0 : nd->c1;
-            if (ref >= 0) continue;
-            const uint32_t desc = ~(uint32_t)ref, first = desc >> 4, cnt = desc & 15u;
-            float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-            for (uint32_t j = 0; j < cnt && first + j < nt; ++j) {
-                const uint32_t p = tris[first + j].prim;
-                if (p >= nt) continue;
-                const float* v = world + (size_t)p * 9;
-                for (int c = 0; c < 9; ++c) { const float f = v[c]; lo[c % 3] = fminf(lo[c % 3], f); hi[c % 3] = fmaxf(hi[c % 3], f); }
-            }
-            refit_store_slot(nd, slot, lo, hi);
-        }
-    }
+    if (nodes[i].c0 >= 0 || nodes[i].c1 >= 0) return;
+    uint32_t h = 1u, node = i;
+    height[node] = 1u;
     for (;;) {
-        MiptBvhNode* nd = &nodes[i];
-        const uint32_t need = 1u + (nd->c0 >= 0 ? 1u : 0u) + (nd->c1 >= 0 ? 1u : 0u);
-        __threadfence();
-        if (atomicAdd(&arrived[i], 1u) + 1u < need) return;
-        __threadfence();
-        const int pr = parent[i];
-        if (pr < 0) return;                                   // the root is complete
-        // the boxes of node i were written by other threads before their fence + atomic: read them past the L1
-        float b[12];
-        const float* src = nd->c0x;
-        for (int k = 0; k < 12; ++k) b[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // b: c0x[2] c0y[2] c1x[2] c1y[2] c0z[2] c1z[2]
-        const float lo[3] = { fminf(b[0], b[4]), fminf(b[2], b[6]), fminf(b[8], b[10]) };
-        const float hi[3] = { fmaxf(b[1], b[5]), fmaxf(b[3], b[7]), fmaxf(b[9], b[11]) };
-        refit_store_slot(&nodes[pr >> 1], pr & 1, lo, hi);
-        i = (uint32_t)(pr >> 1);
+        const int pr = parent[node];
+        if (pr < 0) return;
+        const uint32_t p = (uint32_t)pr >> 1, slot = (uint32_t)pr & 1u;
+        const uint32_t need = (nodes[p].c0 >= 0 ? 1u : 0u) + (nodes[p].c1 >= 0 ? 1u : 0u);
+        const uint32_t old = atomicAdd(&word[p], (h << (8u * slot)) + (1u << 24));
+        if ((old >> 24) + 1u < need) return;
+        const uint32_t other = (old >> (8u * (1u - slot))) & 0xffu;
+        h = 1u + (h > other ? h : other);
+        h = h < 255u ? h : 255u;
+        height[p] = (uint8_t)h;
+        node = p;
+    }
+}
+
+// refit, step 1: the boxes of every LEAF child from the new vertices (all nodes at once)
+__global__ __launch_bounds__(256) void k_refit_leaf_slots(MiptBvhNode* nodes, uint32_t nn, const MiptBvhTri* tris, uint32_t nt, const float* __restrict__ world)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    MiptBvhNode* nd = &nodes[i];
+    for (int slot = 0; slot < 2; ++slot) {
+        const int ref = slot == 0 ? nd->c0 : nd->c1;
+        if (ref >= 0) continue;
+        const uint32_t desc = ~(uint32_t)ref, first = desc >> 4, cnt = desc & 15u;
+        float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        for (uint32_t j = 0; j < cnt && first + j < nt; ++j) {
+            const uint32_t p = tris[first + j].prim;
+            if (p >= nt) continue;
+            const float* v = world + (size_t)p * 9;
+            for (int c = 0; c < 9; ++c) { const float f = v[c]; lo[c % 3] = fminf(lo[c % 3], f); hi[c % 3] = fmaxf(hi[c % 3], f); }
+        }
+        refit_store_slot(nd, slot, lo, hi);
+    }
+}
+
+// refit, step 2, one launch per height h = 2 .. depth: the boxes of the INNER children of the nodes of that height (a child is
+// lower, so its own two boxes are final: written by step 1 or an earlier launch)
+__global__ __launch_bounds__(256) void k_refit_level(MiptBvhNode* nodes, uint32_t nn, const uint8_t* height, uint32_t level)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn || height[i] != level) return;
+    MiptBvhNode* nd = &nodes[i];
+    for (int slot = 0; slot < 2; ++slot) {
+        const int ref = slot == 0 ? nd->c0 : nd->c1;
+        if (ref < 0 || (uint32_t)ref >= nn) continue;
+        const MiptBvhNode* ch = &nodes[ref];
+        const float lo[3] = { fminf(ch->c0x[0], ch->c1x[0]), fminf(ch->c0y[0], ch->c1y[0]), fminf(ch->c0z[0], ch->c1z[0]) };
+        const float hi[3] = { fmaxf(ch->c0x[1], ch->c1x[1]), fmaxf(ch->c0y[1], ch->c1y[1]), fmaxf(ch->c0z[1], ch->c1z[1]) };
+        refit_store_slot(nd, slot, lo, hi);
     }
 }
 
@@ -353,36 +387,7 @@ __global__ __launch_bounds__(256) void k_pack_nodes32(MiptBvhNode* nodes, uint32
 // the BVH4 nodes of level L into 64-byte nodes and allots the indices of level L + 1 (one atomic per workgroup; siblings get
 // consecutive indices, so the four children of a node share two 128-byte lines).  The boxes are read from the PACKED BVH2 mirror
 // (they are the fp16 values already), so the mirror holds the same boxes bit for bit and nothing is converted.
-// Heights (bottom-up, no thread waits: the last reporter of a node carries on to its parent) come first.
-__global__ __launch_bounds__(256) void k_b4_parents(const uint4* n32, uint32_t nn, int* parent)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nn) return;
-    const int c0 = (int)n32[2u * i].w, c1 = (int)n32[2u * i + 1u].w;
-    if (c0 >= 0 && (uint32_t)c0 < nn) parent[c0] = (int)i;
-    if (c1 >= 0 && (uint32_t)c1 < nn) parent[c1] = (int)i;
-}
-
-__global__ __launch_bounds__(256) void k_b4_heights(const uint4* n32, uint32_t nn, const int* parent, uint32_t* arrived, uint32_t* height)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nn) return;
-    for (;;) {
-        const int c0 = (int)n32[2u * i].w, c1 = (int)n32[2u * i + 1u].w;
-        const bool in0 = c0 >= 0 && (uint32_t)c0 < nn, in1 = c1 >= 0 && (uint32_t)c1 < nn;
-        const uint32_t need = 1u + (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
-        __threadfence();
-        if (atomicAdd(&arrived[i], 1u) + 1u < need) return;
-        __threadfence();
-        const uint32_t h0 = in0 ? __hip_atomic_load(&height[c0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        const uint32_t h1 = in1 ? __hip_atomic_load(&height[c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        __hip_atomic_store(&height[i], 1u + (h0 > h1 ? h0 : h1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int pr = parent[i];
-        if (pr < 0) return;
-        i = (uint32_t)pr;
-    }
-}
-
+// The heights come from topo_heights() (once per build: a refit keeps the topology).
 struct B4Work { uint32_t x, budget, used, pad; };      // BVH2 node x is BVH4 node <its position in the work array>
 
 __device__ __forceinline__ float b4_area(const uint4 q)
@@ -394,7 +399,7 @@ __device__ __forceinline__ float b4_area(const uint4 q)
 }
 
 // cnt[k]: BVH4 nodes of level k (cnt[0] = 1, the rest zero at the start); misc[0]: the most stack entries a lane can need
-__global__ __launch_bounds__(256) void k_b4_level(const uint4* __restrict__ n32, uint32_t nn, const uint32_t* __restrict__ height, uint32_t level,
+__global__ __launch_bounds__(256) void k_b4_level(const uint4* __restrict__ n32, uint32_t nn, const uint8_t* __restrict__ height, uint32_t level,
                                                   uint32_t* cnt, B4Work* work, uint32_t cap, uint4* out, uint32_t* misc)
 {
     __shared__ uint32_t s_wave[4], s_base;
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void k_b4_level(const uint4* __restrict__ n32,
             q[0] = n32[2u * w.x]; q[1] = n32[2u * w.x + 1u];
             q[2] = q[3] = make_uint4(0u, 0u, 0u, 0x7fffffffu);
             n = 2;
-            auto h_of = [&](uint32_t ref) { return (int)ref >= 0 && ref < nn ? height[ref] : 0u; };
+            auto h_of = [&](uint32_t ref) { return (int)ref >= 0 && ref < nn ? (uint32_t)height[ref] : 0u; };
             for (;;) {
                 int best = -1; float best_area = -1.0f;
                 if (n < 4) for (int i = 0; i < n; ++i) if ((int)q[i].w >= 0) {
@@ -502,20 +507,49 @@ hipError_t pack_nodes32(hipStream_t st, float4* d_nodes, uint32_t nn, void* d_no
 
 // The BVH4 mirror of the packed BVH2 at d_nodes32, written to d_nodes4 (room for nn nodes of 64 B).  *ok = false (and nothing to
 // use) when the tree is higher than 32 or the mirror would not fit; *n4 nodes, *stack_need entries per lane at most.
-hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4, uint32_t* stack_need, bool* ok)
+// height of every node of the traversal-layout tree (1 = both children are leaves), into d_height[nn]; scratch: 2 * nn words
+size_t topo_heights_scratch_bytes(uint32_t nn) { return 2 * (((size_t)nn * 4u + 255) & ~(size_t)255); }
+
+hipError_t topo_heights(hipStream_t st, const float4* d_nodes, uint32_t nn, uint8_t* d_height, void* scratch, size_t scratch_bytes)
+{
+    const size_t r = ((size_t)nn * 4u + 255) & ~(size_t)255;
+    char* tmp = nullptr; bool own = false;
+    hipError_t e = hipSuccess;
+    if (scratch != nullptr && scratch_bytes >= 2 * r) tmp = (char*)scratch;
+    else { e = hipMalloc((void**)&tmp, 2 * r); own = true; }
+    if (e != hipSuccess) return e;
+    int* parent = (int*)tmp; uint32_t* word = (uint32_t*)(tmp + r);
+    e = hipMemsetAsync(parent, 0xff, (size_t)nn * 4u, st);
+    if (e == hipSuccess) e = hipMemsetAsync(word, 0, (size_t)nn * 4u, st);
+    if (e == hipSuccess) {
+        const MiptBvhNode* nodes = reinterpret_cast<const MiptBvhNode*>(d_nodes);
+        hipLaunchKernelGGL(k_refit_parents, dim3((nn + 255u) / 256u), dim3(256), 0, st, nodes, nn, parent);
+        hipLaunchKernelGGL(k_topo_heights, dim3((nn + 255u) / 256u), dim3(256), 0, st, nodes, nn, parent, word, d_height);
+        e = hipGetLastError();
+        if (own && e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (own) (void)hipFree(tmp);
+    return e;
+}
+
+size_t collapse_bvh4_scratch_bytes(uint32_t nn) { return (((size_t)nn * sizeof(B4Work) + 255) & ~(size_t)255) + 512; }
+
+// The BVH4 mirror of the packed BVH2 at d_nodes32, written to d_nodes4 (room for nn nodes of 64 B); d_height: topo_heights() of the
+// same tree.  *ok = false (and nothing to use) when the tree is higher than 32 or the mirror would not fit; *n4 nodes, *stack_need
+// entries per lane at most.
+hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d_height, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4,
+                         uint32_t* stack_need, bool* ok, void* scratch, size_t scratch_bytes)
 {
     *ok = false; *n4 = 0u; *stack_need = 0u;
     if (nn == 0u || depth == 0u || depth > 32u) return hipSuccess;
-    char* tmp = nullptr;
-    const size_t o_parent = 0, o_arr = o_parent + (((size_t)nn * 4u + 255) & ~(size_t)255), o_h = o_arr + (((size_t)nn * 4u + 255) & ~(size_t)255),
-                 o_work = o_h + (((size_t)nn * 4u + 255) & ~(size_t)255), o_cnt = o_work + (((size_t)nn * sizeof(B4Work) + 255) & ~(size_t)255), total = o_cnt + 512;
-    hipError_t e = hipMalloc((void**)&tmp, total);
+    const size_t o_work = 0, o_cnt = o_work + (((size_t)nn * sizeof(B4Work) + 255) & ~(size_t)255), total = o_cnt + 512;
+    char* tmp = nullptr; bool own = false;
+    hipError_t e = hipSuccess;
+    if (scratch != nullptr && scratch_bytes >= total) tmp = (char*)scratch;
+    else { e = hipMalloc((void**)&tmp, total); own = true; }
     if (e != hipSuccess) return e;
-    int* parent = (int*)(tmp + o_parent); uint32_t* arrived = (uint32_t*)(tmp + o_arr); uint32_t* height = (uint32_t*)(tmp + o_h);
     B4Work* work = (B4Work*)(tmp + o_work); uint32_t* cnt = (uint32_t*)(tmp + o_cnt); uint32_t* misc = cnt + 64;
-    auto fail = [&](hipError_t err) { (void)hipFree(tmp); return err; };
-    if ((e = hipMemsetAsync(parent, 0xff, (size_t)nn * 4u, st)) != hipSuccess) return fail(e);
-    if ((e = hipMemsetAsync(arrived, 0, (size_t)nn * 4u, st)) != hipSuccess) return fail(e);
+    auto fail = [&](hipError_t err) { if (own) (void)hipFree(tmp); return err; };
     if ((e = hipMemsetAsync(cnt, 0, 512, st)) != hipSuccess) return fail(e);
     const uint32_t one = 1u;
     const B4Work root{ 0u, 32u, 0u, 0u };
@@ -523,17 +557,15 @@ hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, uint32_t nn, uin
     if ((e = hipMemcpyAsync(work, &root, sizeof root, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
     const uint4* n32 = reinterpret_cast<const uint4*>(d_nodes32);
     const uint32_t blocks = (nn + 255u) / 256u;
-    hipLaunchKernelGGL(k_b4_parents, dim3(blocks), dim3(256), 0, st, n32, nn, parent);
-    hipLaunchKernelGGL(k_b4_heights, dim3(blocks), dim3(256), 0, st, n32, nn, parent, arrived, height);
     // a BVH4 level is at most a BVH2 level deep, so `depth` passes reach every node; a pass whose level is empty returns at once
     const uint32_t grid = blocks < 2048u ? blocks : 2048u;
     for (uint32_t level = 0; level < depth; ++level)
-        hipLaunchKernelGGL(k_b4_level, dim3(grid), dim3(256), 0, st, n32, nn, height, level, cnt, work, nn, reinterpret_cast<uint4*>(d_nodes4), misc);
+        hipLaunchKernelGGL(k_b4_level, dim3(grid), dim3(256), 0, st, n32, nn, d_height, level, cnt, work, nn, reinterpret_cast<uint4*>(d_nodes4), misc);
     uint32_t h_cnt[66];
     if ((e = hipMemcpyAsync(h_cnt, cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
     if ((e = hipGetLastError()) != hipSuccess) return fail(e);
-    (void)hipFree(tmp);
+    if (own) (void)hipFree(tmp);
     uint64_t tot = 0;
     for (uint32_t k = 0; k <= depth && k < 64u; ++k) tot += h_cnt[k];
     if (h_cnt[65] != 0u || tot > nn || h_cnt[depth < 64u ? depth : 63u] != 0u || h_cnt[64] > 32u) return hipSuccess;      // (none of these can happen)
@@ -541,25 +573,18 @@ hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, uint32_t nn, uin
     return hipSuccess;
 }
 
-hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris)
+// Refit of an existing tree (same topology) to new world-space vertices: triangle records, the boxes of the leaf children, then the
+// inner children's boxes one height at a time (d_height: topo_heights() of the tree; depth = the root's height).  Asynchronous on st.
+hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth)
 {
-    int* parent = nullptr; uint32_t* arrived = nullptr;
-    hipError_t e = hipMalloc((void**)&parent, (size_t)nn * 4u);
-    if (e == hipSuccess) e = hipMalloc((void**)&arrived, (size_t)nn * 4u);
-    if (e == hipSuccess) e = hipMemsetAsync(parent, 0xff, (size_t)nn * 4u, st);
-    if (e == hipSuccess) e = hipMemsetAsync(arrived, 0, (size_t)nn * 4u, st);
-    if (e == hipSuccess) {
-        MiptBvhNode* nodes = reinterpret_cast<MiptBvhNode*>(d_nodes);
-        MiptBvhTri* tris = reinterpret_cast<MiptBvhTri*>(d_tris);
-        hipLaunchKernelGGL(k_refit_tris, dim3((n + 255u) / 256u), dim3(256), 0, st, d_world, n, tris);
-        hipLaunchKernelGGL(k_refit_parents, dim3((nn + 255u) / 256u), dim3(256), 0, st, nodes, nn, parent);
-        hipLaunchKernelGGL(k_refit_nodes, dim3((nn + 255u) / 256u), dim3(256), 0, st, nodes, nn, tris, n, d_world, parent, arrived);
-        e = hipStreamSynchronize(st);
-        if (e == hipSuccess) e = hipGetLastError();
-    }
-    if (parent) (void)hipFree(parent);
-    if (arrived) (void)hipFree(arrived);
-    return e;
+    MiptBvhNode* nodes = reinterpret_cast<MiptBvhNode*>(d_nodes);
+    MiptBvhTri* tris = reinterpret_cast<MiptBvhTri*>(d_tris);
+    const uint32_t blocks = (nn + 255u) / 256u;
+    hipLaunchKernelGGL(k_refit_tris, dim3((n + 255u) / 256u), dim3(256), 0, st, d_world, n, tris);
+    hipLaunchKernelGGL(k_refit_leaf_slots, dim3(blocks), dim3(256), 0, st, nodes, nn, tris, n, d_world);
+    for (uint32_t level = 2; level <= depth; ++level)
+        hipLaunchKernelGGL(k_refit_level, dim3(blocks), dim3(256), 0, st, nodes, nn, d_height, level);
+    return hipGetLastError();
 }
 
 void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, uint32_t* mats, uint32_t* gflags, uint32_t base, uint32_t* error)
@@ -583,7 +608,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     const size_t o_boxes = carve(sizeof(Box6) * n), o_nboxes = carve(sizeof(Box6) * n), o_keys = carve(8ull * n), o_keys2 = carve(8ull * n),
                  o_vals = carve(4ull * n), o_vals2 = carve(4ull * n), o_left = carve(4ull * n), o_right = carve(4ull * n), o_pin = carve(4ull * n),
                  o_plf = carve(4ull * n), o_lo = carve(4ull * n), o_hi = carve(4ull * n), o_arr = carve(4ull * n), o_emit = carve(4ull * n),
-                 o_idx = carve(4ull * n), o_misc = carve(256);
+                 o_idx = carve(4ull * n), o_kh = carve(n), o_misc = carve(256);
     size_t sort_bytes = 0, scan_bytes = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, st);
@@ -608,7 +633,16 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     hipLaunchKernelGGL(k_lbvh_morton, dim3(blocks), dim3(256), 0, st, boxes, n, misc, keys, vals);
     if ((e = hipcub::DeviceRadixSort::SortPairs(tmp + o_cub, sort_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocks), dim3(256), 0, st, keys2, (int)n, left, right, pin, plf, rlo, rhi);
-    hipLaunchKernelGGL(k_lbvh_fit, dim3(blocks), dim3(256), 0, st, boxes, vals2, (int)n, left, right, pin, plf, nboxes, arrived);
+    {   // boxes bottom-up: heights first (one atomic per step), then one launch per height
+        uint8_t* kh = reinterpret_cast<uint8_t*>(tmp + o_kh);
+        hipLaunchKernelGGL(k_lbvh_heights, dim3(blocks), dim3(256), 0, st, left, right, pin, n_inner, arrived, kh);
+        uint8_t root_h = 0;
+        if ((e = hipMemcpyAsync(&root_h, kh, 1, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
+        if (root_h == 0u || root_h >= 255u) { (void)hipFree(tmp); *num_nodes = 0; *depth = 255u; return hipSuccess; }      // (degenerate input: the host builder takes it)
+        for (uint32_t level = 1; level <= root_h; ++level)
+            hipLaunchKernelGGL(k_lbvh_fit_level, dim3(blocks), dim3(256), 0, st, boxes, vals2, n_inner, left, right, kh, level, nboxes);
+    }
     hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit);
     if ((e = hipcub::DeviceScan::ExclusiveSum(tmp + o_cub, scan_bytes, emit, idx, n_inner, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(k_lbvh_depth, dim3(blocks), dim3(256), 0, st, pin, plf, emit, (int)n, misc + 8);

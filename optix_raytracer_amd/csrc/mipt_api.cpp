@@ -68,6 +68,7 @@ struct Accel {
     uint32_t  stack_need = 0;      // format 2: the most entries a lane's stack can hold while walking the BVH4 (<= 32 by construction)
     uint32_t  num_nodes4 = 0;
     uint32_t* d_mat   = nullptr;
+    uint8_t*  d_height = nullptr;  // height of every node (topology only: made at build time, reused by every refit and by the BVH4 collapse)
     uint32_t  n_prims = 0;
     uint64_t  bytes   = 0;
     // two-level structure (mipt_accel_build_instances): d_nodes then holds the BVH over the instance boxes
@@ -157,6 +158,28 @@ struct MiptContext {
     int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
     int       tile_order_mode = 1;       // MIPT_OPT_TILE_ORDER: 0 image order, 1 (default) by the previous launch's costs
     int      profile = 0;
+
+    // scratch arena of the build / refit calls (grow-only, bump-allocated per call): mipt_accel_update allocates nothing in its steady
+    // state -- hipMalloc / hipFree of tens of MB cost more than the refit's kernels (round 3: 5.5 ms of a 1 M-triangle refit)
+    char*  scratch = nullptr;
+    size_t scratch_cap = 0, scratch_off = 0;
+    void   scratch_reset() { scratch_off = 0; }
+    void*  scratch_take(size_t bytes)
+    {
+        const size_t at = (scratch_off + 255) & ~(size_t)255;
+        if (!scratch || at + bytes > scratch_cap) return nullptr;
+        scratch_off = at + bytes;
+        return scratch + at;
+    }
+    hipError_t scratch_ensure(size_t bytes)            // (only between calls' uses: the old block is released)
+    {
+        if (bytes <= scratch_cap) return hipSuccess;
+        if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); scratch = nullptr; scratch_cap = 0; }
+        const size_t want = bytes + bytes / 8 + 4096;
+        const hipError_t e = hipMalloc((void**)&scratch, want);
+        if (e == hipSuccess) scratch_cap = want;
+        return e;
+    }
 
     // launch buffers
     size_t          cap_paths = 0, cap_slots = 0;
@@ -252,6 +275,7 @@ void free_accel(Accel* a)
     if (!a) return;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_mat) (void)hipFree(a->d_mat);
+    if (a->d_height) (void)hipFree(a->d_height);
     if (a->d_inst) (void)hipFree(a->d_inst);
     if (a->d_order) (void)hipFree(a->d_order);
     delete a;
@@ -324,7 +348,7 @@ int default_build_threads()
 // boxes to fp16 in place and write the packed 32-byte mirror (pack_nodes32); format 2 then replaces the mirror by the BVH4
 // collapse of the rounded tree, also on the device: a build or a refit ends without a host copy of the nodes (the one word the host
 // reads is the root box, for the fp16 suitability test).  A scene that does not suit fp16 boxes keeps fp32 nodes.
-hipError_t finish_blob(const MiptContext* c, Accel* a)
+hipError_t finish_blob(MiptContext* c, Accel* a)
 {
     const size_t nb = (size_t)a->num_nodes * sizeof(MiptBvhNode), tb = (size_t)std::max<uint32_t>(a->num_tris, 1u) * sizeof(MiptBvhTri);
     const size_t n32 = (nb + tb + 64 + 127) & ~(size_t)127;                     // a mirror node never straddles a 128-byte line
@@ -333,6 +357,14 @@ hipError_t finish_blob(const MiptContext* c, Accel* a)
     a->tri_byte_off = total < (1ull << 31) ? (uint32_t)nb : 0u;
     a->blob_bytes = a->tri_byte_off ? (uint32_t)total : 0u;
     a->node32_off = 0u; a->node4_off = 0u; a->node_fmt = 0u; a->stack_need = 0u; a->num_nodes4 = 0u;
+    if (!a->d_height && a->num_nodes) {            // a build (a refit keeps the topology and with it the heights)
+        hipError_t e = hipMalloc((void**)&a->d_height, a->num_nodes);
+        if (e != hipSuccess) return e;
+        const size_t hb = topo_heights_scratch_bytes(a->num_nodes);
+        c->scratch_reset();
+        if ((e = c->scratch_ensure(hb)) != hipSuccess) return e;
+        if ((e = topo_heights(nullptr, a->d_nodes, a->num_nodes, a->d_height, c->scratch_take(hb), hb)) != hipSuccess) return e;
+    }
     if (c->node_format != 0 && a->tri_byte_off != 0u && a->num_tris >= 2u) {
         bool ok = false;
         hipError_t e = pack_nodes32(nullptr, a->d_nodes, a->num_nodes, (char*)a->d_nodes + n32, &ok);
@@ -342,7 +374,10 @@ hipError_t finish_blob(const MiptContext* c, Accel* a)
         // the BVH4 mirror, made on the device from the packed mirror (collapse_bvh4, lbvh_build.hip) for either builder's tree
         if (c->node_format == 2 && a->num_nodes < (1u << 24)) {
             uint32_t cnt4 = 0u, need = 0u;
-            e = collapse_bvh4(nullptr, (const char*)a->d_nodes + n32, a->num_nodes, a->depth, (char*)a->d_nodes + n4, &cnt4, &need, &ok);
+            const size_t sb = collapse_bvh4_scratch_bytes(a->num_nodes);
+            c->scratch_reset();                                            // (the call's earlier temporaries are dead: pack_nodes32 has synchronised)
+            if ((e = c->scratch_ensure(sb)) != hipSuccess) return e;
+            e = collapse_bvh4(nullptr, (const char*)a->d_nodes + n32, a->d_height, a->num_nodes, a->depth, (char*)a->d_nodes + n4, &cnt4, &need, &ok, c->scratch_take(sb), sb);
             if (e != hipSuccess) return e;
             if (ok) { a->node_fmt = 2u; a->node4_off = (uint32_t)n4; a->stack_need = need; a->num_nodes4 = cnt4; }
         }
@@ -671,6 +706,7 @@ int mipt_context_destroy(MiptContext* c)
     free_launch_buffers(c);
     if (c->d_hitgroups) (void)hipFree(c->d_hitgroups);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->scratch) (void)hipFree(c->scratch);
     for (void* p : { (void*)c->d_tile_class, (void*)c->d_tile_hist, (void*)c->d_tile_order, (void*)c->d_tile_width }) if (p) (void)hipFree(p);
     if (c->im_sq.ray_o) (void)hipFree(c->im_sq.ray_o);
     if (c->im_sq.contrib) (void)hipFree(c->im_sq.contrib);
@@ -761,15 +797,18 @@ int mipt_get_option(const MiptContext* c, int option, uint64_t* value)
 // world-space triangles (9 floats each), SBT index and geometry flags per triangle of the build inputs, assembled on the
 // device (k_gather_input); host arrays are uploaded as they are.  *n_out = 0: nothing to do on the device (tiny or huge input).
 struct DeviceGather {
-    std::vector<void*> temps;
+    std::vector<void*> temps;          // allocations of this call (what did not fit the context's arena)
     float* world = nullptr; uint32_t* mats = nullptr; uint32_t* gflags = nullptr;
+    bool mats_owned = false;           // mats is an allocation of its own (a build keeps it as the accel's SBT index table)
     uint32_t n = 0, err = 0;
     hipError_t e = hipSuccess;
-    ~DeviceGather() { for (void* p : temps) if (p) (void)hipFree(p); if (mats) (void)hipFree(mats); }
+    ~DeviceGather() { for (void* p : temps) if (p) (void)hipFree(p); if (mats && mats_owned) (void)hipFree(mats); }
     uint32_t* release_mats() { uint32_t* m = mats; mats = nullptr; return m; }
 };
 
-static int gather_on_device(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs, DeviceGather& G)
+// keep_mats: the SBT index table becomes an allocation of its own (builds keep it); extra_scratch: bytes the caller will take from the
+// arena after this (sized in one go, so that the arena is never re-allocated while parts of it are in use)
+static int gather_on_device(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t num_inputs, DeviceGather& G, bool keep_mats, size_t extra_scratch)
 {
     std::vector<uint32_t> counts(num_inputs);
     uint64_t total = 0;
@@ -790,7 +829,15 @@ static int gather_on_device(MiptContext* ctx, const MiptBuildInput* inputs, uint
     }
     if (total <= 4u || total * 36u >= (1ull << 31)) return MIPT_SUCCESS;
     const uint32_t n = (uint32_t)total;
-    auto dev_alloc = [&](size_t bytes, void** out) { hipError_t e = hipMalloc(out, bytes ? bytes : 4); if (e == hipSuccess) G.temps.push_back(*out); return e; };
+    ctx->scratch_reset();
+    {
+        const hipError_t se = ctx->scratch_ensure((size_t)n * (36u + 4u + 4u) + 4096u + extra_scratch);
+        if (se != hipSuccess) return ctx->fail(MIPT_ERROR_OUT_OF_MEMORY, "build scratch: %s", hipGetErrorString(se));
+    }
+    auto dev_alloc = [&](size_t bytes, void** out) {                    // the arena first, an allocation of the call's own when it is full
+        if (void* p = ctx->scratch_take(bytes ? bytes : 4)) { *out = p; return hipSuccess; }
+        hipError_t e = hipMalloc(out, bytes ? bytes : 4); if (e == hipSuccess) G.temps.push_back(*out); return e;
+    };
     auto on_device = [&](const void* p, size_t bytes, const void** out) {          // device copy of a host array, or the pointer itself
         if (!p || bytes == 0) { *out = p; return hipSuccess; }
         if (is_device_pointer(p)) { *out = p; return hipSuccess; }
@@ -802,7 +849,10 @@ static int gather_on_device(MiptContext* ctx, const MiptBuildInput* inputs, uint
     };
     uint32_t* d_err = nullptr;
     hipError_t e = dev_alloc((size_t)n * 36u, (void**)&G.world);
-    if (e == hipSuccess) e = hipMalloc((void**)&G.mats, (size_t)n * 4u);
+    if (e == hipSuccess) {
+        if (keep_mats) { e = hipMalloc((void**)&G.mats, (size_t)n * 4u); G.mats_owned = e == hipSuccess; }
+        else e = dev_alloc((size_t)n * 4u, (void**)&G.mats);
+    }
     if (e == hipSuccess) e = dev_alloc((size_t)n * 4u, (void**)&G.gflags);
     if (e == hipSuccess) e = dev_alloc(4, (void**)&d_err);
     if (e == hipSuccess) e = hipMemset(d_err, 0, 4);
@@ -839,7 +889,7 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     *handle_out = 0;
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGather G;
-    const int grc = gather_on_device(ctx, inputs, num_inputs, G);
+    const int grc = gather_on_device(ctx, inputs, num_inputs, G, /*keep_mats=*/true, 0);
     if (grc != MIPT_SUCCESS || G.n == 0u) return grc;
     const uint32_t n = G.n;
     hipError_t e = G.e;
@@ -1143,13 +1193,14 @@ int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBui
     HIPCHK(ctx, hipDeviceSynchronize());                         // launches that still read the old boxes
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGather G;
-    const int grc = gather_on_device(ctx, inputs, num_inputs, G);
+    const int grc = gather_on_device(ctx, inputs, num_inputs, G, /*keep_mats=*/false, 0);
     if (grc != MIPT_SUCCESS) return grc;
     if (G.n == 0u || G.n != a->num_tris || a->num_nodes == 0u)
         return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update: the inputs hold %u triangles, the traversable was built from %u", G.n, a->num_tris);
     if (G.e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(G.e));
     if (G.err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, G.err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
-    hipError_t e = lbvh_refit(nullptr, G.world, G.n, a->d_nodes, a->num_nodes, a->d_tris);
+    if (!a->d_height) return ctx->fail(MIPT_ERROR_INTERNAL, "accel_update: the traversable has no height table");
+    hipError_t e = lbvh_refit(nullptr, G.world, G.n, a->d_nodes, a->num_nodes, a->d_tris, a->d_height, a->depth);
     if (e == hipSuccess) e = finish_blob(ctx, a);            // the refitted boxes are fp32: round and pack them again
     if (e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(e));
     ctx->log(4, "ACCEL", "refitted BVH2: %u tris, %u nodes, %.4f s", a->num_tris, a->num_nodes,
