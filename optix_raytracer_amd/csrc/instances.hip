@@ -9,14 +9,17 @@
 //   * the mesh's own BVH2 is walked to its end (same slab test, same Moeller-Trumbore test as the one-level kernels);
 //   * a hit reports the FLATTENED primitive index prim_base + local index (the order of mipt_scene_flatten), ties at equal t go
 //     to the lower flattened index.
-// One ray per thread, one LDS stack of 64 entries per lane shared by both levels ([entry][lane]: bank = lane).  This is the
-// straightforward form (the per-ray visiting order of the oracle, exact visit counters); the entry-pool kernels of kernels.hip
-// stay one-level.
+// k_trace_inst: one ray per thread, one LDS stack of 64 entries per lane shared by both levels ([entry][lane]: bank = lane) -- the
+// straightforward form (the per-ray visiting order of the oracle, exact visit counters; counting launches and structures whose
+// meshes have no BVH4 mirror).  k_trace_static_inst / tail_trace_inst: the entry pool of kernels.hip over both levels (round 3).
+#include <cstdlib>
+
 #include "kernels.h"
 #include "detmath.h"
 #include "wave_util.h"
 #include "trav_core.h"
 #include "inst_core.h"
+#include "pool_core.h"
 
 namespace mipt {
 
@@ -113,9 +116,479 @@ __global__ __launch_bounds__(64) void k_trace_inst(TraceArgs a)
     }
 }
 
-template <int MODE>
-void launch_mode(hipStream_t st, const TraceArgs& a, bool count)
+
+// ---- the entry pool over a two-level structure ----------------------------------------------------------------------------------------
+// The same pool as kernels.hip's pool_round (a wave's rays traversed together: each round pops up to 64 entries, whichever rays they
+// belong to, one per lane), with 64-bit entries: .x as there (leaf : 1 | payload : 25 | ray slot : 6), .y = 0 for an entry of the top
+// level, instance + 1 for an entry inside an instance.  All nodes are BVH4 nodes of ONE array (DeviceBvh::inst_node4_off): the top
+// level's mirror, then every mesh's with its references rebased (mipt_accel_build_instances), so an entry inside a mesh looks like an
+// entry of a one-level BVH.  A lane's round is one of
+//   top-level node:      fetch 64 B + the table of its leaf children's mesh roots, slab-test four boxes against the WORLD ray, push the hit
+//                        children: a node with .y = 0, a leaf (an instance) as its mesh's ROOT with .y = instance + 1
+//   top-level leaf:      (an instance that came from a lane's own stack: k_trace_tiled_inst) fetch its mesh's root, push it with .y = instance + 1
+//   node in an instance: fetch 64 B + the instance's world->object matrix (issued together: the entry names both), take the ray
+//                        into object space (inst_core.h's arithmetic: the oracle's), slab-test, push with the same .y
+//   triangle:            fetch 48 B + the matrix + prim_base, test in object space, merge t (the same point in both spaces) and the
+//                        FLATTENED primitive index into the ray's slot: min t, tie -> lowest index
+// Hit records do not depend on the visiting order, so they equal k_trace_inst's and the oracle's bit for bit; visit counters differ
+// (counting launches keep k_trace_inst).
+#ifndef MIPT_INST_STATS            // probe builds (make probe-inststats PROBE_FLAGS=-DMIPT_INST_STATS=1): per-launch sums in DeviceCounters::dbg
+#define MIPT_INST_STATS 0
+#endif
+#if MIPT_INST_STATS
+#define INST_STATS_PARAM , uint32_t* ist
+#define INST_STATS_ARG , ist
+#else
+#define INST_STATS_PARAM
+#define INST_STATS_ARG
+#endif
+
+// slab_children4 that also says WHICH child each hit is (its index rides in the two low mantissa bits of the sort key: the order
+// of near-equal entry distances is free, results do not depend on it)
+struct Slab4i { int ref[4]; uint32_t idx[4]; int n; };
+__device__ __forceinline__ Slab4i slab_children4i(const u32x4 q0, const u32x4 q1, const u32x4 q2, const u32x4 q3, const float ix, const float iy, const float iz,
+                                                  const float nx, const float ny, const float nz, const float tmn, const float tcur)
 {
+    float t[4]; int r[4];
+    slab_piece(q0, ix, iy, iz, nx, ny, nz, tmn, tcur, t[0], r[0]);
+    slab_piece(q1, ix, iy, iz, nx, ny, nz, tmn, tcur, t[1], r[1]);
+    slab_piece(q2, ix, iy, iz, nx, ny, nz, tmn, tcur, t[2], r[2]);
+    slab_piece(q3, ix, iy, iz, nx, ny, nz, tmn, tcur, t[3], r[3]);
+    const float inf = __builtin_inff();
+    Slab4i o;
+    o.n = (t[0] < inf ? 1 : 0) + (t[1] < inf ? 1 : 0) + (t[2] < inf ? 1 : 0) + (t[3] < inf ? 1 : 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = t[c] < inf ? u2f((f2u(t[c]) & ~3u) | (uint32_t)c) : inf;
+    cmp_swap(t[0], r[0], t[1], r[1]); cmp_swap(t[2], r[2], t[3], r[3]);
+    cmp_swap(t[0], r[0], t[2], r[2]); cmp_swap(t[1], r[1], t[3], r[3]);
+    cmp_swap(t[1], r[1], t[2], r[2]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { o.ref[c] = r[c]; o.idx[c] = f2u(t[c]) & 3u; }
+    return o;
+}
+
+// the object-space ray of instance record pieces m0 .. m2 (rows of the world->object matrix): instances.hip's header, the oracle's sequence
+__device__ __forceinline__ RayO to_object(const u32x4 m0, const u32x4 m1, const u32x4 m2, const f3 wo, const f3 wd)
+{
+    const float inv[12] = { u2f(m0.x), u2f(m0.y), u2f(m0.z), u2f(m0.w), u2f(m1.x), u2f(m1.y), u2f(m1.z), u2f(m1.w), u2f(m2.x), u2f(m2.y), u2f(m2.z), u2f(m2.w) };
+    RayO O;
+    const f3 m = xform_vec(inv, wo);
+    O.o = mk3(m.x + inv[3], m.y + inv[7], m.z + inv[11]);
+    O.d = xform_vec(inv, wd);
+    prepare(O);
+    return O;
+}
+
+template <int MODE, int CAP>
+__device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint2* stk, unsigned long long* sh_best,
+                                                float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, int& psize, const bool cull_back INST_STATS_PARAM)
+{
+    int k = psize < 64 ? psize : 64;
+    const int room = CAP - 120 - psize;
+    if (3 * k > room) k = room > 3 ? room / 3 : 1;
+    const bool have = lane < k;
+    uint2 ent = make_uint2(0u, 0u);
+    if (have) ent = stk[psize - 1 - lane];
+    psize -= k;
+    uint32_t slot = ent.x & 63u;
+    bool dead = false;
+    if (MODE != 0) {                                       // an entry of a ray found occluded in the meantime: take one more from the top
+        dead = have && sh_done[slot] != 0u;
+        const unsigned long long dm = __ballot(dead);
+        if (dm != 0ull && psize > 0) {
+            const int nd = __popcll(dm), k2 = nd < psize ? nd : psize;
+            const int r = (int)lane_rank(dm);
+            if (dead && r < k2) { ent = stk[psize - 1 - r]; slot = ent.x & 63u; dead = sh_done[slot] != 0u; }
+            psize -= k2;
+        }
+    }
+    // the WORLD ray of that slot, from its owner's registers
+    float ox = shfl_f(T.o.x, slot), oy = shfl_f(T.o.y, slot), oz = shfl_f(T.o.z, slot);
+    float dx = shfl_f(T.d.x, slot), dy = shfl_f(T.d.y, slot), dz = shfl_f(T.d.z, slot);
+    float ix = shfl_f(T.idir.x, slot), iy = shfl_f(T.idir.y, slot), iz = shfl_f(T.idir.z, slot);
+    float nx = shfl_f(T.nood.x, slot), ny = shfl_f(T.nood.y, slot), nz = shfl_f(T.nood.z, slot);
+    const float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
+    float tcur = tmx;
+    bool live = have;
+    if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[slot] >> 32)); }
+    else if (dead) live = false;
+    const bool leaf = (ent.x >> 31) != 0u;
+    const uint32_t payload = (ent.x >> 6) & 0x1ffffffu;
+    const uint32_t lfirst = payload >> 2, lcnt = (payload & 3u) + 1u;
+    const bool in_inst = ent.y != 0u;
+    const bool do_inner = live && !leaf;
+    const bool do_tri = live && leaf && in_inst;
+    const bool do_enter = live && leaf && !in_inst;        // a top-level leaf from a lane's stack: lfirst is the instance
+#if MIPT_INST_STATS
+    ist[0] += 1u; ist[1] += (uint32_t)__popcll(__ballot(live)); ist[2] += (uint32_t)__popcll(__ballot(do_inner && !in_inst));
+    ist[3] += (uint32_t)__popcll(__ballot(do_inner && in_inst)); ist[4] += (uint32_t)__popcll(__ballot(do_tri)); ist[5] += (uint32_t)psize;
+#endif
+    const uint32_t inst_rec = bvh.inst_off + (in_inst ? ent.y - 1u : lfirst) * (uint32_t)sizeof(DeviceInstance);
+    // ------------------------------------------------------------ this round's loads, all issued before the one wait
+    uint32_t off = bvh.inst_node4_off;                     // idle lanes re-read node 0 (a broadcast)
+    if (do_inner) off = bvh.inst_node4_off + (payload << 6);
+    if (do_tri)   off = bvh.inst_tri_off + lfirst * 48u;
+    u32x4 q0 = ldq(blob, off), q1 = ldq(blob, off + 16u), q2 = ldq(blob, off + 32u);
+    u32x4 q3 = u32x4{ 0u, 0u, 0u, (uint32_t)kNoChild };
+    if (do_inner) q3 = ldq(blob, off + 48u);
+    u32x4 m0 = u32x4{ 0u, 0u, 0u, 0u }, m1 = m0, m2 = m0;
+    uint32_t rec_word = 0u;                                // prim_base (triangles) or root4 (entering an instance)
+    u32x4 r4 = u32x4{ 0u, 0u, 0u, 0u };                    // top-level node: the BVH4 root of the mesh behind each leaf child
+    if (live && in_inst) { m0 = ldq(blob, inst_rec); m1 = ldq(blob, inst_rec + 16u); m2 = ldq(blob, inst_rec + 32u); }
+    if (do_tri)   rec_word = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blob, (int)(inst_rec + (uint32_t)offsetof(DeviceInstance, prim_base)), 0, 0);
+    if (do_enter) rec_word = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blob, (int)(inst_rec + (uint32_t)offsetof(DeviceInstance, root4)), 0, 0);
+    if (do_inner && !in_inst) r4 = ldq(blob, bvh.inst_root4_off + (payload << 4));
+    asm volatile("" ::: "memory");
+    if (live && in_inst) {
+        const RayO O = to_object(m0, m1, m2, mk3(ox, oy, oz), mk3(dx, dy, dz));
+        ox = O.o.x; oy = O.o.y; oz = O.o.z; dx = O.d.x; dy = O.d.y; dz = O.d.z;
+        ix = O.idir.x; iy = O.idir.y; iz = O.idir.z; nx = O.nood.x; ny = O.nood.y; nz = O.nood.z;
+    }
+    uint32_t push0 = 0u, push1 = 0u, push2 = 0u, push3 = 0u;
+    uint32_t y0 = ent.y, y1 = ent.y, y2 = ent.y, y3 = ent.y;
+    int npush = 0;
+    if (do_inner) {
+        const Slab4i b = slab_children4i(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
+        npush = b.n;                                          // push1 = the nearest (ends on top), push0 the next, then push2, push3
+        int ref[4] = { b.ref[0], b.ref[1], b.ref[2], b.ref[3] };
+        uint32_t yy[4] = { ent.y, ent.y, ent.y, ent.y };
+        if (!in_inst) {
+            // a leaf child of the top level is an instance: what is pushed is its mesh's root (from the table beside the node) under
+            // the instance's number -- no round of its own for "entering"
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (ref[c] < 0) {
+                const uint32_t kk = (~(uint32_t)ref[c]) >> 4;
+                const uint32_t id = b.idx[c];
+                ref[c] = (int)(id == 0u ? r4.x : (id == 1u ? r4.y : (id == 2u ? r4.z : r4.w)));
+                yy[c] = kk + 1u;
+            }
+        }
+        if (b.n > 0) { push1 = pool_pack(ref[0], slot); y1 = yy[0]; }
+        if (b.n > 1) { push0 = pool_pack(ref[1], slot); y0 = yy[1]; }
+        if (b.n > 2) { push2 = pool_pack(ref[2], slot); y2 = yy[2]; }
+        if (b.n > 3) { push3 = pool_pack(ref[3], slot); y3 = yy[3]; }
+    }
+    if (do_enter) { push1 = pool_pack((int)rec_word, slot); y1 = lfirst + 1u; npush = 1; }
+    if (do_tri) {
+        const float4 n0 = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), n1 = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
+                     n2 = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
+        const f3 rd = mk3(dx, dy, dz);
+        const f3 e1 = mk3(n1.x, n1.y, n1.z), e2 = mk3(n2.x, n2.y, n2.z);
+        const f3 p = fcross(rd, e2);
+        const float det = fdot(e1, p);
+        const float inv = 1.0f / det;
+        const f3 tv = mk3(ox, oy, oz) - mk3(n0.x, n0.y, n0.z);
+        const float u = fdot(tv, p) * inv;
+        const f3 q = fcross(tv, e1);
+        const float v = fdot(rd, q) * inv;
+        const float t = fdot(e2, q) * inv;
+        const uint32_t prim = rec_word + f2u(n0.w);           // the flattened index
+        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmn && t < tmx &&
+                        (!cull_back || det > 0.0f || (f2u(n1.w) & 4u) != 0u);
+        bool stop = false;
+        if (MODE != 0) {
+            if (ok) { sh_done[slot] = 1u; stop = true; }
+        } else if (ok) {
+            const unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
+            atomicMin(&sh_best[slot], key);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; }
+        }
+        if (!stop && lcnt > 1u) {
+            push1 = 0x80000000u | ((lfirst + 1u) << 8) | ((lcnt - 2u) << 6) | slot;
+            npush = 1;
+        }
+    }
+    {
+        const unsigned long long m4 = __ballot(npush >= 4);
+        if (m4 != 0ull) { if (npush >= 4) stk[psize + (int)lane_rank(m4)] = make_uint2(push3, y3); psize += __popcll(m4); }
+        const unsigned long long m3 = __ballot(npush >= 3);
+        if (m3 != 0ull) { if (npush >= 3) stk[psize + (int)lane_rank(m3)] = make_uint2(push2, y2); psize += __popcll(m3); }
+        const unsigned long long m2_ = __ballot(npush >= 2);
+        if (m2_ != 0ull) { if (npush >= 2) stk[psize + (int)lane_rank(m2_)] = make_uint2(push0, y0); psize += __popcll(m2_); }
+        const unsigned long long m1_ = __ballot(npush >= 1);
+        if (m1_ != 0ull) { if (npush >= 1) stk[psize + (int)lane_rank(m1_)] = make_uint2(push1, y1); psize += __popcll(m1_); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+// a wave's rays (one per lane where has_ray) through the pool from the top level's root; results in sh_best / sh_u / sh_v / sh_done
+template <int MODE, int CAP>
+__device__ __forceinline__ void tail_trace_inst(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint2* stk, unsigned long long* sh_best,
+                                                float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, const bool has_ray, const bool cull_back INST_STATS_PARAM)
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
+    sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u;
+    const unsigned long long m = __ballot(has_ray);
+    if (has_ray) stk[(int)lane_rank(m)] = make_uint2(pool_pack(0, (uint32_t)lane), 0u);
+    int psize = __popcll(m);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    while (psize > 0) pool_round_inst<MODE, CAP>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back INST_STATS_ARG);
+}
+
+// static chunks of `ppw` rays per wave, all on the pool from the root (kernels.hip's k_trace_static over two levels)
+#ifndef MIPT_INST_ROWS
+#define MIPT_INST_ROWS 24                                   // 6 KB of LDS per wave: 576 entries of 8 bytes + the merge state
+#endif
+constexpr int kInstRows = MIPT_INST_ROWS;
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kInstRows <= 24 ? 6 : 5, kInstRows <= 24 ? 6 : 5))) void k_trace_static_inst(TraceArgs a, uint32_t ppw)
+{
+    constexpr int kCap = (kInstRows * 64 - 384) / 2;
+    __shared__ uint2 stk2[kInstRows * 32];
+    uint32_t* const words = reinterpret_cast<uint32_t*>(stk2);
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(words + 2 * kCap);
+    float* const sh_u = reinterpret_cast<float*>(words + 2 * kCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(words + 2 * kCap + 192);
+    uint32_t* const sh_done = words + 2 * kCap + 320;
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.inst_blob_bytes, 0x00020000);
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    const uint32_t chunks = (n + ppw - 1u) / ppw;
+    const bool cull_back = MODE == 0 && (a.ray_flags & 16u) != 0u;
+#if MIPT_INST_STATS
+    uint32_t ist[6] = { 0u, 0u, 0u, 0u, 0u, 0u };
+#endif
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint32_t ray = chunk * ppw + (uint32_t)lane;
+        const bool mine = (uint32_t)lane < ppw && ray < n;
+        Trav T;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
+        T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
+        if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+        tail_trace_inst<MODE, kCap>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel, cull_back INST_STATS_ARG);
+        if (mine) {
+            if (MODE == 0) {
+                const unsigned long long key = sh_best[lane];
+                T.tbest = ord_float((uint32_t)(key >> 32)); T.prim = (uint32_t)key; T.u = sh_u[lane]; T.v = sh_v[lane];
+            }
+            finish_ray<MODE>(a, T, ray, MODE == 0 ? T.prim != 0xffffffffu : sh_done[lane] != 0u);
+        }
+    }
+#if MIPT_INST_STATS
+    if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&a.ctr->dbg[k], (unsigned long long)ist[k]);      // rounds, live lanes, top-level nodes, instance nodes, triangles, pool fill
+#endif
+}
+
+// ---- tiles of 64 rays, one ray per lane, then the pool: kernels.hip's k_trace_pool over two levels ------------------------------------
+// Bulk phase: every lane walks its own ray depth first, near child first, with its stack in LDS ([entry][lane]) shared by both levels,
+// and keeps the ray of the space it is in -- world, or the object space of the instance it has entered -- in its registers: the
+// transform is applied ONCE per instance entered (the pool above applies it in every round, and fetches the matrix for it: with the
+// memory pipeline as the limiter that is what made the pool-only form 2-4 x slower than a flattened tree on scenes of many
+// overlapping instances), and a hit found in a near instance prunes the ones behind it before they are opened.  One unified step per
+// iteration, as kernels.hip's stream_step: each lane fetches 64 bytes -- its BVH4 node, its next triangle, or (standing at a top-level
+// leaf) the instance's record -- then, after one wait, does its slab test / triangle test / transform.  A lane leaves an instance
+// when its stack is back at the height it entered with; the world ray is kept in six registers and its reciprocals recomputed.
+// Tail phase: when half the tile is finished the remaining stack entries go into the pool above (64-bit entries tagged with the
+// instance they belong to) and all 64 lanes work on them.
+constexpr int kTiledInstRows = 32;
+template <int MODE>
+__device__ __forceinline__ void inst_step(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk, const int lane, const bool has_ray, Trav& T,
+                                          f3& wo, f3& wd, uint32_t& cur, int& base_sp, uint32_t& pbase, const bool cull_back)
+{
+    const bool act = has_ray && T.node != kSentinel;
+    const bool inner = act && T.node >= 0;
+    const bool leafref = act && T.node < 0;
+    const bool enter = leafref && cur == 0u;               // a top-level leaf: an instance
+    const bool at_tri = leafref && cur != 0u;
+    const uint32_t desc = ~(uint32_t)T.node;
+    const uint32_t lfirst = desc >> 4, lcnt = desc & 15u;
+    uint32_t off = bvh.inst_node4_off, off3 = off + 48u;
+    if (inner)  { off = bvh.inst_node4_off + ((uint32_t)T.node << 6); off3 = off + 48u; }
+    if (at_tri) { off = bvh.inst_tri_off + lfirst * 48u; off3 = off + 32u; }
+    if (enter)  { off = bvh.inst_off + lfirst * (uint32_t)sizeof(DeviceInstance); off3 = off + (uint32_t)offsetof(DeviceInstance, prim_base); }
+    const u32x4 q0 = ldq(blob, off), q1 = ldq(blob, off + 16u), q2 = ldq(blob, off + 32u);
+    u32x4 q3 = u32x4{ 0u, 0u, 0u, (uint32_t)kNoChild };
+    if (inner || enter) q3 = ldq(blob, off3);
+    asm volatile("" ::: "memory");
+    bool need_pop = false;
+    if (inner) {
+        const Slab4 b = slab_children4(q0, q1, q2, q3, T.idir.x, T.idir.y, T.idir.z, T.nood.x, T.nood.y, T.nood.z, T.tmin, T.tbest);
+        if (b.n == 0) need_pop = true;
+        else {
+            if (b.n > 3) { stk[T.sp * 64 + lane] = (uint32_t)b.ref[3]; ++T.sp; }          // farthest first, the nearest is walked next
+            if (b.n > 2) { stk[T.sp * 64 + lane] = (uint32_t)b.ref[2]; ++T.sp; }
+            if (b.n > 1) { stk[T.sp * 64 + lane] = (uint32_t)b.ref[1]; ++T.sp; }
+            T.node = b.ref[0];
+        }
+    }
+    if (at_tri) {
+        bool stop = false;
+        if (lcnt != 0u) {
+            const float4 ta = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), tb = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
+                         tc = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
+            const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
+            const f3 p = fcross(T.d, e2);
+            const float det = fdot(e1, p);
+            const float inv = 1.0f / det;
+            const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
+            const float u = fdot(tv, p) * inv;
+            const f3 q = fcross(tv, e1);
+            const float v = fdot(T.d, q) * inv;
+            const float t = fdot(e2, q) * inv;
+            const uint32_t prim = pbase + f2u(ta.w);          // the flattened index
+            const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > T.tmin && t < T.tmax &&
+                            (!cull_back || det > 0.0f || (f2u(tb.w) & 4u) != 0u);
+            if (MODE != 0) {
+                stop = ok;
+                if (ok) { T.tbest = t; T.prim = prim; }
+            } else if (ok && (t < T.tbest || (t == T.tbest && prim < T.prim))) {
+                T.tbest = t; T.prim = prim; T.u = u; T.v = v;
+            }
+        }
+        if (stop) T.node = kSentinel;
+        else if (lcnt > 1u) T.node = ~(int)(((lfirst + 1u) << 4) | (lcnt - 1u));
+        else need_pop = true;
+    }
+    if (__ballot(enter) != 0ull) {
+        if (enter) {
+            const RayO O = to_object(q0, q1, q2, wo, wd);
+            T.o = O.o; T.d = O.d; T.idir = O.idir; T.nood = O.nood;
+            pbase = q3.x; cur = lfirst + 1u; base_sp = T.sp;
+            T.node = (int)q3.y;                               // the mesh's BVH4 root
+        }
+    }
+    if (need_pop) {
+        if (cur != 0u && T.sp == base_sp) {                   // the instance is exhausted: back to the world ray
+            RayO W; W.o = wo; W.d = wd; prepare(W);
+            T.o = wo; T.d = wd; T.idir = W.idir; T.nood = W.nood;
+            cur = 0u;
+        }
+        if (T.sp == 0) T.node = kSentinel;
+        else { --T.sp; T.node = (int)stk[T.sp * 64 + lane]; }
+    }
+}
+
+#ifndef MIPT_INST_TILED_WAVES
+#define MIPT_INST_TILED_WAVES 5
+#endif
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_INST_TILED_WAVES, MIPT_INST_TILED_WAVES))) void k_trace_tiled_inst(TraceArgs a)
+{
+    constexpr int kWords = kTiledInstRows * 64;
+    constexpr int kCap = (kWords - 384) / 2;
+    __shared__ uint32_t lds[kWords];
+    uint2* const stk2 = reinterpret_cast<uint2*>(lds);
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(lds + 2 * kCap);
+    float* const sh_u = reinterpret_cast<float*>(lds + 2 * kCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(lds + 2 * kCap + 192);
+    uint32_t* const sh_done = lds + 2 * kCap + 320;
+    const int lane = (int)threadIdx.x;
+    const bool cull_back = MODE == 0 && (a.ray_flags & 16u) != 0u;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.inst_blob_bytes, 0x00020000);
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    // a lane's pool entries take two words where its stack entries took one: the rows are rewritten in place, so at most 32 lanes may
+    // still be busy at the switch (row e is read before (e + 1) * 32 entries = (e + 1) * 64 words are written)
+    const int steal_min = a.steal_min < 32 ? 32 : (a.steal_min < 64 ? a.steal_min : 64);
+    const uint32_t tiles = (n + 63u) >> 6, tiles_seg = (tiles + kNumSegments - 1) / kNumSegments;
+    const uint32_t xcd = blockIdx.x & (kNumSegments - 1), waves_seg = gridDim.x / kNumSegments;
+#if MIPT_INST_STATS
+    uint32_t ist[6] = { 0u, 0u, 0u, 0u, 0u, 0u };
+#endif
+    for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
+        uint32_t tile = xcd * tiles_seg + k;                 // groups of tile_group consecutive tiles dealt to the XCDs in turn (k_trace_pool)
+        if (a.tile_group != 0u) {
+            const uint32_t gq = k / a.tile_group, r = k - gq * a.tile_group;
+            tile = (gq * kNumSegments + xcd) * a.tile_group + r;
+        } else if (k >= tiles_seg) break;
+        if (tile >= tiles) break;
+        const uint32_t ray = tile * 64u + (uint32_t)lane;
+        Trav T;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
+        T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
+        bool has_ray = false;
+        if (ray < n) {
+            trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+            has_ray = T.node != kSentinel;
+            if (!has_ray) finish_ray<MODE>(a, T, ray, false);          // empty interval: a miss, nothing is touched
+        }
+        f3 wo = T.o, wd = T.d;
+        uint32_t cur = 0u, pbase = 0u;
+        int base_sp = 0;
+        // ============================================================ bulk: one ray per lane
+        while (__popcll(__ballot(!has_ray)) < steal_min) {
+            for (int bi = 0; bi < a.burst_bulk; ++bi) {
+                if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
+                inst_step<MODE>(blob, a.bvh, lds, lane, has_ray, T, wo, wd, cur, base_sp, pbase, cull_back);
+#if MIPT_INST_STATS
+                ist[0] += 1u; ist[1] += (uint32_t)__popcll(__ballot(has_ray));
+#endif
+            }
+            const bool done = has_ray && T.node == kSentinel;
+            if (done) { finish_ray<MODE>(a, T, ray, T.prim != 0xffffffffu); has_ray = false; }
+        }
+        if (__ballot(has_ray) == 0ull) continue;
+        // ============================================================ tail: the wave's entry pool
+        // the per-lane stacks become tagged pool entries, row by row and in place: an entry above the height the lane entered its
+        // instance with belongs to that instance, the ones below to the top level
+        int psize = 0;
+        for (int e = 0; e < kTiledInstRows; ++e) {
+            const bool in = has_ray && T.sp > e;
+            const unsigned long long m = __ballot(in);
+            if (m == 0ull) break;
+            uint32_t v = 0u;
+            if (in) v = lds[e * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (in) stk2[psize + (int)lane_rank(m)] = make_uint2(pool_pack((int)v, (uint32_t)lane), (cur != 0u && e >= base_sp) ? cur : 0u);
+            psize += __popcll(m);
+        }
+        {
+            const unsigned long long m = __ballot(has_ray);           // the node (or triangle, or instance) each busy lane stands at
+            if (has_ray) stk2[psize + (int)lane_rank(m)] = make_uint2(pool_pack(T.node, (uint32_t)lane), cur);
+            psize += __popcll(m);
+        }
+        // the pool reads the WORLD ray from its owner's registers
+        if (cur != 0u) { RayO W; W.o = wo; W.d = wd; prepare(W); T.o = wo; T.d = wd; T.idir = W.idir; T.nood = W.nood; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
+        sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        while (psize > 0) pool_round_inst<MODE, kCap>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back INST_STATS_ARG);
+        if (has_ray) {
+            const unsigned long long key = sh_best[lane];
+            T.tbest = ord_float((uint32_t)(key >> 32)); T.prim = (uint32_t)key; T.u = sh_u[lane]; T.v = sh_v[lane];
+            finish_ray<MODE>(a, T, ray, MODE == 0 ? T.prim != 0xffffffffu : sh_done[lane] != 0u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the next tile's stacks overwrite the merge slots
+    }
+#if MIPT_INST_STATS
+    if (lane == 0) for (int k = 0; k < 6; ++k) atomicAdd(&a.ctr->dbg[k], (unsigned long long)ist[k]);
+#endif
+}
+
+template <int MODE>
+void launch_mode(hipStream_t st, const TraceArgs& a, bool count, const TraceOpts& o)
+{
+    // o.inst_form (env MIPT_INST_FORM at context creation): 0 = by launch size, 1 = the pool-only form for every launch, 2 = one ray per lane
+    if (a.bvh.inst_fast && !count && o.persistent == 3 && o.inst_form != 2) {
+        // rays per wave as launch_trace has them for one-level BVHs (kernels.hip): 64 for big any-hit launches, 32 / 16 / 8 for smaller ones
+        // (any hit, 2 M shadow rays of the MeshViewer frame over 151 / 2 001 instances: 16 / 32 / 48 / 64 rays per wave give frames of
+        //  1.62 / 1.29 / 1.20 / 1.18 and 2.43 / 1.94 / 1.79 / 1.77 ms)
+        const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
+        const uint32_t n_est = MODE != 0 && a.n_ptr != nullptr ? a.n_max / 4u : a.n_max;
+        const uint32_t q = n_est / (cus * 16u);
+        const uint32_t ppw = MODE != 0 ? (n_est > cus * 2048u ? 64u : (q >= 24u ? 32u : (q >= 12u ? 16u : 8u))) : (q >= 96u ? 32u : (q >= 12u ? 16u : 8u));
+        unsigned long long want = ((unsigned long long)n_est + ppw - 1u) / ppw;
+        want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
+        const uint32_t g = (uint32_t)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
+        // big CLOSEST-hit launches: tiles of 64 rays, one ray per lane first (k_trace_tiled_inst), when a lane's stack over both levels
+        // fits its rows.  Any-hit launches keep the pool-only form (as over one-level BVHs: occlusion rays start at scattered points
+        // and the per-lane phase buys them nothing -- 151 instances: 376 against 454 us; 2 001: 762 against 692 us).
+        if (o.inst_form == 0 && MODE == 0 && a.bvh.stack4 + 1u <= (uint32_t)kTiledInstRows && n_est > cus * 512u) {
+            TraceArgs b = a;
+            b.tile_group = o.tile_group > 0 ? (uint32_t)o.tile_group : 0u;
+            unsigned long long tw = ((unsigned long long)a.n_max + 63ull) / 64ull;
+            tw = tw < cus * 16ull ? cus * 16ull : (tw > cus * 128ull ? cus * 128ull : tw);
+            const uint32_t tg = (uint32_t)((tw + kNumSegments - 1) / kNumSegments * kNumSegments);
+            hipLaunchKernelGGL((k_trace_tiled_inst<MODE>), dim3(tg), dim3(64), 0, st, b);
+            return;
+        }
+        hipLaunchKernelGGL((k_trace_static_inst<MODE>), dim3(g), dim3(64), 0, st, a, ppw);
+        return;
+    }
     uint32_t blocks = (a.n_max + 63u) / 64u;
     if (blocks > 16384u) blocks = 16384u;
     if (count) hipLaunchKernelGGL((k_trace_inst<MODE, true>), dim3(blocks), dim3(64), 0, st, a);
@@ -124,11 +597,11 @@ void launch_mode(hipStream_t st, const TraceArgs& a, bool count)
 
 }  // namespace
 
-void launch_trace_inst(hipStream_t st, const TraceArgs& a, int mode, bool count)
+void launch_trace_inst(hipStream_t st, const TraceArgs& a, int mode, bool count, const TraceOpts& o)
 {
-    if (mode == 0) launch_mode<0>(st, a, count);
-    else if (mode == 1) launch_mode<1>(st, a, count);
-    else launch_mode<2>(st, a, count);
+    if (mode == 0) launch_mode<0>(st, a, count, o);
+    else if (mode == 1) launch_mode<1>(st, a, count, o);
+    else launch_mode<2>(st, a, count, o);
 }
 
 }  // namespace mipt

@@ -53,6 +53,12 @@ struct DeviceBvh {
     uint32_t node32_off;       // byte offset, in the same allocation, of the entry-pool kernels' node mirror; 0 = this BVH has none
     uint32_t node4_off;        // byte offset of the BVH4 mirror (64-byte nodes of four fp16 boxes) behind the packed one; 0 = none
     uint32_t stack4;           // the most entries a lane's stack can need over the BVH4 mirror
+    // two-level structures on the entry pool (instances.hip, k_trace_static_inst / the path kernel's two-level form): `nodes` is then
+    // the base of ONE allocation -- top-level fp32 nodes | DeviceInstance records | BVH4 nodes (the top level's mirror first, then
+    // every referenced mesh's mirror with its references rebased into this array) | the meshes' triangles -- walked through one
+    // buffer descriptor.  inst_fast = 0: only the one-ray-per-lane walk (k_trace_inst) can traverse the structure.
+    uint32_t inst_fast, inst_off, inst_node4_off, inst_tri_off, inst_blob_bytes;
+    uint32_t inst_root4_off;   // per top-level BVH4 node 4 words: the BVH4 root of the mesh behind each LEAF child (an instance)
     uint32_t node_fmt;         // 0: fp32 64-byte BVH2 nodes only; 1: + packed 32-byte BVH2 nodes at node32_off (MiptBvhNode32: the boxes of
                                // `nodes` as fp16 -- the two arrays hold the SAME values), walked by every entry-pool kernel; 2: + the BVH4
                                // mirror at node4_off, walked by the kernels that live on the pool alone (static chunks, path kernels)
@@ -64,7 +70,8 @@ struct DeviceInstance {
     const float4* nodes;       // the mesh's BVH (64-byte nodes) ...
     const float4* tris;        // ... and triangles (48 bytes each), object space
     uint32_t      prim_base;   // flattened index of the mesh's primitive 0 within this instance
-    uint32_t      pad[3];
+    uint32_t      root4;       // entry-pool form: index of the mesh's BVH4 root in the structure's BVH4 array (DeviceBvh::inst_node4_off)
+    uint32_t      pad[2];
 };
 
 // SoA path queues, capacity `cap` entries each
@@ -128,6 +135,7 @@ struct TraceOpts {
     const uint32_t* class_width_dev;
     int  tail_refill;          // k_tail_pool2 as one set of resident waves that refill ended paths from the queue: 0 never, 1 big trees, 2 always
     int  tiled_bvh4;           // experiments: the tiled kernel walks the BVH4 mirror too (when a lane's stack over it fits 32 rows)
+    int  inst_form;            // two-level structures (instances.hip): 0 by launch size, 1 the pool-only form, 2 one ray per lane (env MIPT_INST_FORM)
 };
 
 // The next primary launch's tile order, made inside the launches the pass has anyway: the tiled kernel leaves a class byte per
@@ -176,6 +184,10 @@ void launch_resolve(hipStream_t st, const FrameConsts& fc, const float4* result,
 // SDK/imgui_test pipeline (imgui_kernels.hip)
 void imgui_run(hipStream_t st, const MiptImguiParams& p, uint32_t n_paths, const DeviceBvh& bvh, PathQueue q, float4* hits,
                ShadowQueue sh, uint32_t* occluded, float4* result, uint32_t* rg_seed, DeviceCounters* ctr, const TraceOpts& opts);
+// two-level structures: a mesh's BVH4 mirror copied into the structure's array with inner references moved by node_base and leaf
+// descriptors by tri_base; the top level's leaf descriptors turned from positions of inst_order into instance indices
+void launch_rebase_nodes4(hipStream_t st, const void* src, void* dst, uint32_t n4, uint32_t node_base, uint32_t tri_base);
+void launch_tlas4_leaves(hipStream_t st, void* nodes4, uint32_t n4, const uint32_t* order, const struct DeviceInstance* inst, uint32_t* root4_out);
 // device-side build-input assembly + BVH build (lbvh_build.hip); every pointer of GatherInput is a DEVICE pointer
 struct GatherInput {
     const void* vertices; uint32_t num_vertices, vertex_stride;
@@ -198,7 +210,8 @@ size_t topo_heights_scratch_bytes(uint32_t nn);
 hipError_t topo_heights(hipStream_t st, const float4* d_nodes, uint32_t nn, uint8_t* d_height, void* scratch = nullptr, size_t scratch_bytes = 0);
 size_t collapse_bvh4_scratch_bytes(uint32_t nn);
 hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d_height, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4,
-                         uint32_t* stack_need, bool* ok, void* scratch = nullptr, size_t scratch_bytes = 0);
+                         uint32_t* stack_need, bool* ok, void* scratch = nullptr, size_t scratch_bytes = 0,
+                         uint32_t budget = 32u);       // budget: the most stack entries a lane may need while walking the mirror
 hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth);
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok);

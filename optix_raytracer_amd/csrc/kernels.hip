@@ -22,6 +22,7 @@
 #include "detmath.h"
 #include "wave_util.h"
 #include "trav_core.h"
+#include "pool_core.h"
 
 namespace mipt {
 
@@ -79,106 +80,6 @@ __device__ __forceinline__ bool visit_leaf(Trav& T, const float4* __restrict__ t
 //     hence COUNT builds do not steal.
 // The per-ray visiting order of a non-shared ray is unchanged (a lane never takes an inner step while
 // it owes a triangle test), so hit records and visit counters equal the oracle's.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 16-byte load through a buffer descriptor: uniform base in SGPRs + 32-bit lane offset, hardware
-// range check (an out-of-range offset reads zeros instead of faulting), never split by the compiler
-__device__ __forceinline__ float4 ld16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off)
-{
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
-    return make_float4(u2f(v.x), u2f(v.y), u2f(v.z), u2f(v.w));
-}
-
-__device__ __forceinline__ u32x4 ldq(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off)
-{
-    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
-}
-
-// ---- the slab test of both children of an inner node, from either node format ------------------------------------------------
-// Q = false: the 64-byte fp32 node (MiptBvhNode) in pieces n0 .. n3.  Q = true: the packed 32-byte node (MiptBvhNode32) in
-// pieces n0, n1 -- child c: {lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16} as fp16, then its reference.  The fp16
-// values ARE the values the 64-byte node holds (pack_nodes32 rounds the fp32 boxes outward to them), a half converts to float
-// exactly, and the plane enters the same fmaf -- so both formats give the same tn / tf bit for bit (v_fma_mix_f32 reads the
-// half operand directly: no conversion instruction).
-__device__ __forceinline__ float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
-__device__ __forceinline__ float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
-struct SlabOut { float tn0, tf0, tn1, tf1; int c0, c1; };
-
-template <int Q>
-__device__ __forceinline__ SlabOut slab_children(const u32x4 n0, const u32x4 n1, const u32x4 n2, const u32x4 n3, const float ix, const float iy,
-                                                 const float iz, const float nx, const float ny, const float nz, const float tmn, const float tcur)
-{
-    float ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1;
-    SlabOut o;
-    if (Q == 1) {
-        // (halves taken by shift / truncate of each dword: a bit_cast of the dword to a half2 vector miscompiles on ROCm 7.2 --
-        // every v_fma_mix_f32 then reads element 0 of the loaded vector, whichever element the source names)
-        ax0 = __builtin_fmaf(half_lo(n0.x), ix, nx); ax1 = __builtin_fmaf(half_hi(n0.x), ix, nx);
-        ay0 = __builtin_fmaf(half_lo(n0.y), iy, ny); ay1 = __builtin_fmaf(half_hi(n0.y), iy, ny);
-        az0 = __builtin_fmaf(half_lo(n0.z), iz, nz); az1 = __builtin_fmaf(half_hi(n0.z), iz, nz);
-        bx0 = __builtin_fmaf(half_lo(n1.x), ix, nx); bx1 = __builtin_fmaf(half_hi(n1.x), ix, nx);
-        by0 = __builtin_fmaf(half_lo(n1.y), iy, ny); by1 = __builtin_fmaf(half_hi(n1.y), iy, ny);
-        bz0 = __builtin_fmaf(half_lo(n1.z), iz, nz); bz1 = __builtin_fmaf(half_hi(n1.z), iz, nz);
-        o.c0 = (int)n0.w; o.c1 = (int)n1.w;
-    } else {
-        ax0 = __builtin_fmaf(u2f(n0.x), ix, nx); ax1 = __builtin_fmaf(u2f(n0.y), ix, nx);
-        ay0 = __builtin_fmaf(u2f(n0.z), iy, ny); ay1 = __builtin_fmaf(u2f(n0.w), iy, ny);
-        az0 = __builtin_fmaf(u2f(n2.x), iz, nz); az1 = __builtin_fmaf(u2f(n2.y), iz, nz);
-        bx0 = __builtin_fmaf(u2f(n1.x), ix, nx); bx1 = __builtin_fmaf(u2f(n1.y), ix, nx);
-        by0 = __builtin_fmaf(u2f(n1.z), iy, ny); by1 = __builtin_fmaf(u2f(n1.w), iy, ny);
-        bz0 = __builtin_fmaf(u2f(n2.z), iz, nz); bz1 = __builtin_fmaf(u2f(n2.w), iz, nz);
-        o.c0 = (int)n3.x; o.c1 = (int)n3.y;
-    }
-    o.tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)), __builtin_fmaxf(__builtin_fminf(az0, az1), tmn));
-    o.tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)), __builtin_fminf(__builtin_fmaxf(az0, az1), tcur));
-    o.tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx0, bx1), __builtin_fminf(by0, by1)), __builtin_fmaxf(__builtin_fminf(bz0, bz1), tmn));
-    o.tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx0, bx1), __builtin_fmaxf(by0, by1)), __builtin_fminf(__builtin_fmaxf(bz0, bz1), tcur));
-    return o;
-}
-
-// ---- node format 2: four children per node (BVH4 mirror of the BVH2, mipt_api.cpp Bvh4Builder) ------------------------------------
-// 64 bytes = four 16-byte pieces, piece c = child c: {lo.x | hi.x << 16, lo.y | hi.y << 16, lo.z | hi.z << 16} as fp16, then its
-// reference (>= 0: BVH4 node, < 0: the BVH2's leaf descriptor, kNoChild: empty slot).  One step tests four boxes and orders the
-// hit children by entry distance: 0.63 x the steps of the BVH2 walk per primary ray, 0.58 x per shadow ray (1 M-triangle
-// scene).  Hit records cannot depend on the tree (closest: min t, tie -> lowest primitive; any: a boolean), so frames equal
-// those of the other formats bit for bit.
-constexpr int kNoChild = 0x7fffffff;
-struct Slab4 { float t[4]; int ref[4]; int n; };       // the hit children, nearest first; n of them
-
-__device__ __forceinline__ void slab_piece(const u32x4 q, const float ix, const float iy, const float iz, const float nx, const float ny, const float nz,
-                                           const float tmn, const float tcur, float& key, int& ref)
-{
-    const float x0 = __builtin_fmaf(half_lo(q.x), ix, nx), x1 = __builtin_fmaf(half_hi(q.x), ix, nx);
-    const float y0 = __builtin_fmaf(half_lo(q.y), iy, ny), y1 = __builtin_fmaf(half_hi(q.y), iy, ny);
-    const float z0 = __builtin_fmaf(half_lo(q.z), iz, nz), z1 = __builtin_fmaf(half_hi(q.z), iz, nz);
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), tmn));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fminf(__builtin_fmaxf(z0, z1), tcur));
-    ref = (int)q.w;
-    key = (tn <= tf && ref != kNoChild) ? tn : __builtin_inff();
-}
-__device__ __forceinline__ void cmp_swap(float& ka, int& ra, float& kb, int& rb)
-{
-    const bool sw = kb < ka;
-    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
-    const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
-    ka = k0; kb = k1; ra = r0; rb = r1;
-}
-__device__ __forceinline__ Slab4 slab_children4(const u32x4 q0, const u32x4 q1, const u32x4 q2, const u32x4 q3, const float ix, const float iy,
-                                                const float iz, const float nx, const float ny, const float nz, const float tmn, const float tcur)
-{
-    Slab4 o;
-    slab_piece(q0, ix, iy, iz, nx, ny, nz, tmn, tcur, o.t[0], o.ref[0]);
-    slab_piece(q1, ix, iy, iz, nx, ny, nz, tmn, tcur, o.t[1], o.ref[1]);
-    slab_piece(q2, ix, iy, iz, nx, ny, nz, tmn, tcur, o.t[2], o.ref[2]);
-    slab_piece(q3, ix, iy, iz, nx, ny, nz, tmn, tcur, o.t[3], o.ref[3]);
-    cmp_swap(o.t[0], o.ref[0], o.t[1], o.ref[1]); cmp_swap(o.t[2], o.ref[2], o.t[3], o.ref[3]);     // 5-comparator network
-    cmp_swap(o.t[0], o.ref[0], o.t[2], o.ref[2]); cmp_swap(o.t[1], o.ref[1], o.t[3], o.ref[3]);
-    cmp_swap(o.t[1], o.ref[1], o.t[2], o.ref[2]);
-    const float inf = __builtin_inff();
-    o.n = (o.t[0] < inf ? 1 : 0) + (o.t[1] < inf ? 1 : 0) + (o.t[2] < inf ? 1 : 0) + (o.t[3] < inf ? 1 : 0);
-    return o;
-}
-
 // this step's 64 (fp32 nodes) or 32 / 48 (packed nodes / triangles) bytes of a lane: inner lanes fetch their node, leaf
 // lanes their next triangle, idle lanes re-read node 0 (a broadcast).  The memory pipeline (TA / TD) spends 16 cycles per
 // dwordx4 wave instruction whatever the exec mask (profiles/r02_l1_*), so the packed form's third piece is fetched by leaf
@@ -261,9 +162,6 @@ __device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, con
 #endif
     asm volatile("" ::: "memory");
 }
-
-__device__ __forceinline__ float shfl_f(float v, uint32_t src) { return __shfl(v, (int)src, 64); }
-__device__ __forceinline__ uint32_t shfl_u(uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src, 64); }
 
 // One step of the lane state machine (see k_trace_stream): every lane loads 64 bytes -- its node, or its next
 // triangle -- then inner lanes do a slab step and leaf lanes one branch-free triangle test.  `sb` is the bottom of
@@ -537,15 +435,6 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
 // first << 2 | (count - 1): leaves of 1 .. 4 triangles, < 2^23 triangles.  The launcher only selects this kernel for BVHs
 // that fit (DeviceBvh::pool_ok; the builders make leaves of at most 4, and only the forced root over 0 or 1 triangles has
 // an empty one).
-
-__device__ __forceinline__ uint32_t pool_pack(int ref, uint32_t slot)
-{
-    if (ref >= 0) return ((uint32_t)ref << 6) | slot;
-    const uint32_t desc = ~(uint32_t)ref;
-    return 0x80000000u | ((desc >> 4) << 8) | (((desc - 1u) & 3u) << 6) | slot;
-}
-__device__ __forceinline__ uint32_t ord_bits(float f) { const uint32_t b = f2u(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
-__device__ __forceinline__ float    ord_float(uint32_t k) { return u2f(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
 
 // The wave's private range of ray indices (all members wave-uniform).  Each per-XCD segment of the ray array is
 // split into a STATIC part -- one first chunk per wave of that XCD, taken without any atomic -- and a dynamic
@@ -2035,7 +1924,7 @@ static void launch_trace(hipStream_t st, TraceArgs a, const TraceOpts& o, const 
 {
     if (a.n_max == 0) return;
     const RaygenJob rg = rgp ? *rgp : RaygenJob{};
-    if (a.bvh.inst) { launch_trace_inst(st, a, MODE, o.count_visits != 0); return; }       // two-level structure: instances.hip
+    if (a.bvh.inst) { launch_trace_inst(st, a, MODE, o.count_visits != 0, o); return; }       // two-level structure: instances.hip
     if (o.persistent >= 2 && a.bvh.tri_byte_off != 0u && a.bvh.depth <= (uint32_t)kStreamStack) {
         int blocks = ((o.blocks > 0 ? o.blocks : 4096) + kNumSegments - 1) / kNumSegments * kNumSegments;
         const bool pool = o.persistent == 3 && !o.count_visits && a.bvh.pool_ok;

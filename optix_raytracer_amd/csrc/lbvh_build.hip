@@ -475,7 +475,46 @@ __global__ __launch_bounds__(256) void k_b4_level(const uint4* __restrict__ n32,
     }
 }
 
+// ---- two-level structures on the entry pool: the pieces of the build that touch BVH4 nodes -------------------------------------------
+__global__ __launch_bounds__(256) void k_rebase_nodes4(const uint4* __restrict__ src, uint4* dst, uint32_t n4, uint32_t node_base, uint32_t tri_base)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece (one child) per thread
+    if (i >= n4 * 4u) return;
+    uint4 q = src[i];
+    const int ref = (int)q.w;
+    if (ref >= 0) { if (ref != 0x7fffffff) q.w = (uint32_t)ref + node_base; }
+    else { const uint32_t desc = ~(uint32_t)ref; q.w = ~((((desc >> 4) + tri_base) << 4) | (desc & 15u)); }
+    dst[i] = q;
+}
+
+__global__ __launch_bounds__(256) void k_tlas4_leaves(uint4* nodes4, uint32_t n4, const uint32_t* __restrict__ order, const DeviceInstance* __restrict__ inst,
+                                                      uint32_t* root4_out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4 * 4u) return;
+    const int ref = (int)nodes4[i].w;
+    uint32_t r4 = 0u;
+    if (ref < 0) {                                                              // leaves hold ONE instance each
+        const uint32_t k = order[(~(uint32_t)ref) >> 4];
+        nodes4[i].w = ~((k << 4) | 1u);
+        r4 = inst[k].root4;
+    }
+    root4_out[i] = r4;
+}
+
 }  // namespace
+
+void launch_rebase_nodes4(hipStream_t st, const void* src, void* dst, uint32_t n4, uint32_t node_base, uint32_t tri_base)
+{
+    if (n4 == 0u) return;
+    hipLaunchKernelGGL(k_rebase_nodes4, dim3((n4 * 4u + 255u) / 256u), dim3(256), 0, st, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n4, node_base, tri_base);
+}
+
+void launch_tlas4_leaves(hipStream_t st, void* nodes4, uint32_t n4, const uint32_t* order, const DeviceInstance* inst, uint32_t* root4_out)
+{
+    if (n4 == 0u) return;
+    hipLaunchKernelGGL(k_tlas4_leaves, dim3((n4 * 4u + 255u) / 256u), dim3(256), 0, st, reinterpret_cast<uint4*>(nodes4), n4, order, inst, root4_out);
+}
 
 hipError_t pack_nodes32(hipStream_t st, float4* d_nodes, uint32_t nn, void* d_nodes32, bool* ok)
 {
@@ -538,10 +577,10 @@ size_t collapse_bvh4_scratch_bytes(uint32_t nn) { return (((size_t)nn * sizeof(B
 // same tree.  *ok = false (and nothing to use) when the tree is higher than 32 or the mirror would not fit; *n4 nodes, *stack_need
 // entries per lane at most.
 hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d_height, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4,
-                         uint32_t* stack_need, bool* ok, void* scratch, size_t scratch_bytes)
+                         uint32_t* stack_need, bool* ok, void* scratch, size_t scratch_bytes, uint32_t budget)
 {
     *ok = false; *n4 = 0u; *stack_need = 0u;
-    if (nn == 0u || depth == 0u || depth > 32u) return hipSuccess;
+    if (nn == 0u || depth == 0u || depth > 32u || depth > budget) return hipSuccess;          // (a tree of height h always fits h entries: the budget must cover that)
     const size_t o_work = 0, o_cnt = o_work + (((size_t)nn * sizeof(B4Work) + 255) & ~(size_t)255), total = o_cnt + 512;
     char* tmp = nullptr; bool own = false;
     hipError_t e = hipSuccess;
@@ -552,7 +591,7 @@ hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d
     auto fail = [&](hipError_t err) { if (own) (void)hipFree(tmp); return err; };
     if ((e = hipMemsetAsync(cnt, 0, 512, st)) != hipSuccess) return fail(e);
     const uint32_t one = 1u;
-    const B4Work root{ 0u, 32u, 0u, 0u };
+    const B4Work root{ 0u, budget < 32u ? budget : 32u, 0u, 0u };
     if ((e = hipMemcpyAsync(cnt, &one, 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
     if ((e = hipMemcpyAsync(work, &root, sizeof root, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
     const uint4* n32 = reinterpret_cast<const uint4*>(d_nodes32);

@@ -80,6 +80,10 @@ struct Accel {
     std::vector<float>         h_inv;            // 12 per instance
     std::vector<unsigned long long> gas;         // child handle per instance
     uint32_t                   users = 0;        // instance structures that reference this mesh BVH
+    // entry-pool form of a two-level structure (DeviceBvh::inst_fast): d_nodes is then ONE allocation, d_inst lies inside it
+    bool                       inst_fast = false;
+    bool                       stale = false;    // a mesh this structure references was refitted since: mipt_accel_update_instances first
+    uint32_t                   inst_off = 0, inst_node4_off = 0, inst_tri_off = 0, inst_blob_bytes = 0, inst_root4_off = 0;
 };
 
 enum TimedKind { T_RAYGEN = 0, T_CLOSEST, T_SHADE, T_ANY, T_RESOLVE, T_KINDS };
@@ -109,6 +113,7 @@ struct MiptContext {
     int      batch_samples = 0;
     int      persistent = 3;
     int      build_mode = 0;              // MIPT_OPT_BUILD: 0 host binned SAH, 1 device LBVH
+    int      lbvh_leaf = 4;               // env MIPT_LBVH_LEAF: subtrees of at most this many triangles become leaves of the device LBVH (1 .. 4)
     int      node_format = 2;             // MIPT_OPT_NODE_FORMAT: 2 fp16 boxes + BVH4 mirror, 1 fp16 boxes + packed 32-byte BVH2 mirror (where the
                                           // scene suits fp16 boxes), 0 fp32 boxes only
     uint32_t tail_paths = 1048576;         // MIPT_OPT_TAIL_PATHS (sweep: profiles/r01_tail_paths.txt)
@@ -156,6 +161,7 @@ struct MiptContext {
     bool      advance_pending = false;   // the last launch ended without its final k_advance step (mipt_get_launch_stats applies it)
     int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
     int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
+    int       inst_form = 0;             // env MIPT_INST_FORM: traversal form over two-level structures (TraceOpts::inst_form)
     int       tile_order_mode = 1;       // MIPT_OPT_TILE_ORDER: 0 image order, 1 (default) by the previous launch's costs
     int      profile = 0;
 
@@ -334,6 +340,7 @@ TraceOpts trace_opts(const MiptContext* c)
     o.tile_group = c->tile_group;
     o.tail_refill = c->tail_refill;
     o.tiled_bvh4 = c->tiled_bvh4;
+    o.inst_form = c->inst_form;
     return o;
 }
 
@@ -399,7 +406,13 @@ DeviceBvh device_bvh(const Accel* a)
     b.pool2_ok = (b.pool_ok && a->num_nodes < (1u << 24) && a->num_tris < (1u << 22)) ? 1u : 0u;
     b.node32_off = a->node32_off; b.node_fmt = a->node32_off ? a->node_fmt : 0u;
     b.node4_off = b.node_fmt == 2u ? a->node4_off : 0u; b.stack4 = a->stack_need;
-    if (a->is_ias) { b.inst = a->d_inst; b.inst_order = a->d_order; b.n_inst = (uint32_t)a->gas.size(); b.pool_ok = b.pool2_ok = 0u; b.tri_byte_off = 0u; b.node32_off = 0u; }
+    if (a->is_ias) {
+        b.inst = a->inst_fast ? reinterpret_cast<const DeviceInstance*>(reinterpret_cast<const char*>(a->d_nodes) + a->inst_off) : a->d_inst;
+        b.inst_order = a->d_order; b.n_inst = (uint32_t)a->gas.size(); b.pool_ok = b.pool2_ok = 0u; b.tri_byte_off = 0u; b.node32_off = 0u;
+        b.node_fmt = 0u; b.node4_off = 0u; b.blob_bytes = 0u;
+        b.inst_fast = a->inst_fast ? 1u : 0u; b.inst_off = a->inst_off; b.inst_node4_off = a->inst_node4_off; b.inst_tri_off = a->inst_tri_off;
+        b.inst_blob_bytes = a->inst_blob_bytes; b.stack4 = a->stack_need; b.inst_root4_off = a->inst_root4_off;
+    }
     return b;
 }
 
@@ -413,6 +426,7 @@ int check_launch(MiptContext* ctx, const MiptParams* p, unsigned width, unsigned
     if (p->samples_per_launch == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "samples_per_launch must be >= 1");
     *acc = find_accel(ctx, p->handle);
     if (!*acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
+    if ((*acc)->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", p->handle);
     if (!ctx->d_hitgroups || ctx->n_hitgroups == 0) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "no hit-group records set (mipt_sbt_set_hitgroups)");
     return MIPT_SUCCESS;
 }
@@ -685,6 +699,8 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_TILE_CLASS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) { c->tile_class_width = (uint32_t)v; c->tile_class_fixed = true; } }
     if (const char* e = std::getenv("MIPT_TILE_CLASS_INIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }   // adapted from there
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_INST_FORM")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->inst_form = v; }
+    if (const char* e = std::getenv("MIPT_LBVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->lbvh_leaf = v; }
     if (const char* e = std::getenv("MIPT_TAIL_REFILL")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tail_refill = v; }
     if (const char* e = std::getenv("MIPT_DIRECT_RESOLVE")) c->direct_resolve = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_FUSE_RAYGEN")) c->fuse_raygen = std::atoi(e) != 0;
@@ -896,7 +912,7 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     const uint32_t err = G.err;
     float* d_world = G.world; uint32_t* d_gf = G.gflags;
     float4* blob = nullptr; uint32_t nn = 0, dep = 0; bool ok = false;
-    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, 4, kStackEntries, &blob, &nn, &dep, &ok);
+    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, ctx->lbvh_leaf, kStackEntries, &blob, &nn, &dep, &ok);
     if (e != hipSuccess) return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e));
     if (err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
     if (!ok) {
@@ -1106,14 +1122,81 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
     if (!build_bvh(boxes.data(), n, 1, kStackEntries, 1, top)) return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "instance BVH over %u instances is too deep", n);
     std::vector<uint32_t> h_order(top.tris.size());
     for (size_t k = 0; k < top.tris.size(); ++k) h_order[k] = top.tris[k].prim;
+    // The entry-pool form (k_trace_static_inst, the path kernel) needs every mesh's BVH4 mirror and at least two instances; the whole
+    // structure then lives in ONE allocation behind one buffer descriptor: top-level fp32 nodes | instance records | BVH4 nodes
+    // (the top level's mirror in the first T slots, then each distinct mesh's, references rebased) | the meshes' triangles.
+    struct MeshSlot { const Accel* g; uint32_t node_base, tri_base; };
+    std::vector<MeshSlot> meshes;
+    std::unordered_map<unsigned long long, size_t> mesh_of;
+    const uint32_t T = (uint32_t)top.nodes.size();
+    bool fast = ctx->node_format == 2 && n >= 2u && T >= 1u;
+    uint64_t n4_total = T, tri_total = 0;
+    for (uint32_t k = 0; k < n && fast; ++k) {
+        if (mesh_of.count(gas[k])) continue;
+        const Accel* g = find_accel(ctx, gas[k]);
+        if (g->node_fmt != 2u || g->node4_off == 0u || g->num_nodes4 == 0u || g->leaf_max > 4u) { fast = false; break; }
+        mesh_of[gas[k]] = meshes.size();
+        meshes.push_back({ g, (uint32_t)n4_total, (uint32_t)tri_total });
+        n4_total += g->num_nodes4; tri_total += g->num_tris;
+    }
+    const size_t o_inst = ((size_t)T * sizeof(MiptBvhNode) + 255) & ~(size_t)255;
+    const size_t o_r4 = (o_inst + (size_t)n * sizeof(DeviceInstance) + 127) & ~(size_t)127;        // 16 B per top-level BVH4 node (at most T of them)
+    const size_t o_n4 = (o_r4 + (size_t)T * 16u + 127) & ~(size_t)127;
+    const size_t o_tri = (o_n4 + (size_t)n4_total * 64u + 127) & ~(size_t)127;
+    const size_t arena = o_tri + (size_t)tri_total * sizeof(MiptBvhTri) + 64;
+    if (n4_total >= (1ull << 25) || tri_total >= (1ull << 23) || arena >= (1ull << 31)) fast = false;      // the pool's packed entries, 32-bit offsets
     // fresh device copies; the structure's current ones stay in place (and in use by nothing: the callers synchronise) until all exist
     IasScratch S;
-    HIPCHK(ctx, hipMalloc((void**)&S.d_nodes, top.nodes.size() * sizeof(MiptBvhNode)));
-    HIPCHK(ctx, hipMemcpy(S.d_nodes, top.nodes.data(), top.nodes.size() * sizeof(MiptBvhNode), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMalloc((void**)&S.d_inst, (size_t)n * sizeof(DeviceInstance)));
-    HIPCHK(ctx, hipMemcpy(S.d_inst, recs.data(), (size_t)n * sizeof(DeviceInstance), hipMemcpyHostToDevice));
+    uint32_t stack4 = 0u;
+    if (fast) {
+        for (uint32_t k = 0; k < n; ++k) recs[k].root4 = meshes[mesh_of[gas[k]]].node_base;
+        HIPCHK(ctx, hipMalloc((void**)&S.d_nodes, arena));
+        char* base = reinterpret_cast<char*>(S.d_nodes);
+        HIPCHK(ctx, hipMemcpy(base, top.nodes.data(), (size_t)T * sizeof(MiptBvhNode), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(base + o_inst, recs.data(), (size_t)n * sizeof(DeviceInstance), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemset(base + o_tri + (size_t)tri_total * sizeof(MiptBvhTri), 0, 64));
+        for (const MeshSlot& m : meshes) {
+            launch_rebase_nodes4(nullptr, reinterpret_cast<const char*>(m.g->d_nodes) + m.g->node4_off, base + o_n4 + (size_t)m.node_base * 64u, m.g->num_nodes4, m.node_base, m.tri_base);
+            HIPCHK(ctx, hipMemcpyAsync(base + o_tri + (size_t)m.tri_base * sizeof(MiptBvhTri), m.g->d_tris, (size_t)m.g->num_tris * sizeof(MiptBvhTri), hipMemcpyDeviceToDevice, nullptr));
+        }
+    } else {
+        HIPCHK(ctx, hipMalloc((void**)&S.d_nodes, top.nodes.size() * sizeof(MiptBvhNode)));
+        HIPCHK(ctx, hipMemcpy(S.d_nodes, top.nodes.data(), top.nodes.size() * sizeof(MiptBvhNode), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMalloc((void**)&S.d_inst, (size_t)n * sizeof(DeviceInstance)));
+        HIPCHK(ctx, hipMemcpy(S.d_inst, recs.data(), (size_t)n * sizeof(DeviceInstance), hipMemcpyHostToDevice));
+    }
     HIPCHK(ctx, hipMalloc((void**)&S.d_order, std::max<size_t>(h_order.size(), 1) * 4u));
     if (!h_order.empty()) HIPCHK(ctx, hipMemcpy(S.d_order, h_order.data(), h_order.size() * 4u, hipMemcpyHostToDevice));
+    if (fast) {
+        // the top level's mirrors, on the device: heights, fp16 boxes (the fp32 nodes are rounded in place, as a mesh's are), BVH4 collapse
+        // into the first T slots of the BVH4 array; its leaves then name instances instead of positions of inst_order
+        char* base = reinterpret_cast<char*>(S.d_nodes);
+        const size_t hb = topo_heights_scratch_bytes(T), cb = collapse_bvh4_scratch_bytes(T);
+        ctx->scratch_reset();
+        HIPCHK(ctx, ctx->scratch_ensure(hb + cb + (size_t)T * (32u + 1u) + 4096u));
+        uint8_t* d_h = (uint8_t*)ctx->scratch_take(T);
+        void* d_n32 = ctx->scratch_take((size_t)T * 32u);
+        HIPCHK(ctx, topo_heights(nullptr, S.d_nodes, T, d_h, ctx->scratch_take(hb), hb));
+        bool ok = false;
+        HIPCHK(ctx, pack_nodes32(nullptr, S.d_nodes, T, d_n32, &ok));
+        uint32_t cnt4 = 0u;
+        // (the top level is collapsed under a stack budget that leaves room for the deepest mesh: k_trace_tiled_inst keeps ONE 32-row
+        //  stack per lane for both levels, + 1 for the node a lane stands at)
+        uint32_t mesh_need = 0u;
+        for (const MeshSlot& m : meshes) mesh_need = std::max(mesh_need, m.g->stack_need);
+        const uint32_t tl_budget = mesh_need + 1u < 31u ? std::max<uint32_t>(31u - mesh_need, top.depth) : 32u;
+        if (ok) HIPCHK(ctx, collapse_bvh4(nullptr, d_n32, d_h, T, top.depth, base + o_n4, &cnt4, &stack4, &ok, ctx->scratch_take(cb), cb, tl_budget));
+        if (ok) {
+            launch_tlas4_leaves(nullptr, base + o_n4, cnt4, S.d_order, reinterpret_cast<const DeviceInstance*>(base + o_inst), reinterpret_cast<uint32_t*>(base + o_r4));
+            HIPCHK(ctx, hipStreamSynchronize(nullptr)); HIPCHK(ctx, hipGetLastError());
+        }
+        if (!ok) {
+            // (a top level that does not suit fp16 boxes: the one-ray-per-lane walk over the same allocation)
+            fast = false;
+            HIPCHK(ctx, hipMalloc((void**)&S.d_inst, (size_t)n * sizeof(DeviceInstance)));
+            HIPCHK(ctx, hipMemcpy(S.d_inst, recs.data(), (size_t)n * sizeof(DeviceInstance), hipMemcpyHostToDevice));
+        }
+    }
     // hit-group record index per FLATTENED primitive: the meshes' own tables, one after the other
     HIPCHK(ctx, hipMalloc((void**)&S.d_mat, std::max<uint64_t>(total_tris, 1) * 4u));
     for (uint32_t k = 0; k < n; ++k) {
@@ -1125,8 +1208,13 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
     a->h_inv.swap(h_inv); a->h_base.swap(h_base); a->gas.swap(gas); a->h_order.swap(h_order); a->h_tlas = top.nodes;
     a->d_tris = nullptr; a->tri_byte_off = 0; a->blob_bytes = 0; a->node32_off = 0;
     a->num_nodes = (uint32_t)top.nodes.size(); a->num_tris = (uint32_t)total_tris; a->n_prims = (uint32_t)total_tris;
-    a->depth = top.depth + max_depth; a->leaf_max = 1; a->is_ias = true;
-    a->bytes = top.nodes.size() * sizeof(MiptBvhNode) + (size_t)n * (sizeof(DeviceInstance) + 4u) + total_tris * 4u;
+    a->depth = top.depth + max_depth; a->leaf_max = 1; a->is_ias = true; a->stale = false;
+    uint32_t mesh_stack = 0u;
+    for (const MeshSlot& m : meshes) mesh_stack = std::max(mesh_stack, m.g->stack_need);
+    a->inst_fast = fast; a->stack_need = fast ? stack4 + mesh_stack : 0u;      // the most entries a lane's stack over BOTH levels can hold
+    a->inst_off = fast ? (uint32_t)o_inst : 0u; a->inst_node4_off = fast ? (uint32_t)o_n4 : 0u; a->inst_tri_off = fast ? (uint32_t)o_tri : 0u;
+    a->inst_blob_bytes = fast ? (uint32_t)arena : 0u; a->inst_root4_off = fast ? (uint32_t)o_r4 : 0u;
+    a->bytes = (fast ? arena : top.nodes.size() * sizeof(MiptBvhNode) + (size_t)n * sizeof(DeviceInstance)) + (size_t)n * 4u + total_tris * 4u;
     return MIPT_SUCCESS;
 }
 
@@ -1203,6 +1291,11 @@ int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBui
     hipError_t e = lbvh_refit(nullptr, G.world, G.n, a->d_nodes, a->num_nodes, a->d_tris, a->d_height, a->depth);
     if (e == hipSuccess) e = finish_blob(ctx, a);            // the refitted boxes are fp32: round and pack them again
     if (e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(e));
+    // an instance structure that references this mesh holds copies of its mirrors and a world box made from its old root box: it has to
+    // be brought up to date (mipt_accel_update_instances, as OptiX requires an IAS update after a GAS update) before it is traced again
+    if (a->users != 0u)
+        for (auto& kv : ctx->accels)
+            if (kv.second->is_ias && std::find(kv.second->gas.begin(), kv.second->gas.end(), handle) != kv.second->gas.end()) kv.second->stale = true;
     ctx->log(4, "ACCEL", "refitted BVH2: %u tris, %u nodes, %.4f s", a->num_tris, a->num_nodes,
              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return MIPT_SUCCESS;
@@ -1452,6 +1545,7 @@ int mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* p, 
     if (p->nlights < 0 || p->nlights > 31 || (p->nlights > 0 && !p->lights)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0..31 lights supported");
     Accel* acc = find_accel(ctx, p->handle);
     if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
+    if (acc->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", p->handle);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
     int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);
@@ -1557,6 +1651,7 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     if (!ctx->wh_geo.vertices4 || !ctx->d_wh_materials) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "mipt_whitted_set_geometry was not called");
     Accel* acc = find_accel(ctx, p->handle);
     if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
+    if (acc->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", p->handle);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
     int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);
@@ -1621,6 +1716,7 @@ int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     const Accel* a = find_accel(ctx, handle);
     if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
+    if (a->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", handle);
     if (n == 0) return MIPT_SUCCESS;
     if (!rays || !hits) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "trace_closest: null buffer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1647,6 +1743,7 @@ int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, co
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     const Accel* a = find_accel(ctx, handle);
     if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
+    if (a->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", handle);
     if (n == 0) return MIPT_SUCCESS;
     if (!rays || !occluded) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "trace_any: null buffer");
     HIPCHK(ctx, hipSetDevice(ctx->device));

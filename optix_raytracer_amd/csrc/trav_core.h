@@ -170,6 +170,6 @@ __device__ __forceinline__ void finish_ray(const TraceArgs& a, const Trav& T, ui
 }
 
 
-void launch_trace_inst(hipStream_t st, const TraceArgs& a, int mode, bool count);       // instances.hip
+void launch_trace_inst(hipStream_t st, const TraceArgs& a, int mode, bool count, const struct TraceOpts& o);       // instances.hip
 
 }  // namespace mipt

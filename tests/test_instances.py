@@ -273,3 +273,85 @@ def test_any_hit_programs_inside_instances(tmp_path):
     assert (d > 1e-5).mean() < 0.02 and (d > 1e-2).mean() < 0.005 and d.mean() < 1e-3
     # the any-hit programs did run: ignored candidates make radiance rays continue, attenuated shadows are neither 0 nor 1
     assert stats[True]["closest_rays"] > w * h and abs(stats[True]["shadow_rays"] - stats[False]["shadow_rays"]) < 0.01 * stats[False]["shadow_rays"]
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_every_traversal_form_gives_the_same_records(tmp_path, monkeypatch, form):
+    """Round 3: three forms walk a two-level structure -- tiles of 64 rays, one ray per lane with the object-space ray in registers, then
+    the entry pool (k_trace_tiled_inst: big closest-hit launches); the entry pool from the root (k_trace_static_inst: any-hit launches,
+    small launches); one ray per lane to the end (k_trace_inst: counting launches, meshes without a BVH4 mirror).  MIPT_INST_FORM pins
+    form 1 or 2 for a context; hit records and occlusion flags of 0.3 M rays must equal those of the default context (which takes the
+    tiled form for the closest-hit launch) bit for bit, and the oracle's."""
+    import torch
+    from optix_raytracer_amd import api, scenes
+    path = scenes.write_instanced_gltf(tmp_path / "instanced.gltf", n_instances=90, seed=11)
+    results = []
+    for env in (None, str(form)):
+        if env is None:
+            monkeypatch.delenv("MIPT_INST_FORM", raising=False)
+        else:
+            monkeypatch.setenv("MIPT_INST_FORM", env)
+        ctx = api.Context(0)
+        flat, ias, gas, inst, keep = _build(ctx, torch, path)
+        osc = _oracle_two_level(ctx, flat, ias)
+        rays = osc.primary_rays(scenes.launch_desc(flat, 720, 405))
+        rng = np.random.default_rng(8)
+        extra = np.zeros((30000, 8), np.float32)
+        extra[:, :3] = rng.uniform(-8, 8, (30000, 3)) * (1, 0.4, 1) + (0, 1.5, 0)
+        extra[:, 4:7] = rng.normal(size=(30000, 3))
+        extra[:, 3], extra[:, 7] = 0.01, 1e16
+        rays = np.concatenate([rays, extra])
+        n = rays.shape[0]
+        d_rays = torch.from_numpy(rays).cuda()
+        d_hits = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+        seg = rays.copy(); seg[:, 7] = np.where(seg[:, 7] > 1.0, 5.0, seg[:, 7])
+        d_seg = torch.from_numpy(seg).cuda()
+        d_occ = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ctx.trace_any(ias, d_seg.data_ptr(), n, d_occ.data_ptr()); ctx.sync()
+        results.append((d_hits.cpu().numpy(), d_occ.cpu().numpy()))
+        if env is None:
+            t, prim, u, v = osc.trace_closest(rays, O.MODE_INST)
+            h = results[0][0]
+            assert np.array_equal(h[:, 1].view(np.uint32), prim) and np.array_equal(h[:, 0].view(np.uint32), t.view(np.uint32))
+            assert np.array_equal(results[0][1].astype(np.uint8), osc.trace_any(seg, O.MODE_INST))
+        ctx.destroy()
+    assert np.array_equal(results[0][0].view(np.uint32), results[1][0].view(np.uint32))
+    assert np.array_equal(results[0][1], results[1][1])
+
+
+def test_a_refitted_mesh_makes_its_instance_structures_stale(tmp_path):
+    """An instance structure holds copies of its meshes' mirrors and world boxes made from their root boxes.  After mipt_accel_update of a
+    mesh it must be brought up to date (OptiX asks for an IAS update after a GAS update too); until then tracing it is an error, not
+    a picture from old boxes.  After mipt_accel_update_instances it equals a fresh build over the moved mesh."""
+    import torch
+    from optix_raytracer_amd import api, scenes
+    ctx = api.Context(0)
+    path = scenes.write_instanced_gltf(tmp_path / "instanced.gltf", n_instances=40, seed=5)
+    flat, ias, gas, inst, keep = _build(ctx, torch, path)
+    osc = _oracle_two_level(ctx, flat, ias)
+    rays = osc.primary_rays(scenes.launch_desc(flat, 320, 180))
+    n = rays.shape[0]
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+    before = d_hits.cpu().numpy()
+    # move mesh 0's vertices (same topology) and refit it
+    dv, dm = keep[0], keep[1]
+    v = dv.cpu().numpy().copy()
+    v[:, :3] *= np.float32(1.15)
+    dv.copy_(torch.from_numpy(v))
+    ctx.accel_update(gas[0], [{"vertices": dv.data_ptr(), "num_vertices": v.shape[0], "stride": 16, "sbt_index_offsets": dm.data_ptr()}])
+    with pytest.raises(api.MiptError) as e:
+        ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr())
+    assert "mipt_accel_update_instances" in str(e.value)
+    ctx.accel_update_instances(ias, inst)
+    ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+    after = d_hits.cpu().numpy()
+    fresh = ctx.accel_build_instances(inst)
+    ctx.trace_closest(fresh, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+    assert np.array_equal(after.view(np.uint32), d_hits.cpu().numpy().view(np.uint32))
+    assert not np.array_equal(after.view(np.uint32), before.view(np.uint32))
+    t, prim, _, _ = _oracle_two_level(ctx, flat, ias).trace_closest(rays, O.MODE_INST)
+    assert np.array_equal(after[:, 1].view(np.uint32), prim) and np.array_equal(after[:, 0].view(np.uint32), t.view(np.uint32))
+    ctx.destroy()

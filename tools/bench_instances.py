@@ -14,7 +14,8 @@ import torch
 from optix_raytracer_amd import meshviewer as MV, scenes
 
 tmp = pathlib.Path(tempfile.mkdtemp())
-for n_inst in (150, 2000):
+counts = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [150, 2000]
+for n_inst in counts:
     path = scenes.write_instanced_gltf(tmp / ("inst%d.gltf" % n_inst), n_instances=n_inst, seed=3)
     frames = {}
     for two_level in (True, False):
