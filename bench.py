@@ -29,6 +29,8 @@ L2_PEAK_GBS = 34500.0      # aggregate L2, 8 XCDs (:316)
 CLOCK_HZ = 2.4e9           # max clock (:34)
 N_CUS, N_SIMDS = 256, 1024
 VALU_CYCLES = 2.0          # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles when other waves fill the SIMD (:54, :473)
+VMEM_BASE_CYCLES, VMEM_LANE_CYCLES = 16.0, 0.48   # measured on this chip (profiles/r03_micro_vmem.txt): cycles a lane-divergent wave-level
+                                                  # load costs its CU = 16 + 0.48 x lanes with an address of their own, any width
 L1_PEAK_ACC_PER_CU_CLK = 1.0   # the vector L1 (TCP) looks up one cache line per cycle: a lane-divergent 16-byte load costs a
                                # lookup per lane (DESIGN.md 3.1 "what bounds it": measured 64 per wave instruction)
 
@@ -47,6 +49,9 @@ def parse():
     ap.add_argument("--persistent", type=int, default=-1, help="tuning: traversal kernel variant (3 entry pool, 2 streaming waves, 0 one thread per ray)")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="N > 1: all-gather + scatter on the launch stream instead of overlapping the next frame's tracing")
+    ap.add_argument("--scatter-all", action="store_true",
+                    help="N > 1: every rank un-permutes the gathered frame into the canonical layout (default: rank 0 only -- the rank that "
+                         "shows the frame, as optixMultiGPU's GPU 0; the others hold the gathered float4 buffer)")
     ap.add_argument("--verify", action="store_true", help="debug: compare the gathered frame with a single-launch frame, bit for bit")
     ap.add_argument("--force-shard-path", action="store_true", help="debug: run the N > 1 code path (shard, gather, scatter) on one GPU")
     ap.add_argument("--grid", type=int, default=0, help="tuning: persistent workgroups per CU")
@@ -91,6 +96,7 @@ def ceilings(counters, t_s, alg_bytes):
     l1    vector-L1 cache-line lookups per CU-cycle, TCP_TOTAL_CACHE_ACCESSES / (256 CUs * t * 2.4 GHz), peak 1
     ta    busy cycles of the texture addresser per CU-cycle (TA_TA_BUSY)
     td    TRANSFER cycles of the data-return unit per CU-cycle (TD_TD_BUSY - TD_TC_STALL; the stall share is reported beside it)
+    vmem  wave-level divergent loads (TA_BUFFER_READ_WAVEFRONTS) * their measured cost in vector-memory pipeline cycles / (256 CUs * t * 2.4 GHz)
     valu  wave64 VALU instructions * 2 cycles / (1024 SIMDs * t * 2.4 GHz)
     Counter values come from the committed profile, the duration t from THIS run's HIP events."""
     c = {}
@@ -121,6 +127,20 @@ def ceilings(counters, t_s, alg_bytes):
         c["td"] = {"achieved": round(a, 4), "peak": 1.0, "unit": "TD transfer cycles per CU-cycle (TD_TD_BUSY - TD_TC_STALL)", "frac": round(a, 4),
                    "busy_incl_stall": round(counters["TD_TD_BUSY_sum"] / (N_CUS * cyc), 4),
                    "stall_share_of_busy": round(stall / counters["TD_TD_BUSY_sum"], 4) if counters["TD_TD_BUSY_sum"] else None}
+    # The rate at which a CU takes lane-DIVERGENT loads (profiles/r03_micro_vmem.txt, tools/micro/tcp_*.hip on this chip): a wave-level
+    # buffer load costs its CU's vector-memory pipeline ~16 + 0.48 x (lanes with an address of their own) cycles whatever its width
+    # (46.8 with 64 such lanes), L1-resident data.  `frac` prices each load at the kernel's lane activity (VALU lane utilisation as the
+    # proxy), `frac_if_every_lane_diverges` at 46.8 cycles.
+    if "TA_BUFFER_READ_WAVEFRONTS_sum" in counters:
+        loads = counters["TA_BUFFER_READ_WAVEFRONTS_sum"]
+        util = 1.0
+        if counters.get("SQ_THREAD_CYCLES_VALU") and counters.get("SQ_ACTIVE_INST_VALU"):
+            util = min(1.0, counters["SQ_THREAD_CYCLES_VALU"] / (counters["SQ_ACTIVE_INST_VALU"] * 64.0))
+        cost = VMEM_BASE_CYCLES + VMEM_LANE_CYCLES * 64.0 * util
+        a = loads * cost / (N_CUS * cyc)
+        c["vmem"] = {"achieved": round(a, 4), "peak": 1.0, "unit": "vector-memory pipeline cycles per CU-cycle (wave-level divergent loads x measured cost)",
+                     "frac": round(a, 4), "frac_if_every_lane_diverges": round(loads * (VMEM_BASE_CYCLES + VMEM_LANE_CYCLES * 64.0) / (N_CUS * cyc), 4),
+                     "wave_loads_per_launch": int(loads), "cycles_per_wave_load": round(cost, 1), "lane_activity": round(util, 3)}
     if "SQ_INSTS_VALU" in counters:
         a = counters["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMDS * cyc)
         c["valu"] = {"achieved": round(a, 4), "peak": 1.0, "unit": "SIMD issue cycles per cycle", "frac": round(a, 4)}
@@ -322,7 +342,8 @@ def main():
             else:
                 gathered[b].copy_(D.all_gather_shards(compact[b].cpu(), world))   # debug backend: staged through the host
             consumed[b].record(xstream)
-            st.context.unpermute(gathered[b].data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=xstream.cuda_stream)
+            if rank == 0 or args.scatter_all:
+                st.context.unpermute(gathered[b].data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=xstream.cuda_stream)
 
     def fence():
         if world > 1:
@@ -404,12 +425,13 @@ def main():
                 ev[i][3].record(xstream)
                 consumed[b].record(xstream)
                 ev[i][4].record(xstream)
-                st.context.unpermute(gathered[b].data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=xstream.cuda_stream)
+                if rank == 0 or args.scatter_all:
+                    st.context.unpermute(gathered[b].data_ptr(), world, w, h, st.accum.data_ptr(), frame.data_ptr(), stream=xstream.cuda_stream)
                 ev[i][5].record(xstream)
         fence()
         per_rank = [sum(e[2 * j].elapsed_time(e[2 * j + 1]) for e in ev) / ne for j in range(3)]
 
-    if args.verify and sharded:
+    if args.verify and sharded and (rank == 0 or args.scatter_all):
         got = st.accum.clone()
         st.context.launch(st.params, w, h, 1, stream=stream.cuda_stream)
         torch.cuda.synchronize()
@@ -478,7 +500,7 @@ def main():
             bound = top if thr[top] >= 0.7 else "latency"
             limiter = {"largest_throughput_ceiling": top, "its_frac": thr[top],
                        "td_stall_share_of_busy": ceil.get("td", {}).get("stall_share_of_busy"),
-                       "reading": "no pipe above 0.7 busy: the kernel waits for dependent L1-miss fetches behind the CU's in-order data return"
+                       "reading": ("no throughput ceiling above 0.7: the kernel waits for dependent fetches; the nearest ceiling is %s" % top)
                                   if bound == "latency" else "bound by the %s ceiling" % top}
         out = {
             "metric": "Mray/s (primary+shadow), 1920x1080 spp=1, 1M-tri scene",
@@ -507,7 +529,8 @@ def main():
         if sharded:
             out["per_rank_ms"] = {"render": round(per_rank[0], 4), "gather": round(per_rank[1], 4), "scatter": round(per_rank[2], 4),
                                   "is": "max over ranks of the mean over 8 extra untimed steps (events on the launch / exchange streams); "
-                                        "gather and scatter of frame k run beside the render of frame k+1%s" % ("" if args.overlap else " (not in this run: --no-overlap)"),
+                                        "gather and scatter of frame k run beside the render of frame k+1%s; the scatter into the canonical layout "
+                                        "runs on %s" % ("" if args.overlap else " (not in this run: --no-overlap)", "every rank" if args.scatter_all else "rank 0 only"),
                                   "ranks": world, "backend": ("rccl (torch.distributed nccl), %d ranks" % dist.get_world_size()) if world > 1 and args.backend == "nccl"
                                   else (args.backend if world > 1 else "none (one rank: device copy)")}
         if world == 1 and not args.no_cpu_baseline:

@@ -59,6 +59,7 @@ struct DeviceBvh {
     // buffer descriptor.  inst_fast = 0: only the one-ray-per-lane walk (k_trace_inst) can traverse the structure.
     uint32_t inst_fast, inst_off, inst_node4_off, inst_tri_off, inst_blob_bytes;
     uint32_t inst_root4_off;   // per top-level BVH4 node 4 words: the BVH4 root of the mesh behind each LEAF child (an instance)
+    uint32_t top_off;          // experiment MIPT_TOP_CACHE: byte offset of the top-of-tree copy of the packed mirror (64 nodes + their real indices); 0 = none
     uint32_t node_fmt;         // 0: fp32 64-byte BVH2 nodes only; 1: + packed 32-byte BVH2 nodes at node32_off (MiptBvhNode32: the boxes of
                                // `nodes` as fp16 -- the two arrays hold the SAME values), walked by every entry-pool kernel; 2: + the BVH4
                                // mirror at node4_off, walked by the kernels that live on the pool alone (static chunks, path kernels)
@@ -188,6 +189,7 @@ void imgui_run(hipStream_t st, const MiptImguiParams& p, uint32_t n_paths, const
 // descriptors by tri_base; the top level's leaf descriptors turned from positions of inst_order into instance indices
 void launch_rebase_nodes4(hipStream_t st, const void* src, void* dst, uint32_t n4, uint32_t node_base, uint32_t tri_base);
 void launch_tlas4_leaves(hipStream_t st, void* nodes4, uint32_t n4, const uint32_t* order, const struct DeviceInstance* inst, uint32_t* root4_out);
+void launch_build_top(hipStream_t st, const void* d_nodes32, uint32_t nn, void* d_top);      // experiment MIPT_TOP_CACHE (kernels.hip)
 // device-side build-input assembly + BVH build (lbvh_build.hip); every pointer of GatherInput is a DEVICE pointer
 struct GatherInput {
     const void* vertices; uint32_t num_vertices, vertex_stride;

@@ -123,13 +123,45 @@ __device__ __forceinline__ float probe_valu(float seed)
     return (a0 + a1) + (a2 + a3);
 }
 
-template <int Q>
-__device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, const bool inner, const bool tri,
-                                          const uint32_t node, const uint32_t lfirst, u32x4& n0, u32x4& n1, u32x4& n2, u32x4& n3 PROBE_PARAM)
+// ---- experiment MIPT_TOP_CACHE = 1 (probe builds): the first levels of the packed mirror in the wave's LDS -----------------------------
+// 63 nodes in breadth-first order (k_build_top), their references to each other flagged (kTopFlag | position), copied into LDS behind
+// the stacks by every wave; a lane at such a node reads it with two ds_read_b128 instead of two buffer loads, and the wave issues no
+// vector-memory instruction in a step whose lanes all stand in the top.
+#ifndef MIPT_TOP_CACHE
+#define MIPT_TOP_CACHE 0
+#endif
+constexpr uint32_t kTopFlag = 0x40000000u, kTopNodes = 64u, kTopWords = kTopNodes * 8u + kTopNodes;     // nodes (8 words each), then their real indices
+
+template <int Q, bool TOP = false>
+__device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, const bool inner_in, const bool tri,
+                                          const uint32_t node, const uint32_t lfirst, u32x4& n0, u32x4& n1, u32x4& n2, u32x4& n3 PROBE_PARAM,
+                                          const uint32_t* top_lds = nullptr)
 {
 #if MIPT_PROBE_STAMP
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
+    const bool in_top = TOP && inner_in && (node & kTopFlag) != 0u;
+    const bool inner = inner_in && !in_top;
+    if (TOP && Q == 1) {
+        n0 = u32x4{ 0u, 0u, 0u, 0u }; n1 = n0; n2 = n0; n3 = n0;
+        if (__ballot(inner || tri) != 0ull) {
+            uint32_t off = bvh.node32_off;
+            if (inner) off = bvh.node32_off + (node << 5);
+            if (tri)   off = bvh.tri_byte_off + lfirst * 48u;
+            const u32x4 g0 = ldq(blob, off), g1 = ldq(blob, off + 16u);
+            if (!in_top) { n0 = g0; n1 = g1; }
+            if (tri) n2 = ldq(blob, off + 32u);
+        }
+        if (__ballot(in_top) != 0ull) {
+            if (in_top) {
+                const uint4* p = reinterpret_cast<const uint4*>(top_lds + (node & (kTopNodes - 1u)) * 8u);
+                const uint4 a0 = p[0], a1 = p[1];
+                n0 = u32x4{ a0.x, a0.y, a0.z, a0.w }; n1 = u32x4{ a1.x, a1.y, a1.z, a1.w };
+            }
+        }
+        asm volatile("" ::: "memory");
+        return;
+    }
     uint32_t off = Q == 2 ? bvh.node4_off : (Q == 1 ? bvh.node32_off : 0u);
     if (inner) off = Q == 2 ? bvh.node4_off + (node << 6) : (Q == 1 ? bvh.node32_off + (node << 5) : node << 6);
     if (tri)   off = bvh.tri_byte_off + lfirst * 48u;
@@ -166,9 +198,9 @@ __device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, con
 // One step of the lane state machine (see k_trace_stream): every lane loads 64 bytes -- its node, or its next
 // triangle -- then inner lanes do a slab step and leaf lanes one branch-free triangle test.  `sb` is the bottom of
 // the lane's stack (entries below it were given away); shared by k_trace_stream and the bulk phase of k_trace_pool.
-template <int MODE, bool COUNT, int Q = 0>
+template <int MODE, bool COUNT, int Q = 0, bool TOP = false>
 __device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_buffer_rsrc_t blob, uint32_t* stk, int lane, bool has_ray, Trav& T,
-                                            int sb, bool cull_back, uint32_t& n_visits, uint32_t& n_tests PROBE_PARAM)
+                                            int sb, bool cull_back, uint32_t& n_visits, uint32_t& n_tests PROBE_PARAM, const uint32_t* top_lds = nullptr)
 {
     // ------------------------------------------------------------ this iteration's load
     const bool inner   = has_ray && T.node >= 0;
@@ -176,7 +208,7 @@ __device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_b
     const uint32_t ldesc = ~(uint32_t)T.node;
     const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
     u32x4 q0, q1, q2, q3;
-    load_step<Q>(blob, a.bvh, inner, at_leaf && lcnt != 0u, (uint32_t)T.node, lfirst, q0, q1, q2, q3 PROBE_ARG);
+    load_step<Q, TOP>(blob, a.bvh, inner, at_leaf && lcnt != 0u, (uint32_t)T.node, lfirst, q0, q1, q2, q3 PROBE_ARG, top_lds);
 #if MIPT_PROBE_VALU > 0
     if (probe_valu(T.tmin) == 12345.678f) T.tbest = 0.0f;                 // never true (tmin is 0.01 or a hit distance)
 #endif
@@ -668,7 +700,15 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
     // pool in its first kPoolCap words and the per-slot merge state in the last 384 (written only after the stacks
     // have been moved into the pool).  ROWS = 24: 6 KB, 26 waves per CU by LDS; 24 by registers (<= 80 VGPRs).
     constexpr int kPoolCap = ROWS * 64 - 384;
-    __shared__ uint32_t stk[ROWS * 64];
+    constexpr bool TOP = MIPT_TOP_CACHE != 0 && Q == 1 && MODE == 0;
+    __shared__ __attribute__((aligned(16))) uint32_t stk[ROWS * 64 + (TOP ? kTopWords : 0u)];
+    const uint32_t* const top_lds = stk + ROWS * 64;
+    const bool use_top = TOP && a.bvh.top_off != 0u;
+    if (use_top) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.bvh.nodes) + a.bvh.top_off);
+        for (uint32_t i = threadIdx.x; i < kTopWords; i += 64u) stk[ROWS * 64 + i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);   // per ray slot
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
@@ -744,6 +784,7 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
             }
             has_ray = T.node != kSentinel;
             if (!has_ray) finish_ray<MODE>(a, T, ray, false);      // empty interval: a miss, no BVH access
+            if (use_top && has_ray) T.node = (int)kTopFlag;        // the root's copy
         }
 #if MIPT_PROBE_STAMP
         const unsigned long long pw_b0 = __builtin_amdgcn_s_memtime();
@@ -752,7 +793,8 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
             for (int bi = 0; bi < a.burst_bulk; ++bi) {
                 if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
                 uint32_t nv_ = 0u, nt_ = 0u;
-                stream_step<MODE, false, Q>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_ PROBE_ARG);
+                if (use_top) stream_step<MODE, false, Q, TOP>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_ PROBE_ARG, top_lds);
+                else         stream_step<MODE, false, Q>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_ PROBE_ARG);
 #if MIPT_PROBE_STAMP
                 ++pw_steps;
 #endif
@@ -786,13 +828,16 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
             if (m == 0ull) break;
             uint32_t v = 0u;
             if (in) v = stk[e * 64 + lane];
+            if (TOP && in && (int)v >= 0 && (v & kTopFlag) != 0u) v = top_lds[kTopNodes * 8u + (v & (kTopNodes - 1u))];     // a cached node: its real index
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             if (in) stk[psize + (int)lane_rank(m)] = pool_pack((int)v, (uint32_t)lane);
             psize += __popcll(m);
         }
         {
             const unsigned long long m = __ballot(has_ray);           // the node each busy lane stands at
-            if (has_ray) stk[psize + (int)lane_rank(m)] = pool_pack(T.node, (uint32_t)lane);
+            int cur = T.node;
+            if (TOP && has_ray && cur >= 0 && ((uint32_t)cur & kTopFlag) != 0u) cur = (int)top_lds[kTopNodes * 8u + ((uint32_t)cur & (kTopNodes - 1u))];
+            if (has_ray) stk[psize + (int)lane_rank(m)] = pool_pack(cur, (uint32_t)lane);
             psize += __popcll(m);
         }
         // open the merge slots (they overlay the top rows of the stacks: only now) with what each lane has found so far
@@ -1054,7 +1099,10 @@ struct ShadeOut {
 // One path at one bounce: the arithmetic of the miss / closest-hit programs and of the caller's bookkeeping, shared by
 // k_shade (wavefront bounces) and k_tail (the last few paths) so that both produce the same bits.  `res` is the path's
 // accumulator (read and written back by the caller); load_ray fetches the ray only when the path hit something.
-template <class LoadRay>
+// LAST: the caller knows that the depth cap ends every path at this bounce (max_depth == 1: the headline frame) -- the continuation
+// direction (a sincos, two square roots, an orthonormal basis) and the roulette draw are then dead work; the two draws that pick the
+// direction still advance the seed, so the light sample is the same.
+template <bool LAST = false, class LoadRay>
 __device__ __forceinline__ void shade_path(const ShadeArgs& a, float4 hit, float4 sa, uint32_t slot, uint32_t depth, float4& res,
                                            ShadeOut& o, LoadRay load_ray)
 {
@@ -1091,9 +1139,12 @@ __device__ __forceinline__ void shade_path(const ShadeArgs& a, float4 hit, float
 
     const float z1 = rnd(seed);
     const float z2 = rnd(seed);
-    f3 w_in;
-    cosine_sample_hemisphere(z1, z2, w_in);
-    const f3 new_dir = onb_inverse_transform(N, w_in);
+    f3 new_dir = mk3(0.0f, 0.0f, 0.0f);
+    if (!LAST) {
+        f3 w_in;
+        cosine_sample_hemisphere(z1, z2, w_in);
+        new_dir = onb_inverse_transform(N, w_in);
+    }
     att = att * mk3(rec.diffuse_color[0], rec.diffuse_color[1], rec.diffuse_color[2]);
 
     const float l1 = rnd(seed);
@@ -1116,6 +1167,7 @@ __device__ __forceinline__ void shade_path(const ShadeArgs& a, float4 hit, float
         o.srd = make_float4(L.x, L.y, L.z, Ldist - 0.01f);
         o.sc  = make_float4(c.x, c.y, c.z, u2f(slot));
     }
+    if (LAST) return;
     // Russian roulette + continuation (:294-303)
     const float lum = dot(att, mk3(0.30f, 0.59f, 0.11f));
     const bool done = rnd(seed) > lum;
@@ -1210,6 +1262,7 @@ __device__ void tile_order_job(const TileOrderJob& j, uint32_t chunk)
     }
 }
 
+template <bool LAST>           // LAST: max_depth == 1 -- every path ends at this bounce (shade_path<LAST>)
 __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a)
 {
     __shared__ uint32_t s_cnt[2], s_base[2];
@@ -1231,7 +1284,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a)
                 const float4 hit = a.hits[i];
                 const float4 sa = compact ? make_float4(1.0f, 1.0f, 1.0f, u2f(sb.y)) : a.cur.state_a[i];
                 float4 res = (a.primary & 2u) != 0u ? make_float4(0.f, 0.f, 0.f, 0.f) : a.result[slot];
-                shade_path(a, hit, sa, slot, depth, res, o, [&](float4& ro4, float4& rd4) {
+                shade_path<LAST>(a, hit, sa, slot, depth, res, o, [&](float4& ro4, float4& rd4) {
                     ro4 = compact ? make_float4(a.fc.eye[0], a.fc.eye[1], a.fc.eye[2], 0.01f) : a.cur.ray_o[i];
                     rd4 = a.cur.ray_d[i];
                 });
@@ -1491,6 +1544,61 @@ __global__ __launch_bounds__(64) void k_tail_pool(TailArgs k)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t v = (uint32_t)__shfl_down((int)n_iter, off, 64); n_iter = v > n_iter ? v : n_iter; }
     if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
+}
+
+// ---- k_tail_pool1: k_tail_pool for passes whose depth cap is ONE bounce (the headline frame's shards at N >= 4) -----------------------
+// Same traversal, same shading arithmetic, no loop: nothing of the path outlives its first bounce, so the ray, its attenuation and the
+// depth are dead once the shadow ray exists, and the continuation direction is never made (shade_path<LAST>).  The point is
+// registers: k_tail_pool needs 118 VGPRs (16 waves per CU) and a rank's 1/8 shard -- 8 100 waves of 32 paths -- runs as two
+// generations of chains of ~75 dependent pool rounds; fewer registers put more of them on the chip at once.
+#ifndef MIPT_TAIL1_WAVES
+#define MIPT_TAIL1_WAVES 6
+#endif
+template <int Q>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_TAIL1_WAVES, MIPT_TAIL1_WAVES))) void k_tail_pool1(TailArgs k)
+{
+    const ShadeArgs& a = k.a;
+    const uint32_t ppw = k.ppw;
+    const bool use_rg = k.rg.ctr != nullptr;
+    if (use_rg && blockIdx.x == 0u) { begin_sample(k.rg.ctr, threadIdx.x, k.rg.fc.n_paths, k.rg.n_valid, k.rg.zero_stats); tail_publish_epoch(k.rg.ctr, k.epoch); }
+    constexpr int kPoolCap = 24 * 64 - 384;
+    __shared__ uint32_t stk[24 * 64];
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
+    float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
+    uint32_t* const sh_done = stk + kPoolCap + 320;
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+    uint32_t n = a.n_max;
+    if (!use_rg) { const uint32_t m = a.ctr->n_cur; n = m < n ? m : n; }
+    const uint32_t i = blockIdx.x * ppw + threadIdx.x;
+    uint32_t slot = kInvalidSlot, depth = 0;
+    float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
+    if (i < n && threadIdx.x < ppw) tail_load_path(k, use_rg, i, slot, depth, ro4, rd4, sa, res);
+    const bool active = slot != kInvalidSlot;
+    ShadeOut o;
+    o.push_next = false; o.push_shadow = false;
+    {
+        Trav T;
+        trav_init(T, ro4, rd4);
+        tail_trace<0, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, active && T.node != kSentinel);
+        const unsigned long long key = sh_best[lane];
+        const uint32_t prim = (uint32_t)key;
+        const float4 hit = prim != 0xffffffffu ? make_float4(ord_float((uint32_t)(key >> 32)), u2f(prim), sh_u[lane], sh_v[lane])
+                                               : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        if (active) shade_path<true>(a, hit, sa, slot, depth, res, o, [&](float4& o4, float4& d4) { o4 = ro4; d4 = rd4; });
+    }
+    const bool sh = active && o.push_shadow;
+    if (__ballot(sh) != 0ull) {
+        Trav S;
+        trav_init(S, sh ? o.sro : make_float4(0.f, 0.f, 0.f, 1.0f), sh ? o.srd : make_float4(0.f, 0.f, 1.f, 0.0f));
+        tail_trace<2, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel);
+        if (sh && sh_done[lane] == 0u) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
+    }
+    if (active) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
+    if (use_rg) tail_await_epoch(a.ctr, k.epoch);
+    wave_add64(&a.ctr->shadow_rays, sh ? 1u : 0u);
+    if (lane == 0 && __ballot(active) != 0ull) atomicMax(&a.ctr->tail_max, 1ull);
 }
 
 // ---- k_tail_pool2: the occlusion ray of bounce b and the closest-hit ray of bounce b + 1 of every path in ONE pool pass ------
@@ -1881,6 +1989,30 @@ __global__ __launch_bounds__(256) void k_unpermute(const float4* gathered, uint3
     if (frame) frame[p] = make_color(mk3(v.x, v.y, v.z));
 }
 
+// experiment MIPT_TOP_CACHE: the first 63 nodes of the packed mirror in breadth-first order, references among them flagged; word
+// 8 * kTopNodes + i = the real index of copy i.  One thread (63 nodes: tens of microseconds, once per build / refit).
+__global__ void k_build_top(const uint4* __restrict__ n32, uint32_t nn, uint32_t* top)
+{
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    uint32_t real[kTopNodes];
+    uint32_t head = 0u, tail = 1u;
+    real[0] = 0u;
+    for (; head < tail; ++head) {
+        uint4 c[2] = { n32[2u * real[head]], n32[2u * real[head] + 1u] };
+        for (int k = 0; k < 2; ++k) {
+            const int ref = (int)c[k].w;
+            if (ref >= 0 && (uint32_t)ref < nn && tail < kTopNodes - 1u) { real[tail] = (uint32_t)ref; c[k].w = kTopFlag | tail; ++tail; }
+        }
+        for (int k = 0; k < 2; ++k) { top[head * 8u + 4u * k] = c[k].x; top[head * 8u + 4u * k + 1u] = c[k].y; top[head * 8u + 4u * k + 2u] = c[k].z; top[head * 8u + 4u * k + 3u] = c[k].w; }
+        top[kTopNodes * 8u + head] = real[head];
+    }
+}
+
+void launch_build_top(hipStream_t st, const void* d_nodes32, uint32_t nn, void* d_top)
+{
+    hipLaunchKernelGGL(k_build_top, dim3(1), dim3(64), 0, st, reinterpret_cast<const uint4*>(d_nodes32), nn, reinterpret_cast<uint32_t*>(d_top));
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
@@ -2027,7 +2159,8 @@ void launch_shade(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, c
     if (blocks > 65536u) blocks = 65536u;
     if (blocks == 0u) blocks = 1u;
     blocks += order.n_chunks;
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, st, a);
+    if (fc.max_depth == 1u) hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(kShadeBlock), 0, st, a);
+    else                    hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(kShadeBlock), 0, st, a);
 }
 
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
@@ -2079,6 +2212,15 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
             return;
         }
         k.ppw = ppw;
+        static const int e_t1 = [] { const char* e = std::getenv("MIPT_TAIL1"); return e ? std::atoi(e) : 1; }();      // 0: k_tail_pool for one-bounce passes too (A/B)
+        if (fc.max_depth == 1u && e_t1) {
+            static const int e_ppw1 = [] { const char* e = std::getenv("MIPT_TAIL1_PPW"); return e ? std::atoi(e) : 0; }();
+            if (e_ppw1 >= 8 && e_ppw1 <= 64) k.ppw = ppw = (uint32_t)e_ppw1;
+            if (bvh.node_fmt == 2)      hipLaunchKernelGGL(k_tail_pool1<2>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
+            else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool1<1>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
+            else                        hipLaunchKernelGGL(k_tail_pool1<0>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
+            return;
+        }
         if (bvh.node_fmt == 2)      hipLaunchKernelGGL(k_tail_pool<2>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
         else if (bvh.node_fmt == 1) hipLaunchKernelGGL(k_tail_pool<1>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
         else                        hipLaunchKernelGGL(k_tail_pool<0>, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);

@@ -695,7 +695,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     if ((int)dep > depth_cap) { (void)hipFree(tmp); return hipSuccess; }                 // ok stays false
     const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
     float4* blob = nullptr;
-    if ((e = hipMalloc((void**)&blob, nb + tb + 64 + 256 + (size_t)nn * 96u)) != hipSuccess) return fail(e);     // + room for the packed nodes
+    if ((e = hipMalloc((void**)&blob, nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u)) != hipSuccess) return fail(e);     // + room for the packed nodes
     hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks), dim3(256), 0, st, left, right, rlo, rhi, n_inner, leaf_max, emit, idx, boxes, vals2, nboxes, (MiptBvhNode*)blob);
     hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb));
     if ((e = hipMemsetAsync((char*)blob + nb + tb, 0, 64, st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }

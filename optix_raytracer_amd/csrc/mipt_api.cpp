@@ -31,6 +31,9 @@ using namespace mipt;
 #ifndef MIPT_PROBE_WAVES
 #define MIPT_PROBE_WAVES 0
 #endif
+#ifndef MIPT_TOP_CACHE              // experiment (kernels.hip): a top-of-tree copy of the packed mirror behind the blob's mirrors
+#define MIPT_TOP_CACHE 0
+#endif
 
 // the kept layouts: each figure below is what the reference's own headers state (oracle/ref_kat.cpp prints sizeof / offsetof from
 // optixPathTracer.h, cuda/whitted.h, BufferView.h, Light.h, optix_types.h into tests/golden/ref_kat.json "layouts";
@@ -64,6 +67,7 @@ struct Accel {
     uint32_t  blob_bytes = 0;
     uint32_t  node32_off = 0;      // byte offset of the packed 32-byte BVH2 mirror behind the triangles (node formats 1 and 2); 0 = none
     uint32_t  node4_off = 0;       // ... and of the BVH4 mirror behind that (format 2)
+    uint32_t  top_off = 0;         // experiment MIPT_TOP_CACHE
     uint32_t  node_fmt = 0;        // the format in effect: 0 fp32 only, 1 + packed BVH2 mirror, 2 + BVH4 mirror
     uint32_t  stack_need = 0;      // format 2: the most entries a lane's stack can hold while walking the BVH4 (<= 32 by construction)
     uint32_t  num_nodes4 = 0;
@@ -378,6 +382,15 @@ hipError_t finish_blob(MiptContext* c, Accel* a)
         if (e != hipSuccess) return e;
         if (!ok) return hipSuccess;
         a->node32_off = (uint32_t)n32; a->node_fmt = 1u;
+#if MIPT_TOP_CACHE
+        {
+            const size_t top = (n4 + (size_t)a->num_nodes * 64u + 127) & ~(size_t)127;      // behind the BVH4 mirror's room (the allocations carry 4 KB for it)
+            launch_build_top(nullptr, (const char*)a->d_nodes + n32, a->num_nodes, (char*)a->d_nodes + top);
+            a->top_off = (uint32_t)top;
+            if (top + 4096 > (1ull << 31)) a->top_off = 0u;
+            else a->blob_bytes = (uint32_t)(top + 4096);
+        }
+#endif
         // the BVH4 mirror, made on the device from the packed mirror (collapse_bvh4, lbvh_build.hip) for either builder's tree
         if (c->node_format == 2 && a->num_nodes < (1u << 24)) {
             uint32_t cnt4 = 0u, need = 0u;
@@ -405,7 +418,7 @@ DeviceBvh device_bvh(const Accel* a)
     b.pool_ok = (a->num_nodes < (1u << 25) && a->num_tris >= 2u && a->num_tris < (1u << 23) && a->leaf_max <= 4u) ? 1u : 0u;
     b.pool2_ok = (b.pool_ok && a->num_nodes < (1u << 24) && a->num_tris < (1u << 22)) ? 1u : 0u;
     b.node32_off = a->node32_off; b.node_fmt = a->node32_off ? a->node_fmt : 0u;
-    b.node4_off = b.node_fmt == 2u ? a->node4_off : 0u; b.stack4 = a->stack_need;
+    b.node4_off = b.node_fmt == 2u ? a->node4_off : 0u; b.stack4 = a->stack_need; b.top_off = b.node_fmt >= 1u ? a->top_off : 0u;
     if (a->is_ias) {
         b.inst = a->inst_fast ? reinterpret_cast<const DeviceInstance*>(reinterpret_cast<const char*>(a->d_nodes) + a->inst_off) : a->d_inst;
         b.inst_order = a->d_order; b.n_inst = (uint32_t)a->gas.size(); b.pool_ok = b.pool2_ok = 0u; b.tri_byte_off = 0u; b.node32_off = 0u;
@@ -925,7 +938,7 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
     a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = 1;
     if ((e = finish_blob(ctx, a)) != hipSuccess) { free_accel(a); return ctx->fail(MIPT_ERROR_HIP, "device BVH build: %s", hipGetErrorString(e)); }
-    a->bytes = nb + tb + 64 + 256 + (size_t)nn * 96u + (size_t)n * 4u;         // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table
+    a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u + (size_t)n * 4u;         // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
@@ -1015,7 +1028,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         for (MiptBvhTri& t : a->host.tris) t.pad1 = gflags[t.prim];
         nb = a->host.nodes.size() * sizeof(MiptBvhNode);
         tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
-        e = hipMalloc((void**)&a->d_nodes, nb + tb + 64 + 256 + a->host.nodes.size() * 96u);      // + room for the node mirrors (finish_blob)
+        e = hipMalloc((void**)&a->d_nodes, nb + tb + 64 + 256 + 8192 + a->host.nodes.size() * 96u);      // + room for the node mirrors (finish_blob)
         if (e == hipSuccess) {
             a->d_tris = a->d_nodes + nb / sizeof(float4);
             e = hipMemset((char*)a->d_nodes + nb + tb, 0, 64);
@@ -1033,7 +1046,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         free_accel(a);
         return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "accel upload failed: %s", hipGetErrorString(e));
     }
-    a->bytes = nb + tb + 64 + 256 + (size_t)a->num_nodes * 96u + mb;             // the whole allocation: nodes | triangles | pad | room for both node mirrors, + the SBT index table
+    a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)a->num_nodes * 96u + mb;             // the whole allocation: nodes | triangles | pad | room for both node mirrors, + the SBT index table
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
     *handle_out = h;
