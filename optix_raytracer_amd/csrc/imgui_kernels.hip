@@ -107,6 +107,9 @@ __device__ __forceinline__ f3 onb_inverse(f3 n, f3 p)
 __global__ __launch_bounds__(256) void k_imgui_shade(ImguiConsts c, PathQueue cur, const float4* hits, ShadowQueue sh,
                                                      float4* result, DeviceCounters* ctr)
 {
+    __shared__ uint32_t s_app[2];
+    if (threadIdx.x < 2u) s_app[threadIdx.x] = 0u;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;     // grid covers n_paths rounded up to 256
     bool is_hit = false;
     uint32_t slot = kInvalidSlot;
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(256) void k_imgui_shade(ImguiConsts c, PathQueue cu
             } else is_hit = true;
         }
     }
-    // group index: one atomic per wave (hits are a fraction of ~2 M paths; the counter is not the bottleneck here)
-    const uint32_t j = wave_append(is_hit, &ctr->n_next);
+    // group index: one atomic per workgroup (a returning atomic per wave on the one counter word serialises: wave_util.h)
+    const uint32_t j = block_append(is_hit, &ctr->n_next, s_app);
     if (!is_hit) return;
     const uint32_t K = (uint32_t)c.nlights + 1u;
     const uint32_t prim = f2u(hit.y);

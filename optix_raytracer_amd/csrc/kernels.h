@@ -29,11 +29,16 @@ struct DeviceCounters {
     unsigned long long iterations;                      // wavefront bounces that had live paths (+ the tails of finished passes)
     unsigned long long tail_max;                        // deepest path of the current pass's k_tail launch (bounces it ran)
     unsigned long long dbg[6];
+    // what the waves of a path kernel add when they end, spread over kStatBins cache lines (bin = workgroup % kStatBins; words 0 / 1 / 2
+    // of a bin: continuation rays, shadow rays, most bounces): atomics on ONE address take ~8 ns each whether they return or not, and
+    // 8 000 waves ending within the same 0.2 ms queued 25 us of them behind a rank's 1/8 shard.  Read as sums / a maximum (tail_stats_*).
+    unsigned long long bins[64 * 16];
     uint32_t epoch;            // path kernels that do their own begin_sample (TailArgs): the launch whose first workgroup is through it
     uint32_t pad_;
     uint32_t* fault_host;      // pinned host word (MiptContext::h_pinned + kFaultWord): a kernel that gave up on a bounded wait ORs its
                                // kFault* bit into it; mipt_sync / mipt_get_launch_stats / the next launch turn it into an error
 };
+constexpr uint32_t kStatBins = 64, kStatBinWords = 16;      // DeviceCounters::bins
 constexpr uint32_t kFaultWord = 8;              // index into MiptContext::h_pinned (words 0 .. 3: run_wavefront's ring of live counts)
 constexpr uint32_t kFaultEpochTimeout = 1u;     // tail_await_epoch ran out: the statistics race it guards against may have happened
 

@@ -925,15 +925,48 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
 // what a pass starts with; zero_stats: the first pass of a launch also clears the launch statistics (14 words from closest_rays on)
 __device__ __forceinline__ void begin_sample(DeviceCounters* c, uint32_t i, uint32_t n_paths, uint32_t n_valid, uint32_t zero_stats)
 {
+    // (called by the 64+ threads of a launch's first workgroup.)  The bins of the path kernels' end-of-wave statistics: the previous pass's
+    // deepest path is folded into `iterations` and cleared; the first pass of a launch clears the ray sums too.
+    unsigned long long tmax = i < kStatBins ? c->bins[i * kStatBinWords + 2u] : 0ull;
+    if (i < kStatBins) {
+        c->bins[i * kStatBinWords + 2u] = 0ull;
+        if (zero_stats) { c->bins[i * kStatBinWords] = 0ull; c->bins[i * kStatBinWords + 1u] = 0ull; }
+    }
+    if (i < 64u) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_down((int)(uint32_t)(tmax >> 32), off, 64) << 32) | (uint32_t)__shfl_down((int)(uint32_t)tmax, off, 64);
+            tmax = o > tmax ? o : tmax;
+        }
+    }
     if (i == 0) {
         if (zero_stats) {
             unsigned long long* w = &c->closest_rays;
             for (int k = 0; k < (MIPT_PROBE_STAMP ? 14 : 8); ++k) w[k] = 0ull;     // (dbg[]: only the stamp probe's sums are per launch)
+            tmax = 0ull;
         }
         c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0;
-        c->iterations += c->tail_max; c->tail_max = 0;       // the previous pass's tail (iterations is zeroed per launch)
+        c->iterations += (c->tail_max > tmax ? c->tail_max : tmax); c->tail_max = 0;       // the previous pass's tail (iterations is zeroed per launch)
     }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
+}
+
+// a path-kernel wave's end-of-life statistics: continuation rays, shadow rays, bounces of its deepest path -- into the wave's bin
+__device__ __forceinline__ void tail_stats(DeviceCounters* c, uint32_t n_closest, uint32_t n_shadow, uint32_t n_iter)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_closest += (uint32_t)__shfl_down((int)n_closest, off, 64);
+        n_shadow += (uint32_t)__shfl_down((int)n_shadow, off, 64);
+        const uint32_t v = (uint32_t)__shfl_down((int)n_iter, off, 64);
+        n_iter = v > n_iter ? v : n_iter;
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        unsigned long long* b = &c->bins[(blockIdx.x % kStatBins) * kStatBinWords];
+        if (n_closest) atomicAdd(&b[0], (unsigned long long)n_closest);
+        if (n_shadow) atomicAdd(&b[1], (unsigned long long)n_shadow);
+        if (n_iter) atomicMax(&b[2], (unsigned long long)n_iter);
+    }
 }
 
 __global__ void k_begin_sample(DeviceCounters* c, uint32_t n_paths, uint32_t n_valid)
@@ -1376,11 +1409,7 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
         }
         if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res;
     }
-    wave_add64(&a.ctr->closest_rays, n_closest);
-    wave_add64(&a.ctr->shadow_rays, n_shadow);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t v = (uint32_t)__shfl_down((int)n_iter, off, 64); n_iter = v > n_iter ? v : n_iter; }
-    if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
+    tail_stats(a.ctr, n_closest, n_shadow, n_iter);
 }
 
 // ---- the same loop with the wave's 64 rays traversed together on the entry pool (pool_round): a bounce then lasts as long
@@ -1539,11 +1568,7 @@ __global__ __launch_bounds__(64) void k_tail_pool(TailArgs k)
     }
     if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
     if (use_rg) tail_await_epoch(a.ctr, k.epoch);
-    wave_add64(&a.ctr->closest_rays, n_closest);
-    wave_add64(&a.ctr->shadow_rays, n_shadow);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t v = (uint32_t)__shfl_down((int)n_iter, off, 64); n_iter = v > n_iter ? v : n_iter; }
-    if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
+    tail_stats(a.ctr, n_closest, n_shadow, n_iter);
 }
 
 // ---- k_tail_pool1: k_tail_pool for passes whose depth cap is ONE bounce (the headline frame's shards at N >= 4) -----------------------
@@ -1596,9 +1621,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_TAIL1_W
         if (sh && sh_done[lane] == 0u) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
     }
     if (active) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
+#ifndef MIPT_PROBE_NO_TAIL_STATS
     if (use_rg) tail_await_epoch(a.ctr, k.epoch);
-    wave_add64(&a.ctr->shadow_rays, sh ? 1u : 0u);
-    if (lane == 0 && __ballot(active) != 0ull) atomicMax(&a.ctr->tail_max, 1ull);
+    tail_stats(a.ctr, 0u, sh ? 1u : 0u, active ? 1u : 0u);
+#endif
 }
 
 // ---- k_tail_pool2: the occlusion ray of bounce b and the closest-hit ray of bounce b + 1 of every path in ONE pool pass ------
@@ -1872,11 +1898,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
     n_iter = n_iter > n_iter_max ? n_iter : n_iter_max;
     if (use_rg && !synced) tail_await_epoch(a.ctr, k.epoch);
-    wave_add64(&a.ctr->closest_rays, n_closest);
-    wave_add64(&a.ctr->shadow_rays, n_shadow);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t v = (uint32_t)__shfl_down((int)n_iter, off, 64); n_iter = v > n_iter ? v : n_iter; }
-    if (lane == 0 && n_iter) atomicMax(&a.ctr->tail_max, (unsigned long long)n_iter);
+    tail_stats(a.ctr, n_closest, n_shadow, n_iter);
 }
 
 // Static chunks of `ppw` rays per wave, traversed together on the entry pool from the root (tail_trace): every any-hit launch

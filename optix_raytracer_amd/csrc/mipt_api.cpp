@@ -163,6 +163,7 @@ struct MiptContext {
     uint32_t  profile_launch = 0;        // launches since MIPT_OPT_PROFILE was set (mode 3 brackets every 8th)
     int       direct_resolve = 1;        // env MIPT_DIRECT_RESOLVE=0: always a k_resolve launch (A/B)
     bool      advance_pending = false;   // the last launch ended without its final k_advance step (mipt_get_launch_stats applies it)
+    bool      bins_live = false;         // the last launch was the path tracer's: DeviceCounters::bins belong to its statistics
     int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
     int       tiled_bvh4 = 0;            // env MIPT_TILED_BVH4: experiments (kernels.hip launch_trace)
     int       inst_form = 0;             // env MIPT_INST_FORM: traversal form over two-level structures (TraceOpts::inst_form)
@@ -646,6 +647,7 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
     // (with ResolveJob the pixels are written already; the last bounce's queue bookkeeping, which rides on k_resolve, only feeds the
     //  statistics then and is applied to their copy when they are read: advance_pending)
     ctx->advance_pending = rj.on != 0u && advance_in_resolve;
+    ctx->bins_live = true;
     if (!rj.on) { TimedScope t(ctx, st, T_RESOLVE); launch_resolve(st, fc, ctx->result, accum_out, frame_out, (uint32_t)n_slots, advance_in_resolve ? ctx->d_ctr : nullptr); }
     ctx->bounces_on_device = true;
     ++ctx->profile_launch;
@@ -1502,6 +1504,10 @@ int mipt_get_launch_stats(MiptContext* ctx, MiptLaunchStats* stats)
     if (const int frc = check_device_faults(ctx)) return frc;
     DeviceCounters h;
     HIPCHK(ctx, hipMemcpy(&h, ctx->d_ctr, sizeof h, hipMemcpyDeviceToHost));
+    for (uint32_t b = 0; ctx->bins_live && b < kStatBins; ++b) {      // the path kernels' end-of-wave statistics (DeviceCounters::bins)
+        h.closest_rays += h.bins[b * kStatBinWords]; h.shadow_rays += h.bins[b * kStatBinWords + 1u];
+        h.tail_max = std::max(h.tail_max, h.bins[b * kStatBinWords + 2u]);
+    }
     if (ctx->advance_pending) {            // advance() of the launch's last bounce (kernels.hip), on the copy
         if (h.n_cur) h.iterations += 1;
         h.closest_rays += h.n_next; h.shadow_rays += h.n_shadow;
@@ -1567,8 +1573,8 @@ int mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* p, 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    ctx->advance_pending = false;
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    ctx->advance_pending = false; ctx->bins_live = false;
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, (14 + kStatBins * kStatBinWords) * sizeof(unsigned long long), st));
     imgui_run(st, *p, n_paths, device_bvh(acc), ctx->q[0], ctx->hits, ctx->im_sq, ctx->im_flags, ctx->result, ctx->rg_seed,
               ctx->d_ctr, trace_opts(ctx));
     ctx->last_bounces = p->samples_per_frame; ctx->bounces_on_device = false;
@@ -1688,8 +1694,8 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     }
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    ctx->advance_pending = false;
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    ctx->advance_pending = false; ctx->bins_live = false;
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, (14 + kStatBins * kStatBinWords) * sizeof(unsigned long long), st));
     WhBuffers B{};
     B.q[0] = ctx->q[0]; B.q[1] = ctx->q[1]; B.hits = ctx->hits; B.sh = ctx->im_sq; B.e1 = ctx->wh_e1; B.flags = ctx->im_flags;
     B.group = ctx->wh_group; B.n_levels = ctx->rg_seed;
@@ -1735,8 +1741,8 @@ int mipt_trace_closest(MiptContext* ctx, void* stream, unsigned long long handle
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    ctx->advance_pending = false;
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    ctx->advance_pending = false; ctx->bins_live = false;
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, (14 + kStatBins * kStatBinWords) * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, n);
 #if MIPT_PROBE_WAVES
     if (const char* e = std::getenv("MIPT_PROBE_WAVES")) {          // probe builds only: address of a caller-allocated device buffer for per-wave records
@@ -1762,8 +1768,8 @@ int mipt_trace_any(MiptContext* ctx, void* stream, unsigned long long handle, co
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     ctx->last_stream = st;
-    ctx->advance_pending = false;
-    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, 14 * sizeof(unsigned long long), st));
+    ctx->advance_pending = false; ctx->bins_live = false;
+    HIPCHK(ctx, hipMemsetAsync(&ctx->d_ctr->closest_rays, 0, (14 + kStatBins * kStatBinWords) * sizeof(unsigned long long), st));
     launch_begin_sample(st, ctx->d_ctr, n, 0);
 #if MIPT_PROBE_WAVES
     if (const char* e = std::getenv("MIPT_PROBE_WAVES_ANY")) {      // probe builds only: per-wave records of k_trace_static (tools/probe_shadow_order.py)

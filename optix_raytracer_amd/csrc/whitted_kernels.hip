@@ -351,6 +351,9 @@ struct WhLevel {
 
 __global__ __launch_bounds__(256) void k_wh_shade(WhConsts c, WhLevel L, DeviceCounters* ctr)
 {
+    __shared__ uint32_t s_app[2][2];
+    if (threadIdx.x < 4u) s_app[threadIdx.x >> 1][threadIdx.x & 1u] = 0u;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_cur = ctr->n_cur < L.bound ? ctr->n_cur : L.bound;
     bool is_hit = false;
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256) void k_wh_shade(WhConsts c, WhLevel L, DeviceC
             } else is_hit = true;
         }
     }
-    const uint32_t j = wave_append(is_hit, &ctr->n_shadow);                      // group index (scaled to rays by k_wh_scale)
+    const uint32_t j = block_append(is_hit, &ctr->n_shadow, s_app[0]);           // group index (scaled to rays by k_wh_scale); one atomic per workgroup
     // ---- surface
     bool spawn = false;
     float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4;
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void k_wh_shade(WhConsts c, WhLevel L, DeviceC
         L.n_levels[slot] = L.level + 1u;
         spawn = blend && depth < kWhMaxTraceDepth;                                          // continuation ray, whitted.cu:272-283
     }
-    const uint32_t jn = wave_append(spawn, &ctr->n_next);
+    const uint32_t jn = block_append(spawn, &ctr->n_next, s_app[1]);
     if (spawn) {
         L.next.ray_o[jn] = make_float4(ro4.x, ro4.y, ro4.z, hit.x);                         // tmin = optixGetRayTmax() = the hit distance
         L.next.ray_d[jn] = make_float4(rd4.x, rd4.y, rd4.z, 1e16f);
@@ -471,14 +474,17 @@ __global__ void k_wh_scale(DeviceCounters* ctr, uint32_t K)
 }
 
 // adds the entries of a group in the reference's order: result = 0 + emission, then the lights
-__global__ __launch_bounds__(256) void k_wh_gather(uint32_t K, WhLevel L, const uint32_t* occluded, const float* attenuation, DeviceCounters* ctr)
+__global__ __launch_bounds__(1024) void k_wh_gather(uint32_t K, WhLevel L, const uint32_t* occluded, const float* attenuation, DeviceCounters* ctr)
 {
+    __shared__ uint32_t s_traced;
+    if (threadIdx.x == 0u) s_traced = 0u;
+    __syncthreads();
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ctr->bounce) return;
+    const bool mine = j < ctr->bounce;
     const size_t base = (size_t)j * K;
     f3 r = mk3(0.0f, 0.0f, 0.0f);
     uint32_t traced = 0;
-    for (uint32_t k = 0; k < K; ++k) {
+    for (uint32_t k = 0; mine && k < K; ++k) {
         const float4 e0 = L.sh.contrib[base + k], e1 = L.e1[base + k];
         if (e0.w == -1.0f) continue;
         if (e0.w == -2.0f) { r = r + mk3(e1.x, e1.y, e1.z); continue; }
@@ -489,12 +495,14 @@ __global__ __launch_bounds__(256) void k_wh_gather(uint32_t K, WhLevel L, const 
             r = r + lc * mk3(e1.x, e1.y, e1.z);
         }
     }
-    const float4 gh = L.group[j];
-    const uint32_t slot = f2u(gh.z);
-    float w = 0.0f;
-    if (gh.y != 0.0f) { r = r * gh.x; w = 1.0f - gh.x; }                                    // ALPHA_MODE_BLEND: result *= base_color.w
-    L.levels[(size_t)L.level * L.n_pixels + slot] = make_float4(r.x, r.y, r.z, w);
-    if (traced) atomicAdd(&ctr->shadow_rays, (unsigned long long)traced);                   // occlusion rays really cast
+    if (mine) {
+        const float4 gh = L.group[j];
+        const uint32_t slot = f2u(gh.z);
+        float w = 0.0f;
+        if (gh.y != 0.0f) { r = r * gh.x; w = 1.0f - gh.x; }                                // ALPHA_MODE_BLEND: result *= base_color.w
+        L.levels[(size_t)L.level * L.n_pixels + slot] = make_float4(r.x, r.y, r.z, w);
+    }
+    block_add64(&ctr->shadow_rays, traced, &s_traced);                                      // occlusion rays really cast: one atomic per 1024 groups
 }
 
 __global__ void k_wh_advance(DeviceCounters* c)
@@ -567,7 +575,7 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
                                (float*)B.flags, ctr);
         else
             launch_trace_any(st, bvh, B.sh.ray_o, B.sh.ray_d, 1, &ctr->n_shadow, n_paths * K, B.flags, nullptr, nullptr, ctr, opts);
-        hipLaunchKernelGGL(k_wh_gather, dim3(blocks), dim3(256), 0, st, K, L, (const uint32_t*)B.flags,
+        hipLaunchKernelGGL(k_wh_gather, dim3((blocks + 3u) / 4u), dim3(1024), 0, st, K, L, (const uint32_t*)B.flags,
                            B.any_hit_programs ? (const float*)B.flags : (const float*)nullptr, ctr);
         hipLaunchKernelGGL(k_wh_advance, dim3(1), dim3(64), 0, st, ctr);
     }
