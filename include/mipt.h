@@ -199,17 +199,19 @@ typedef enum MiptOption {
     MIPT_OPT_BATCH_SAMPLES = 10, /* 0 (default): one wavefront pass per sample, contributions added in the reference's
                                   order (bit-identical to the oracle); 1: all samples_per_launch samples of a launch are
                                   paths of ONE pass with per-sample accumulators (same values to rounding, far fewer passes) */
-    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build: 0 (default) binned SAH on the host cores, 1 linear BVH built on the
-                                  device (Morton codes + radix sort + Karras' radix tree; ~ PREFER_FAST_BUILD: a few ms per
-                                  million triangles, slower to traverse); falls back to 0 when that tree is too deep */
+    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build: 1 (default since round 3) on the device, as optixAccelBuild -- Morton codes,
+                                  radix sort, Karras' radix tree, every subtree of <= 64 triangles rebuilt by full-sweep SAH (one
+                                  wave each), leaves by the SAH termination rule: 4 ms per million triangles, frames within 1 % of
+                                  the host tree's; 0: binned SAH on the host cores (155 ms per million).  1 falls back to 0 for
+                                  inputs of <= 4 triangles and when the tree is deeper than the 32-entry traversal stack */
     MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late;
                                   half the value when MAX_DEPTH caps the paths), one kernel runs each of them to its
                                   end, a wave per 64 paths, instead of five kernels per bounce; a pass that starts with at
                                   most this many paths (three quarters of it when capped) starts there.  Same pixels, same ray counts.  Default 1048576, 0 = off */
     MIPT_OPT_NODE_FORMAT  = 14, /* set before mipt_accel_build.  What the entry-pool traversal kernels walk:
                                   2 (default): child boxes rounded outward to fp16 values + a BVH4 mirror of the tree (64-byte nodes
-                                     of four fp16 boxes, collapsed on the host so that a lane's stack never needs more than 32 entries);
-                                     the device LBVH builder (MIPT_OPT_BUILD = 1, the fast-build path) keeps format 1;
+                                     of four fp16 boxes, collapsed on the device so that a lane's stack never needs more than 32 entries),
+                                     for either builder's tree;
                                   1: the rounded boxes + the packed 32-byte BVH2 mirror (MiptBvhNode32);
                                   0: fp32 boxes, 64-byte nodes only.
                                   Scenes that do not suit fp16 boxes (a coordinate beyond +-32768, or the largest extent below a

@@ -221,7 +221,7 @@ hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d
                          uint32_t budget = 32u);       // budget: the most stack entries a lane may need while walking the mirror
 hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth);
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
-                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok);
+                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets = true);
 
 // SDK/cuda/whitted.cu pipeline (whitted_kernels.hip)
 struct WhGeometry {                // MiptWhittedGeometry with typed pointers

@@ -113,6 +113,113 @@ __device__ __forceinline__ Box6 box_union(const Box6& a, const Box6& b)
     return r;
 }
 
+// ---- SAH treelets (round 3): the bottom of the radix tree rebuilt by surface-area heuristic ----------------------------------------------
+// The radix tree splits space at Morton-code bits: near the root of a scene of evenly spread triangles that is what a SAH builder
+// does too, but the last levels -- which triangles share a leaf, which leaves share a node -- are where it loses (LBVH frames 7 %
+// behind the host SAH tree's).  Every subtree of at most 64 triangles whose parent holds more is a TREELET: one wave rebuilds it top
+// down with a full-sweep SAH (one triangle per lane; per level and axis: rank the segment's centroids, scan the sorted boxes from both
+// ends, cost = area(left) * count + area(right) * count, best split per segment; all segments of a level at once).  A treelet over the
+// sorted positions [lo, hi] owns hi - lo inner-node slots of Karras' numbering: lo .. hi - 1 when its root is node lo, lo + 1 .. hi
+// when its root is node hi (a radix-tree node's index is one end of its range; the other end's index belongs to an ancestor).  The
+// node that splits a segment after position m takes the m-th of them (each slot once), the triangles are permuted inside [lo, hi]
+// only, so ranges stay contiguous and the leaf folding, emission, depth and height passes that follow see an ordinary tree.
+constexpr int kTreelet = 64;
+
+__global__ __launch_bounds__(256) void k_treelet_roots(const int* range_lo, const int* range_hi, const int* parent_inner, int n_inner, uint32_t* roots, uint32_t* n_roots)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner) return;
+    const int sz = range_hi[i] - range_lo[i] + 1;
+    const int p = parent_inner[i];
+    if (sz > kTreelet || sz < 3 || p < 0) return;                     // (the root keeps slot 0; two triangles have one shape)
+    if (range_hi[p] - range_lo[p] + 1 <= kTreelet) return;            // inside a treelet, not its root
+    roots[atomicAdd(n_roots, 1u)] = (uint32_t)i;
+}
+
+__device__ __forceinline__ float box_area6(const float* b) { const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return dx * dy + dy * dz + dz * dx; }
+
+__global__ __launch_bounds__(64) void k_lbvh_treelets(const uint32_t* __restrict__ roots, const uint32_t* __restrict__ n_roots, const Box6* __restrict__ prim_boxes,
+                                                      uint32_t* sorted_prims, int* left, int* right, int* parent_inner, int* parent_leaf, int* range_lo, int* range_hi)
+{
+    __shared__ float s_box[64][7];                                    // a record per position: box + prim (as bits)
+    const int lane = (int)threadIdx.x;
+    const uint32_t n_t = *n_roots;
+    for (uint32_t t = blockIdx.x; t < n_t; t += gridDim.x) {
+        const int root = (int)roots[t];
+        const int lo = range_lo[root], hi = range_hi[root], n = hi - lo + 1;
+        const int slot0 = root == lo ? lo : lo + 1;                      // the first of the treelet's own slots
+        const int P = parent_inner[root];
+        const bool valid = lane < n;
+        uint32_t prim = valid ? sorted_prims[lo + lane] : 0u;
+        float b[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        if (valid) { const Box6 pb = prim_boxes[prim]; for (int k = 0; k < 3; ++k) { b[k] = pb.lo[k]; b[3 + k] = pb.hi[k]; } }
+        int sa = 0, sb = n - 1, sp = P, ss = left[P] == root ? 0 : 1;  // my segment (positions = lanes), the node above it and the side it hangs on
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int level = 0; level < kTreelet; ++level) {
+            const bool active = valid && sb > sa;
+            if (__ballot(active) == 0ull) break;
+            float best_cost = __builtin_inff(); int best_m = sa, best_axis = 0;
+            int pos_axis[3] = { lane, lane, lane };
+            for (int axis = 0; axis < 3; ++axis) {
+                const float key = b[axis] + b[3 + axis];
+                int rank = 0;
+                for (int k = 0; k < kTreelet; ++k) {
+                    const float kk = __shfl(key, k, 64);
+                    rank += (k >= sa && k <= sb && (kk < key || (kk == key && k < lane))) ? 1 : 0;
+                }
+                const int pos = sa + rank;
+                pos_axis[axis] = pos;
+                // the segment's boxes in this axis' order: lane j gets the box of sorted position j
+                if (valid) for (int c = 0; c < 6; ++c) s_box[pos][c] = b[c];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                float L[6], R[6];
+                for (int c = 0; c < 6; ++c) { L[c] = valid ? s_box[lane][c] : 0.f; R[c] = L[c]; }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                for (int d = 1; d < kTreelet; d <<= 1) {              // union of positions sa .. j (L) and j .. sb (R)
+                    for (int c = 0; c < 6; ++c) {
+                        const float u = __shfl_up(L[c], d, 64), w = __shfl_down(R[c], d, 64);
+                        if (lane - d >= sa) L[c] = c < 3 ? fminf(L[c], u) : fmaxf(L[c], u);
+                        if (lane + d <= sb) R[c] = c < 3 ? fminf(R[c], w) : fmaxf(R[c], w);
+                    }
+                }
+                float Rn[6];
+                for (int c = 0; c < 6; ++c) Rn[c] = __shfl_down(R[c], 1, 64);      // union of positions j + 1 .. sb
+                float cost = __builtin_inff();
+                if (active && lane < sb) cost = box_area6(L) * (float)(lane - sa + 1) + box_area6(Rn) * (float)(sb - lane);
+                // the cheapest split of my segment along this axis (ties: the lowest position)
+                float seg_cost = __builtin_inff(); int seg_m = sa;
+                for (int k = 0; k < kTreelet; ++k) {
+                    const float ck = __shfl(cost, k, 64);
+                    if (k >= sa && k < sb && ck < seg_cost) { seg_cost = ck; seg_m = k; }
+                }
+                if (seg_cost < best_cost) { best_cost = seg_cost; best_m = seg_m; best_axis = axis; }
+            }
+            if (active && !(best_cost < __builtin_inff())) { best_m = (sa + sb) >> 1; best_axis = 0; }       // (NaN boxes: any split)
+            // move every record to its place in its segment's best order (an inactive lane keeps its position)
+            const int to = active ? (best_axis == 0 ? pos_axis[0] : (best_axis == 1 ? pos_axis[1] : pos_axis[2])) : lane;
+            if (valid) { for (int c = 0; c < 6; ++c) s_box[to][c] = b[c]; s_box[to][6] = __uint_as_float(prim); }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (valid) { for (int c = 0; c < 6; ++c) b[c] = s_box[lane][c]; prim = __float_as_uint(s_box[lane][6]); }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (active) {
+                const int N = slot0 + best_m;                           // the new node's slot
+                if (lane == best_m) {
+                    range_lo[N] = lo + sa; range_hi[N] = lo + sb; parent_inner[N] = sp;
+                    if (ss == 0) left[sp] = N; else right[sp] = N;
+                }
+                if (lane <= best_m) { sb = best_m; ss = 0; } else { sa = best_m + 1; ss = 1; }
+                sp = N;
+                if (sa == sb) {                                         // a single triangle: the leaf link
+                    if (ss == 0) left[sp] = ~(lo + sa); else right[sp] = ~(lo + sa);
+                    parent_leaf[lo + sa] = sp;
+                }
+            }
+        }
+        if (valid) sorted_prims[lo + lane] = prim;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+}
+
 // ---- bottom-up passes without fences ---------------------------------------------------------------------------------------------
 // Round 2 fitted boxes with "the second thread to arrive at a node computes it and climbs on": every step of the climb needs an
 // agent-scope release / acquire pair (__threadfence = L2 write-back + invalidate, microseconds each on a chip of eight L2s), and
@@ -156,11 +263,36 @@ __global__ __launch_bounds__(256) void k_lbvh_fit_level(const Box6* prim_boxes, 
     node_boxes[i] = box_union(a, b);
 }
 
-__global__ __launch_bounds__(256) void k_lbvh_flags(const int* range_lo, const int* range_hi, int n_inner, int leaf_max, uint32_t* emit)
+// Which radix-tree nodes become nodes of the BVH.  A node over more than leaf_max triangles always does.  A smaller one does when
+// splitting pays for the extra node by the surface-area heuristic -- the host builder's rule (bvh_build.cpp: keep the leaf unless
+// (area(L) nL + area(R) nR) / area + node cost < n, node cost 1.2 triangle tests) -- and every node above it up to the first big one
+// decided the same (a folded node takes its whole subtree into the leaf).  sah = false: every subtree of at most leaf_max triangles
+// is a leaf (round 2).
+__device__ __forceinline__ float half_area(const Box6& b) { const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2]; return dx * dy + dy * dz + dz * dx; }
+
+__device__ __forceinline__ bool split_pays(int i, const int* left, const int* right, const int* range_lo, const int* range_hi, const Box6* prim_boxes,
+                                           const uint32_t* sorted_prims, const Box6* node_boxes, float node_cost)
+{
+    const int lc = left[i], rc = right[i];
+    const float al = half_area(lc >= 0 ? node_boxes[lc] : prim_boxes[sorted_prims[~lc]]), ar = half_area(rc >= 0 ? node_boxes[rc] : prim_boxes[sorted_prims[~rc]]);
+    const float nl = lc >= 0 ? (float)(range_hi[lc] - range_lo[lc] + 1) : 1.0f, nr = rc >= 0 ? (float)(range_hi[rc] - range_lo[rc] + 1) : 1.0f;
+    const float area = half_area(node_boxes[i]);
+    return area > 0.0f && (al * nl + ar * nr) / area + node_cost < nl + nr;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_flags(const int* range_lo, const int* range_hi, int n_inner, int leaf_max, uint32_t* emit, bool sah, const int* left,
+                                                    const int* right, const int* parent_inner, const Box6* prim_boxes, const uint32_t* sorted_prims, const Box6* node_boxes,
+                                                    float node_cost)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n_inner) return;
-    emit[i] = (i == 0 || range_hi[i] - range_lo[i] + 1 > leaf_max) ? 1u : 0u;
+    bool on = i == 0 || range_hi[i] - range_lo[i] + 1 > leaf_max;
+    if (!on && sah) {
+        on = true;
+        for (int a = i; on && a > 0 && range_hi[a] - range_lo[a] + 1 <= leaf_max; a = parent_inner[a])
+            on = split_pays(a, left, right, range_lo, range_hi, prim_boxes, sorted_prims, node_boxes, node_cost);
+    }
+    emit[i] = on ? 1u : 0u;
 }
 
 __device__ __forceinline__ void put_child(MiptBvhNode& nd, int c, const Box6& b, int ref)
@@ -636,7 +768,7 @@ void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, ui
 // nodes | triangles | 64 B pad (as mipt_accel_build makes for the host builder).  Returns hipSuccess and ok = false
 // when the tree is deeper than depth_cap (the caller falls back to the host builder).
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
-                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok)
+                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets)
 {
     *ok = false; *d_blob = nullptr;
     const int n_inner = (int)n - 1;
@@ -672,6 +804,13 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     hipLaunchKernelGGL(k_lbvh_morton, dim3(blocks), dim3(256), 0, st, boxes, n, misc, keys, vals);
     if ((e = hipcub::DeviceRadixSort::SortPairs(tmp + o_cub, sort_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocks), dim3(256), 0, st, keys2, (int)n, left, right, pin, plf, rlo, rhi);
+    if (sah_treelets && n > (uint32_t)kTreelet) {
+        // the subtrees of at most 64 triangles, rebuilt by SAH (reuses `idx` as the list of their roots until the scan needs it)
+        if ((e = hipMemsetAsync(misc + 16, 0, 4, st)) != hipSuccess) return fail(e);
+        hipLaunchKernelGGL(k_treelet_roots, dim3(blocks), dim3(256), 0, st, rlo, rhi, pin, n_inner, idx, misc + 16);
+        const uint32_t tg = blocks * 4u < 16384u ? blocks * 4u : 16384u;
+        hipLaunchKernelGGL(k_lbvh_treelets, dim3(tg), dim3(64), 0, st, idx, misc + 16, boxes, vals2, left, right, pin, plf, rlo, rhi);
+    }
     {   // boxes bottom-up: heights first (one atomic per step), then one launch per height
         uint8_t* kh = reinterpret_cast<uint8_t*>(tmp + o_kh);
         hipLaunchKernelGGL(k_lbvh_heights, dim3(blocks), dim3(256), 0, st, left, right, pin, n_inner, arrived, kh);
@@ -682,7 +821,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
         for (uint32_t level = 1; level <= root_h; ++level)
             hipLaunchKernelGGL(k_lbvh_fit_level, dim3(blocks), dim3(256), 0, st, boxes, vals2, n_inner, left, right, kh, level, nboxes);
     }
-    hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit);
+    hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit, sah_treelets, left, right, pin, boxes, vals2, nboxes, 1.2f);
     if ((e = hipcub::DeviceScan::ExclusiveSum(tmp + o_cub, scan_bytes, emit, idx, n_inner, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(k_lbvh_depth, dim3(blocks), dim3(256), 0, st, pin, plf, emit, (int)n, misc + 8);
     uint32_t last[2] = { 0, 0 }, dep = 0;
