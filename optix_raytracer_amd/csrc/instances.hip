@@ -179,9 +179,14 @@ __device__ __forceinline__ RayO to_object(const u32x4 m0, const u32x4 m1, const 
     return O;
 }
 
-template <int MODE, int CAP>
+// CACHE: the object-space ray of each ray slot's CURRENT instance is kept in LDS (xr: per slot a tag = instance + 1, then o', d'): a
+// round inside that instance reads it instead of fetching the instance's matrix (3 of the round's 7 loads) and transforming again.
+// One entry per slot, replaced on a miss; a slot whose entries alternate between instances misses on each change, no more.
+constexpr int kXrWords = 64 * 8;                           // [slot][8]: tag, o'.xyz, d'.xyz, writer
+template <int MODE, int CAP, bool CACHE = false>
 __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint2* stk, unsigned long long* sh_best,
-                                                float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, int& psize, const bool cull_back INST_STATS_PARAM)
+                                                float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, int& psize, const bool cull_back INST_STATS_PARAM,
+                                                uint32_t* xr = nullptr)
 {
     int k = psize < 64 ? psize : 64;
     const int room = CAP - 120 - psize;
@@ -234,15 +239,35 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
     u32x4 m0 = u32x4{ 0u, 0u, 0u, 0u }, m1 = m0, m2 = m0;
     uint32_t rec_word = 0u;                                // prim_base (triangles) or root4 (entering an instance)
     u32x4 r4 = u32x4{ 0u, 0u, 0u, 0u };                    // top-level node: the BVH4 root of the mesh behind each leaf child
-    if (live && in_inst) { m0 = ldq(blob, inst_rec); m1 = ldq(blob, inst_rec + 16u); m2 = ldq(blob, inst_rec + 32u); }
+    bool xr_hit = false;
+    float cx0 = 0.f, cx1 = 0.f, cx2 = 0.f, cx3 = 0.f, cx4 = 0.f, cx5 = 0.f;
+    if (CACHE && live && in_inst) {
+        const uint4 c0 = *reinterpret_cast<const uint4*>(xr + slot * 8u);
+        const uint4 c1 = *reinterpret_cast<const uint4*>(xr + slot * 8u + 4u);
+        xr_hit = c0.x == ent.y;
+        cx0 = u2f(c0.y); cx1 = u2f(c0.z); cx2 = u2f(c0.w); cx3 = u2f(c1.x); cx4 = u2f(c1.y); cx5 = u2f(c1.z);
+    }
+    const bool need_m = live && in_inst && !xr_hit;
+    if (!CACHE || __ballot(need_m) != 0ull) { if (need_m) { m0 = ldq(blob, inst_rec); m1 = ldq(blob, inst_rec + 16u); m2 = ldq(blob, inst_rec + 32u); } }
     if (do_tri)   rec_word = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blob, (int)(inst_rec + (uint32_t)offsetof(DeviceInstance, prim_base)), 0, 0);
     if (do_enter) rec_word = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blob, (int)(inst_rec + (uint32_t)offsetof(DeviceInstance, root4)), 0, 0);
     if (do_inner && !in_inst) r4 = ldq(blob, bvh.inst_root4_off + (payload << 4));
     asm volatile("" ::: "memory");
     if (live && in_inst) {
-        const RayO O = to_object(m0, m1, m2, mk3(ox, oy, oz), mk3(dx, dy, dz));
+        RayO O;
+        if (CACHE && xr_hit) { O.o = mk3(cx0, cx1, cx2); O.d = mk3(cx3, cx4, cx5); prepare(O); }
+        else O = to_object(m0, m1, m2, mk3(ox, oy, oz), mk3(dx, dy, dz));
         ox = O.o.x; oy = O.o.y; oz = O.o.z; dx = O.d.x; dy = O.d.y; dz = O.d.z;
         ix = O.idir.x; iy = O.idir.y; iz = O.idir.z; nx = O.nood.x; ny = O.nood.y; nz = O.nood.z;
+    }
+    if (CACHE && __ballot(need_m) != 0ull) {
+        // a miss replaces the slot's entry: ONE writer per slot (several lanes may hold entries of one ray in different instances)
+        if (need_m) xr[slot * 8u + 7u] = (uint32_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (need_m && xr[slot * 8u + 7u] == (uint32_t)lane) {
+            *reinterpret_cast<uint4*>(xr + slot * 8u) = make_uint4(ent.y, f2u(ox), f2u(oy), f2u(oz));
+            xr[slot * 8u + 4u] = f2u(dx); xr[slot * 8u + 5u] = f2u(dy); xr[slot * 8u + 6u] = f2u(dz);
+        }
     }
     uint32_t push0 = 0u, push1 = 0u, push2 = 0u, push3 = 0u;
     uint32_t y0 = ent.y, y1 = ent.y, y2 = ent.y, y3 = ent.y;
@@ -313,21 +338,28 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
 }
 
 // a wave's rays (one per lane where has_ray) through the pool from the top level's root; results in sh_best / sh_u / sh_v / sh_done
-template <int MODE, int CAP>
+template <int MODE, int CAP, bool CACHE = false>
 __device__ __forceinline__ void tail_trace_inst(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint2* stk, unsigned long long* sh_best,
-                                                float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, const bool has_ray, const bool cull_back INST_STATS_PARAM)
+                                                float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, const bool has_ray, const bool cull_back INST_STATS_PARAM,
+                                                uint32_t* xr = nullptr)
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
     sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u;
+    if (CACHE) xr[lane * 8] = 0u;                            // no instance cached for this slot's (new) ray
     const unsigned long long m = __ballot(has_ray);
     if (has_ray) stk[(int)lane_rank(m)] = make_uint2(pool_pack(0, (uint32_t)lane), 0u);
     int psize = __popcll(m);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    while (psize > 0) pool_round_inst<MODE, CAP>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back INST_STATS_ARG);
+    while (psize > 0) pool_round_inst<MODE, CAP, CACHE>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, cull_back INST_STATS_ARG, xr);
 }
 
 // static chunks of `ppw` rays per wave, all on the pool from the root (kernels.hip's k_trace_static over two levels)
+#ifndef MIPT_INST_XR_CACHE
+#define MIPT_INST_XR_CACHE 0                                // 1 (probe builds): the LDS cache of object-space rays above.  Measured SLOWER: MeshViewer over 151 /
+                                                            // 2 001 instances 0.942 / 1.559 ms against 0.882 / 1.437 ms without -- its 2 KB of LDS and ~10 VGPRs cost
+                                                            // a wave per SIMD, its reads sit in front of the round's loads, and a ray's entries alternate instances
+#endif
 #ifndef MIPT_INST_ROWS
 #define MIPT_INST_ROWS 24                                   // 6 KB of LDS per wave: 576 entries of 8 bytes + the merge state
 #endif
@@ -336,8 +368,10 @@ template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kInstRows <= 24 ? 6 : 5, kInstRows <= 24 ? 6 : 5))) void k_trace_static_inst(TraceArgs a, uint32_t ppw)
 {
     constexpr int kCap = (kInstRows * 64 - 384) / 2;
-    __shared__ uint2 stk2[kInstRows * 32];
+    constexpr bool CACHE = MIPT_INST_XR_CACHE != 0;
+    __shared__ __attribute__((aligned(16))) uint2 stk2[kInstRows * 32 + (CACHE ? kXrWords / 2 : 0)];
     uint32_t* const words = reinterpret_cast<uint32_t*>(stk2);
+    uint32_t* const xr = words + kInstRows * 64;
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(words + 2 * kCap);
     float* const sh_u = reinterpret_cast<float*>(words + 2 * kCap + 128);
     float* const sh_v = reinterpret_cast<float*>(words + 2 * kCap + 192);
@@ -358,7 +392,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kInstRows <=
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
-        tail_trace_inst<MODE, kCap>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel, cull_back INST_STATS_ARG);
+        tail_trace_inst<MODE, kCap, CACHE>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel, cull_back INST_STATS_ARG, xr);
         if (mine) {
             if (MODE == 0) {
                 const unsigned long long key = sh_best[lane];
