@@ -199,11 +199,13 @@ typedef enum MiptOption {
     MIPT_OPT_BATCH_SAMPLES = 10, /* 0 (default): one wavefront pass per sample, contributions added in the reference's
                                   order (bit-identical to the oracle); 1: all samples_per_launch samples of a launch are
                                   paths of ONE pass with per-sample accumulators (same values to rounding, far fewer passes) */
-    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build: 1 (default since round 3) on the device, as optixAccelBuild -- Morton codes,
-                                  radix sort, Karras' radix tree, every subtree of <= 64 triangles rebuilt by full-sweep SAH (one
-                                  wave each), leaves by the SAH termination rule: 4 ms per million triangles, frames within 1 % of
-                                  the host tree's; 0: binned SAH on the host cores (155 ms per million).  1 falls back to 0 for
-                                  inputs of <= 4 triangles and when the tree is deeper than the 32-entry traversal stack */
+    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build: 0 (default) binned SAH on the host cores (155 ms per million triangles);
+                                  1: on the device, as optixAccelBuild -- Morton codes, radix sort, Karras' radix tree, every subtree
+                                  of <= 64 triangles rebuilt by full-sweep SAH (one wave each), leaves by the SAH termination rule:
+                                  4 ms per million triangles (~ PREFER_FAST_BUILD); frames equal the host tree's on evenly spread
+                                  triangles (the headline scene), 10-60 % slower on scenes whose top levels need SAH (large
+                                  triangles, height fields).  1 falls back to 0 for inputs of <= 4 triangles and when the tree is
+                                  deeper than the 32-entry traversal stack */
     MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late;
                                   half the value when MAX_DEPTH caps the paths), one kernel runs each of them to its
                                   end, a wave per 64 paths, instead of five kernels per bounce; a pass that starts with at

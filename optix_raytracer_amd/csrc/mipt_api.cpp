@@ -116,7 +116,7 @@ struct MiptContext {
     int      blocks_per_cu = 0;
     int      batch_samples = 0;
     int      persistent = 3;
-    int      build_mode = 1;              // MIPT_OPT_BUILD: 1 (default) on the device (LBVH + SAH treelets, lbvh_build.hip), 0 host binned SAH
+    int      build_mode = 0;              // MIPT_OPT_BUILD: 0 (default) host binned SAH, 1 on the device (LBVH + SAH treelets, lbvh_build.hip)
     int      lbvh_treelets = 1;           // env MIPT_LBVH_TREELETS=0: the plain radix tree (A/B of the SAH treelets, lbvh_build.hip)
     int      lbvh_leaf = 4;               // env MIPT_LBVH_LEAF: subtrees of at most this many triangles become leaves of the device LBVH (1 .. 4)
     int      node_format = 2;             // MIPT_OPT_NODE_FORMAT: 2 fp16 boxes + BVH4 mirror, 1 fp16 boxes + packed 32-byte BVH2 mirror (where the
