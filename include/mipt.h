@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 2   /* 2: MiptAccelInfo.node_format, MIPT_OPT_NODE_FORMAT, mipt_group_* */
+#define MIPT_ABI_VERSION 3   /* 2: MiptAccelInfo.node_format, MIPT_OPT_NODE_FORMAT, mipt_group_*; 3: mipt_whitted_set_geometry_instanced, mipt_scene_mesh_normals / _texcoords / _colors */
 
 typedef enum MiptResult {
     MIPT_SUCCESS                 = 0,
@@ -471,6 +471,27 @@ typedef struct MiptWhittedGeometry {
 int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geometry,
                               const MiptMaterialData* materials, uint32_t num_materials,
                               const MiptTextureData* textures, uint32_t num_textures);
+/* The same with the shading tables the reference keeps (Scene::createSBT, Scene.cpp:1368-1480: one set of buffers per MESH, one SBT
+ * record per instance x primitive over them): per-mesh OBJECT-space tables + instance records instead of flattened world-space arrays,
+ * so that instancing saves shading memory as well as BVH memory.  A hit's flattened primitive index (instances in order, mesh-local
+ * index inside: what the instance structure of mipt_accel_build_instances over the same records reports) is resolved through a table
+ * of one word per flattened primitive; a corner is taken to world space in the kernel with the arithmetic mipt_scene_flatten uses on
+ * the host (and a normal with mipt_scene_flatten_normals'), so frames are bit-identical to those over the flattened arrays.
+ * meshes[m].geometry: DEVICE pointers as in MiptWhittedGeometry (caller-owned, alive until the next set_geometry* call), vertices and
+ * normals in object space (normals4: {n, 1} or all 0); instances[i].transform: row-major 3x4 object -> world (the OptixInstance's). */
+typedef struct MiptWhittedMesh {
+    MiptWhittedGeometry geometry;
+    uint32_t            num_triangles;
+    uint32_t            reserved;
+} MiptWhittedMesh;
+typedef struct MiptWhittedInstance {
+    uint32_t mesh;
+    float    transform[12];
+} MiptWhittedInstance;
+int mipt_whitted_set_geometry_instanced(MiptContext* ctx, const MiptWhittedMesh* meshes, uint32_t num_meshes,
+                                        const MiptWhittedInstance* instances, uint32_t num_instances,
+                                        const MiptMaterialData* materials, uint32_t num_materials,
+                                        const MiptTextureData* textures, uint32_t num_textures);
 /* replaces optixLaunch( scene.pipeline(), ... ) of optixMeshViewer.cpp:283-308; params is a HOST pointer */
 int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchParams* params,
                         unsigned int width, unsigned int height, unsigned int depth);
@@ -554,6 +575,12 @@ int mipt_scene_flatten(const MiptScene* scene, float* vertices4_out, uint32_t* m
 int mipt_scene_mesh_num_triangles(const MiptScene* scene, uint32_t mesh, uint32_t* n_out);
 int mipt_scene_mesh_triangles(const MiptScene* scene, uint32_t mesh, float* vertices4_out, uint32_t* material_index_out);
 int mipt_scene_instance(const MiptScene* scene, uint32_t index, uint32_t* mesh_out, float transform12_out[12]);
+/* ... and the per-mesh shading attributes in the same order, as the flatten_* functions below hand them out per instance
+ * (mipt_whitted_set_geometry_instanced): normals4_out: n*3 float4 {OBJECT-space normal as stored, 1}, all 0 where a primitive has no
+ * NORMAL; uv2_out / rgba4_out / present_out as mipt_scene_flatten_texcoords / _colors */
+int mipt_scene_mesh_normals(const MiptScene* scene, uint32_t mesh, float* normals4_out);
+int mipt_scene_mesh_texcoords(const MiptScene* scene, uint32_t mesh, uint32_t set, float* uv2_out, uint8_t* present_out);
+int mipt_scene_mesh_colors(const MiptScene* scene, uint32_t mesh, float* rgba4_out, uint8_t* present_out);
 /* normals4_out: num_triangles*3 float4 {world-space normal (M^-T n, un-normalised), 1}; all 0 where a primitive has no NORMAL */
 int mipt_scene_flatten_normals(const MiptScene* scene, float* normals4_out);
 /* texture i of the scene (glTF "textures"); the texel pointer stays valid until mipt_scene_destroy */

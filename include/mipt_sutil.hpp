@@ -257,8 +257,9 @@ namespace sutil {
 // loadScene parses the glTF (mipt_scene_load); finalize() does what Scene::finalize does (Scene.cpp:803-815): creates the
 // context, uploads the geometry, builds the acceleration structures -- one triangle structure per mesh plus the instance
 // structure over them (buildMeshAccels + buildInstanceAccel), or ONE structure over the flattened world-space triangles when
-// asked for (AccelMode::FLATTENED: 1.5 x faster, twenty times the memory) -- and hands the Whitted programs their geometry, material
-// and texture tables (the reference's createSBT).  The programs are fixed-function kernels: pipeline() / sbt() do not exist.
+// asked for (AccelMode::FLATTENED: 1.2-1.3 x faster, twenty times the memory) -- and hands the Whitted programs their geometry (per-mesh
+// object-space tables + instance records for the two-level form, as the reference's createSBT keeps them; flattened world-space
+// arrays otherwise), material and texture tables.  The programs are fixed-function kernels: pipeline() / sbt() do not exist.
 class Scene {
 public:
     enum class AccelMode { AUTO, TWO_LEVEL, FLATTENED };
@@ -296,11 +297,9 @@ public:
     {
         if (!m_scene) throw Exception("Scene::finalize: no scene loaded");
         createContext();
-        uploadGeometry();
         m_two_level = m_mode != AccelMode::FLATTENED;              // AUTO: what the reference builds
-        if (m_two_level) { buildMeshAccels(); buildInstanceAccel(); }
-        else             buildFlattenedAccel();
-        createGeometryTables();
+        if (m_two_level) { buildMeshAccels(); buildInstanceAccel(); createInstancedTables(); }
+        else             { uploadGeometry(); buildFlattenedAccel(); createGeometryTables(); }
     }
 
     void cleanup()
@@ -399,6 +398,7 @@ private:
     {
         const std::vector<uint32_t> flags = geometryFlags();
         m_mesh_handles.assign(m_info.num_meshes, 0ull);
+        m_mesh_tables.assign(m_info.num_meshes, MiptWhittedMesh{});
         for (uint32_t m = 0; m < m_info.num_meshes; ++m) {
             uint32_t n = 0;
             MIPT_CHECK(nullptr, mipt_scene_mesh_num_triangles(m_scene, m, &n));
@@ -406,6 +406,8 @@ private:
             std::vector<float> v((size_t)n * 12); std::vector<uint32_t> mat(n);
             MIPT_CHECK(nullptr, mipt_scene_mesh_triangles(m_scene, m, v.data(), mat.data()));
             float* dv = upload(v);
+            m_mesh_tables[m].geometry.vertices4 = dv; m_mesh_tables[m].num_triangles = n;
+            m_mesh_tables[m].geometry.material_index = upload(mat);
             const std::vector<uint32_t> sbt = clampMaterials(mat);
             MiptBuildInput in{};
             in.vertices = dv; in.num_vertices = n * 3u; in.vertex_stride_bytes = 16;
@@ -430,7 +432,45 @@ private:
         MIPT_CHECK(m_context, mipt_accel_build_instances(m_context, inst.data(), (uint32_t)inst.size(), &m_handle));
     }
 
-    void createGeometryTables()                                         // the data side of Scene::createSBT (Scene.cpp:1368-1470)
+    // the data side of Scene::createSBT (Scene.cpp:1368-1480) as the reference keeps it: one set of OBJECT-space buffers per mesh, one
+    // record per instance -- instancing saves shading memory as well as BVH memory (mipt_whitted_set_geometry_instanced)
+    void createInstancedTables()
+    {
+        HIP_CHECK(hipSetDevice(m_device));
+        if (m_info.num_triangles == 0) throw Exception("scene has no triangles");
+        for (uint32_t m = 0; m < m_info.num_meshes; ++m) {
+            const uint32_t n = m_mesh_tables[m].num_triangles;
+            if (n == 0) continue;
+            MiptWhittedGeometry& g = m_mesh_tables[m].geometry;
+            std::vector<float> nrm((size_t)n * 12);
+            MIPT_CHECK(nullptr, mipt_scene_mesh_normals(m_scene, m, nrm.data()));
+            bool any = false;
+            for (size_t i = 3; i < nrm.size(); i += 4) any = any || nrm[i] != 0.0f;
+            g.normals4 = any ? upload(nrm) : nullptr;
+            for (uint32_t set = 0; set < 2; ++set) {
+                std::vector<float> uv((size_t)n * 6); std::vector<uint8_t> present(n);
+                MIPT_CHECK(nullptr, mipt_scene_mesh_texcoords(m_scene, m, set, uv.data(), present.data()));
+                any = false;
+                for (uint8_t p : present) any = any || p != 0;
+                g.texcoords[set] = any ? upload(uv) : nullptr;
+                g.texcoord_present[set] = any ? upload(present) : nullptr;
+            }
+            std::vector<float> col((size_t)n * 12); std::vector<uint8_t> cpresent(n);
+            MIPT_CHECK(nullptr, mipt_scene_mesh_colors(m_scene, m, col.data(), cpresent.data()));
+            any = false;
+            for (uint8_t p : cpresent) any = any || p != 0;
+            g.colors4 = any ? upload(col) : nullptr;
+            g.color_present = any ? upload(cpresent) : nullptr;
+        }
+        std::vector<MiptWhittedInstance> inst(m_info.num_instances);
+        for (uint32_t i = 0; i < m_info.num_instances; ++i) MIPT_CHECK(nullptr, mipt_scene_instance(m_scene, i, &inst[i].mesh, inst[i].transform));
+        std::vector<MiptTextureData> tex(m_info.num_textures);
+        for (uint32_t t = 0; t < m_info.num_textures; ++t) MIPT_CHECK(nullptr, mipt_scene_texture(m_scene, t, &tex[t]));
+        MIPT_CHECK(m_context, mipt_whitted_set_geometry_instanced(m_context, m_mesh_tables.data(), (uint32_t)m_mesh_tables.size(), inst.data(), (uint32_t)inst.size(),
+                                                                  m_materials.data(), (uint32_t)m_materials.size(), tex.empty() ? nullptr : tex.data(), (uint32_t)tex.size()));
+    }
+
+    void createGeometryTables()                                         // ... and over flattened world-space arrays (AccelMode::FLATTENED)
     {
         std::vector<MiptTextureData> tex(m_info.num_textures);
         for (uint32_t t = 0; t < m_info.num_textures; ++t) MIPT_CHECK(nullptr, mipt_scene_texture(m_scene, t, &tex[t]));
@@ -452,6 +492,7 @@ private:
     bool                          m_two_level = false;
     unsigned long long            m_handle = 0;
     std::vector<unsigned long long> m_mesh_handles;
+    std::vector<MiptWhittedMesh>  m_mesh_tables;                        // two-level scenes: per-mesh object-space shading tables
     std::vector<void*>            m_device_allocs;
     float *m_d_vertices = nullptr, *m_d_normals = nullptr, *m_d_texcoords[2] = { nullptr, nullptr }, *m_d_colors = nullptr;
     uint32_t*                     m_d_material_index = nullptr;

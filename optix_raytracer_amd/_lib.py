@@ -102,6 +102,15 @@ class MiptWhittedGeometry(C.Structure):
                 ("color_present", C.c_void_p)]
 
 
+class MiptWhittedMesh(C.Structure):
+    """per-mesh OBJECT-space shading tables of mipt_whitted_set_geometry_instanced"""
+    _fields_ = [("geometry", MiptWhittedGeometry), ("num_triangles", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class MiptWhittedInstance(C.Structure):
+    _fields_ = [("mesh", C.c_uint32), ("transform", C.c_float * 12)]
+
+
 class MiptImguiCamera(C.Structure):
     """class Camera of SDK/imgui_test (camera.h:155-173), 92 bytes"""
     _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("ortho", C.c_uint8),
@@ -207,6 +216,11 @@ SYMBOLS = [
     ("mipt_save_image", C.c_int, [C.c_char_p, _vp, _u32, _u32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     ("mipt_whitted_set_geometry", C.c_int, [_vp, C.POINTER(MiptWhittedGeometry), C.POINTER(MiptMaterialData), _u32,
                                             C.POINTER(MiptTextureData), _u32]),
+    ("mipt_whitted_set_geometry_instanced", C.c_int, [_vp, C.POINTER(MiptWhittedMesh), _u32, C.POINTER(MiptWhittedInstance), _u32,
+                                                      C.POINTER(MiptMaterialData), _u32, C.POINTER(MiptTextureData), _u32]),
+    ("mipt_scene_mesh_normals", C.c_int, [_vp, _u32, _vp]),
+    ("mipt_scene_mesh_texcoords", C.c_int, [_vp, _u32, _u32, _vp, _vp]),
+    ("mipt_scene_mesh_colors", C.c_int, [_vp, _u32, _vp, _vp]),
     ("mipt_whitted_launch", C.c_int, [_vp, _vp, C.POINTER(MiptWhittedLaunchParams), C.c_uint, C.c_uint, C.c_uint]),
     ("mipt_camera_uvw", None, [_fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp]),
     ("mipt_scene_random_triangles", C.c_int, [_u32, _u32, C.c_float, _vp]),
@@ -232,7 +246,7 @@ def load():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if L.mipt_abi_version() != 2:
+    if L.mipt_abi_version() != 3:
         raise RuntimeError("libmipt.so ABI version mismatch")
     _lib = L
     return L

@@ -146,6 +146,23 @@ class Scene:
         self._check(self._lib.mipt_scene_mesh_triangles(self._h, mesh, v.ctypes.data, m.ctypes.data))
         return v, m[:n.value]
 
+    def mesh_shading(self, mesh):
+        """the per-mesh OBJECT-space shading attributes (mipt_whitted_set_geometry_instanced), in mesh_triangles' order:
+        dict(normals (n*3, 4) {n, 1} or zeros, texcoords [(uv (n*3, 2), present (n,))] * 2, colors (rgba (n*3, 4), present (n,)))"""
+        n = C.c_uint32()
+        self._check(self._lib.mipt_scene_mesh_num_triangles(self._h, mesh, C.byref(n)))
+        k = max(n.value, 1)
+        nrm = np.zeros((k * 3, 4), np.float32)
+        self._check(self._lib.mipt_scene_mesh_normals(self._h, mesh, nrm.ctypes.data))
+        tcs = []
+        for j in range(2):
+            uv, has = np.zeros((k * 3, 2), np.float32), np.zeros(k, np.uint8)
+            self._check(self._lib.mipt_scene_mesh_texcoords(self._h, mesh, j, uv.ctypes.data, has.ctypes.data))
+            tcs.append((uv[:n.value * 3], has[:n.value]))
+        col, has = np.ones((k * 3, 4), np.float32), np.zeros(k, np.uint8)
+        self._check(self._lib.mipt_scene_mesh_colors(self._h, mesh, col.ctypes.data, has.ctypes.data))
+        return {"normals": nrm[:n.value * 3], "texcoords": tcs, "colors": (col[:n.value * 3], has[:n.value])}
+
     def instances(self):
         """[(mesh index, (3, 4) float32 row-major object->world matrix)] in Scene::instances() order"""
         out = []

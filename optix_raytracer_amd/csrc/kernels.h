@@ -224,10 +224,21 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets = true);
 
 // SDK/cuda/whitted.cu pipeline (whitted_kernels.hip)
-struct WhGeometry {                // MiptWhittedGeometry with typed pointers
+struct WhTables {                  // MiptWhittedGeometry with typed pointers: the shading tables of a flattened scene, or of one mesh
     const float4* vertices4; const float4* normals4; const uint32_t* material_index;
     const float2* texcoords[2]; const uint8_t* texcoord_present[2];
     const float4* colors4; const uint8_t* color_present;
+};
+struct WhInstGeo {                 // one instance of mipt_whitted_set_geometry_instanced
+    float    m[12];                // object -> world, row-major 3x4
+    float    cof[9];               // cofactors of its upper 3x3 (= det * inverse transpose) ...
+    float    inv_det;              // ... and 1 / det (0 when singular): mipt_scene_flatten_normals' arithmetic
+    uint32_t mesh, prim_base;      // its mesh; flattened index of its primitive 0
+};
+struct WhGeometry : WhTables {     // prim_inst == null: the flattened tables above, indexed by the flattened primitive
+    const uint32_t*  prim_inst;    // per flattened primitive: its instance
+    const WhInstGeo* inst;
+    const WhTables*  meshes;       // per-mesh OBJECT-space tables, indexed by the mesh-local primitive
 };
 struct WhTexture {                 // MiptTextureData with the texels in device memory
     uint32_t width, height, bits, address_s, address_t, filter;

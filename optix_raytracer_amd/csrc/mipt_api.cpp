@@ -135,6 +135,9 @@ struct MiptContext {
     WhTexture*        d_wh_textures = nullptr;          // descriptor table on the device
     std::vector<void*> wh_texels;                       // device copies of the texel arrays
     uint32_t          n_wh_textures = 0;
+    WhInstGeo*        d_wh_inst = nullptr;              // mipt_whitted_set_geometry_instanced: instance records, per-mesh tables,
+    WhTables*         d_wh_meshes = nullptr;            // instance of every flattened primitive (library copies)
+    uint32_t*         d_wh_prim_inst = nullptr;
     bool              wh_any_hit = false, wh_blend = false;   // a MASK / BLEND material exists
     float4*           wh_e1 = nullptr;                  // second float4 per occlusion entry (capacity im_cap)
     float4*           wh_group = nullptr;               // per hit (capacity wh_group_cap)
@@ -747,6 +750,7 @@ int mipt_context_destroy(MiptContext* c)
     if (c->im_flags) (void)hipFree(c->im_flags);
     if (c->d_wh_materials) (void)hipFree(c->d_wh_materials);
     if (c->d_wh_textures) (void)hipFree(c->d_wh_textures);
+    for (void* p : { (void*)c->d_wh_inst, (void*)c->d_wh_meshes, (void*)c->d_wh_prim_inst }) if (p) (void)hipFree(p);
     if (c->wh_e1) (void)hipFree(c->wh_e1);
     if (c->wh_group) (void)hipFree(c->wh_group);
     if (c->wh_levels) (void)hipFree(c->wh_levels);
@@ -1608,12 +1612,10 @@ static int ensure_group_capacity(MiptContext* ctx, size_t need)
     return MIPT_SUCCESS;
 }
 
-int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geo, const MiptMaterialData* materials, uint32_t num_materials,
-                              const MiptTextureData* textures, uint32_t num_textures)
+// materials + textures of the Whitted programs (library copies); shared by the two set_geometry forms
+static int set_whitted_tables(MiptContext* ctx, const MiptMaterialData* materials, uint32_t num_materials, const MiptTextureData* textures, uint32_t num_textures)
 {
-    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
-    if (!geo || !geo->vertices4 || !materials || num_materials == 0)
-        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry: vertices and >= 1 material required");
+    if (!materials || num_materials == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry: >= 1 material required");
     if (num_textures && !textures) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry: num_textures without textures");
     for (uint32_t i = 0; i < num_textures; ++i)
         if (textures[i].texels && textures[i].width && textures[i].bits != 8 && textures[i].bits != 16)
@@ -1624,6 +1626,8 @@ int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geo, 
     if (ctx->d_wh_textures) { (void)hipFree(ctx->d_wh_textures); ctx->d_wh_textures = nullptr; }
     for (void* t : ctx->wh_texels) if (t) (void)hipFree(t);
     ctx->wh_texels.clear(); ctx->n_wh_textures = 0;
+    for (void** p : { (void**)&ctx->d_wh_inst, (void**)&ctx->d_wh_meshes, (void**)&ctx->d_wh_prim_inst }) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    ctx->wh_geo = WhGeometry{};
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_materials, (size_t)num_materials * sizeof(MiptMaterialData)));
     HIPCHK(ctx, hipMemcpy(ctx->d_wh_materials, materials, (size_t)num_materials * sizeof(MiptMaterialData), hipMemcpyHostToDevice));
     ctx->n_wh_materials = num_materials;
@@ -1652,10 +1656,71 @@ int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geo, 
         HIPCHK(ctx, hipMemcpy(ctx->d_wh_textures, table.data(), (size_t)num_textures * sizeof(WhTexture), hipMemcpyHostToDevice));
         ctx->n_wh_textures = num_textures;
     }
+    return MIPT_SUCCESS;
+}
+
+static WhTables typed_tables(const MiptWhittedGeometry& geo)
+{
+    WhTables g{};
+    g.vertices4 = (const float4*)geo.vertices4; g.normals4 = (const float4*)geo.normals4; g.material_index = geo.material_index;
+    for (int j = 0; j < 2; ++j) { g.texcoords[j] = (const float2*)geo.texcoords[j]; g.texcoord_present[j] = geo.texcoord_present[j]; }
+    g.colors4 = (const float4*)geo.colors4; g.color_present = geo.color_present;
+    return g;
+}
+
+int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geo, const MiptMaterialData* materials, uint32_t num_materials,
+                              const MiptTextureData* textures, uint32_t num_textures)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!geo || !geo->vertices4) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry: vertices required");
+    const int rc = set_whitted_tables(ctx, materials, num_materials, textures, num_textures);
+    if (rc) return rc;
     WhGeometry g{};
-    g.vertices4 = (const float4*)geo->vertices4; g.normals4 = (const float4*)geo->normals4; g.material_index = geo->material_index;
-    for (int j = 0; j < 2; ++j) { g.texcoords[j] = (const float2*)geo->texcoords[j]; g.texcoord_present[j] = geo->texcoord_present[j]; }
-    g.colors4 = (const float4*)geo->colors4; g.color_present = geo->color_present;
+    static_cast<WhTables&>(g) = typed_tables(*geo);
+    ctx->wh_geo = g;
+    return MIPT_SUCCESS;
+}
+
+// Scene::createSBT's shading data (Scene.cpp:1368-1480): per-mesh object-space buffers + one record per instance
+int mipt_whitted_set_geometry_instanced(MiptContext* ctx, const MiptWhittedMesh* meshes, uint32_t num_meshes, const MiptWhittedInstance* instances,
+                                        uint32_t num_instances, const MiptMaterialData* materials, uint32_t num_materials,
+                                        const MiptTextureData* textures, uint32_t num_textures)
+{
+    if (!ctx) return MIPT_ERROR_INVALID_VALUE;
+    if (!meshes || num_meshes == 0 || !instances || num_instances == 0) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "whitted_set_geometry_instanced: meshes and instances required");
+    std::vector<WhTables> tabs(num_meshes);
+    for (uint32_t m = 0; m < num_meshes; ++m) {
+        if (meshes[m].num_triangles && !meshes[m].geometry.vertices4) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "mesh %u: vertices required", m);
+        tabs[m] = typed_tables(meshes[m].geometry);
+    }
+    std::vector<WhInstGeo> recs(num_instances);
+    std::vector<uint32_t> prim_inst;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < num_instances; ++i) {
+        if (instances[i].mesh >= num_meshes) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance %u: mesh %u of %u", i, instances[i].mesh, num_meshes);
+        WhInstGeo& r = recs[i];
+        std::memcpy(r.m, instances[i].transform, 48);
+        const float* m = r.m;           // (rows of 4: m[4 r + c]; the upper 3x3's cofactors exactly as mipt_scene_flatten_normals forms them, scene.cpp)
+        r.cof[0] = m[5] * m[10] - m[6] * m[9]; r.cof[1] = m[6] * m[8] - m[4] * m[10]; r.cof[2] = m[4] * m[9] - m[5] * m[8];
+        r.cof[3] = m[2] * m[9] - m[1] * m[10]; r.cof[4] = m[0] * m[10] - m[2] * m[8]; r.cof[5] = m[1] * m[8] - m[0] * m[9];
+        r.cof[6] = m[1] * m[6] - m[2] * m[5];  r.cof[7] = m[2] * m[4] - m[0] * m[6];  r.cof[8] = m[0] * m[5] - m[1] * m[4];
+        const float det = (m[0] * r.cof[0] + m[1] * r.cof[1]) + m[2] * r.cof[2];
+        r.inv_det = det != 0.0f ? 1.0f / det : 0.0f;
+        r.mesh = instances[i].mesh; r.prim_base = (uint32_t)total;
+        total += meshes[instances[i].mesh].num_triangles;
+        if (total >= (1ull << 31)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instances reference more than 2^31 triangles");
+        prim_inst.resize((size_t)total, i);
+    }
+    const int rc = set_whitted_tables(ctx, materials, num_materials, textures, num_textures);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_meshes, (size_t)num_meshes * sizeof(WhTables)));
+    HIPCHK(ctx, hipMemcpy(ctx->d_wh_meshes, tabs.data(), (size_t)num_meshes * sizeof(WhTables), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_inst, (size_t)num_instances * sizeof(WhInstGeo)));
+    HIPCHK(ctx, hipMemcpy(ctx->d_wh_inst, recs.data(), (size_t)num_instances * sizeof(WhInstGeo), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_prim_inst, std::max<size_t>(prim_inst.size(), 1) * 4u));
+    if (!prim_inst.empty()) HIPCHK(ctx, hipMemcpy(ctx->d_wh_prim_inst, prim_inst.data(), prim_inst.size() * 4u, hipMemcpyHostToDevice));
+    WhGeometry g{};
+    g.prim_inst = ctx->d_wh_prim_inst; g.inst = ctx->d_wh_inst; g.meshes = ctx->d_wh_meshes;
     ctx->wh_geo = g;
     return MIPT_SUCCESS;
 }
@@ -1670,7 +1735,7 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     if (p->lights.count > 31 || (p->lights.count && !p->lights.data)) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0..31 lights supported");
     if (p->lights.count && p->lights.byte_stride != 0 && p->lights.byte_stride != sizeof(MiptLight))
         return ctx->fail(MIPT_ERROR_INVALID_VALUE, "lights must be tightly packed (BufferView stride %u)", (unsigned)p->lights.byte_stride);
-    if (!ctx->wh_geo.vertices4 || !ctx->d_wh_materials) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "mipt_whitted_set_geometry was not called");
+    if ((!ctx->wh_geo.vertices4 && !ctx->wh_geo.prim_inst) || !ctx->d_wh_materials) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "mipt_whitted_set_geometry was not called");
     Accel* acc = find_accel(ctx, p->handle);
     if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
     if (acc->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", p->handle);

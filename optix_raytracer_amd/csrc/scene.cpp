@@ -513,33 +513,43 @@ void load_scene(const std::string& filename, MiptScene& sc)           // Scene.c
 }  // namespace
 
 namespace {
-// per-corner attribute of every flattened triangle, in mipt_scene_flatten's triangle order
+// per-corner attribute of the triangles of one mesh, in mipt_scene_mesh_triangles' order, appended at triangle t_out
+template <int N>
+int mesh_attribute(const MiptScene* sc, size_t mesh, int which, float fill, float* out, uint8_t* present, size_t& t_out)
+{
+    for (const Primitive& p : sc->meshes[mesh].prims) {
+        const View& v = which < 2 ? p.texcoords[which] : p.colors;
+        const uint32_t n_tris = (p.indices.valid() ? p.indices.count : p.positions.count) / 3u;
+        for (uint32_t t = 0; t < n_tris; ++t) {
+            for (int c = 0; c < 3; ++c) {
+                float* o = out + (t_out * 3 + (size_t)c) * N;
+                for (int k = 0; k < N; ++k) o[k] = fill;
+                if (!v.valid()) continue;
+                uint32_t vi = 3u * t + (uint32_t)c;
+                if (p.indices.valid()) {
+                    const uint8_t* ip = sc->buffers[(size_t)p.indices.buffer].data() + p.indices.offset + (size_t)vi * p.indices.byte_stride;
+                    if (p.indices.elmt_byte_size == 2) { uint16_t x; std::memcpy(&x, ip, 2); vi = x; } else { std::memcpy(&vi, ip, 4); }
+                }
+                if (vi >= v.count) return MIPT_ERROR_INVALID_VALUE;
+                std::memcpy(o, sc->buffers[(size_t)v.buffer].data() + v.offset + (size_t)vi * v.byte_stride, sizeof(float) * N);
+            }
+            if (present) present[t_out] = v.valid() ? 1 : 0;
+            ++t_out;
+        }
+    }
+    return MIPT_SUCCESS;
+}
+
+// ... of every flattened triangle, in mipt_scene_flatten's triangle order
 template <int N>
 int flatten_attribute(const MiptScene* sc, int which, float fill, float* out, uint8_t* present)
 {
     if (!sc || (!out && sc->num_triangles)) return MIPT_ERROR_INVALID_VALUE;
     size_t t_out = 0;
-    for (const Instance& in : sc->instances)
-        for (const Primitive& p : sc->meshes[(size_t)in.mesh].prims) {
-            const View& v = which < 2 ? p.texcoords[which] : p.colors;
-            const uint32_t n_tris = (p.indices.valid() ? p.indices.count : p.positions.count) / 3u;
-            for (uint32_t t = 0; t < n_tris; ++t) {
-                for (int c = 0; c < 3; ++c) {
-                    float* o = out + (t_out * 3 + (size_t)c) * N;
-                    for (int k = 0; k < N; ++k) o[k] = fill;
-                    if (!v.valid()) continue;
-                    uint32_t vi = 3u * t + (uint32_t)c;
-                    if (p.indices.valid()) {
-                        const uint8_t* ip = sc->buffers[(size_t)p.indices.buffer].data() + p.indices.offset + (size_t)vi * p.indices.byte_stride;
-                        if (p.indices.elmt_byte_size == 2) { uint16_t x; std::memcpy(&x, ip, 2); vi = x; } else { std::memcpy(&vi, ip, 4); }
-                    }
-                    if (vi >= v.count) return MIPT_ERROR_INVALID_VALUE;
-                    std::memcpy(o, sc->buffers[(size_t)v.buffer].data() + v.offset + (size_t)vi * v.byte_stride, sizeof(float) * N);
-                }
-                if (present) present[t_out] = v.valid() ? 1 : 0;
-                ++t_out;
-            }
-        }
+    for (const Instance& in : sc->instances) {
+        const int rc = mesh_attribute<N>(sc, (size_t)in.mesh, which, fill, out, present, t_out);
+        if (rc) return rc;
+    }
     return MIPT_SUCCESS;
 }
 }  // namespace
@@ -741,6 +751,46 @@ int mipt_scene_flatten_texcoords(const MiptScene* sc, uint32_t set, float* uv2_o
 int mipt_scene_flatten_colors(const MiptScene* sc, float* rgba4_out, uint8_t* present_out)
 {
     return flatten_attribute<4>(sc, 2, 1.0f, rgba4_out, present_out);
+}
+
+// ---- per-mesh OBJECT-space shading attributes (mipt_whitted_set_geometry_instanced): the same values the flatten_* functions hand
+// out, once per mesh instead of once per instance -- the triangle order of mipt_scene_mesh_triangles
+int mipt_scene_mesh_normals(const MiptScene* sc, uint32_t mesh, float* normals4_out)
+{
+    if (!sc || mesh >= sc->meshes.size() || !normals4_out) return MIPT_ERROR_INVALID_VALUE;
+    size_t t_out = 0;
+    for (const Primitive& p : sc->meshes[mesh].prims) {
+        const uint32_t n_tris = (p.indices.valid() ? p.indices.count : p.positions.count) / 3u;
+        for (uint32_t t = 0; t < n_tris; ++t, ++t_out)
+            for (int c = 0; c < 3; ++c) {
+                float* o = normals4_out + (t_out * 3 + (size_t)c) * 4;
+                o[0] = o[1] = o[2] = o[3] = 0.0f;
+                if (!p.normals.valid() || p.normals.elmt_byte_size != 4) continue;
+                uint32_t vi = 3u * t + (uint32_t)c;
+                if (p.indices.valid()) {
+                    const uint8_t* ip = sc->buffers[(size_t)p.indices.buffer].data() + p.indices.offset + (size_t)vi * p.indices.byte_stride;
+                    if (p.indices.elmt_byte_size == 2) { uint16_t v; std::memcpy(&v, ip, 2); vi = v; } else std::memcpy(&vi, ip, 4);
+                }
+                if (vi >= p.normals.count) return MIPT_ERROR_INVALID_VALUE;
+                std::memcpy(o, sc->buffers[(size_t)p.normals.buffer].data() + p.normals.offset + (size_t)vi * p.normals.byte_stride, 12);
+                o[3] = 1.0f;
+            }
+    }
+    return MIPT_SUCCESS;
+}
+
+int mipt_scene_mesh_texcoords(const MiptScene* sc, uint32_t mesh, uint32_t set, float* uv2_out, uint8_t* present_out)
+{
+    if (!sc || mesh >= sc->meshes.size() || set >= 2 || !uv2_out) return MIPT_ERROR_INVALID_VALUE;
+    size_t t_out = 0;
+    return mesh_attribute<2>(sc, mesh, (int)set, 0.0f, uv2_out, present_out, t_out);
+}
+
+int mipt_scene_mesh_colors(const MiptScene* sc, uint32_t mesh, float* rgba4_out, uint8_t* present_out)
+{
+    if (!sc || mesh >= sc->meshes.size() || !rgba4_out) return MIPT_ERROR_INVALID_VALUE;
+    size_t t_out = 0;
+    return mesh_attribute<4>(sc, mesh, 2, 1.0f, rgba4_out, present_out, t_out);
 }
 
 }  // extern "C"

@@ -95,31 +95,68 @@ __device__ __forceinline__ bool sample_material_texture(const WhConsts& c, const
     return true;
 }
 
-// getLocalGeometry (cuda/LocalGeometry.h:59-176) on world-space corners
-__device__ __forceinline__ void local_geometry(const WhConsts& c, uint32_t prim, float bu, float bv, WhLocalGeom& g)
+// The shading tables of a hit: the flattened ones and the primitive index itself, or (mipt_whitted_set_geometry_instanced) the tables of
+// the instance's MESH, the mesh-local index and the instance's record -- what the reference's per-instance SBT records point at.
+struct WhSite { WhTables t; uint32_t l; const WhInstGeo* inst; };
+__device__ __forceinline__ WhSite geo_site(const WhConsts& c, uint32_t prim)
 {
-    const float4 a0 = c.geo.vertices4[(size_t)prim * 3u], a1 = c.geo.vertices4[(size_t)prim * 3u + 1u], a2 = c.geo.vertices4[(size_t)prim * 3u + 2u];
-    const f3 P0 = mk3(a0.x, a0.y, a0.z), P1 = mk3(a1.x, a1.y, a1.z), P2 = mk3(a2.x, a2.y, a2.z);
+    WhSite s;
+    s.t = c.geo; s.l = prim; s.inst = nullptr;
+    if (c.geo.prim_inst) {
+        s.inst = &c.geo.inst[c.geo.prim_inst[prim]];
+        s.t = c.geo.meshes[s.inst->mesh];
+        s.l = prim - s.inst->prim_base;
+    }
+    return s;
+}
+// a corner into world space: mipt_scene_flatten's m4_apply, term by term (scene.cpp:164: sum = 0; sum += m[j] * v[j])
+__device__ __forceinline__ f3 inst_point(const WhInstGeo& I, float4 v)
+{
+    float r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float sum = 0.0f; sum += I.m[4 * i] * v.x; sum += I.m[4 * i + 1] * v.y; sum += I.m[4 * i + 2] * v.z; sum += I.m[4 * i + 3] * 1.0f; r[i] = sum; }
+    return mk3(r[0], r[1], r[2]);
+}
+// a normal: mipt_scene_flatten_normals' (M^-T) n, un-normalised
+__device__ __forceinline__ f3 inst_normal(const WhInstGeo& I, float4 n)
+{
+    return mk3(((I.cof[0] * n.x + I.cof[1] * n.y) + I.cof[2] * n.z) * I.inv_det, ((I.cof[3] * n.x + I.cof[4] * n.y) + I.cof[5] * n.z) * I.inv_det,
+               ((I.cof[6] * n.x + I.cof[7] * n.y) + I.cof[8] * n.z) * I.inv_det);
+}
+
+// getLocalGeometry (cuda/LocalGeometry.h:59-176) on world-space corners
+__device__ __forceinline__ void local_geometry(const WhConsts& c, uint32_t prim_in, float bu, float bv, WhLocalGeom& g)
+{
+    const WhSite site = geo_site(c, prim_in);
+    const WhTables& G = site.t;
+    const uint32_t prim = site.l;
+    const float4 a0 = G.vertices4[(size_t)prim * 3u], a1 = G.vertices4[(size_t)prim * 3u + 1u], a2 = G.vertices4[(size_t)prim * 3u + 2u];
+    f3 P0 = mk3(a0.x, a0.y, a0.z), P1 = mk3(a1.x, a1.y, a1.z), P2 = mk3(a2.x, a2.y, a2.z);
+    if (site.inst) { P0 = inst_point(*site.inst, a0); P1 = inst_point(*site.inst, a1); P2 = inst_point(*site.inst, a2); }
     const float b0 = 1.0f - bu - bv;
     g.P = b0 * P0 + bu * P1 + bv * P2;
     g.color = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    if (c.geo.colors4 && (!c.geo.color_present || c.geo.color_present[prim])) {
-        const float4* cc = c.geo.colors4 + (size_t)prim * 3u;
+    if (G.colors4 && (!G.color_present || G.color_present[prim])) {
+        const float4* cc = G.colors4 + (size_t)prim * 3u;
         const float4 c0 = cc[0], c1 = cc[1], c2 = cc[2];
         g.color = make_float4((b0 * c0.x + bu * c1.x) + bv * c2.x, (b0 * c0.y + bu * c1.y) + bv * c2.y,
                               (b0 * c0.z + bu * c1.z) + bv * c2.z, (b0 * c0.w + bu * c1.w) + bv * c2.w);
     }
     g.N = normalize(cross(P1 - P0, P2 - P0));
-    if (c.geo.normals4) {
-        const float4 n0 = c.geo.normals4[(size_t)prim * 3u], n1 = c.geo.normals4[(size_t)prim * 3u + 1u], n2 = c.geo.normals4[(size_t)prim * 3u + 2u];
-        if (n0.w != 0.0f) g.N = normalize(b0 * mk3(n0.x, n0.y, n0.z) + bu * mk3(n1.x, n1.y, n1.z) + bv * mk3(n2.x, n2.y, n2.z));
+    if (G.normals4) {
+        const float4 n0 = G.normals4[(size_t)prim * 3u], n1 = G.normals4[(size_t)prim * 3u + 1u], n2 = G.normals4[(size_t)prim * 3u + 2u];
+        if (n0.w != 0.0f) {
+            f3 N0 = mk3(n0.x, n0.y, n0.z), N1 = mk3(n1.x, n1.y, n1.z), N2 = mk3(n2.x, n2.y, n2.z);
+            if (site.inst) { N0 = inst_normal(*site.inst, n0); N1 = inst_normal(*site.inst, n1); N2 = inst_normal(*site.inst, n2); }
+            g.N = normalize(b0 * N0 + bu * N1 + bv * N2);
+        }
     }
     const f3 dp1 = P0 - P2, dp2 = P1 - P2;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         WhTexcoord& tc = g.tc[j];
-        if (c.geo.texcoords[j] && (!c.geo.texcoord_present[j] || c.geo.texcoord_present[j][prim])) {
-            const float2* uv = c.geo.texcoords[j] + (size_t)prim * 3u;
+        if (G.texcoords[j] && (!G.texcoord_present[j] || G.texcoord_present[j][prim])) {
+            const float2* uv = G.texcoords[j] + (size_t)prim * 3u;
             const float2 uv0 = uv[0], uv1 = uv[1], uv2 = uv[2];
             tc.u = (b0 * uv0.x + bu * uv1.x) + bv * uv2.x;
             tc.v = (b0 * uv0.y + bu * uv1.y) + bv * uv2.y;
@@ -138,7 +175,12 @@ __device__ __forceinline__ void local_geometry(const WhConsts& c, uint32_t prim,
 
 __device__ __forceinline__ uint32_t prim_material(const WhConsts& c, uint32_t prim)
 {
-    const uint32_t mi = c.geo.material_index ? c.geo.material_index[prim] : 0u;
+    uint32_t mi = 0u;
+    if (c.geo.prim_inst) {
+        const WhInstGeo& I = c.geo.inst[c.geo.prim_inst[prim]];
+        const uint32_t* tab = c.geo.meshes[I.mesh].material_index;
+        mi = tab ? tab[prim - I.prim_base] : 0u;
+    } else mi = c.geo.material_index ? c.geo.material_index[prim] : 0u;
     return mi >= c.nmaterials ? c.nmaterials - 1u : mi;
 }
 

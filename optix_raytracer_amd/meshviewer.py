@@ -52,28 +52,33 @@ class MeshViewerState:
         self.width, self.height = 1024, 768       # optixMeshViewer.cpp:84-85
 
 
-def loadScene(state, filename, device_index=0, log=None, log_level=0, two_level=False):
-    """sutil::loadScene( infile, scene ); scene.finalize();"""
+def loadScene(state, filename, device_index=0, log=None, log_level=0, two_level=False, instanced_shading=None):
+    """sutil::loadScene( infile, scene ); scene.finalize();
+    two_level: one triangle structure per mesh + the instance structure (what the reference builds); instanced_shading (default: with
+    two_level): the shading tables per MESH in object space + instance records (Scene::createSBT) instead of flattened world-space arrays"""
     state.device = torch.device("cuda", device_index)
     torch.cuda.set_device(state.device)
     state.scene = api.Scene(filename)
     state.context = api.Context(device_index, log=log, log_level=log_level)
-    verts, mat = state.scene.flatten()
-    if verts.shape[0] == 0:
+    instanced_shading = two_level if instanced_shading is None else (instanced_shading and two_level)
+    if state.scene.info()["num_triangles"] == 0:
         raise api.MiptError(1, "MIPT_ERROR_INVALID_VALUE", "scene has no triangles")
-    normals = state.scene.flatten_normals()
-    state.d_vertices = torch.from_numpy(np.ascontiguousarray(verts)).to(state.device)
-    state.d_normals = torch.from_numpy(np.ascontiguousarray(normals)).to(state.device) if np.any(normals[:, 3] != 0) else None
-    state.d_material_index = torch.from_numpy(mat.astype(np.int32)).to(state.device)
-    for j in range(2):
-        uv, has = state.scene.flatten_texcoords(j)
+    state.instanced_shading = False
+    if not instanced_shading:
+        verts, mat = state.scene.flatten()
+        normals = state.scene.flatten_normals()
+        state.d_vertices = torch.from_numpy(np.ascontiguousarray(verts)).to(state.device)
+        state.d_normals = torch.from_numpy(np.ascontiguousarray(normals)).to(state.device) if np.any(normals[:, 3] != 0) else None
+        state.d_material_index = torch.from_numpy(mat.astype(np.int32)).to(state.device)
+        for j in range(2):
+            uv, has = state.scene.flatten_texcoords(j)
+            if has.any():
+                state.d_texcoords[j] = torch.from_numpy(np.ascontiguousarray(uv)).to(state.device)
+                state.d_texcoord_present[j] = torch.from_numpy(np.ascontiguousarray(has)).to(state.device)
+        col, has = state.scene.flatten_colors()
         if has.any():
-            state.d_texcoords[j] = torch.from_numpy(np.ascontiguousarray(uv)).to(state.device)
-            state.d_texcoord_present[j] = torch.from_numpy(np.ascontiguousarray(has)).to(state.device)
-    col, has = state.scene.flatten_colors()
-    if has.any():
-        state.d_colors = torch.from_numpy(np.ascontiguousarray(col)).to(state.device)
-        state.d_color_present = torch.from_numpy(np.ascontiguousarray(has)).to(state.device)
+            state.d_colors = torch.from_numpy(np.ascontiguousarray(col)).to(state.device)
+            state.d_color_present = torch.from_numpy(np.ascontiguousarray(has)).to(state.device)
     state.materials = state.scene.material_table()
     if two_level:
         # Scene::buildMeshAccels (one GAS per mesh, object space) + Scene::buildInstanceAccel (Scene.cpp:817-1212)
@@ -95,6 +100,38 @@ def loadScene(state, filename, device_index=0, log=None, log_level=0, two_level=
         }])
     state.textures = state.scene.texture_table()
     ptr = lambda t: t.data_ptr() if t is not None else None            # noqa: E731
+    if two_level and instanced_shading:
+        # Scene::createSBT's shading data (Scene.cpp:1368-1480): one set of OBJECT-space buffers per mesh, one record per instance --
+        # instancing then saves shading memory as well as BVH memory (the flattened arrays above are dropped)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(state.device)   # noqa: E731
+        state.d_mesh_shading = []
+        mesh_recs = (L.MiptWhittedMesh * len(meshes))()
+        for m, (mv, mm) in enumerate(meshes):
+            sh = state.scene.mesh_shading(m)
+            keep = {"v": state.d_mesh_vertices[m], "mat": dev(mm.astype(np.int32)), "n": dev(sh["normals"]) if np.any(sh["normals"][:, 3] != 0) else None,
+                    "uv": [None, None], "uvp": [None, None], "c": None, "cp": None}
+            for j in range(2):
+                uv, has = sh["texcoords"][j]
+                if has.any():
+                    keep["uv"][j], keep["uvp"][j] = dev(uv), dev(has)
+            col, has = sh["colors"]
+            if has.any():
+                keep["c"], keep["cp"] = dev(col), dev(has)
+            state.d_mesh_shading.append(keep)
+            g = mesh_recs[m].geometry
+            g.vertices4, g.normals4, g.material_index = ptr(keep["v"]), ptr(keep["n"]), ptr(keep["mat"])
+            g.texcoords = (C.c_void_p * 2)(ptr(keep["uv"][0]), ptr(keep["uv"][1]))
+            g.texcoord_present = (C.c_void_p * 2)(ptr(keep["uvp"][0]), ptr(keep["uvp"][1]))
+            g.colors4, g.color_present = ptr(keep["c"]), ptr(keep["cp"])
+            mesh_recs[m].num_triangles = mv.shape[0] // 3
+        inst_recs = (L.MiptWhittedInstance * len(insts))()
+        for i, (m, xf) in enumerate(insts):
+            inst_recs[i].mesh = m
+            inst_recs[i].transform = (C.c_float * 12)(*[float(x) for x in np.asarray(xf, np.float32).reshape(-1)])
+        state.context._check(state.context._lib.mipt_whitted_set_geometry_instanced(
+            state.context._h, mesh_recs, len(meshes), inst_recs, len(insts), state.materials, len(state.materials), state.textures[0], state.textures[1]))
+        state.instanced_shading = True
+        return
     geo = L.MiptWhittedGeometry()
     geo.vertices4, geo.normals4, geo.material_index = ptr(state.d_vertices), ptr(state.d_normals), ptr(state.d_material_index)
     geo.texcoords = (C.c_void_p * 2)(ptr(state.d_texcoords[0]), ptr(state.d_texcoords[1]))
@@ -209,10 +246,10 @@ def cleanup(state):
     state.d_texcoords = [None, None]; state.d_texcoord_present = [None, None]; state.d_colors = state.d_color_present = None
 
 
-def render(filename, width, height, subframes=1, lights=None, device_index=0, two_level=False):
+def render(filename, width, height, subframes=1, lights=None, device_index=0, two_level=False, instanced_shading=None):
     """main() of the sample in file-output mode (:466-485): returns (state, uchar4 image as numpy)"""
     st = MeshViewerState()
-    loadScene(st, filename, device_index, two_level=two_level)
+    loadScene(st, filename, device_index, two_level=two_level, instanced_shading=instanced_shading)
     initCameraState(st)
     initLaunchParams(st, width, height, lights)
     out = OutputBuffer(width, height, st.device)

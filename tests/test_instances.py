@@ -214,8 +214,8 @@ def test_whitted_programs_over_the_instance_structure(tmp_path):
         tot[0] += s["closest_rays"]; tot[1] += s["shadow_rays"]
         st.params.subframe_index += 1
     ctx = st.context
-    verts = st.d_vertices.cpu().numpy()
-    mat = st.d_material_index.cpu().numpy().view(np.uint32)
+    assert st.instanced_shading and st.d_vertices is None           # the shading tables are per mesh + instance records: nothing flattened on the device
+    verts, mat = st.scene.flatten()                                 # (the oracle shades from the flattened world-space arrays)
     flat = {"vertices": verts, "mat_index": np.zeros(mat.shape[0], np.uint32), "emission": np.zeros((1, 3), np.float32), "diffuse": np.ones((1, 3), np.float32)}
     osc = _oracle_two_level(ctx, flat, st.handle)
     gf = MV.geometry_flags(st.materials)
@@ -355,3 +355,29 @@ def test_a_refitted_mesh_makes_its_instance_structures_stale(tmp_path):
     t, prim, _, _ = _oracle_two_level(ctx, flat, ias).trace_closest(rays, O.MODE_INST)
     assert np.array_equal(after[:, 1].view(np.uint32), prim) and np.array_equal(after[:, 0].view(np.uint32), t.view(np.uint32))
     ctx.destroy()
+
+
+def test_instanced_shading_tables_give_the_flattened_frame(tmp_path):
+    """Round 3: the shading tables the reference keeps (Scene::createSBT, Scene.cpp:1368-1480) -- per-mesh OBJECT-space buffers + one
+    record per instance (mipt_whitted_set_geometry_instanced) -- against the flattened world-space arrays over the same instance
+    structure: a corner is taken to world space in the kernel with the arithmetic mipt_scene_flatten uses on the host, a normal with
+    mipt_scene_flatten_normals', so the frames are bit-identical (textured BLEND / MASK materials, normals, general affine transforms)."""
+    import torch
+    from optix_raytracer_amd import meshviewer as MV
+    from optix_raytracer_amd import scenes
+    import _png_fixture as PF
+    rng = np.random.default_rng(4)
+    film = np.zeros((8, 8, 4), np.int64); film[..., :3] = rng.integers(60, 255, (8, 8, 3)); film[..., 3] = rng.integers(40, 230, (8, 8))
+    fence = np.zeros((8, 8, 4), np.int64); fence[..., :3] = 200; fence[..., 3] = np.where((np.add.outer(np.arange(8), np.arange(8)) % 3) == 0, 0, 255)
+    png = (PF.encode(film, 6, 8)[0], PF.encode(fence, 6, 8)[0])
+    frames = []
+    for inst_sh in (True, False):
+        path = scenes.write_instanced_gltf(tmp_path / ("instanced%d.gltf" % inst_sh), n_instances=70, seed=6, alpha_textures=png)
+        st, image = MV.render(path, 320, 180, subframes=2, two_level=True, instanced_shading=inst_sh)
+        assert st.instanced_shading == inst_sh
+        frames.append((st.accum.cpu().numpy().copy(), image.copy(), st.context.launch_stats()))
+        MV.cleanup(st)
+    (a0, f0, s0), (a1, f1, s1) = frames
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and np.array_equal(f0, f1)
+    assert s0["closest_rays"] == s1["closest_rays"] and s0["shadow_rays"] == s1["shadow_rays"] > 0
+    assert (a0[..., :3] > 0).mean() > 0.2
