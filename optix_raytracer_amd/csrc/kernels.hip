@@ -23,6 +23,7 @@
 #include "wave_util.h"
 #include "trav_core.h"
 #include "pool_core.h"
+#include "inst_pool.h"
 
 namespace mipt {
 
@@ -1627,6 +1628,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_TAIL1_W
 #endif
 }
 
+// ---- k_tail_pool_inst: k_tail_pool over a two-level (instance) structure (round 3) ------------------------------------------------------
+// The same loop -- closest hit, shade_path, the occlusion ray, the next bounce -- with the wave's rays traversed on the two-level entry pool
+// (inst_pool.h: 64-bit entries tagged with the instance they belong to).  A path-traced launch over an instance structure used to run
+// wavefront bounces to the end: five nearly empty kernels per bounce for the last few hundred paths of a Russian-roulette pass.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tail_pool_inst(TailArgs k)
+{
+    const ShadeArgs& a = k.a;
+    const uint32_t ppw = k.ppw;
+    const bool use_rg = k.rg.ctr != nullptr;
+    if (use_rg && blockIdx.x == 0u) { begin_sample(k.rg.ctr, threadIdx.x, k.rg.fc.n_paths, k.rg.n_valid, k.rg.zero_stats); tail_publish_epoch(k.rg.ctr, k.epoch); }
+    constexpr int kRows = 24, kCap = (kRows * 64 - 384) / 2;
+    __shared__ __attribute__((aligned(16))) uint2 stk2[kRows * 32];
+    uint32_t* const words = reinterpret_cast<uint32_t*>(stk2);
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(words + 2 * kCap);
+    float* const sh_u = reinterpret_cast<float*>(words + 2 * kCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(words + 2 * kCap + 192);
+    uint32_t* const sh_done = words + 2 * kCap + 320;
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.inst_blob_bytes, 0x00020000);
+    uint32_t n = a.n_max;
+    if (!use_rg) { const uint32_t m = a.ctr->n_cur; n = m < n ? m : n; }
+    const uint32_t i = blockIdx.x * ppw + threadIdx.x;
+    uint32_t n_closest = 0, n_shadow = 0, n_iter = 0;
+    uint32_t slot = kInvalidSlot, depth = 0;
+    float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
+    if (i < n && threadIdx.x < ppw) tail_load_path(k, use_rg, i, slot, depth, ro4, rd4, sa, res);
+    bool active = slot != kInvalidSlot;
+#if MIPT_INST_STATS
+    uint32_t ist[6] = { 0u, 0u, 0u, 0u, 0u, 0u };
+#endif
+    while (__ballot(active) != 0ull) {
+        Trav T;
+        trav_init(T, ro4, rd4);
+        tail_trace_inst<0, kCap>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, active && T.node != kSentinel, false INST_STATS_ARG);
+        const unsigned long long key = sh_best[lane];
+        const uint32_t prim = (uint32_t)key;
+        const float4 hit = prim != 0xffffffffu ? make_float4(ord_float((uint32_t)(key >> 32)), u2f(prim), sh_u[lane], sh_v[lane])
+                                               : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        ShadeOut o;
+        o.push_next = false; o.push_shadow = false;
+        if (active) {
+            ++n_iter;
+            shade_path(a, hit, sa, slot, depth, res, o, [&](float4& o4, float4& d4) { o4 = ro4; d4 = rd4; });
+        }
+        const bool sh = active && o.push_shadow;
+        if (__ballot(sh) != 0ull) {
+            Trav S;
+            trav_init(S, sh ? o.sro : ro4, sh ? o.srd : rd4);
+            tail_trace_inst<2, kCap>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel, false INST_STATS_ARG);
+            if (sh) {
+                ++n_shadow;
+                if (sh_done[lane] == 0u) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
+            }
+        }
+        active = active && o.push_next;
+        if (active) { ++n_closest; ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y; }
+    }
+    if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
+    if (use_rg) tail_await_epoch(a.ctr, k.epoch);
+    tail_stats(a.ctr, n_closest, n_shadow, n_iter);
+}
+
 // ---- k_tail_pool2: the occlusion ray of bounce b and the closest-hit ray of bounce b + 1 of every path in ONE pool pass ------
 // The tail of a pass is bound by the chain of dependent fetches per bounce (closest hit, then shading, then the occlusion ray);
 // the two rays are independent once bounce b is shaded, so tracing them together halves the chain.  Entries carry a 7-bit slot
@@ -2196,6 +2259,14 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
     a.resolve = resolve;
     a.fc = fc; a.bvh = bvh; a.hitgroups = hitgroups; a.n_hitgroups = n_hitgroups; a.cur = cur;
     a.result = result; a.ctr = ctr; a.n_max = n_max; a.common_vertices = common_vertices;
+    if (bvh.inst) {                        // a two-level structure in its entry-pool form (run_wavefront comes here for no other)
+        const uint32_t slots = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256) * 16u;
+        uint32_t ppw = ((n_max + slots - 1u) / slots + 15u) & ~15u;
+        ppw = ppw < 16u ? 16u : (ppw > 64u ? 64u : ppw);
+        k.ppw = ppw;
+        hipLaunchKernelGGL(k_tail_pool_inst, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
+        return;
+    }
     // the pool variant needs a BVH that fits k_trace_pool's packed entries; MIPT_OPT_PERSISTENT != 3 selects the plain loop
     if (o.persistent == 3 && bvh.pool_ok && bvh.tri_byte_off != 0u && bvh.depth <= 32u)
     {
@@ -2253,6 +2324,7 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
 
 bool tail_launch_makes_rays(const DeviceBvh& bvh, const TraceOpts& o)
 {
+    if (bvh.inst) return o.persistent == 3 && bvh.inst_fast != 0u && o.inst_form != 2;          // k_tail_pool_inst
     return o.persistent == 3 && bvh.pool_ok && bvh.tri_byte_off != 0u && bvh.depth <= 32u;      // the pool forms of launch_tail
 }
 

@@ -529,8 +529,10 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
         // packed entries, other kernel variants) pays off at a quarter of it, and not at all for depth-capped passes from
         // the start.  Depth-capped paths have few bounces left, so a switch inside the loop pays later: at half the count
         // (1 M-triangle scene, 1080p, depth 8: limit 2^18 / 2^19 / 2^20 -> 3.79 / 3.61 / 4.28 ms).
-        const bool use_tail = ctx->tail_paths != 0u && !ctx->count_visits && !acc->is_ias;      // the path kernels walk one-level BVHs
-        const bool pool_tail = opts.persistent == 3 && bvh.pool_ok != 0u && bvh.tri_byte_off != 0u && bvh.depth <= 32u;
+        // (the path kernels walk one-level BVHs, or -- k_tail_pool_inst -- a two-level structure in its entry-pool form)
+        const bool inst_tail = acc->is_ias && tail_launch_makes_rays(bvh, opts);
+        const bool use_tail = ctx->tail_paths != 0u && !ctx->count_visits && (!acc->is_ias || inst_tail);
+        const bool pool_tail = inst_tail || (opts.persistent == 3 && bvh.pool_ok != 0u && bvh.tri_byte_off != 0u && bvh.depth <= 32u);
         const uint32_t tail_paths = !use_tail ? 0u : (pool_tail ? ctx->tail_paths : ctx->tail_paths / 4u);
         const uint32_t tail_limit = fc.max_depth != 0u ? tail_paths / 2u : tail_paths;
         // (a capped pass of a million paths is as fast in the wavefront kernels: half the headline frame 0.54 vs 0.56 ms)
