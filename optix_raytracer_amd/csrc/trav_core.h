@@ -24,6 +24,8 @@ struct Trav {
     float    u, v;
     uint32_t prim;
     int      node, sp;
+    uint32_t skip;               // AH kernels only (pool_trace.h): with tmin = the t of a candidate the any-hit program ignored, that
+                                 // candidate's primitive -- candidates AT tmin count when their primitive index is greater
 };
 
 __device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd)

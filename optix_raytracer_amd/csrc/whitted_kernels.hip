@@ -8,11 +8,17 @@
 // Point and ambient lights; the BLEND continuation ray (:268-286) makes the pipeline a loop over up to
 // MAX_TRACE_DEPTH levels whose results are composed back to front, like the recursion.
 // schlick's powf(x, 5) is x^2 * x^2 * x (detmath: no libm transcendentals).
+#include <cstdlib>
+#include <cstring>
+
 #include "kernels.h"
 #include "detmath.h"
 #include "wave_util.h"
 #include "trav_core.h"
 #include "inst_core.h"
+#include "pool_core.h"
+#include "pool_trace.h"
+#include "inst_pool.h"
 
 namespace mipt {
 
@@ -185,10 +191,28 @@ __device__ __forceinline__ uint32_t prim_material(const WhConsts& c, uint32_t pr
 }
 
 // ---- optixTrace with the any-hit programs of cuda/whitted.cu:100-136 ------------------------------------
-// One ray per thread, the sequential visiting order (= the oracle's), so that the product of the BLEND
-// attenuations is taken in a defined order.  Used instead of the fast kernels when a scene has MASK / BLEND
-// materials.  MODE 0: traceRadiance (closest hit, back-face culling, __anyhit__radiance) -> hit records;
-// MODE 1: traceOcclusion (__anyhit__occlusion, terminate on first accepted hit) -> attenuation per ray.
+// Used instead of the fast kernels when a scene has MASK / BLEND materials.  MODE 0: traceRadiance (closest hit, back-face
+// culling, __anyhit__radiance) -> hit records; MODE 1: traceOcclusion (__anyhit__occlusion) -> attenuation per ray.
+//
+// The programs run DEFERRED: a ray's candidates are taken in the order of (t, primitive index) -- a closest-hit traversal finds the
+// first, the any-hit program is run on it, and when the program ignores it (optixIgnoreIntersection: below the cutoff, or a surface
+// that only attenuates) the ray is traced again for the closest candidate BEYOND the key (t, primitive): tmin = t, and candidates AT
+// tmin count when their primitive index is greater (Trav::skip; coincident surfaces are visited one by one).  That is
+//   * MODE 0: the closest candidate the program accepts -- what a traversal that runs the program at every candidate reports;
+//   * MODE 1: the product of the attenuations (1 - alpha) in the order of (t, primitive index), 0 as soon as a candidate is opaque or
+//     the product reaches 0.  OptiX leaves the order of any-hit invocations open; this order is the build's definition
+//     (oracle/pt_oracle.c: whitted occlusion), independent of the acceleration structure.
+// So the traversal itself is the entry pool's (pool_trace.h / inst_pool.h, AH form) -- k_wh_trace_pool / k_wh_trace_pool_inst: a
+// wave's chunk of rays, all lanes serving whichever rays are still open -- and the texture fetch happens once per candidate that
+// IS a ray's next one instead of inside the traversal loop at every candidate in the ray's interval (round 2's one-ray-per-thread
+// walk).  Measured, 1080p subframe over 2 000 instances / 782 k triangles, ALL of them alpha-textured (tools/bench_alpha.py,
+// profiles/r03_bench_alpha.txt): MASK materials with hard alpha (a ray ends at the first solid texel) 2.9 ms against 1.1 ms for the
+// same scene with opaque materials; BLEND films everywhere -- an occlusion ray crosses 7 attenuating surfaces on average, up to 78, and
+// none ends it, so every ray is traversed to its end -- 33.8 ms against round 2's 45.5 ms.
+// Tried for the occlusion rays and dropped (same file): ONE traversal that records every candidate of the interval (16 records per ray,
+// narrower windows for rays with more) and then sorts -- without a running closest hit nothing prunes the traversal, and the rays that
+// end early pay for the whole interval: 20 ms on the MASK scene, 40-76 ms on the BLEND scene.
+// k_wh_trace / k_wh_trace_inst: the same loop one ray per thread, for structures the pool cannot walk (5.8 / 107 ms on the two scenes).
 __device__ __forceinline__ bool candidate_alpha(const WhConsts& c, uint32_t prim, float u, float v, uint32_t& mi, float& alpha)
 {
     mi = prim_material(c, prim);
@@ -202,148 +226,263 @@ __device__ __forceinline__ bool candidate_alpha(const WhConsts& c, uint32_t prim
     return true;
 }
 
+// the any-hit program at a ray's next candidate; true: the ray is finished (MODE 0: the candidate is its hit; MODE 1: occluded)
 template <int MODE>
-__global__ __launch_bounds__(64) void k_wh_trace(WhConsts c, DeviceBvh bvh, const float4* ray_o, const float4* ray_d, const uint32_t* n_ptr,
-                                                 uint32_t n_max, float4* hits, float* attenuation, DeviceCounters* ctr)
+__device__ __forceinline__ bool anyhit_step(const WhConsts& c, uint32_t gflags, uint32_t prim, float u, float v, float& occlusion)
+{
+    if ((gflags & 1u) == 0u) {                                                           // any-hit program enabled
+        uint32_t mi; float alpha;
+        if (candidate_alpha(c, prim, u, v, mi, alpha)) {
+            const MiptMaterialData& m = c.materials[mi];
+            if (MODE == 0) {
+                if (alpha < m.alpha_cutoff) return false;                                // optixIgnoreIntersection
+            } else if (m.alpha_mode != 0) {
+                if (m.alpha_mode == 1 && alpha < m.alpha_cutoff) return false;
+                const float att = occlusion * (1.0f - alpha);
+                if (att > 0.0f) { occlusion = att; return false; }
+            }
+        }
+    }
+    if (MODE != 0) occlusion = 0.0f;                                                     // optixTerminateRay
+    return true;
+}
+
+// rays per wave, from the ray count the DEVICE knows (a level's queue length; the host only knows the capacity): a chunk's traversals
+// run one after the other, so a launch of few rays finishes sooner with few rays per wave -- all 64 lanes serve them
+__device__ __forceinline__ uint32_t ah_rays_per_wave(uint32_t fixed, uint32_t n, uint32_t cus)
+{
+    if (fixed != 0u) return fixed;
+    const uint32_t q = n / (cus * 64u);
+    return q >= 32u ? 32u : (q >= 16u ? 16u : (q >= 8u ? 8u : 4u));
+}
+
+struct WhTraceArgs {
+    DeviceBvh bvh;
+    const float4* ray_o; const float4* ray_d;
+    const uint32_t* n_ptr; uint32_t n_max;
+    float4* hits; float* attenuation;
+    uint32_t ppw, cus;             // ppw 0: chosen on the device (ah_rays_per_wave)
+};
+
+// one ray's bookkeeping after a traversal: `key` / u / v / gflags = the closest remaining candidate (sh_best and its fellows)
+template <int MODE>
+__device__ __forceinline__ void anyhit_advance(const WhConsts& c, Trav& T, bool& open, float& occlusion, float4& rec, const unsigned long long key,
+                                               const float u, const float v, const uint32_t gflags)
+{
+    const uint32_t prim = (uint32_t)key;
+    if (prim == 0xffffffffu) { open = false; return; }                                   // nothing left in the interval
+    const float t = ord_float((uint32_t)(key >> 32));
+    if (anyhit_step<MODE>(c, gflags, prim, u, v, occlusion)) { open = false; rec = make_float4(t, u2f(prim), u, v); }
+    else { T.tmin = t; T.skip = prim; }
+}
+
+#ifndef MIPT_WH_AH_ROWS
+#define MIPT_WH_AH_ROWS 24
+#endif
+template <int MODE, int Q>
+__global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
+{
+    constexpr int kPoolCap = MIPT_WH_AH_ROWS * 64 - 384;
+    __shared__ uint32_t stk[MIPT_WH_AH_ROWS * 64];
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
+    float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
+    uint32_t* const sh_done = stk + kPoolCap + 320;
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    const uint32_t ppw = ah_rays_per_wave(a.ppw, n, a.cus);
+    const uint32_t chunks = (n + ppw - 1u) / ppw;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint32_t ray = chunk * ppw + (uint32_t)lane;
+        const bool mine = (uint32_t)lane < ppw && ray < n;
+        Trav T;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu;
+        T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
+        if (mine) trav_init(T, a.ray_o[ray], a.ray_d[ray]);
+        bool open = mine && T.node != kSentinel;
+        float occlusion = 1.0f;
+        float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        while (__ballot(open) != 0ull) {
+            tail_trace<0, Q, kPoolCap, true>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, open, MODE == 0);
+            if (open) anyhit_advance<MODE>(c, T, open, occlusion, rec, sh_best[lane], sh_u[lane], sh_v[lane], sh_done[lane]);
+        }
+        if (mine) {
+            if (MODE == 0) a.hits[ray] = rec;
+            else           a.attenuation[ray] = occlusion;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wh_trace_pool_inst(WhConsts c, WhTraceArgs a)
+{
+    constexpr int kRows = 24;
+    constexpr int kCap = (kRows * 64 - 384) / 2;
+    __shared__ __attribute__((aligned(16))) uint2 stk2[kRows * 32];
+    uint32_t* const words = reinterpret_cast<uint32_t*>(stk2);
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(words + 2 * kCap);
+    float* const sh_u = reinterpret_cast<float*>(words + 2 * kCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(words + 2 * kCap + 192);
+    uint32_t* const sh_done = words + 2 * kCap + 320;
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.inst_blob_bytes, 0x00020000);
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
+    const uint32_t ppw = ah_rays_per_wave(a.ppw, n, a.cus);
+    const uint32_t chunks = (n + ppw - 1u) / ppw;
+#if MIPT_INST_STATS
+    uint32_t ist[6] = { 0u, 0u, 0u, 0u, 0u, 0u };
+#endif
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint32_t ray = chunk * ppw + (uint32_t)lane;
+        const bool mine = (uint32_t)lane < ppw && ray < n;
+        Trav T;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu;
+        T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
+        if (mine) trav_init(T, a.ray_o[ray], a.ray_d[ray]);
+        bool open = mine && T.node != kSentinel;
+        float occlusion = 1.0f;
+        float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        while (__ballot(open) != 0ull) {
+            tail_trace_inst<0, kCap, false, true>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, open, MODE == 0 INST_STATS_ARG);
+            if (open) anyhit_advance<MODE>(c, T, open, occlusion, rec, sh_best[lane], sh_u[lane], sh_v[lane], sh_done[lane]);
+        }
+        if (mine) {
+            if (MODE == 0) a.hits[ray] = rec;
+            else           a.attenuation[ray] = occlusion;
+        }
+    }
+}
+
+// ---- the same loop, one ray per thread (structures without the entry pool's mirrors) -----------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wh_trace(WhConsts c, WhTraceArgs a)
 {
     __shared__ uint32_t stk_lds[kStackEntries * 64];
     const int lane = (int)threadIdx.x;
     const Stack stk{ stk_lds, lane };
-    uint32_t n = n_max;
-    if (n_ptr) { const uint32_t m = *n_ptr; n = m < n ? m : n; }
+    const DeviceBvh& bvh = a.bvh;
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     for (uint32_t ray = blockIdx.x * 64u + threadIdx.x; ray < n; ray += gridDim.x * 64u) {
-        Trav T;
-        trav_init(T, ray_o[ray], ray_d[ray]);
+        const float4 ro = a.ray_o[ray], rd = a.ray_d[ray];
         float occlusion = 1.0f;
-        bool terminated = false;
-        while (T.node != kSentinel) {
-            while (T.node >= 0) visit_inner(T, bvh.nodes, stk);
-            if (T.node == kSentinel) break;
-            const uint32_t desc = ~(uint32_t)T.node;
-            const uint32_t first = desc >> 4, cnt = desc & 15u;
-            for (uint32_t i = 0; i < cnt && !terminated; ++i) {
-                const float4* tp = bvh.tris + (size_t)(first + i) * 3u;
-                const float4 a = tp[0], b = tp[1], cc = tp[2];
-                const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(cc.x, cc.y, cc.z);
-                const f3 p = fcross(T.d, e2);
-                const float det = fdot(e1, p);
-                if (det == 0.0f) continue;
-                const float inv = 1.0f / det;
-                const f3 tv = T.o - mk3(a.x, a.y, a.z);
-                const float u = fdot(tv, p) * inv;
-                const f3 q = fcross(tv, e1);
-                const float v = fdot(T.d, q) * inv;
-                const float t = fdot(e2, q) * inv;
-                if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) continue;
-                if (!(t > T.tmin && t < T.tmax)) continue;
-                const uint32_t prim = f2u(a.w), gflags = f2u(b.w);
-                if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;            // back face of a single-sided triangle
-                if ((gflags & 1u) == 0u) {                                               // any-hit program enabled
-                    uint32_t mi; float alpha;
-                    if (candidate_alpha(c, prim, u, v, mi, alpha)) {
-                        const MiptMaterialData& m = c.materials[mi];
-                        if (MODE == 0) {
-                            if (alpha < m.alpha_cutoff) continue;                        // optixIgnoreIntersection
-                        } else if (m.alpha_mode != 0) {
-                            if (m.alpha_mode == 1 && alpha < m.alpha_cutoff) continue;
-                            const float att = occlusion * (1.0f - alpha);
-                            if (att > 0.0f) { occlusion = att; continue; }
-                        }
-                    }
+        float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        float tmin = ro.w; uint32_t skip = 0xffffffffu;
+        for (bool open = true; open;) {
+            Trav T;
+            trav_init(T, make_float4(ro.x, ro.y, ro.z, tmin), rd);
+            uint32_t gflags_best = 0u;
+            while (T.node != kSentinel) {
+                while (T.node >= 0) visit_inner(T, bvh.nodes, stk);
+                if (T.node == kSentinel) break;
+                const uint32_t desc = ~(uint32_t)T.node;
+                const uint32_t first = desc >> 4, cnt = desc & 15u;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const float4* tp = bvh.tris + (size_t)(first + i) * 3u;
+                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                    const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
+                    const f3 p = fcross(T.d, e2);
+                    const float det = fdot(e1, p);
+                    if (det == 0.0f) continue;
+                    const float inv = 1.0f / det;
+                    const f3 tv = T.o - mk3(ta.x, ta.y, ta.z);
+                    const float u = fdot(tv, p) * inv;
+                    const f3 q = fcross(tv, e1);
+                    const float v = fdot(T.d, q) * inv;
+                    const float t = fdot(e2, q) * inv;
+                    if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) continue;
+                    const uint32_t prim = f2u(ta.w), gflags = f2u(tb.w);
+                    if (!((t > T.tmin || (t == T.tmin && prim > skip)) && t < T.tmax)) continue;
+                    if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;            // back face of a single-sided triangle
+                    if (t < T.tbest || (t == T.tbest && prim < T.prim)) { T.tbest = t; T.prim = prim; T.u = u; T.v = v; gflags_best = gflags; }
                 }
-                if (MODE != 0) { terminated = true; }
-                else if (t < T.tbest || (t == T.tbest && prim < T.prim)) { T.tbest = t; T.prim = prim; T.u = u; T.v = v; }
+                T.node = stk.pop(T.sp);
             }
-            if (terminated) break;
-            T.node = stk.pop(T.sp);
+            if (T.prim == 0xffffffffu) break;
+            if (anyhit_step<MODE>(c, gflags_best, T.prim, T.u, T.v, occlusion)) { rec = make_float4(T.tbest, u2f(T.prim), T.u, T.v); open = false; }
+            else { tmin = T.tbest; skip = T.prim; }
         }
-        if (MODE == 0) hits[ray] = T.prim != 0xffffffffu ? make_float4(T.tbest, u2f(T.prim), T.u, T.v) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
-        else           attenuation[ray] = terminated ? 0.0f : occlusion;
+        if (MODE == 0) a.hits[ray] = rec;
+        else           a.attenuation[ray] = occlusion;
     }
 }
 
-// The same queries over a two-level (instance) structure (instances.hip's walk: the world ray over the instances' boxes, the
-// object-space ray -- not re-normalised, so distances carry over -- through each mesh), with the any-hit programs at every
-// candidate.  A candidate's primitive is its FLATTENED index (prim_base + local), which is what the shading tables and
-// candidate_alpha are laid out by.
+// ... over a two-level (instance) structure (instances.hip's walk: the world ray over the instances' boxes, the object-space ray --
+// not re-normalised, so distances carry over -- through each mesh).  A candidate's primitive is its FLATTENED index (prim_base +
+// local), which is what the shading tables and candidate_alpha are laid out by.
 template <int MODE>
-__global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, DeviceBvh bvh, const float4* ray_o, const float4* ray_d, const uint32_t* n_ptr,
-                                                      uint32_t n_max, float4* hits, float* attenuation, DeviceCounters* ctr)
+__global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, WhTraceArgs a)
 {
     __shared__ uint32_t stk_lds[kInstStack * 64];
     const int lane = (int)threadIdx.x;
     const Stack2 stk{ stk_lds, lane };
-    uint32_t n = n_max;
-    if (n_ptr) { const uint32_t m = *n_ptr; n = m < n ? m : n; }
+    const DeviceBvh& bvh = a.bvh;
+    uint32_t n = a.n_max;
+    if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     for (uint32_t ray = blockIdx.x * 64u + threadIdx.x; ray < n; ray += gridDim.x * 64u) {
-        const float4 ro = ray_o[ray], rd = ray_d[ray];
+        const float4 ro = a.ray_o[ray], rd = a.ray_d[ray];
         RayO W;
         W.o = mk3(ro.x, ro.y, ro.z); W.d = mk3(rd.x, rd.y, rd.z);
         prepare(W);
-        const float tmin = ro.w, tmax = rd.w;
-        float tbest = tmax, bu = 0.0f, bv = 0.0f; uint32_t bprim = 0xffffffffu;
+        const float tmax = rd.w;
+        float tmin = ro.w; uint32_t skip = 0xffffffffu;
         float occlusion = 1.0f;
-        bool terminated = false;
-        int sp = 0;
-        int node = tmax > tmin ? 0 : kSentinel;
-        while (node != kSentinel && !terminated) {
-            while (node >= 0) node = step_inner(bvh.nodes, node, W, tmin, tbest, stk, sp, 0);
-            if (node == kSentinel) break;
-            const uint32_t idesc = ~(uint32_t)node, ifirst = idesc >> 4, icnt = idesc & 15u;
-            for (uint32_t k = 0; k < icnt && !terminated; ++k) {
-                const DeviceInstance& in = bvh.inst[bvh.inst_order[ifirst + k]];
-                RayO O;
-                const f3 mo = xform_vec(in.inv, W.o);
-                O.o = mk3(mo.x + in.inv[3], mo.y + in.inv[7], mo.z + in.inv[11]);
-                O.d = xform_vec(in.inv, W.d);
-                prepare(O);
-                const int base = sp;
-                int mn = 0;
-                while (mn != kSentinel && !terminated) {
-                    while (mn >= 0) mn = step_inner(in.nodes, mn, O, tmin, tbest, stk, sp, base);
-                    if (mn == kSentinel) break;
-                    const uint32_t desc = ~(uint32_t)mn, first = desc >> 4, cnt = desc & 15u;
-                    for (uint32_t i = 0; i < cnt && !terminated; ++i) {
-                        const float4* tp = in.tris + (size_t)(first + i) * 3u;
-                        const float4 a = tp[0], b = tp[1], cc = tp[2];
-                        const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(cc.x, cc.y, cc.z);
-                        const f3 p = fcross(O.d, e2);
-                        const float det = fdot(e1, p);
-                        if (det == 0.0f) continue;
-                        const float inv = 1.0f / det;
-                        const f3 tv = O.o - mk3(a.x, a.y, a.z);
-                        const float u = fdot(tv, p) * inv;
-                        const f3 q = fcross(tv, e1);
-                        const float v = fdot(O.d, q) * inv;
-                        const float t = fdot(e2, q) * inv;
-                        if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) continue;
-                        if (!(t > tmin && t < tmax)) continue;
-                        const uint32_t prim = in.prim_base + f2u(a.w), gflags = f2u(b.w);
-                        if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;            // back face of a single-sided triangle
-                        if ((gflags & 1u) == 0u) {                                               // any-hit program enabled
-                            uint32_t mi; float alpha;
-                            if (candidate_alpha(c, prim, u, v, mi, alpha)) {
-                                const MiptMaterialData& m = c.materials[mi];
-                                if (MODE == 0) {
-                                    if (alpha < m.alpha_cutoff) continue;                        // optixIgnoreIntersection
-                                } else if (m.alpha_mode != 0) {
-                                    if (m.alpha_mode == 1 && alpha < m.alpha_cutoff) continue;
-                                    const float att = occlusion * (1.0f - alpha);
-                                    if (att > 0.0f) { occlusion = att; continue; }
-                                }
-                            }
+        float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        for (bool open = tmax > tmin; open;) {
+            float tbest = tmax, bu = 0.0f, bv = 0.0f; uint32_t bprim = 0xffffffffu, bflags = 0u;
+            int sp = 0;
+            int node = 0;
+            while (node != kSentinel) {
+                while (node >= 0) node = step_inner(bvh.nodes, node, W, tmin, tbest, stk, sp, 0);
+                if (node == kSentinel) break;
+                const uint32_t idesc = ~(uint32_t)node, ifirst = idesc >> 4, icnt = idesc & 15u;
+                for (uint32_t k = 0; k < icnt; ++k) {
+                    const DeviceInstance& in = bvh.inst[bvh.inst_order[ifirst + k]];
+                    RayO O;
+                    const f3 mo = xform_vec(in.inv, W.o);
+                    O.o = mk3(mo.x + in.inv[3], mo.y + in.inv[7], mo.z + in.inv[11]);
+                    O.d = xform_vec(in.inv, W.d);
+                    prepare(O);
+                    const int base = sp;
+                    int mn = 0;
+                    while (mn != kSentinel) {
+                        while (mn >= 0) mn = step_inner(in.nodes, mn, O, tmin, tbest, stk, sp, base);
+                        if (mn == kSentinel) break;
+                        const uint32_t desc = ~(uint32_t)mn, first = desc >> 4, cnt = desc & 15u;
+                        for (uint32_t i = 0; i < cnt; ++i) {
+                            const float4* tp = in.tris + (size_t)(first + i) * 3u;
+                            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                            const f3 e1 = mk3(tb.x, tb.y, tb.z), e2 = mk3(tc.x, tc.y, tc.z);
+                            const f3 p = fcross(O.d, e2);
+                            const float det = fdot(e1, p);
+                            if (det == 0.0f) continue;
+                            const float inv = 1.0f / det;
+                            const f3 tv = O.o - mk3(ta.x, ta.y, ta.z);
+                            const float u = fdot(tv, p) * inv;
+                            const f3 q = fcross(tv, e1);
+                            const float v = fdot(O.d, q) * inv;
+                            const float t = fdot(e2, q) * inv;
+                            if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) continue;
+                            const uint32_t prim = in.prim_base + f2u(ta.w), gflags = f2u(tb.w);
+                            if (!((t > tmin || (t == tmin && prim > skip)) && t < tmax)) continue;
+                            if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;        // back face of a single-sided triangle
+                            if (bprim == 0xffffffffu || t < tbest || (t == tbest && prim < bprim)) { tbest = t; bprim = prim; bu = u; bv = v; bflags = gflags; }
                         }
-                        if (MODE != 0) { terminated = true; }
-                        else if (bprim == 0xffffffffu || t < tbest || (t == tbest && prim < bprim)) { tbest = t; bprim = prim; bu = u; bv = v; }
+                        mn = stk.pop(sp, base);
                     }
-                    if (!terminated) mn = stk.pop(sp, base);
+                    sp = base;
                 }
-                sp = base;
+                node = stk.pop(sp, 0);
             }
-            if (!terminated) node = stk.pop(sp, 0);
+            if (bprim == 0xffffffffu) break;
+            if (anyhit_step<MODE>(c, bflags, bprim, bu, bv, occlusion)) { rec = make_float4(tbest, u2f(bprim), bu, bv); open = false; }
+            else { tmin = tbest; skip = bprim; }
         }
-        if (MODE == 0) hits[ray] = bprim != 0xffffffffu ? make_float4(tbest, u2f(bprim), bu, bv) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
-        else           attenuation[ray] = terminated ? 0.0f : occlusion;
+        if (MODE == 0) a.hits[ray] = rec;
+        else           a.attenuation[ray] = occlusion;
     }
 }
 
@@ -580,6 +719,36 @@ __global__ __launch_bounds__(256) void k_wh_resolve(WhConsts c, const float4* le
     if (frame) frame[i] = make_color(col);
 }
 
+// The launch of the any-hit-program traversal: the entry pool's form when the structure has the mirrors for it (a one-level BVH
+// whose packed entries fit, a two-level structure in its arena form), else one ray per thread.  MIPT_WH_ANYHIT=walk forces the
+// latter (tests compare the two).  Rays per wave: chosen on the device from the queue's length (ah_rays_per_wave).
+template <int MODE>
+static void launch_wh_trace(hipStream_t st, const WhConsts& c, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, const uint32_t* n_ptr,
+                            uint32_t n_max, float4* hits, float* attenuation, const TraceOpts& o)
+{
+    if (n_max == 0u) return;
+    static const int e_form = [] { const char* e = std::getenv("MIPT_WH_ANYHIT"); return e && std::strcmp(e, "walk") == 0 ? 1 : 0; }();
+    static const int e_ppw = [] { const char* e = std::getenv("MIPT_WH_AH_PPW"); return e ? std::atoi(e) : 0; }();
+    WhTraceArgs a{};
+    a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.n_ptr = n_ptr; a.n_max = n_max; a.hits = hits; a.attenuation = attenuation;
+    const bool pool = e_form == 0 && o.persistent == 3 && (bvh.inst ? bvh.inst_fast != 0u : (bvh.pool_ok && bvh.tri_byte_off != 0u));
+    if (!pool) {
+        const int tblocks = o.blocks > 0 ? o.blocks : 4096;
+        if (bvh.inst) hipLaunchKernelGGL((k_wh_trace_inst<MODE>), dim3(tblocks), dim3(64), 0, st, c, a);
+        else          hipLaunchKernelGGL((k_wh_trace<MODE>), dim3(tblocks), dim3(64), 0, st, c, a);
+        return;
+    }
+    const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
+    a.ppw = e_ppw >= 1 && e_ppw <= 64 ? (uint32_t)e_ppw : 0u; a.cus = cus;
+    unsigned long long want = ((unsigned long long)n_max + 3u) / 4u;
+    want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
+    const uint32_t g = (uint32_t)want;
+    if (bvh.inst)                hipLaunchKernelGGL((k_wh_trace_pool_inst<MODE>), dim3(g), dim3(64), 0, st, c, a);
+    else if (bvh.node_fmt == 2u) hipLaunchKernelGGL((k_wh_trace_pool<MODE, 2>), dim3(g), dim3(64), 0, st, c, a);
+    else if (bvh.node_fmt == 1u) hipLaunchKernelGGL((k_wh_trace_pool<MODE, 1>), dim3(g), dim3(64), 0, st, c, a);
+    else                         hipLaunchKernelGGL((k_wh_trace_pool<MODE, 0>), dim3(g), dim3(64), 0, st, c, a);
+}
+
 void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_paths, const DeviceBvh& bvh, const WhGeometry& geo,
                  const MiptMaterialData* d_materials, uint32_t n_materials, const WhTexture* d_textures, uint32_t n_textures,
                  const WhBuffers& B, DeviceCounters* ctr, const TraceOpts& opts)
@@ -594,13 +763,9 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
     const uint32_t n_pixels = p.width * p.height;
     launch_begin_sample(st, ctr, n_paths, n_pixels);
     hipLaunchKernelGGL(k_wh_raygen, dim3(blocks), dim3(256), 0, st, c, B.q[0], B.n_levels);
-    const int tblocks = opts.blocks > 0 ? opts.blocks : 4096;
     for (uint32_t level = 0; level < B.max_levels; ++level) {
         const PathQueue cur = B.q[level & 1u], next = B.q[(level & 1u) ^ 1u];
-        if (B.any_hit_programs && bvh.inst)
-            hipLaunchKernelGGL((k_wh_trace_inst<0>), dim3(tblocks), dim3(64), 0, st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, (float*)nullptr, ctr);
-        else if (B.any_hit_programs)
-            hipLaunchKernelGGL((k_wh_trace<0>), dim3(tblocks), dim3(64), 0, st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, (float*)nullptr, ctr);
+        if (B.any_hit_programs) launch_wh_trace<0>(st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, nullptr, opts);
         else
             launch_trace_closest(st, bvh, cur.ray_o, cur.ray_d, 1, &ctr->n_cur, n_paths, B.hits, ctr, opts,
                                  MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES);          // traceRadiance, whitted_cuda.h:110
@@ -609,12 +774,7 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
         L.level = level; L.n_pixels = n_pixels; L.bound = n_paths;
         hipLaunchKernelGGL(k_wh_shade, dim3(blocks), dim3(256), 0, st, c, L, ctr);
         hipLaunchKernelGGL(k_wh_scale, dim3(1), dim3(64), 0, st, ctr, K);
-        if (B.any_hit_programs && bvh.inst)
-            hipLaunchKernelGGL((k_wh_trace_inst<1>), dim3(tblocks), dim3(64), 0, st, c, bvh, B.sh.ray_o, B.sh.ray_d, &ctr->n_shadow, n_paths * K, (float4*)nullptr,
-                               (float*)B.flags, ctr);
-        else if (B.any_hit_programs)
-            hipLaunchKernelGGL((k_wh_trace<1>), dim3(tblocks), dim3(64), 0, st, c, bvh, B.sh.ray_o, B.sh.ray_d, &ctr->n_shadow, n_paths * K, (float4*)nullptr,
-                               (float*)B.flags, ctr);
+        if (B.any_hit_programs) launch_wh_trace<1>(st, c, bvh, B.sh.ray_o, B.sh.ray_d, &ctr->n_shadow, n_paths * K, nullptr, (float*)B.flags, opts);
         else
             launch_trace_any(st, bvh, B.sh.ray_o, B.sh.ray_d, 1, &ctr->n_shadow, n_paths * K, B.flags, nullptr, nullptr, ctr, opts);
         hipLaunchKernelGGL(k_wh_gather, dim3((blocks + 3u) / 4u), dim3(1024), 0, st, K, L, (const uint32_t*)B.flags,

@@ -236,13 +236,14 @@ def write_duck_like_gltf(path, seed=3):
     return path
 
 
-def write_instanced_gltf(path, n_instances=150, seed=9, alpha_textures=None):
+def write_instanced_gltf(path, n_instances=150, seed=9, alpha_textures=None, blob_mode="BLEND"):
     """An instanced scene for the two-level (instance) acceleration structure: TWO meshes -- a bumpy blob of 960 triangles
     (u16 indices) and a box of 12 -- placed `n_instances` times by nodes with random translation / rotation / NON-uniform
     scale (some nested under a scaled parent, so matrices are general affine), over a floor quad; three opaque materials, a
     camera node.  Every node with a mesh becomes one sutil::Scene instance (Scene.cpp:192-205).  Returns the path.
     alpha_textures = (png bytes, png bytes): the blob becomes a BLEND material and the box a double-sided MASK material over
-    those RGBA images (both meshes get TEXCOORD_0), so the Whitted any-hit programs run inside the instances."""
+    those RGBA images (both meshes get TEXCOORD_0), so the Whitted any-hit programs run inside the instances.
+    blob_mode = "MASK": the blob is cut out by the second image as well (foliage-like: rays end at the first solid texel)."""
     import base64
     import json
     rng = np.random.default_rng(seed)
@@ -317,10 +318,15 @@ def write_instanced_gltf(path, n_instances=150, seed=9, alpha_textures=None):
         doc["images"] = [{"uri": uri(alpha_textures[0])}, {"uri": uri(alpha_textures[1])}]
         doc["samplers"] = [{"minFilter": 9728, "magFilter": 9728}, {}]
         doc["textures"] = [{"source": 0, "sampler": 0}, {"source": 1, "sampler": 1}]
-        doc["materials"][0].update({"alphaMode": "BLEND", "doubleSided": True})
-        doc["materials"][0]["pbrMetallicRoughness"].update({"baseColorFactor": [0.85, 0.55, 0.2, 0.8], "baseColorTexture": {"index": 0}})
+        if blob_mode == "MASK":
+            doc["textures"].append({"source": 1, "sampler": 0})             # nearest texel: alpha is 0 or 1, a ray ends at the first solid one
+            doc["materials"][0].update({"alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True})
+            doc["materials"][0]["pbrMetallicRoughness"].update({"baseColorTexture": {"index": 2}})
+        else:
+            doc["materials"][0].update({"alphaMode": "BLEND", "doubleSided": True})
+            doc["materials"][0]["pbrMetallicRoughness"].update({"baseColorFactor": [0.85, 0.55, 0.2, 0.8], "baseColorTexture": {"index": 0}})
         doc["materials"][1].update({"alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True})
-        doc["materials"][1]["pbrMetallicRoughness"].update({"baseColorTexture": {"index": 1}})
+        doc["materials"][1]["pbrMetallicRoughness"].update({"baseColorTexture": {"index": 2 if blob_mode == "MASK" else 1}})
     path.write_text(json.dumps(doc))
     return path
 

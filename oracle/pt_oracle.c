@@ -1418,10 +1418,10 @@ static int anyhit_radiance(void* ctx, uint32_t prim, float t, float u, float v)
     return 1;
 }
 
-/* __anyhit__occlusion, cuda/whitted.cu:113-136 */
-static int anyhit_occlusion(void* ctx, uint32_t prim, float t, float u, float v)
+/* __anyhit__occlusion, cuda/whitted.cu:113-136, at ONE candidate: 1 = the ray terminates there (occluded), 0 = ignored (below the
+ * cutoff, or attenuating: c->occlusion is then the product so far) */
+static int anyhit_occlusion(AnyhitCtx* c, uint32_t prim, float t, float u, float v)
 {
-    AnyhitCtx* c = (AnyhitCtx*)ctx;
     const OrcMaterialW* m; float alpha;
     if (candidate_alpha(c, prim, t, u, v, &m, &alpha) && m->alpha_mode != 0) {
         if (m->alpha_mode == 1 && alpha < m->alpha_cutoff) return 0;
@@ -1431,14 +1431,48 @@ static int anyhit_occlusion(void* ctx, uint32_t prim, float t, float u, float v)
     return 1;
 }
 
+/* OptiX leaves the order in which a ray's candidates meet the any-hit program open, and a product of floats depends on it.  The
+ * build's definition (csrc/whitted_kernels.hip: the deferred any-hit programs): the candidates of the ray's interval in the order
+ * of (t, primitive index).  Restated here the direct way: the traversal only COLLECTS the candidates whose any-hit program is
+ * enabled (it stops at one whose program is disabled: opaque), then they are sorted and the program runs over them in order. */
+typedef struct { float t, u, v; uint32_t prim; } OccCand;
+typedef struct { OccCand* v; size_t n, cap; } OccList;
+
+static int occ_collect(void* ctx, uint32_t prim, float t, float u, float v)
+{
+    OccList* l = (OccList*)ctx;
+    if (l->n == l->cap) {
+        l->cap = l->cap ? l->cap * 2 : 16;
+        l->v = (OccCand*)realloc(l->v, l->cap * sizeof(OccCand));
+        if (!l->v) abort();
+    }
+    OccCand c = { t, u, v, prim };
+    l->v[l->n++] = c;
+    return 0;                                              /* never accepted during the traversal */
+}
+
+static int occ_order(const void* a, const void* b)
+{
+    const OccCand* x = (const OccCand*)a; const OccCand* y = (const OccCand*)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->prim < y->prim ? -1 : (x->prim > y->prim ? 1 : 0);
+}
+
 /* whitted::traceOcclusion, cuda/whitted_cuda.h:127-160: pending attenuation, committed by the miss program only */
 static float whitted_trace_occlusion(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 o, v3 d, float tmin, float tmax, OrcStats* st)
 {
-    AnyhitCtx c = { s, f, 1.0f };
-    TraceFilter flt = { 0u, anyhit_occlusion, &c };
+    OccList l = { NULL, 0, 0 };
+    TraceFilter flt = { 0u, occ_collect, &l };
     HitRec sh;
     trace_ex(s, mode, o, d, tmin, tmax, 1, &sh, st, &flt);
-    return sh.hit ? 0.0f : c.occlusion;
+    AnyhitCtx c = { s, f, 1.0f };
+    int occluded = sh.hit;                                 /* a candidate without any-hit program */
+    if (!occluded && l.n) {
+        qsort(l.v, l.n, sizeof(OccCand), occ_order);
+        for (size_t i = 0; i < l.n && !occluded; ++i) occluded = anyhit_occlusion(&c, l.v[i].prim, l.v[i].t, l.v[i].u, l.v[i].v);
+    }
+    free(l.v);
+    return occluded ? 0.0f : c.occlusion;
 }
 
 static v3 whitted_closesthit(const OrcScene* s, int mode, const OrcWhittedFrame* f, v3 ray_o, v3 ray_d, const HitRec* h,

@@ -280,9 +280,11 @@ def write_textured(tmpdir, seed=3):
     return path
 
 
-def write_alpha(tmpdir, seed=4):
+def write_alpha(tmpdir, seed=4, stack=0):
     """Alpha MASK / BLEND materials, single- and double-sided: a ground, a masked fence, two stacked blend panes (textured
-    alpha), an untextured blend pane, and two opaque panes seen from behind (one single sided -> culled for camera rays)."""
+    alpha), an untextured blend pane, and two opaque panes seen from behind (one single sided -> culled for camera rays).
+    stack = n: n more horizontal glass panes above the ground, every fifth one TWICE (coincident surfaces: candidates at equal t) --
+    occlusion rays from below cross up to n + n // 5 attenuating surfaces."""
     import _png_fixture as PF
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:8, 0:8]
@@ -308,6 +310,10 @@ def write_alpha(tmpdir, seed=4):
         quad((1.9, 0.1, -0.5), (0, 1.2, 0), (0, 0, 1.0)),   # 6 opaque double sided, faces -x as well from the camera? (+x normal flipped)
     ]
     mats_of = [0, 1, 2, 2, 3, 4, 5]
+    for k in range(stack):
+        pane = quad((0.9, 0.25 + 0.06 * k, 0.2), (1.8, 0, 0), (0, 0, -2.2))
+        for _ in range(2 if k % 5 == 4 else 1):
+            quads.append(pane); mats_of.append(2 if k % 3 else 1)          # glass, every third one the masked fence texture
     parts, views, accs, prims = [], [], [], []
     blob = b""
     for k, qv in enumerate(quads):
@@ -343,6 +349,6 @@ def write_alpha(tmpdir, seed=4):
         "nodes": [{"mesh": 0}, {"camera": 0, "translation": [0.0, 1.6, 5.0], "rotation": [-0.1305261922, 0.0, 0.0, 0.9914448614]}],
         "scenes": [{"nodes": [0, 1]}], "scene": 0,
     }
-    path = tmpdir / "alpha.gltf"
+    path = tmpdir / ("alpha.gltf" if not stack else "alpha_stack%d.gltf" % stack)
     path.write_text(json.dumps(doc))
     return path

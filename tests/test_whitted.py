@@ -493,18 +493,18 @@ def test_oracle_blend_depth_limit():
     assert st["closest_rays"] == 8 * 8 * 8
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("w,h,subframes", [(150, 100, 1), (90, 60, 2)])
-def test_alpha_modes_and_culling_match_the_oracle(tmp_path, w, h, subframes):
+def _alpha_frames_match_the_oracle(gltf, w, h, subframes, persistent=None):
     import torch
     assert torch.cuda.is_available()
     from optix_raytracer_amd import meshviewer as MV
-    gltf = FX.write_alpha(tmp_path)
+    from optix_raytracer_amd import _lib as L
     lights = [{"type": MV.LIGHT_AMBIENT, "color": (0.08, 0.08, 0.1)},
               {"type": MV.LIGHT_POINT, "color": (1.0, 0.95, 0.9), "intensity": 12.0, "position": (0.5, 4.0, 4.0)},
               {"type": MV.LIGHT_POINT, "color": (0.5, 0.7, 1.0), "intensity": 6.0, "position": (-2.5, 2.5, 2.0)}]
     st = MV.MeshViewerState()
     MV.loadScene(st, gltf)
+    if persistent is not None:
+        st.context.set_option(L.OPT_PERSISTENT, persistent)
     MV.initCameraState(st)
     MV.initLaunchParams(st, w, h, lights)
     out = MV.OutputBuffer(w, h, st.device)
@@ -537,6 +537,25 @@ def test_alpha_modes_and_culling_match_the_oracle(tmp_path, w, h, subframes):
     assert np.array_equal(out.getHostPointer(), frame)
     assert tot_c == oc > w * h * subframes and tot_s == osr > 0                      # continuation rays were traced
     MV.cleanup(st)
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,subframes", [(150, 100, 1), (90, 60, 2)])
+def test_alpha_modes_and_culling_match_the_oracle(tmp_path, w, h, subframes):
+    _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path), w, h, subframes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stack,persistent", [(7, None), (24, None), (24, 2)])
+def test_deferred_any_hit_programs_over_many_layers(tmp_path, stack, persistent):
+    """The any-hit programs run deferred, a ray's candidates in the order of (t, primitive index) (whitted_kernels.hip): a closest-hit
+    traversal on the entry pool finds the next candidate, the program runs on it, and an ignored candidate becomes the continuation
+    key (tmin = t; at equal t only primitives above the ignored one count).  7 / 24 more panes, every fifth one TWICE -- coincident
+    surfaces, candidates at bit-equal t -- so occlusion rays from the ground cross up to 30 attenuating surfaces and camera rays run
+    into the depth limit.  persistent = 2: the same loop one ray per thread (structures without the pool's mirrors).  Every frame
+    equals the oracle's -- which COLLECTS the candidates of a ray, SORTS them and multiplies -- bit for bit."""
+    _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path, stack=stack), 120, 80, 2, persistent=persistent)
 
 
 @pytest.mark.parametrize("name", ["textured", "alpha"])
