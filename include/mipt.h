@@ -277,7 +277,7 @@ int mipt_accel_export(const MiptContext* ctx, unsigned long long handle,
  * i.e. the order of mipt_scene_flatten*, so hit-group records, the Whitted geometry arrays and the launch functions are used
  * exactly as with one flattened BVH.  instanceId / sbtOffset / visibilityMask / flags are stored but not interpreted (the samples
  * use mask 1 and no flags).  mipt_accel_update_instances takes the same instances with new transforms (an instance moved).
- * Alpha-tested / blended materials (the Whitted any-hit programs) work over an instance structure too (k_wh_trace_inst).
+ * Alpha-tested / blended materials (the Whitted any-hit programs) work over an instance structure too (k_wh_trace_pool_inst).
  * ------------------------------------------------------------------------- */
 typedef struct MiptInstance {
     float              transform[12];
@@ -454,7 +454,8 @@ typedef struct MiptLight {
  * material table and a texture table.  Radiance rays cull back faces of single-sided materials
  * (OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES, whitted_cuda.h:110; per-triangle geometry flags from MiptBuildInput::flags).
  * When a material is MASK or BLEND the traversal runs the any-hit programs (cuda/whitted.cu:100-136: alpha test for
- * radiance rays, accumulated attenuation for occlusion rays) and BLEND hits continue with a ray from the hit distance,
+ * radiance rays, accumulated attenuation for occlusion rays -- a ray's candidates in the order of (t, primitive index), which OptiX
+ * leaves open) and BLEND hits continue with a ray from the hit distance,
  * composed back to front over at most MAX_TRACE_DEPTH = 8 levels (:268-286).
  * Texture fetches use fp32 bilinear weights (the hardware's 8-bit weights are not modelled). */
 typedef struct MiptWhittedGeometry {

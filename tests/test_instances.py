@@ -241,8 +241,8 @@ def test_whitted_programs_over_the_instance_structure(tmp_path):
 
 def test_any_hit_programs_inside_instances(tmp_path):
     """MASK and BLEND materials on the INSTANCED meshes: the Whitted any-hit programs (alpha test for radiance rays, attenuation
-    for occlusion rays, cuda/whitted.cu:100-136) run inside the two-level walk (k_wh_trace_inst).  Checked against the same scene
-    flattened under one BVH (k_wh_trace, which the oracle pins in tests/test_whitted.py): only the roundings of the instance
+    for occlusion rays, cuda/whitted.cu:100-136) run over the two-level structure (k_wh_trace_pool_inst).  Checked against the same scene
+    flattened under one BVH (k_wh_trace_pool, which the oracle pins in tests/test_whitted.py): only the roundings of the instance
     transform differ, so almost every pixel is bit-identical and the rest are pixels whose ray passes within rounding of a
     triangle or texel edge."""
     import torch
@@ -266,8 +266,8 @@ def test_any_hit_programs_inside_instances(tmp_path):
         MV.cleanup(st)
     a, b = frames[True], frames[False]
     assert np.isfinite(a).all() and a[..., :3].max() > 0.05
-    # (an occlusion ray multiplies the (1 - alpha) of the BLEND surfaces it crosses in the order it meets them, which differs
-    #  between the two structures: the products agree to rounding, not bit for bit)
+    # (an occlusion ray multiplies the (1 - alpha) of the surfaces it crosses in the order of t over both structures; what differs are
+    #  the roundings of t, u, v themselves -- the object-space ray -- so products agree to rounding, not bit for bit)
     d = np.abs(a - b)[..., :3].max(-1)
     print("pixels that differ by more than 1e-5: %.4f, more than 1e-2: %.4f, mean |d| %.2e" % ((d > 1e-5).mean(), (d > 1e-2).mean(), d.mean()))
     assert (d > 1e-5).mean() < 0.02 and (d > 1e-2).mean() < 0.005 and d.mean() < 1e-3
