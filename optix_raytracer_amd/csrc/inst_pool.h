@@ -76,7 +76,7 @@ __device__ __forceinline__ RayO to_object(const u32x4 m0, const u32x4 m1, const 
 // round inside that instance reads it instead of fetching the instance's matrix (3 of the round's 7 loads) and transforming again.
 // One entry per slot, replaced on a miss; a slot whose entries alternate between instances misses on each change, no more.
 constexpr int kXrWords = 64 * 8;                           // [slot][8]: tag, o'.xyz, d'.xyz, writer
-template <int MODE, int CAP, bool CACHE = false, bool AH = false>
+template <int MODE, int CAP, bool CACHE = false, int AH = 0>
 __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint2* stk, unsigned long long* sh_best,
                                                 float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, int& psize, const bool cull_back INST_STATS_PARAM,
                                                 uint32_t* xr = nullptr)
@@ -106,7 +106,7 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
     float ix = shfl_f(T.idir.x, slot), iy = shfl_f(T.idir.y, slot), iz = shfl_f(T.idir.z, slot);
     float nx = shfl_f(T.nood.x, slot), ny = shfl_f(T.nood.y, slot), nz = shfl_f(T.nood.z, slot);
     const float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
-    const uint32_t skp = AH ? shfl_u(T.skip, slot) : 0xffffffffu;       // continuation key of the any-hit-program kernels (Trav::skip)
+    const uint32_t skp = AH != 0 ? shfl_u(T.skip, slot) : 0xffffffffu;       // continuation key of the any-hit-program kernels (Trav::skip)
     float tcur = tmx;
     bool live = have;
     if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[slot] >> 32)); }
@@ -202,16 +202,20 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
         const float v = fdot(rd, q) * inv;
         const float t = fdot(e2, q) * inv;
         const uint32_t prim = rec_word + f2u(n0.w);           // the flattened index
-        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && (t > tmn || (AH && t == tmn && prim > skp)) && t < tmx &&
+        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && (t > tmn || (AH != 0 && t == tmn && prim > skp)) && t < tmx &&
                         (!cull_back || det > 0.0f || (f2u(n1.w) & 4u) != 0u);
         bool stop = false;
         if (MODE != 0) {
             if (ok) { sh_done[slot] = 1u; stop = true; }
+        } else if (AH == 2 && ok && (f2u(n1.w) & 1u) != 0u) {
+            // AH 2 (occlusion rays with any-hit programs): a candidate WITHOUT program ends the ray wherever it lies in the interval -- the
+            // slot's key drops below every real one (t = -inf: the ray's other entries fail their box tests at once), the owner sees it
+            atomicMin(&sh_best[slot], kAhOccludedKey);
         } else if (ok) {
             const unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
             atomicMin(&sh_best[slot], key);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; if (AH) sh_done[slot] = f2u(n1.w); }   // AH: the winner's geometry flags
+            if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; if (AH != 0) sh_done[slot] = f2u(n1.w); }   // AH: the winner's geometry flags
         }
         if (!stop && lcnt > 1u) {
             push1 = 0x80000000u | ((lfirst + 1u) << 8) | ((lcnt - 2u) << 6) | slot;
@@ -232,7 +236,7 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
 }
 
 // a wave's rays (one per lane where has_ray) through the pool from the top level's root; results in sh_best / sh_u / sh_v / sh_done
-template <int MODE, int CAP, bool CACHE = false, bool AH = false>
+template <int MODE, int CAP, bool CACHE = false, int AH = 0>
 __device__ __forceinline__ void tail_trace_inst(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint2* stk, unsigned long long* sh_best,
                                                 float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, const bool has_ray, const bool cull_back INST_STATS_PARAM,
                                                 uint32_t* xr = nullptr)

@@ -1,6 +1,6 @@
 // pool_trace.h -- the entry-pool traversal of a one-level BVH: a step's loads (load_step), one round of a wave's pool (pool_round)
 // and a chunk of rays traversed from the root (tail_trace).  Moved out of kernels.hip unchanged (round 3) so that the Whitted
-// any-hit-program kernels (whitted_kernels.hip) traverse with the same code; AH = true adds their continuation key (below).
+// any-hit-program kernels (whitted_kernels.hip) traverse with the same code; AH = 1 / 2 adds their continuation key (below).
 #pragma once
 #include "kernels.h"
 #include "detmath.h"
@@ -130,7 +130,7 @@ __device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, con
 // each lane processes one -- an inner node: slab-test both children against the ray's current best t and push the
 // survivors, nearer on top; a leaf reference: test its first triangle and push the rest of the leaf.  The ray of slot s is
 // read from the registers of lane s; its best hit is merged in LDS (min t, tie -> lowest primitive).
-template <int MODE, int CAP, int Q, bool AH = false>
+template <int MODE, int CAP, int Q, int AH = 0>
 __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, int& psize, const bool cull_back PROBE_PARAM)
@@ -168,7 +168,7 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
     const float ix = shfl_f(T.idir.x, slot), iy = shfl_f(T.idir.y, slot), iz = shfl_f(T.idir.z, slot);
     const float nx = shfl_f(T.nood.x, slot), ny = shfl_f(T.nood.y, slot), nz = shfl_f(T.nood.z, slot);
     const float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
-    const uint32_t skp = AH ? shfl_u(T.skip, slot) : 0xffffffffu;       // continuation key of the any-hit-program kernels (Trav::skip)
+    const uint32_t skp = AH != 0 ? shfl_u(T.skip, slot) : 0xffffffffu;       // continuation key of the any-hit-program kernels (Trav::skip)
     float tcur = tmx;
     bool live = have;
     if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[slot] >> 32)); }
@@ -222,16 +222,20 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
         const float v = fdot(rd, q) * inv;
         const float t = fdot(e2, q) * inv;
         const uint32_t prim = f2u(n0.w);
-        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && (t > tmn || (AH && t == tmn && prim > skp)) && t < tmx &&
+        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && (t > tmn || (AH != 0 && t == tmn && prim > skp)) && t < tmx &&
                         (!cull_back || det > 0.0f || (f2u(n1.w) & 4u) != 0u);
         bool stop = false;
         if (MODE != 0) {
             if (ok) { sh_done[slot] = 1u; stop = true; }
+        } else if (AH == 2 && ok && (f2u(n1.w) & 1u) != 0u) {
+            // AH 2 (occlusion rays with any-hit programs): a candidate WITHOUT program ends the ray wherever it lies in the interval -- the
+            // slot's key drops below every real one (t = -inf: the ray's other entries fail their box tests at once), the owner sees it
+            atomicMin(&sh_best[slot], kAhOccludedKey);
         } else if (ok) {
             const unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
             atomicMin(&sh_best[slot], key);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; if (AH) sh_done[slot] = f2u(n1.w); }   // AH: the winner's geometry flags
+            if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; if (AH != 0) sh_done[slot] = f2u(n1.w); }   // AH: the winner's geometry flags
         }
         if (!stop && lcnt > 1u) {
             push1 = 0x80000000u | ((lfirst + 1u) << 8) | ((lcnt - 2u) << 6) | slot;
@@ -266,7 +270,7 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
 }
 
 
-template <int MODE, int Q, int CAP = 24 * 64 - 384, bool AH = false>
+template <int MODE, int Q, int CAP = 24 * 64 - 384, int AH = 0>
 __device__ __forceinline__ uint2 tail_trace(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
                                            unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done,
                                            const int lane, const Trav& T, const bool has_ray, const bool cull_back = false)

@@ -270,6 +270,7 @@ __device__ __forceinline__ void anyhit_advance(const WhConsts& c, Trav& T, bool&
                                                const float u, const float v, const uint32_t gflags)
 {
     const uint32_t prim = (uint32_t)key;
+    if (MODE != 0 && key == kAhOccludedKey) { occlusion = 0.0f; open = false; return; }  // a candidate without program somewhere in the interval
     if (prim == 0xffffffffu) { open = false; return; }                                   // nothing left in the interval
     const float t = ord_float((uint32_t)(key >> 32));
     if (anyhit_step<MODE>(c, gflags, prim, u, v, occlusion)) { open = false; rec = make_float4(t, u2f(prim), u, v); }
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
         float occlusion = 1.0f;
         float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
         while (__ballot(open) != 0ull) {
-            tail_trace<0, Q, kPoolCap, true>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, open, MODE == 0);
+            tail_trace<0, Q, kPoolCap, MODE == 0 ? 1 : 2>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, open, MODE == 0);
             if (open) anyhit_advance<MODE>(c, T, open, occlusion, rec, sh_best[lane], sh_u[lane], sh_v[lane], sh_done[lane]);
         }
         if (mine) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool_inst(WhConsts c, WhTraceAr
         float occlusion = 1.0f;
         float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
         while (__ballot(open) != 0ull) {
-            tail_trace_inst<0, kCap, false, true>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, open, MODE == 0 INST_STATS_ARG);
+            tail_trace_inst<0, kCap, false, MODE == 0 ? 1 : 2>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, open, MODE == 0 INST_STATS_ARG);
             if (open) anyhit_advance<MODE>(c, T, open, occlusion, rec, sh_best[lane], sh_u[lane], sh_v[lane], sh_done[lane]);
         }
         if (mine) {
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(64) void k_wh_trace(WhConsts c, WhTraceArgs a)
                     const uint32_t prim = f2u(ta.w), gflags = f2u(tb.w);
                     if (!((t > T.tmin || (t == T.tmin && prim > skip)) && t < T.tmax)) continue;
                     if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;            // back face of a single-sided triangle
+                    if (MODE != 0 && (gflags & 1u) != 0u) { occlusion = 0.0f; T.prim = 0xffffffffu; T.sp = 0; T.node = kSentinel; break; }   // no program: occluded, wherever it lies
                     if (t < T.tbest || (t == T.tbest && prim < T.prim)) { T.tbest = t; T.prim = prim; T.u = u; T.v = v; gflags_best = gflags; }
                 }
                 T.node = stk.pop(T.sp);
@@ -435,11 +437,12 @@ __global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, WhTraceArgs a)
             float tbest = tmax, bu = 0.0f, bv = 0.0f; uint32_t bprim = 0xffffffffu, bflags = 0u;
             int sp = 0;
             int node = 0;
-            while (node != kSentinel) {
+            bool dead = false;                                  // MODE 1: a candidate without program was met
+            while (node != kSentinel && !dead) {
                 while (node >= 0) node = step_inner(bvh.nodes, node, W, tmin, tbest, stk, sp, 0);
                 if (node == kSentinel) break;
                 const uint32_t idesc = ~(uint32_t)node, ifirst = idesc >> 4, icnt = idesc & 15u;
-                for (uint32_t k = 0; k < icnt; ++k) {
+                for (uint32_t k = 0; k < icnt && !dead; ++k) {
                     const DeviceInstance& in = bvh.inst[bvh.inst_order[ifirst + k]];
                     RayO O;
                     const f3 mo = xform_vec(in.inv, W.o);
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, WhTraceArgs a)
                     prepare(O);
                     const int base = sp;
                     int mn = 0;
-                    while (mn != kSentinel) {
+                    while (mn != kSentinel && !dead) {
                         while (mn >= 0) mn = step_inner(in.nodes, mn, O, tmin, tbest, stk, sp, base);
                         if (mn == kSentinel) break;
                         const uint32_t desc = ~(uint32_t)mn, first = desc >> 4, cnt = desc & 15u;
@@ -469,6 +472,7 @@ __global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, WhTraceArgs a)
                             const uint32_t prim = in.prim_base + f2u(ta.w), gflags = f2u(tb.w);
                             if (!((t > tmin || (t == tmin && prim > skip)) && t < tmax)) continue;
                             if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;        // back face of a single-sided triangle
+                            if (MODE != 0 && (gflags & 1u) != 0u) { occlusion = 0.0f; dead = true; break; }
                             if (bprim == 0xffffffffu || t < tbest || (t == tbest && prim < bprim)) { tbest = t; bprim = prim; bu = u; bv = v; bflags = gflags; }
                         }
                         mn = stk.pop(sp, base);
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, WhTraceArgs a)
                 }
                 node = stk.pop(sp, 0);
             }
-            if (bprim == 0xffffffffu) break;
+            if (dead || bprim == 0xffffffffu) break;
             if (anyhit_step<MODE>(c, bflags, bprim, bu, bv, occlusion)) { rec = make_float4(tbest, u2f(bprim), bu, bv); open = false; }
             else { tmin = tbest; skip = bprim; }
         }

@@ -243,7 +243,8 @@ def write_instanced_gltf(path, n_instances=150, seed=9, alpha_textures=None, blo
     camera node.  Every node with a mesh becomes one sutil::Scene instance (Scene.cpp:192-205).  Returns the path.
     alpha_textures = (png bytes, png bytes): the blob becomes a BLEND material and the box a double-sided MASK material over
     those RGBA images (both meshes get TEXCOORD_0), so the Whitted any-hit programs run inside the instances.
-    blob_mode = "MASK": the blob is cut out by the second image as well (foliage-like: rays end at the first solid texel)."""
+    blob_mode = "MASK": the blob is cut out by the second image as well (foliage-like: rays end at the first solid texel);
+    "OPAQUE": the blob stays opaque and only the boxes are cut out (a mostly opaque scene with one alpha-tested material)."""
     import base64
     import json
     rng = np.random.default_rng(seed)
@@ -318,15 +319,16 @@ def write_instanced_gltf(path, n_instances=150, seed=9, alpha_textures=None, blo
         doc["images"] = [{"uri": uri(alpha_textures[0])}, {"uri": uri(alpha_textures[1])}]
         doc["samplers"] = [{"minFilter": 9728, "magFilter": 9728}, {}]
         doc["textures"] = [{"source": 0, "sampler": 0}, {"source": 1, "sampler": 1}]
-        if blob_mode == "MASK":
+        if blob_mode in ("MASK", "OPAQUE"):
             doc["textures"].append({"source": 1, "sampler": 0})             # nearest texel: alpha is 0 or 1, a ray ends at the first solid one
-            doc["materials"][0].update({"alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True})
-            doc["materials"][0]["pbrMetallicRoughness"].update({"baseColorTexture": {"index": 2}})
+            if blob_mode == "MASK":
+                doc["materials"][0].update({"alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True})
+                doc["materials"][0]["pbrMetallicRoughness"].update({"baseColorTexture": {"index": 2}})
         else:
             doc["materials"][0].update({"alphaMode": "BLEND", "doubleSided": True})
             doc["materials"][0]["pbrMetallicRoughness"].update({"baseColorFactor": [0.85, 0.55, 0.2, 0.8], "baseColorTexture": {"index": 0}})
         doc["materials"][1].update({"alphaMode": "MASK", "alphaCutoff": 0.5, "doubleSided": True})
-        doc["materials"][1]["pbrMetallicRoughness"].update({"baseColorTexture": {"index": 2 if blob_mode == "MASK" else 1}})
+        doc["materials"][1]["pbrMetallicRoughness"].update({"baseColorTexture": {"index": 2 if blob_mode in ("MASK", "OPAQUE") else 1}})
     path.write_text(json.dumps(doc))
     return path
 
