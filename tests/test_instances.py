@@ -275,6 +275,70 @@ def test_any_hit_programs_inside_instances(tmp_path):
     assert stats[True]["closest_rays"] > w * h and abs(stats[True]["shadow_rays"] - stats[False]["shadow_rays"]) < 0.01 * stats[False]["shadow_rays"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("persistent", [None, 2])
+def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, persistent):
+    """The deferred any-hit programs over the two-level structure (k_wh_trace_pool_inst; persistent = 2: k_wh_trace_inst, one ray per
+    thread) against the ORACLE's two-level render of the same structure: textured BLEND and MASK materials on the instanced meshes,
+    frames, frame buffer and ray counters bit for bit -- candidates in the order of (t, flattened primitive index), t taken with the
+    object-space ray, exactly as the oracle's gas_traverse has it."""
+    import torch
+    import _png_fixture as PF
+    from optix_raytracer_amd import meshviewer as MV
+    from optix_raytracer_amd import scenes
+    from optix_raytracer_amd import _lib as L
+    rng = np.random.default_rng(12)
+    film = np.zeros((8, 8, 4), np.int64); film[..., :3] = rng.integers(60, 255, (8, 8, 3)); film[..., 3] = rng.integers(40, 230, (8, 8))
+    fence = np.zeros((8, 8, 4), np.int64); fence[..., :3] = 200; fence[..., 3] = np.where((np.add.outer(np.arange(8), np.arange(8)) % 3) == 0, 0, 255)
+    path = scenes.write_instanced_gltf(tmp_path / "instanced_alpha.gltf", n_instances=70, seed=8,
+                                       alpha_textures=(PF.encode(film, 6, 8)[0], PF.encode(fence, 6, 8)[0]))
+    w, h = 200, 112
+    st = MV.MeshViewerState()
+    MV.loadScene(st, path, two_level=True)
+    if persistent is not None:
+        st.context.set_option(L.OPT_PERSISTENT, persistent)
+    MV.initCameraState(st)
+    MV.initLaunchParams(st, w, h)
+    out = MV.OutputBuffer(w, h, st.device)
+    tot = [0, 0]
+    for _ in range(2):
+        MV.updateState(st)
+        MV.launchSubframe(out, st)
+        s = st.context.launch_stats()
+        tot[0] += s["closest_rays"]; tot[1] += s["shadow_rays"]
+        st.params.subframe_index += 1
+    ctx = st.context
+    assert any(m.alpha_mode != 0 for m in st.materials) and ctx.accel_info(st.handle)["num_instances"] > 0
+    verts, mat = st.scene.flatten()
+    flat = {"vertices": verts, "mat_index": np.zeros(mat.shape[0], np.uint32), "emission": np.zeros((1, 3), np.float32), "diffuse": np.ones((1, 3), np.float32)}
+    osc = _oracle_two_level(ctx, flat, st.handle)
+    gf = MV.geometry_flags(st.materials)
+    osc.set_prim_flags(gf[np.minimum(mat, len(gf) - 1)])
+    mats = [{"base_color": list(m.base_color), "metallic": m.metallic, "roughness": m.roughness, "emissive_factor": list(m.emissive_factor),
+             "alpha_mode": m.alpha_mode, "alpha_cutoff": m.alpha_cutoff, "double_sided": m.double_sided} for m in st.materials]
+    for m, sm in zip(mats, st.scene.materials()):
+        for k in ("base_color_tex", "metallic_roughness_tex", "normal_tex", "emissive_tex"):
+            m[k] = sm[k]
+    lights = [{"type": l.type, "color": list(l.color), "intensity": l.intensity, "position": list(l.position), "falloff": l.falloff}
+              for l in list(st.lights)[: st.params.lights.count]]
+    uv = st.scene.flatten_texcoords(0)
+    normals = st.scene.flatten_normals()
+    p = st.params
+    acc = np.zeros((h, w, 4), np.float32)
+    oc = [0, 0]
+    for sf in range(2):
+        la = {"width": w, "height": h, "subframe": sf, "eye": list(p.eye), "U": list(p.U), "V": list(p.V), "W": list(p.W), "miss_color": list(p.miss_color)}
+        acc, frame, ost = osc.render_whitted(la, lights, mats, mat, normals4=normals, accum=acc, texcoords=(uv[0], None), texcoord_present=(uv[1], None),
+                                            textures=st.scene.textures(), mode=O.MODE_INST)
+        oc[0] += ost["closest_rays"]; oc[1] += ost["shadow_rays"]
+    got = st.accum.cpu().numpy()
+    bad = np.argwhere(got.view(np.uint32) != acc.view(np.uint32))
+    assert bad.size == 0, "first differing pixel %s: gpu %s cpu %s (%d differ)" % (bad[0], got[tuple(bad[0][:2])], acc[tuple(bad[0][:2])], len(bad))
+    assert np.array_equal(out.getHostPointer(), frame)
+    assert tot == oc and tot[0] > w * h * 2 and tot[1] > 1000                      # continuation rays were traced
+    MV.cleanup(st)
+
+
 @pytest.mark.parametrize("form", [1, 2])
 def test_every_traversal_form_gives_the_same_records(tmp_path, monkeypatch, form):
     """Round 3: three forms walk a two-level structure -- tiles of 64 rays, one ray per lane with the object-space ray in registers, then
