@@ -34,7 +34,7 @@ struct DeviceCounters {
     // 8 000 waves ending within the same 0.2 ms queued 25 us of them behind a rank's 1/8 shard.  Read as sums / a maximum (tail_stats_*).
     unsigned long long bins[64 * 16];
     uint32_t epoch;            // path kernels that do their own begin_sample (TailArgs): the launch whose first workgroup is through it
-    uint32_t pad_;
+    uint32_t n_open;           // Whitted any-hit programs, seeded radiance launches: rays whose closest candidate the program ignored (k_wh_seed)
     uint32_t* fault_host;      // pinned host word (MiptContext::h_pinned + kFaultWord): a kernel that gave up on a bounded wait ORs its
                                // kFault* bit into it; mipt_sync / mipt_get_launch_stats / the next launch turn it into an error
 };
@@ -64,6 +64,8 @@ struct DeviceBvh {
     // buffer descriptor.  inst_fast = 0: only the one-ray-per-lane walk (k_trace_inst) can traverse the structure.
     uint32_t inst_fast, inst_off, inst_node4_off, inst_tri_off, inst_blob_bytes;
     uint32_t inst_root4_off;   // per top-level BVH4 node 4 words: the BVH4 root of the mesh behind each LEAF child (an instance)
+    const uint8_t* prim_flags; // one-level: geometry flags per ORIGINAL primitive (null: not kept by the builder that made this BVH)
+    uint32_t inst_flags;       // two-level: every DeviceInstance::prim_flags is set
     uint32_t top_off;          // experiment MIPT_TOP_CACHE: byte offset of the top-of-tree copy of the packed mirror (64 nodes + their real indices); 0 = none
     uint32_t node_fmt;         // 0: fp32 64-byte BVH2 nodes only; 1: + packed 32-byte BVH2 nodes at node32_off (MiptBvhNode32: the boxes of
                                // `nodes` as fp16 -- the two arrays hold the SAME values), walked by every entry-pool kernel; 2: + the BVH4
@@ -77,8 +79,10 @@ struct DeviceInstance {
     const float4* tris;        // ... and triangles (48 bytes each), object space
     uint32_t      prim_base;   // flattened index of the mesh's primitive 0 within this instance
     uint32_t      root4;       // entry-pool form: index of the mesh's BVH4 root in the structure's BVH4 array (DeviceBvh::inst_node4_off)
-    uint32_t      pad[2];
+    const uint8_t* prim_flags; // the mesh's geometry flags per mesh-local primitive (null: not kept)
 };
+
+static_assert(sizeof(DeviceInstance) == 80, "the pool kernels fetch an instance record in 16-byte pieces");
 
 // SoA path queues, capacity `cap` entries each
 struct PathQueue {

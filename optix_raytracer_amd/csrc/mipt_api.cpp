@@ -73,6 +73,7 @@ struct Accel {
     uint32_t  num_nodes4 = 0;
     uint32_t* d_mat   = nullptr;
     uint8_t*  d_height = nullptr;  // height of every node (topology only: made at build time, reused by every refit and by the BVH4 collapse)
+    uint8_t*  d_prim_flags = nullptr;   // geometry flags per ORIGINAL primitive (host builder; null: not kept) -- the Whitted any-hit kernels look a hit's flags up here
     uint32_t  n_prims = 0;
     uint64_t  bytes   = 0;
     // two-level structure (mipt_accel_build_instances): d_nodes then holds the BVH over the instance boxes
@@ -87,6 +88,7 @@ struct Accel {
     // entry-pool form of a two-level structure (DeviceBvh::inst_fast): d_nodes is then ONE allocation, d_inst lies inside it
     bool                       inst_fast = false;
     bool                       stale = false;    // a mesh this structure references was refitted since: mipt_accel_update_instances first
+    bool                       inst_flags = false;   // every instance record carries its mesh's d_prim_flags
     uint32_t                   inst_off = 0, inst_node4_off = 0, inst_tri_off = 0, inst_blob_bytes = 0, inst_root4_off = 0;
 };
 
@@ -291,6 +293,7 @@ void free_accel(Accel* a)
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_mat) (void)hipFree(a->d_mat);
     if (a->d_height) (void)hipFree(a->d_height);
+    if (a->d_prim_flags) (void)hipFree(a->d_prim_flags);
     if (a->d_inst) (void)hipFree(a->d_inst);
     if (a->d_order) (void)hipFree(a->d_order);
     delete a;
@@ -424,12 +427,14 @@ DeviceBvh device_bvh(const Accel* a)
     b.pool2_ok = (b.pool_ok && a->num_nodes < (1u << 24) && a->num_tris < (1u << 22)) ? 1u : 0u;
     b.node32_off = a->node32_off; b.node_fmt = a->node32_off ? a->node_fmt : 0u;
     b.node4_off = b.node_fmt == 2u ? a->node4_off : 0u; b.stack4 = a->stack_need; b.top_off = b.node_fmt >= 1u ? a->top_off : 0u;
+    b.prim_flags = a->d_prim_flags;
     if (a->is_ias) {
         b.inst = a->inst_fast ? reinterpret_cast<const DeviceInstance*>(reinterpret_cast<const char*>(a->d_nodes) + a->inst_off) : a->d_inst;
         b.inst_order = a->d_order; b.n_inst = (uint32_t)a->gas.size(); b.pool_ok = b.pool2_ok = 0u; b.tri_byte_off = 0u; b.node32_off = 0u;
         b.node_fmt = 0u; b.node4_off = 0u; b.blob_bytes = 0u;
         b.inst_fast = a->inst_fast ? 1u : 0u; b.inst_off = a->inst_off; b.inst_node4_off = a->inst_node4_off; b.inst_tri_off = a->inst_tri_off;
         b.inst_blob_bytes = a->inst_blob_bytes; b.stack4 = a->stack_need; b.inst_root4_off = a->inst_root4_off;
+        b.prim_flags = nullptr; b.inst_flags = a->inst_flags ? 1u : 0u;
     }
     return b;
 }
@@ -1052,6 +1057,12 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     }
     if (e == hipSuccess) e = finish_blob(ctx, a);
     if (e == hipSuccess) e = hipMalloc((void**)&a->d_mat, mb);
+    if (e == hipSuccess && n_tris && gflags.size() >= n_tris) {
+        std::vector<uint8_t> fb(n_tris);
+        for (uint32_t t = 0; t < n_tris; ++t) fb[t] = (uint8_t)gflags[t];
+        e = hipMalloc((void**)&a->d_prim_flags, n_tris);
+        if (e == hipSuccess) e = hipMemcpy(a->d_prim_flags, fb.data(), n_tris, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && n_tris) e = hipMemcpy(a->d_mat, mats.data(), (size_t)n_tris * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         free_accel(a);
@@ -1108,6 +1119,7 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
     std::vector<uint32_t> h_base(n, 0u);
     std::vector<unsigned long long> gas(n, 0ull);
     uint64_t total_tris = 0; uint32_t max_depth = 0;
+    bool all_flags = n != 0u;
     for (uint32_t k = 0; k < n; ++k) {
         Accel* g = find_accel(ctx, inst[k].traversableHandle);
         if (!g || g->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "instance %u: traversableHandle 0x%llx is not a triangle acceleration structure of this context",
@@ -1137,6 +1149,7 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
         DeviceInstance& d = recs[k];
         std::memcpy(d.inv, &h_inv[(size_t)k * 12], 48);
         d.nodes = g->d_nodes; d.tris = g->d_tris; d.prim_base = (uint32_t)total_tris;
+        d.prim_flags = g->d_prim_flags; all_flags = all_flags && g->d_prim_flags != nullptr;
         h_base[k] = (uint32_t)total_tris; gas[k] = inst[k].traversableHandle;
         total_tris += g->n_prims;
         max_depth = std::max(max_depth, g->depth);
@@ -1235,6 +1248,7 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
     a->depth = top.depth + max_depth; a->leaf_max = 1; a->is_ias = true; a->stale = false;
     uint32_t mesh_stack = 0u;
     for (const MeshSlot& m : meshes) mesh_stack = std::max(mesh_stack, m.g->stack_need);
+    a->inst_flags = all_flags;
     a->inst_fast = fast; a->stack_need = fast ? stack4 + mesh_stack : 0u;      // the most entries a lane's stack over BOTH levels can hold
     a->inst_off = fast ? (uint32_t)o_inst : 0u; a->inst_node4_off = fast ? (uint32_t)o_n4 : 0u; a->inst_tri_off = fast ? (uint32_t)o_tri : 0u;
     a->inst_blob_bytes = fast ? (uint32_t)arena : 0u; a->inst_root4_off = fast ? (uint32_t)o_r4 : 0u;

@@ -262,6 +262,7 @@ struct WhTraceArgs {
     const uint32_t* n_ptr; uint32_t n_max;
     float4* hits; float* attenuation;
     uint32_t ppw, cus;             // ppw 0: chosen on the device (ah_rays_per_wave)
+    const uint32_t* open_list;     // MODE 0, seeded launch: the rays to trace (k_wh_seed; n_ptr counts them), each from beyond the candidate in hits[ray]
 };
 
 // one ray's bookkeeping after a traversal: `key` / u / v / gflags = the closest remaining candidate (sh_best and its fellows)
@@ -275,6 +276,50 @@ __device__ __forceinline__ void anyhit_advance(const WhConsts& c, Trav& T, bool&
     const float t = ord_float((uint32_t)(key >> 32));
     if (anyhit_step<MODE>(c, gflags, prim, u, v, occlusion)) { open = false; rec = make_float4(t, u2f(prim), u, v); }
     else { T.tmin = t; T.skip = prim; }
+}
+
+// geometry flags of a (flattened) primitive from the builders' tables: the instance is the last one whose prim_base is <= prim
+__device__ __forceinline__ uint32_t prim_geometry_flags(const DeviceBvh& bvh, uint32_t prim)
+{
+    if (!bvh.inst) return bvh.prim_flags[prim];
+    uint32_t lo = 0u, hi = bvh.n_inst;                  // invariant: inst[lo].prim_base <= prim < inst[hi].prim_base (hi = n: the end)
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (bvh.inst[mid].prim_base <= prim) lo = mid; else hi = mid; }
+    const DeviceInstance& in = bvh.inst[lo];
+    return in.prim_flags[prim - in.prim_base];
+}
+
+// A seeded launch (MODE 0): the fast closest-hit kernels -- tiles of 64 rays for a level's millions of rays -- have found every ray's
+// closest candidate with all geometry taken as opaque; that candidate is exactly the first one of the loop below.  k_wh_seed runs the
+// program on it, one ray per thread: accepted (or no program, or a miss) -> the hit record stands; IGNORED -> the ray's index joins
+// the list `open` (one atomic per workgroup), and only the listed rays, densely packed into chunks, are traversed here, starting
+// beyond their candidate.  Needs the geometry flags of a hit's primitive: the builders' per-primitive tables (DeviceBvh::prim_flags,
+// DeviceInstance::prim_flags; structures without them take the unseeded launch).  Default over two-level structures only.  1080p,
+// 2 000 instances, boxes MASK / everything
+// MASK (profiles/r03_bench_alpha.txt): two-level 3.29 -> 2.86 / 4.41 -> 3.92 ms; one level 2.10 -> 2.12 / 2.87 -> 2.90 ms -- there the
+// tiled launch (0.35 ms) + this filter (0.05) + the listed rays (0.37: few rays, but each ignored candidate is one more traversal from
+// the root, and the longest such chain sets the launch's duration) only just beat the unseeded launch (0.81).
+// (Seeding inside the traversal kernel instead, ray i in lane i: a chunk with ONE open ray costs a traversal's latency all the same,
+// and most chunks have one -- no gain at all.)
+__global__ __launch_bounds__(256) void k_wh_seed(WhConsts c, DeviceBvh bvh, const uint32_t* n_ptr, uint32_t n_max, const float4* hits, uint32_t* open_list,
+                                                 DeviceCounters* ctr)
+{
+    __shared__ uint32_t s2[2];
+    if (threadIdx.x == 0u) s2[0] = 0u;
+    __syncthreads();
+    uint32_t n = n_max;
+    if (n_ptr) { const uint32_t m = *n_ptr; n = m < n ? m : n; }
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {       // (uniform trip count: block_append synchronises)
+        const uint32_t ray = base + threadIdx.x;
+        bool push = false;
+        if (ray < n) {
+            const float4 h = hits[ray];
+            const uint32_t prim = f2u(h.y);
+            float occlusion = 1.0f;
+            push = prim != 0xffffffffu && !anyhit_step<0>(c, prim_geometry_flags(bvh, prim), prim, h.z, h.w, occlusion);
+        }
+        const uint32_t at = block_append(push, &ctr->n_open, s2);
+        if (push) open_list[at] = ray;
+    }
 }
 
 #ifndef MIPT_WH_AH_ROWS
@@ -296,12 +341,14 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
     const uint32_t ppw = ah_rays_per_wave(a.ppw, n, a.cus);
     const uint32_t chunks = (n + ppw - 1u) / ppw;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
-        const uint32_t ray = chunk * ppw + (uint32_t)lane;
+        uint32_t ray = chunk * ppw + (uint32_t)lane;
         const bool mine = (uint32_t)lane < ppw && ray < n;
+        if (MODE == 0 && a.open_list != nullptr && mine) ray = a.open_list[ray];
         Trav T;
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[ray], a.ray_d[ray]);
+        if (MODE == 0 && a.open_list != nullptr && mine) { const float4 h = a.hits[ray]; T.tmin = h.x; T.skip = f2u(h.y); }      // beyond the ignored candidate
         bool open = mine && T.node != kSentinel;
         float occlusion = 1.0f;
         float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
@@ -337,12 +384,14 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool_inst(WhConsts c, WhTraceAr
     uint32_t ist[6] = { 0u, 0u, 0u, 0u, 0u, 0u };
 #endif
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
-        const uint32_t ray = chunk * ppw + (uint32_t)lane;
+        uint32_t ray = chunk * ppw + (uint32_t)lane;
         const bool mine = (uint32_t)lane < ppw && ray < n;
+        if (MODE == 0 && a.open_list != nullptr && mine) ray = a.open_list[ray];
         Trav T;
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[ray], a.ray_d[ray]);
+        if (MODE == 0 && a.open_list != nullptr && mine) { const float4 h = a.hits[ray]; T.tmin = h.x; T.skip = f2u(h.y); }      // beyond the ignored candidate
         bool open = mine && T.node != kSentinel;
         float occlusion = 1.0f;
         float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
@@ -693,7 +742,7 @@ __global__ __launch_bounds__(1024) void k_wh_gather(uint32_t K, WhLevel L, const
 __global__ void k_wh_advance(DeviceCounters* c)
 {
     const uint32_t i = threadIdx.x;
-    if (i == 0) { c->closest_rays += c->n_next; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; }
+    if (i == 0) { c->closest_rays += c->n_next; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; c->n_open = 0; }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
@@ -726,16 +775,28 @@ __global__ __launch_bounds__(256) void k_wh_resolve(WhConsts c, const float4* le
 // The launch of the any-hit-program traversal: the entry pool's form when the structure has the mirrors for it (a one-level BVH
 // whose packed entries fit, a two-level structure in its arena form), else one ray per thread.  MIPT_WH_ANYHIT=walk forces the
 // latter (tests compare the two).  Rays per wave: chosen on the device from the queue's length (ah_rays_per_wave).
+// MIPT_WH_ANYHIT = walk: one ray per thread (what structures without the pool's mirrors get); unseeded / seeded: never / wherever the
+// flag tables exist a fast closest-hit launch in front of the radiance rays (default: over two-level structures, where it gains)
+static int wh_anyhit_env()
+{
+    static const int v = [] { const char* e = std::getenv("MIPT_WH_ANYHIT"); return !e ? 0 : (std::strcmp(e, "walk") == 0 ? 1 : (std::strcmp(e, "unseeded") == 0 ? 2 : (std::strcmp(e, "seeded") == 0 ? 3 : 0))); }();
+    return v;
+}
+static bool wh_trace_on_pool(const DeviceBvh& bvh, const TraceOpts& o)
+{
+    return wh_anyhit_env() != 1 && o.persistent == 3 && (bvh.inst ? bvh.inst_fast != 0u : (bvh.pool_ok && bvh.tri_byte_off != 0u));
+}
+
 template <int MODE>
 static void launch_wh_trace(hipStream_t st, const WhConsts& c, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, const uint32_t* n_ptr,
-                            uint32_t n_max, float4* hits, float* attenuation, const TraceOpts& o)
+                            uint32_t n_max, float4* hits, float* attenuation, const TraceOpts& o, const uint32_t* open_list = nullptr)
 {
     if (n_max == 0u) return;
-    static const int e_form = [] { const char* e = std::getenv("MIPT_WH_ANYHIT"); return e && std::strcmp(e, "walk") == 0 ? 1 : 0; }();
     static const int e_ppw = [] { const char* e = std::getenv("MIPT_WH_AH_PPW"); return e ? std::atoi(e) : 0; }();
     WhTraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.n_ptr = n_ptr; a.n_max = n_max; a.hits = hits; a.attenuation = attenuation;
-    const bool pool = e_form == 0 && o.persistent == 3 && (bvh.inst ? bvh.inst_fast != 0u : (bvh.pool_ok && bvh.tri_byte_off != 0u));
+    a.open_list = open_list;
+    const bool pool = wh_trace_on_pool(bvh, o);
     if (!pool) {
         const int tblocks = o.blocks > 0 ? o.blocks : 4096;
         if (bvh.inst) hipLaunchKernelGGL((k_wh_trace_inst<MODE>), dim3(tblocks), dim3(64), 0, st, c, a);
@@ -766,13 +827,22 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
     const uint32_t blocks = (n_paths + 255u) / 256u;
     const uint32_t n_pixels = p.width * p.height;
     launch_begin_sample(st, ctr, n_paths, n_pixels);
+    if (B.any_hit_programs) (void)hipMemsetAsync(&ctr->n_open, 0, sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_wh_raygen, dim3(blocks), dim3(256), 0, st, c, B.q[0], B.n_levels);
     for (uint32_t level = 0; level < B.max_levels; ++level) {
         const PathQueue cur = B.q[level & 1u], next = B.q[(level & 1u) ^ 1u];
-        if (B.any_hit_programs) launch_wh_trace<0>(st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, nullptr, opts);
+        // (any-hit programs: the fast launch first when the structure's builders kept the geometry flags per primitive -- anyhit_seed)
+        const bool seeded = B.any_hit_programs && wh_anyhit_env() != 2 && wh_trace_on_pool(bvh, opts) &&
+                            (bvh.inst ? bvh.inst_flags != 0u : (wh_anyhit_env() == 3 && bvh.prim_flags != nullptr));
+        if (B.any_hit_programs && !seeded) launch_wh_trace<0>(st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, nullptr, opts);
         else
             launch_trace_closest(st, bvh, cur.ray_o, cur.ray_d, 1, &ctr->n_cur, n_paths, B.hits, ctr, opts,
                                  MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES);          // traceRadiance, whitted_cuda.h:110
+        if (seeded) {
+            uint32_t* const open_list = reinterpret_cast<uint32_t*>(B.group);          // (the group records are written by the shade launch that follows)
+            hipLaunchKernelGGL(k_wh_seed, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, c, bvh, &ctr->n_cur, n_paths, (const float4*)B.hits, open_list, ctr);
+            launch_wh_trace<0>(st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_open, n_paths, B.hits, nullptr, opts, open_list);
+        }
         WhLevel L{};
         L.cur = cur; L.next = next; L.hits = B.hits; L.sh = B.sh; L.e1 = B.e1; L.group = B.group; L.levels = B.levels; L.n_levels = B.n_levels;
         L.level = level; L.n_pixels = n_pixels; L.bound = n_paths;
