@@ -61,19 +61,26 @@ def parse():
     return ap.parse_args()
 
 
+KERNEL_SOURCES = ("kernels.hip", "kernels.h", "pool_trace.h", "pool_core.h", "trav_core.h", "inst_pool.h", "inst_core.h", "wave_util.h", "detmath.h")
+
+
 def kernels_blob_sha():
-    """git's blob id of the traversal kernels' source as it is in THIS tree (sha1 of "blob <len>\\0" + content): the GPU box has no
-    .git, so the profile carries the id it was measured on (tools/pmc_json.py) and the two are compared here."""
+    """An id of the traversal kernels' source as it is in THIS tree: sha1 over the git blob ids (sha1 of "blob <len>\\0" + content) of
+    kernels.hip and every header it includes, in KERNEL_SOURCES' order.  The GPU box has no .git, so the profile carries the id it was
+    measured on (tools/pmc_json.py imports this function) and the two are compared here."""
     import hashlib
-    data = open(os.path.join(ROOT, "optix_raytracer_amd", "csrc", "kernels.hip"), "rb").read()
-    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    h = hashlib.sha1()
+    for name in KERNEL_SOURCES:
+        data = open(os.path.join(ROOT, "optix_raytracer_amd", "csrc", name), "rb").read()
+        h.update(hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest().encode())
+    return h.hexdigest()
 
 
 def pmc_counters(kernel):
     """Per-launch PMC counters of `kernel` from the COMMITTED rocprofv3 passes (profiles/pmc_kernels.json, written by
     tools/prof_l1.sh + tools/pmc_json.py).  They are properties of the kernel on this workload, not of this run: bench.py
     cannot collect them itself (that takes ~20 rocprofv3 passes).  The profile is used only when it was measured on the
-    kernels.hip of this tree (blob id recorded in the file) and names exactly this kernel: a profile of other kernel source is
+    kernel sources of this tree (kernels_blob_sha(), recorded in the file) and names exactly this kernel: a profile of other kernel source is
     refused, not matched by name.  -> (counters or None, provenance)."""
     src = {"file": "profiles/pmc_kernels.json"}
     try:
@@ -82,7 +89,7 @@ def pmc_counters(kernel):
         return None, dict(src, refused="no profile on file")
     src.update(commit=d.get("commit"), source=d.get("source"), kernels_hip_blob=d.get("kernels_hip_blob"))
     if d.get("kernels_hip_blob") != kernels_blob_sha():
-        return None, dict(src, refused="the profile was measured on another kernels.hip (blob %s, this tree %s): re-run tools/prof_l1.sh" % (
+        return None, dict(src, refused="the profile was measured on other kernel sources (id %s, this tree %s: kernels.hip and its headers): re-run tools/prof_l1.sh" % (
             str(d.get("kernels_hip_blob"))[:12], kernels_blob_sha()[:12]))
     if kernel not in d["kernels"]:
         return None, dict(src, refused="the profile holds no kernel named %s" % kernel)

@@ -14,15 +14,32 @@ def _bench():
     return m
 
 
-def test_blob_id_is_gits():
+def test_source_id_covers_the_kernels_and_their_headers():
+    """bench.kernels_blob_sha(): sha1 over git's blob ids of kernels.hip and every header it includes -- a change in pool_trace.h is a
+    change of the kernels just as one in kernels.hip"""
     import hashlib
+    import re
     import subprocess
     b = _bench()
-    path = os.path.join(ROOT, "optix_raytracer_amd", "csrc", "kernels.hip")
-    data = open(path, "rb").read()
-    assert b.kernels_blob_sha() == hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
-    if os.path.isdir(os.path.join(ROOT, ".git")):
-        assert b.kernels_blob_sha() == subprocess.run(["git", "-C", ROOT, "hash-object", path], capture_output=True, text=True).stdout.strip()
+    csrc = os.path.join(ROOT, "optix_raytracer_amd", "csrc")
+    h = hashlib.sha1()
+    for name in b.KERNEL_SOURCES:
+        data = open(os.path.join(csrc, name), "rb").read()
+        blob = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+        if os.path.isdir(os.path.join(ROOT, ".git")):
+            assert blob == subprocess.run(["git", "-C", ROOT, "hash-object", os.path.join(csrc, name)], capture_output=True, text=True).stdout.strip()
+        h.update(blob.encode())
+    assert b.kernels_blob_sha() == h.hexdigest()
+    # every local header kernels.hip pulls in (transitively) is on the list
+    seen, todo = set(), ["kernels.hip"]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'#include "([^"/]+)"', open(os.path.join(csrc, f)).read()):
+            todo.append(inc)
+    assert seen <= set(b.KERNEL_SOURCES), seen - set(b.KERNEL_SOURCES)
 
 
 def test_profile_of_other_kernel_source_is_refused(tmp_path, monkeypatch):
@@ -31,10 +48,11 @@ def test_profile_of_other_kernel_source_is_refused(tmp_path, monkeypatch):
     (tmp_path / "profiles").mkdir()
     (tmp_path / "profiles" / "pmc_kernels.json").write_text(json.dumps(prof))
     (tmp_path / "optix_raytracer_amd" / "csrc").mkdir(parents=True)
-    (tmp_path / "optix_raytracer_amd" / "csrc" / "kernels.hip").write_bytes(b"// other source\n")
+    for name in b.KERNEL_SOURCES:
+        (tmp_path / "optix_raytracer_amd" / "csrc" / name).write_bytes(b"// other source\n")
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
     c, src = b.pmc_counters("k_trace_pool<0, 24, 1, true>")
-    assert c is None and "refused" in src and "another kernels.hip" in src["refused"]
+    assert c is None and "refused" in src and "other kernel sources" in src["refused"]
     prof["kernels_hip_blob"] = b.kernels_blob_sha()
     (tmp_path / "profiles" / "pmc_kernels.json").write_text(json.dumps(prof))
     c, src = b.pmc_counters("k_trace_pool<0, 24, 1, true>")

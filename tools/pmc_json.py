@@ -11,10 +11,10 @@ import sys
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 commit = sys.argv[4] if len(sys.argv) > 4 else subprocess.run(
     ["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-import hashlib
 import os
-_k = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "optix_raytracer_amd", "csrc", "kernels.hip"), "rb").read()
-blob = hashlib.sha1(b"blob %d\0" % len(_k) + _k).hexdigest()      # git's blob id of the kernel source the profile was taken on (bench.py checks it)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+blob = bench.kernels_blob_sha()      # the id of the kernel sources (kernels.hip + its headers) the profile was taken on: bench.py checks it
 out = {"source": tag, "commit": commit, "kernels_hip_blob": blob,
        "note": "rocprofv3 --pmc, separate passes (tools/prof_l1.sh); per-launch means of the timed dispatches; FETCH_SIZE / "
                "WRITE_SIZE in KB as rocprofv3 reports them (FETCH_SIZE counts 64 B per 128-B request on gfx950: double it)",
