@@ -784,7 +784,9 @@ static int wh_anyhit_env()
 }
 static bool wh_trace_on_pool(const DeviceBvh& bvh, const TraceOpts& o)
 {
-    return wh_anyhit_env() != 1 && o.persistent == 3 && (bvh.inst ? bvh.inst_fast != 0u : (bvh.pool_ok && bvh.tri_byte_off != 0u));
+    // (a tree of a few levels -- the alpha fixture's 14 triangles -- is walked faster one ray per thread: a chunk on the pool costs a
+    //  handful of rounds whatever the tree, 0.82 against 0.55 ms per 1080p subframe; from 2 k triangles on the pool wins, 0.48 against 0.65)
+    return wh_anyhit_env() != 1 && o.persistent == 3 && bvh.depth > 8u && (bvh.inst ? bvh.inst_fast != 0u : (bvh.pool_ok && bvh.tri_byte_off != 0u));
 }
 
 template <int MODE>
@@ -806,7 +808,9 @@ static void launch_wh_trace(hipStream_t st, const WhConsts& c, const DeviceBvh& 
     const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
     a.ppw = e_ppw >= 1 && e_ppw <= 64 ? (uint32_t)e_ppw : 0u; a.cus = cus;
     unsigned long long want = ((unsigned long long)n_max + 3u) / 4u;
-    want = want < cus * 16ull ? cus * 16ull : (want > cus * 256ull ? cus * 256ull : want);
+    static const int e_grid = [] { const char* e = std::getenv("MIPT_WH_AH_GRID"); return e ? std::atoi(e) : 0; }();      // waves per CU at most (experiments)
+    const unsigned long long cap = cus * (unsigned long long)(e_grid >= 1 && e_grid <= 1024 ? e_grid : 256);
+    want = want < cus * 16ull ? cus * 16ull : (want > cap ? cap : want);
     const uint32_t g = (uint32_t)want;
     if (bvh.inst)                hipLaunchKernelGGL((k_wh_trace_pool_inst<MODE>), dim3(g), dim3(64), 0, st, c, a);
     else if (bvh.node_fmt == 2u) hipLaunchKernelGGL((k_wh_trace_pool<MODE, 2>), dim3(g), dim3(64), 0, st, c, a);

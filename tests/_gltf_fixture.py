@@ -280,11 +280,12 @@ def write_textured(tmpdir, seed=3):
     return path
 
 
-def write_alpha(tmpdir, seed=4, stack=0):
+def write_alpha(tmpdir, seed=4, stack=0, tess=1):
     """Alpha MASK / BLEND materials, single- and double-sided: a ground, a masked fence, two stacked blend panes (textured
     alpha), an untextured blend pane, and two opaque panes seen from behind (one single sided -> culled for camera rays).
     stack = n: n more horizontal glass panes above the ground, every fifth one TWICE (coincident surfaces: candidates at equal t) --
-    occlusion rays from below cross up to n + n // 5 attenuating surfaces."""
+    occlusion rays from below cross up to n + n // 5 attenuating surfaces.  tess = k: the ground as k x k quads (a tree deep enough for
+    the entry-pool form of the any-hit kernels, which shallow trees do not take)."""
     import _png_fixture as PF
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:8, 0:8]
@@ -310,6 +311,13 @@ def write_alpha(tmpdir, seed=4, stack=0):
         quad((1.9, 0.1, -0.5), (0, 1.2, 0), (0, 0, 1.0)),   # 6 opaque double sided, faces -x as well from the camera? (+x normal flipped)
     ]
     mats_of = [0, 1, 2, 2, 3, 4, 5]
+    if tess > 1:
+        quads[0:1] = []
+        mats_of[0:1] = []
+        c = 6.0 / tess
+        for i in range(tess):
+            for j in range(tess):
+                quads.append(quad((-3 + c * i, 0, 3 - c * j), (c, 0, 0), (0, 0, -c))); mats_of.append(0)
     for k in range(stack):
         pane = quad((0.9, 0.25 + 0.06 * k, 0.2), (1.8, 0, 0), (0, 0, -2.2))
         for _ in range(2 if k % 5 == 4 else 1):
@@ -349,6 +357,6 @@ def write_alpha(tmpdir, seed=4, stack=0):
         "nodes": [{"mesh": 0}, {"camera": 0, "translation": [0.0, 1.6, 5.0], "rotation": [-0.1305261922, 0.0, 0.0, 0.9914448614]}],
         "scenes": [{"nodes": [0, 1]}], "scene": 0,
     }
-    path = tmpdir / ("alpha.gltf" if not stack else "alpha_stack%d.gltf" % stack)
+    path = tmpdir / ("alpha.gltf" if not stack and tess == 1 else "alpha_stack%d_%d.gltf" % (stack, tess))
     path.write_text(json.dumps(doc))
     return path

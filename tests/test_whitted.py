@@ -493,7 +493,7 @@ def test_oracle_blend_depth_limit():
     assert st["closest_rays"] == 8 * 8 * 8
 
 
-def _alpha_frames_match_the_oracle(gltf, w, h, subframes, persistent=None):
+def _alpha_frames_match_the_oracle(gltf, w, h, subframes, persistent=None, deep=None):
     import torch
     assert torch.cuda.is_available()
     from optix_raytracer_amd import meshviewer as MV
@@ -515,6 +515,8 @@ def _alpha_frames_match_the_oracle(gltf, w, h, subframes, persistent=None):
         s = st.context.launch_stats()
         tot_c += s["closest_rays"]; tot_s += s["shadow_rays"]
         st.params.subframe_index += 1
+    if deep is not None:
+        assert (st.context.accel_info(st.handle)["depth"] > 8) == deep        # which form of the any-hit kernels ran (wh_trace_on_pool)
     nodes, tris = st.context.accel_export(st.handle)
     sc, mats, lts, mat, normals = _oracle_for_state(st, nodes, tris)
     for m, sm in zip(mats, st.scene.materials()):
@@ -547,15 +549,16 @@ def test_alpha_modes_and_culling_match_the_oracle(tmp_path, w, h, subframes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stack,persistent", [(7, None), (24, None), (24, 2)])
-def test_deferred_any_hit_programs_over_many_layers(tmp_path, stack, persistent):
+@pytest.mark.parametrize("stack,tess,persistent", [(7, 1, None), (24, 1, None), (7, 24, None), (24, 24, None), (24, 24, 2)])
+def test_deferred_any_hit_programs_over_many_layers(tmp_path, stack, tess, persistent):
     """The any-hit programs run deferred, a ray's candidates in the order of (t, primitive index) (whitted_kernels.hip): a closest-hit
-    traversal on the entry pool finds the next candidate, the program runs on it, and an ignored candidate becomes the continuation
-    key (tmin = t; at equal t only primitives above the ignored one count).  7 / 24 more panes, every fifth one TWICE -- coincident
-    surfaces, candidates at bit-equal t -- so occlusion rays from the ground cross up to 30 attenuating surfaces and camera rays run
-    into the depth limit.  persistent = 2: the same loop one ray per thread (structures without the pool's mirrors).  Every frame
-    equals the oracle's -- which COLLECTS the candidates of a ray, SORTS them and multiplies -- bit for bit."""
-    _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path, stack=stack), 120, 80, 2, persistent=persistent)
+    traversal finds the next candidate, the program runs on it, and an ignored candidate becomes the continuation key (tmin = t; at
+    equal t only primitives above the ignored one count).  7 / 24 more panes, every fifth one TWICE -- coincident surfaces, candidates
+    at bit-equal t -- so occlusion rays from the ground cross up to 30 attenuating surfaces and camera rays run into the depth limit.
+    tess = 24: the ground as 1 152 triangles, a tree deep enough for the ENTRY-POOL form (k_wh_trace_pool; trees of up to 8 levels take
+    the one-ray-per-thread form by themselves); persistent = 2 pins that form for the deep tree too.  Every frame equals the oracle's --
+    which COLLECTS the candidates of a ray, SORTS them and multiplies -- bit for bit."""
+    _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path, stack=stack, tess=tess), 120, 80, 2, persistent=persistent, deep=tess > 1)
 
 
 @pytest.mark.parametrize("name", ["textured", "alpha"])
