@@ -107,9 +107,10 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
     float nx = shfl_f(T.nood.x, slot), ny = shfl_f(T.nood.y, slot), nz = shfl_f(T.nood.z, slot);
     const float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
     const uint32_t skp = AH != 0 ? shfl_u(T.skip, slot) : 0xffffffffu;       // continuation key of the any-hit-program kernels (Trav::skip)
+    const uint32_t ahk = AH != 0 ? shfl_u(T.ahk, slot) : 1u;                 // ... and how many candidates the ray wants from this traversal
     float tcur = tmx;
     bool live = have;
-    if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[slot] >> 32)); }
+    if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[(AH != 0 && ahk > 1u ? (kAhLevels - 1) * 64 : 0) + slot] >> 32)); }      // AH: pruned at the last wanted candidate
     else if (dead) live = false;
     const bool leaf = (ent.x >> 31) != 0u;
     const uint32_t payload = (ent.x >> 6) & 0x1ffffffu;
@@ -210,12 +211,21 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
         } else if (AH == 2 && ok && (f2u(n1.w) & 1u) != 0u) {
             // AH 2 (occlusion rays with any-hit programs): a candidate WITHOUT program ends the ray wherever it lies in the interval -- the
             // slot's key drops below every real one (t = -inf: the ray's other entries fail their box tests at once), the owner sees it
-            atomicMin(&sh_best[slot], kAhOccludedKey);
+#pragma unroll
+            for (int l = 0; l < kAhLevels; ++l) atomicMin(&sh_best[l * 64 + slot], kAhOccludedKey);
         } else if (ok) {
-            const unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
-            atomicMin(&sh_best[slot], key);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; if (AH != 0) sh_done[slot] = f2u(n1.w); }   // AH: the winner's geometry flags
+            unsigned long long key = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
+            if (AH != 0) {
+                // AH: the slot's kAhLevels least keys, level l the (l + 1)-th: every level takes the minimum of what reaches it and hands
+                // the larger key down -- whatever the interleaving with other lanes' candidates, level l ends as the (l + 1)-th least
+#pragma unroll
+                for (int l = 0; l < kAhLevels; ++l) { const unsigned long long prev = atomicMin(&sh_best[l * 64 + slot], key); key = prev > key ? prev : key; }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            } else {
+                atomicMin(&sh_best[slot], key);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (*(volatile unsigned long long*)&sh_best[slot] == key) { sh_u[slot] = u; sh_v[slot] = v; }
+            }
         }
         if (!stop && lcnt > 1u) {
             push1 = 0x80000000u | ((lfirst + 1u) << 8) | ((lcnt - 2u) << 6) | slot;
@@ -243,7 +253,8 @@ __device__ __forceinline__ void tail_trace_inst(const __amdgpu_buffer_rsrc_t blo
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
-    sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u;
+    if (AH != 0) { for (int l = 1; l < kAhLevels; ++l) sh_best[l * 64 + lane] = sh_best[lane]; }       // (the levels lie over sh_u / sh_v / sh_done)
+    else { sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u; }
     if (CACHE) xr[lane * 8] = 0u;                            // no instance cached for this slot's (new) ray
     const unsigned long long m = __ballot(has_ray);
     if (has_ray) stk[(int)lane_rank(m)] = make_uint2(pool_pack(0, (uint32_t)lane), 0u);

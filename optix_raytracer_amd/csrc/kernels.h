@@ -64,8 +64,8 @@ struct DeviceBvh {
     // buffer descriptor.  inst_fast = 0: only the one-ray-per-lane walk (k_trace_inst) can traverse the structure.
     uint32_t inst_fast, inst_off, inst_node4_off, inst_tri_off, inst_blob_bytes;
     uint32_t inst_root4_off;   // per top-level BVH4 node 4 words: the BVH4 root of the mesh behind each LEAF child (an instance)
-    const uint8_t* prim_flags; // one-level: geometry flags per ORIGINAL primitive (null: not kept by the builder that made this BVH)
-    uint32_t inst_flags;       // two-level: every DeviceInstance::prim_flags is set
+    const uint32_t* prim_slot; // one-level: per ORIGINAL primitive the position of its triangle record (null: not kept by the builder that made this BVH)
+    uint32_t inst_slots;       // two-level: every DeviceInstance::prim_slot is set
     uint32_t top_off;          // experiment MIPT_TOP_CACHE: byte offset of the top-of-tree copy of the packed mirror (64 nodes + their real indices); 0 = none
     uint32_t node_fmt;         // 0: fp32 64-byte BVH2 nodes only; 1: + packed 32-byte BVH2 nodes at node32_off (MiptBvhNode32: the boxes of
                                // `nodes` as fp16 -- the two arrays hold the SAME values), walked by every entry-pool kernel; 2: + the BVH4
@@ -79,7 +79,7 @@ struct DeviceInstance {
     const float4* tris;        // ... and triangles (48 bytes each), object space
     uint32_t      prim_base;   // flattened index of the mesh's primitive 0 within this instance
     uint32_t      root4;       // entry-pool form: index of the mesh's BVH4 root in the structure's BVH4 array (DeviceBvh::inst_node4_off)
-    const uint8_t* prim_flags; // the mesh's geometry flags per mesh-local primitive (null: not kept)
+    const uint32_t* prim_slot; // the mesh's table: mesh-local primitive -> position of its triangle record (null: not kept)
 };
 
 static_assert(sizeof(DeviceInstance) == 80, "the pool kernels fetch an instance record in 16-byte pieces");
@@ -225,7 +225,8 @@ hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d
                          uint32_t budget = 32u);       // budget: the most stack entries a lane may need while walking the mirror
 hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth);
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
-                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets = true);
+                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets = true,
+                      uint32_t* d_prim_slot = nullptr);       // d_prim_slot: n words, filled with primitive -> position of its triangle record
 
 // SDK/cuda/whitted.cu pipeline (whitted_kernels.hip)
 struct WhTables {                  // MiptWhittedGeometry with typed pointers: the shading tables of a flattened scene, or of one mesh

@@ -329,11 +329,13 @@ __global__ __launch_bounds__(256) void k_lbvh_emit(const int* left, const int* r
     out[new_index[i]] = nd;
 }
 
-__global__ __launch_bounds__(256) void k_lbvh_tris(const float* __restrict__ world, const uint32_t* sorted_prims, const uint32_t* gflags, uint32_t n, MiptBvhTri* out)
+__global__ __launch_bounds__(256) void k_lbvh_tris(const float* __restrict__ world, const uint32_t* sorted_prims, const uint32_t* gflags, uint32_t n, MiptBvhTri* out,
+                                                  uint32_t* prim_slot)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t p = sorted_prims[k];
+    if (prim_slot) prim_slot[p] = k;
     const float* v = world + (size_t)p * 9;
     MiptBvhTri t;
     for (int c = 0; c < 3; ++c) { t.v0[c] = v[c]; t.e1[c] = v[3 + c] - v[c]; t.e2[c] = v[6 + c] - v[c]; }
@@ -774,7 +776,7 @@ void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, ui
 // nodes | triangles | 64 B pad (as mipt_accel_build makes for the host builder).  Returns hipSuccess and ok = false
 // when the tree is deeper than depth_cap (the caller falls back to the host builder).
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
-                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets)
+                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets, uint32_t* d_prim_slot)
 {
     *ok = false; *d_blob = nullptr;
     const int n_inner = (int)n - 1;
@@ -842,7 +844,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     float4* blob = nullptr;
     if ((e = hipMalloc((void**)&blob, nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u)) != hipSuccess) return fail(e);     // + room for the packed nodes
     hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks), dim3(256), 0, st, left, right, rlo, rhi, n_inner, leaf_max, emit, idx, boxes, vals2, nboxes, (MiptBvhNode*)blob);
-    hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb));
+    hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb), d_prim_slot);
     if ((e = hipMemsetAsync((char*)blob + nb + tb, 0, 64, st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }
     if ((e = hipStreamSynchronize(st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }
     (void)hipFree(tmp);

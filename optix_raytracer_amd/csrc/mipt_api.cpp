@@ -73,7 +73,8 @@ struct Accel {
     uint32_t  num_nodes4 = 0;
     uint32_t* d_mat   = nullptr;
     uint8_t*  d_height = nullptr;  // height of every node (topology only: made at build time, reused by every refit and by the BVH4 collapse)
-    uint8_t*  d_prim_flags = nullptr;   // geometry flags per ORIGINAL primitive (host builder; null: not kept) -- the Whitted any-hit kernels look a hit's flags up here
+    uint32_t* d_prim_slot = nullptr;    // per ORIGINAL primitive: the position of its triangle record (host builder; null: not kept) -- the Whitted any-hit kernels
+                                        // re-test a candidate's triangle through it (u, v, geometry flags of a key they hold)
     uint32_t  n_prims = 0;
     uint64_t  bytes   = 0;
     // two-level structure (mipt_accel_build_instances): d_nodes then holds the BVH over the instance boxes
@@ -88,7 +89,7 @@ struct Accel {
     // entry-pool form of a two-level structure (DeviceBvh::inst_fast): d_nodes is then ONE allocation, d_inst lies inside it
     bool                       inst_fast = false;
     bool                       stale = false;    // a mesh this structure references was refitted since: mipt_accel_update_instances first
-    bool                       inst_flags = false;   // every instance record carries its mesh's d_prim_flags
+    bool                       inst_slots = false;   // every instance record carries its mesh's d_prim_slot
     uint32_t                   inst_off = 0, inst_node4_off = 0, inst_tri_off = 0, inst_blob_bytes = 0, inst_root4_off = 0;
 };
 
@@ -293,7 +294,7 @@ void free_accel(Accel* a)
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_mat) (void)hipFree(a->d_mat);
     if (a->d_height) (void)hipFree(a->d_height);
-    if (a->d_prim_flags) (void)hipFree(a->d_prim_flags);
+    if (a->d_prim_slot) (void)hipFree(a->d_prim_slot);
     if (a->d_inst) (void)hipFree(a->d_inst);
     if (a->d_order) (void)hipFree(a->d_order);
     delete a;
@@ -427,14 +428,14 @@ DeviceBvh device_bvh(const Accel* a)
     b.pool2_ok = (b.pool_ok && a->num_nodes < (1u << 24) && a->num_tris < (1u << 22)) ? 1u : 0u;
     b.node32_off = a->node32_off; b.node_fmt = a->node32_off ? a->node_fmt : 0u;
     b.node4_off = b.node_fmt == 2u ? a->node4_off : 0u; b.stack4 = a->stack_need; b.top_off = b.node_fmt >= 1u ? a->top_off : 0u;
-    b.prim_flags = a->d_prim_flags;
+    b.prim_slot = a->d_prim_slot;
     if (a->is_ias) {
         b.inst = a->inst_fast ? reinterpret_cast<const DeviceInstance*>(reinterpret_cast<const char*>(a->d_nodes) + a->inst_off) : a->d_inst;
         b.inst_order = a->d_order; b.n_inst = (uint32_t)a->gas.size(); b.pool_ok = b.pool2_ok = 0u; b.tri_byte_off = 0u; b.node32_off = 0u;
         b.node_fmt = 0u; b.node4_off = 0u; b.blob_bytes = 0u;
         b.inst_fast = a->inst_fast ? 1u : 0u; b.inst_off = a->inst_off; b.inst_node4_off = a->inst_node4_off; b.inst_tri_off = a->inst_tri_off;
         b.inst_blob_bytes = a->inst_blob_bytes; b.stack4 = a->stack_need; b.inst_root4_off = a->inst_root4_off;
-        b.prim_flags = nullptr; b.inst_flags = a->inst_flags ? 1u : 0u;
+        b.prim_slot = nullptr; b.inst_slots = a->inst_slots ? 1u : 0u;
     }
     return b;
 }
@@ -941,7 +942,10 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     const uint32_t err = G.err;
     float* d_world = G.world; uint32_t* d_gf = G.gflags;
     float4* blob = nullptr; uint32_t nn = 0, dep = 0; bool ok = false;
-    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, ctx->lbvh_leaf, kStackEntries, &blob, &nn, &dep, &ok, ctx->lbvh_treelets != 0);
+    uint32_t* d_slot = nullptr;                                  // primitive -> triangle record (Accel::d_prim_slot)
+    if (e == hipSuccess && err == 0u) e = hipMalloc((void**)&d_slot, (size_t)n * 4u);
+    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, ctx->lbvh_leaf, kStackEntries, &blob, &nn, &dep, &ok, ctx->lbvh_treelets != 0, d_slot);
+    if ((e != hipSuccess || err != 0u || !ok) && d_slot) { (void)hipFree(d_slot); d_slot = nullptr; }
     if (e != hipSuccess) return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e));
     if (err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
     if (!ok) {
@@ -953,6 +957,7 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
     a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
     a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = 1;
+    a->d_prim_slot = d_slot;
     if ((e = finish_blob(ctx, a)) != hipSuccess) { free_accel(a); return ctx->fail(MIPT_ERROR_HIP, "device BVH build: %s", hipGetErrorString(e)); }
     a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u + (size_t)n * 4u;         // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1035,6 +1040,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     a->n_prims = n_tris;
     const size_t mb = std::max<size_t>(n_tris, 1) * sizeof(uint32_t);
     size_t nb = 0, tb = 0;
+    std::vector<uint32_t> prim_slot;
     hipError_t e = hipSuccess;
     {
         if (!build_bvh(world.data(), n_tris, 4, kStackEntries, default_build_threads(), a->host)) {
@@ -1042,6 +1048,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
             return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "BVH over %u triangles does not fit a %d-entry traversal stack", n_tris, kStackEntries);
         }
         for (MiptBvhTri& t : a->host.tris) t.pad1 = gflags[t.prim];
+        if (a->host.tris.size() == n_tris) { prim_slot.resize(n_tris); for (uint32_t i = 0; i < n_tris; ++i) prim_slot[a->host.tris[i].prim] = i; }
         nb = a->host.nodes.size() * sizeof(MiptBvhNode);
         tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
         e = hipMalloc((void**)&a->d_nodes, nb + tb + 64 + 256 + 8192 + a->host.nodes.size() * 96u);      // + room for the node mirrors (finish_blob)
@@ -1057,11 +1064,9 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     }
     if (e == hipSuccess) e = finish_blob(ctx, a);
     if (e == hipSuccess) e = hipMalloc((void**)&a->d_mat, mb);
-    if (e == hipSuccess && n_tris && gflags.size() >= n_tris) {
-        std::vector<uint8_t> fb(n_tris);
-        for (uint32_t t = 0; t < n_tris; ++t) fb[t] = (uint8_t)gflags[t];
-        e = hipMalloc((void**)&a->d_prim_flags, n_tris);
-        if (e == hipSuccess) e = hipMemcpy(a->d_prim_flags, fb.data(), n_tris, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_tris && prim_slot.size() == n_tris) {
+        e = hipMalloc((void**)&a->d_prim_slot, (size_t)n_tris * 4u);
+        if (e == hipSuccess) e = hipMemcpy(a->d_prim_slot, prim_slot.data(), (size_t)n_tris * 4u, hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && n_tris) e = hipMemcpy(a->d_mat, mats.data(), (size_t)n_tris * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -1119,7 +1124,7 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
     std::vector<uint32_t> h_base(n, 0u);
     std::vector<unsigned long long> gas(n, 0ull);
     uint64_t total_tris = 0; uint32_t max_depth = 0;
-    bool all_flags = n != 0u;
+    bool all_slots = n != 0u;
     for (uint32_t k = 0; k < n; ++k) {
         Accel* g = find_accel(ctx, inst[k].traversableHandle);
         if (!g || g->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "instance %u: traversableHandle 0x%llx is not a triangle acceleration structure of this context",
@@ -1149,7 +1154,7 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
         DeviceInstance& d = recs[k];
         std::memcpy(d.inv, &h_inv[(size_t)k * 12], 48);
         d.nodes = g->d_nodes; d.tris = g->d_tris; d.prim_base = (uint32_t)total_tris;
-        d.prim_flags = g->d_prim_flags; all_flags = all_flags && g->d_prim_flags != nullptr;
+        d.prim_slot = g->d_prim_slot; all_slots = all_slots && g->d_prim_slot != nullptr;
         h_base[k] = (uint32_t)total_tris; gas[k] = inst[k].traversableHandle;
         total_tris += g->n_prims;
         max_depth = std::max(max_depth, g->depth);
@@ -1248,7 +1253,7 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
     a->depth = top.depth + max_depth; a->leaf_max = 1; a->is_ias = true; a->stale = false;
     uint32_t mesh_stack = 0u;
     for (const MeshSlot& m : meshes) mesh_stack = std::max(mesh_stack, m.g->stack_need);
-    a->inst_flags = all_flags;
+    a->inst_slots = all_slots;
     a->inst_fast = fast; a->stack_need = fast ? stack4 + mesh_stack : 0u;      // the most entries a lane's stack over BOTH levels can hold
     a->inst_off = fast ? (uint32_t)o_inst : 0u; a->inst_node4_off = fast ? (uint32_t)o_n4 : 0u; a->inst_tri_off = fast ? (uint32_t)o_tri : 0u;
     a->inst_blob_bytes = fast ? (uint32_t)arena : 0u; a->inst_root4_off = fast ? (uint32_t)o_r4 : 0u;

@@ -117,6 +117,8 @@ __device__ __forceinline__ uint32_t pool_pack(int ref, uint32_t slot)
     const uint32_t desc = ~(uint32_t)ref;
     return 0x80000000u | ((desc >> 4) << 8) | (((desc - 1u) & 3u) << 6) | slot;
 }
+constexpr int kAhLevels = 3;     // AH kernels: a traversal can keep a ray's 3 nearest candidates (keys only: level l of slot s at sh_best[l * 64 + s], over the
+                                 // merge words sh_u / sh_v / sh_done, which the AH kernels do not use -- they re-test a candidate's triangle for u, v)
 constexpr unsigned long long kAhOccludedKey = 0x007fffffull << 32;      // ord_bits(-inf) in the t half: below every key of a real candidate (t > tmin)
 __device__ __forceinline__ uint32_t ord_bits(float f) { const uint32_t b = f2u(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
 __device__ __forceinline__ float    ord_float(uint32_t k) { return u2f(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }

@@ -24,6 +24,7 @@ struct Trav {
     float    u, v;
     uint32_t prim;
     int      node, sp;
+    uint32_t ahk;                // AH kernels only: how many of the ray's nearest candidates this traversal is to find (1 or kAhLevels)
     uint32_t skip;               // AH kernels only (pool_trace.h): with tmin = the t of a candidate the any-hit program ignored, that
                                  // candidate's primitive -- candidates AT tmin count when their primitive index is greater
 };

@@ -205,14 +205,20 @@ __device__ __forceinline__ uint32_t prim_material(const WhConsts& c, uint32_t pr
 // So the traversal itself is the entry pool's (pool_trace.h / inst_pool.h, AH form) -- k_wh_trace_pool / k_wh_trace_pool_inst: a
 // wave's chunk of rays, all lanes serving whichever rays are still open -- and the texture fetch happens once per candidate that
 // IS a ray's next one instead of inside the traversal loop at every candidate in the ray's interval (round 2's one-ray-per-thread
-// walk).  Measured, 1080p subframe over 2 000 instances / 782 k triangles, ALL of them alpha-textured (tools/bench_alpha.py,
-// profiles/r03_bench_alpha.txt): MASK materials with hard alpha (a ray ends at the first solid texel) 2.9 ms against 1.1 ms for the
+// walk).  A ray's first traversal finds ONE candidate (pruned like a closest-hit ray: rays that end at their first solid texel pay no
+// more); once a candidate has been ignored the ray asks for its THREE nearest per traversal (kAhLevels: per slot three 64-bit keys
+// in LDS, each level keeping the minimum of what reaches it and handing the larger key down; pruned at the third) -- a third of the
+// restarts for rays through many surfaces.  The pool reports keys only; u, v and the geometry flags of a key come from testing its
+// triangle again (candidate_record: the builders' primitive -> record tables).
+// Measured, 1080p subframe over 2 000 instances / 782 k triangles, ALL of them alpha-textured (tools/bench_alpha.py,
+// profiles/r03_bench_alpha.txt): MASK materials with hard alpha (a ray ends at the first solid texel) 2.74 ms against 1.10 ms for the
 // same scene with opaque materials; BLEND films everywhere -- an occlusion ray crosses 7 attenuating surfaces on average, up to 78, and
-// none ends it, so every ray is traversed to its end -- 33.8 ms against round 2's 45.5 ms.
-// Tried for the occlusion rays and dropped (same file): ONE traversal that records every candidate of the interval (16 records per ray,
+// none ends it, so every ray is traversed to its end -- 20.8 ms (one candidate per traversal: 33.8) against round 2's 45.5 ms.
+// Tried for the occlusion rays and dropped: ONE traversal that records every candidate of the interval (16 records per ray,
 // narrower windows for rays with more) and then sorts -- without a running closest hit nothing prunes the traversal, and the rays that
 // end early pay for the whole interval: 20 ms on the MASK scene, 40-76 ms on the BLEND scene.
-// k_wh_trace / k_wh_trace_inst: the same loop one ray per thread, for structures the pool cannot walk (5.8 / 107 ms on the two scenes).
+// k_wh_trace / k_wh_trace_inst: the same loop one ray per thread, one candidate per traversal: structures the pool cannot walk, and
+// trees of up to 8 levels (wh_trace_on_pool).
 __device__ __forceinline__ bool candidate_alpha(const WhConsts& c, uint32_t prim, float u, float v, uint32_t& mi, float& alpha)
 {
     mi = prim_material(c, prim);
@@ -265,43 +271,72 @@ struct WhTraceArgs {
     const uint32_t* open_list;     // MODE 0, seeded launch: the rays to trace (k_wh_seed; n_ptr counts them), each from beyond the candidate in hits[ray]
 };
 
-// one ray's bookkeeping after a traversal: `key` / u / v / gflags = the closest remaining candidate (sh_best and its fellows)
-template <int MODE>
-__device__ __forceinline__ void anyhit_advance(const WhConsts& c, Trav& T, bool& open, float& occlusion, float4& rec, const unsigned long long key,
-                                               const float u, const float v, const uint32_t gflags)
+// A candidate the traversal reports by its key (t, flattened primitive) alone: u, v and the geometry flags by testing its triangle again --
+// the record through the builders' tables (DeviceBvh::prim_slot; two-level: the instance is the last one whose prim_base is <= prim,
+// then DeviceInstance::prim_slot), the ray taken to object space as the traversal takes it, the traversal's own sequence of operations:
+// t comes out as the key has it, bit for bit.
+__device__ __forceinline__ void candidate_record(const DeviceBvh& bvh, f3 o, f3 d, const uint32_t prim, float& t, float& u, float& v, uint32_t& gflags)
 {
-    const uint32_t prim = (uint32_t)key;
-    if (MODE != 0 && key == kAhOccludedKey) { occlusion = 0.0f; open = false; return; }  // a candidate without program somewhere in the interval
-    if (prim == 0xffffffffu) { open = false; return; }                                   // nothing left in the interval
-    const float t = ord_float((uint32_t)(key >> 32));
-    if (anyhit_step<MODE>(c, gflags, prim, u, v, occlusion)) { open = false; rec = make_float4(t, u2f(prim), u, v); }
-    else { T.tmin = t; T.skip = prim; }
+    const float4* tp;
+    if (bvh.inst) {
+        uint32_t lo = 0u, hi = bvh.n_inst;                  // invariant: inst[lo].prim_base <= prim < inst[hi].prim_base (hi = n: the end)
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (bvh.inst[mid].prim_base <= prim) lo = mid; else hi = mid; }
+        const DeviceInstance& in = bvh.inst[lo];
+        tp = in.tris + (size_t)in.prim_slot[prim - in.prim_base] * 3u;
+        const u32x4* m = reinterpret_cast<const u32x4*>(&in);
+        const RayO O = to_object(m[0], m[1], m[2], o, d);
+        o = O.o; d = O.d;
+    } else {
+        tp = bvh.tris + (size_t)bvh.prim_slot[prim] * 3u;
+    }
+    const float4 n0 = tp[0], n1 = tp[1], n2 = tp[2];
+    const f3 e1 = mk3(n1.x, n1.y, n1.z), e2 = mk3(n2.x, n2.y, n2.z);
+    const f3 p = fcross(d, e2);
+    const float det = fdot(e1, p);
+    const float inv = 1.0f / det;
+    const f3 tv = o - mk3(n0.x, n0.y, n0.z);
+    u = fdot(tv, p) * inv;
+    const f3 q = fcross(tv, e1);
+    v = fdot(d, q) * inv;
+    t = fdot(e2, q) * inv;
+    gflags = f2u(n1.w);
 }
 
-// geometry flags of a (flattened) primitive from the builders' tables: the instance is the last one whose prim_base is <= prim
-__device__ __forceinline__ uint32_t prim_geometry_flags(const DeviceBvh& bvh, uint32_t prim)
+// one ray's bookkeeping after a traversal.  `lv`: the slot's candidate levels (sh_best: level l at lv[l * 64]), the T.ahk nearest remaining
+// candidates in order.  The program runs over them; the first one it accepts ends the ray; when it ignores them all the ray goes on
+// beyond the last -- and asks for kAhLevels candidates per traversal from then on (a ray
+// whose first candidate is ignored is likely to meet more such surfaces; a ray's FIRST traversal keeps to one candidate, so that rays
+// that end at their first solid texel are pruned as closest-hit rays are).
+template <int MODE>
+__device__ __forceinline__ void anyhit_advance(const WhConsts& c, const DeviceBvh& bvh, Trav& T, bool& open, float& occlusion, float4& rec, const unsigned long long* lv)
 {
-    if (!bvh.inst) return bvh.prim_flags[prim];
-    uint32_t lo = 0u, hi = bvh.n_inst;                  // invariant: inst[lo].prim_base <= prim < inst[hi].prim_base (hi = n: the end)
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (bvh.inst[mid].prim_base <= prim) lo = mid; else hi = mid; }
-    const DeviceInstance& in = bvh.inst[lo];
-    return in.prim_flags[prim - in.prim_base];
+    const uint32_t want = T.ahk;
+    for (uint32_t l = 0; l < want; ++l) {
+        const unsigned long long key = lv[l * 64u];
+        if (MODE != 0 && key == kAhOccludedKey) { occlusion = 0.0f; open = false; return; }  // a candidate without program somewhere in the interval
+        const uint32_t prim = (uint32_t)key;
+        if (prim == 0xffffffffu) { open = false; return; }                                   // nothing left in the interval
+        float t, u, v; uint32_t gflags;
+        candidate_record(bvh, T.o, T.d, prim, t, u, v, gflags);
+        t = ord_float((uint32_t)(key >> 32));
+        if (anyhit_step<MODE>(c, gflags, prim, u, v, occlusion)) { open = false; rec = make_float4(t, u2f(prim), u, v); return; }
+        T.tmin = t; T.skip = prim;
+    }
+    T.ahk = (uint32_t)kAhLevels;
 }
 
 // A seeded launch (MODE 0): the fast closest-hit kernels -- tiles of 64 rays for a level's millions of rays -- have found every ray's
 // closest candidate with all geometry taken as opaque; that candidate is exactly the first one of the loop below.  k_wh_seed runs the
 // program on it, one ray per thread: accepted (or no program, or a miss) -> the hit record stands; IGNORED -> the ray's index joins
 // the list `open` (one atomic per workgroup), and only the listed rays, densely packed into chunks, are traversed here, starting
-// beyond their candidate.  Needs the geometry flags of a hit's primitive: the builders' per-primitive tables (DeviceBvh::prim_flags,
-// DeviceInstance::prim_flags; structures without them take the unseeded launch).  Default over two-level structures only.  1080p,
-// 2 000 instances, boxes MASK / everything
-// MASK (profiles/r03_bench_alpha.txt): two-level 3.29 -> 2.86 / 4.41 -> 3.92 ms; one level 2.10 -> 2.12 / 2.87 -> 2.90 ms -- there the
+// beyond their candidate.  Default over two-level structures only.  1080p, 2 000 instances, boxes MASK / everything MASK
+// (profiles/r03_bench_alpha.txt): two-level 3.29 -> 2.86 / 4.41 -> 3.92 ms; one level 2.10 -> 2.12 / 2.87 -> 2.90 ms -- there the
 // tiled launch (0.35 ms) + this filter (0.05) + the listed rays (0.37: few rays, but each ignored candidate is one more traversal from
 // the root, and the longest such chain sets the launch's duration) only just beat the unseeded launch (0.81).
 // (Seeding inside the traversal kernel instead, ray i in lane i: a chunk with ONE open ray costs a traversal's latency all the same,
 // and most chunks have one -- no gain at all.)
-__global__ __launch_bounds__(256) void k_wh_seed(WhConsts c, DeviceBvh bvh, const uint32_t* n_ptr, uint32_t n_max, const float4* hits, uint32_t* open_list,
-                                                 DeviceCounters* ctr)
+__global__ __launch_bounds__(256) void k_wh_seed(WhConsts c, DeviceBvh bvh, const float4* ray_o, const float4* ray_d, const uint32_t* n_ptr, uint32_t n_max,
+                                                 const float4* hits, uint32_t* open_list, DeviceCounters* ctr)
 {
     __shared__ uint32_t s2[2];
     if (threadIdx.x == 0u) s2[0] = 0u;
@@ -315,7 +350,12 @@ __global__ __launch_bounds__(256) void k_wh_seed(WhConsts c, DeviceBvh bvh, cons
             const float4 h = hits[ray];
             const uint32_t prim = f2u(h.y);
             float occlusion = 1.0f;
-            push = prim != 0xffffffffu && !anyhit_step<0>(c, prim_geometry_flags(bvh, prim), prim, h.z, h.w, occlusion);
+            if (prim != 0xffffffffu) {
+                float t, u, v; uint32_t gflags;
+                const float4 ro = ray_o[ray], rd = ray_d[ray];
+                candidate_record(bvh, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), prim, t, u, v, gflags);
+                push = !anyhit_step<0>(c, gflags, prim, h.z, h.w, occlusion);
+            }
         }
         const uint32_t at = block_append(push, &ctr->n_open, s2);
         if (push) open_list[at] = ray;
@@ -345,16 +385,16 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
         const bool mine = (uint32_t)lane < ppw && ray < n;
         if (MODE == 0 && a.open_list != nullptr && mine) ray = a.open_list[ray];
         Trav T;
-        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu; T.ahk = 1u;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[ray], a.ray_d[ray]);
-        if (MODE == 0 && a.open_list != nullptr && mine) { const float4 h = a.hits[ray]; T.tmin = h.x; T.skip = f2u(h.y); }      // beyond the ignored candidate
+        if (MODE == 0 && a.open_list != nullptr && mine) { const float4 h = a.hits[ray]; T.tmin = h.x; T.skip = f2u(h.y); T.ahk = (uint32_t)kAhLevels; }      // beyond the ignored candidate
         bool open = mine && T.node != kSentinel;
         float occlusion = 1.0f;
         float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
         while (__ballot(open) != 0ull) {
             tail_trace<0, Q, kPoolCap, MODE == 0 ? 1 : 2>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, open, MODE == 0);
-            if (open) anyhit_advance<MODE>(c, T, open, occlusion, rec, sh_best[lane], sh_u[lane], sh_v[lane], sh_done[lane]);
+            if (open) anyhit_advance<MODE>(c, a.bvh, T, open, occlusion, rec, sh_best + lane);
         }
         if (mine) {
             if (MODE == 0) a.hits[ray] = rec;
@@ -388,16 +428,16 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool_inst(WhConsts c, WhTraceAr
         const bool mine = (uint32_t)lane < ppw && ray < n;
         if (MODE == 0 && a.open_list != nullptr && mine) ray = a.open_list[ray];
         Trav T;
-        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu; T.ahk = 1u;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[ray], a.ray_d[ray]);
-        if (MODE == 0 && a.open_list != nullptr && mine) { const float4 h = a.hits[ray]; T.tmin = h.x; T.skip = f2u(h.y); }      // beyond the ignored candidate
+        if (MODE == 0 && a.open_list != nullptr && mine) { const float4 h = a.hits[ray]; T.tmin = h.x; T.skip = f2u(h.y); T.ahk = (uint32_t)kAhLevels; }      // beyond the ignored candidate
         bool open = mine && T.node != kSentinel;
         float occlusion = 1.0f;
         float4 rec = make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
         while (__ballot(open) != 0ull) {
             tail_trace_inst<0, kCap, false, MODE == 0 ? 1 : 2>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, open, MODE == 0 INST_STATS_ARG);
-            if (open) anyhit_advance<MODE>(c, T, open, occlusion, rec, sh_best[lane], sh_u[lane], sh_v[lane], sh_done[lane]);
+            if (open) anyhit_advance<MODE>(c, a.bvh, T, open, occlusion, rec, sh_best + lane);
         }
         if (mine) {
             if (MODE == 0) a.hits[ray] = rec;
@@ -786,7 +826,9 @@ static bool wh_trace_on_pool(const DeviceBvh& bvh, const TraceOpts& o)
 {
     // (a tree of a few levels -- the alpha fixture's 14 triangles -- is walked faster one ray per thread: a chunk on the pool costs a
     //  handful of rounds whatever the tree, 0.82 against 0.55 ms per 1080p subframe; from 2 k triangles on the pool wins, 0.48 against 0.65)
-    return wh_anyhit_env() != 1 && o.persistent == 3 && bvh.depth > 8u && (bvh.inst ? bvh.inst_fast != 0u : (bvh.pool_ok && bvh.tri_byte_off != 0u));
+    // (and the builders' primitive -> record tables: the pool reports a candidate by its key, candidate_record() finds the rest)
+    return wh_anyhit_env() != 1 && o.persistent == 3 && bvh.depth > 8u &&
+           (bvh.inst ? bvh.inst_fast != 0u && bvh.inst_slots != 0u : (bvh.pool_ok && bvh.tri_byte_off != 0u && bvh.prim_slot != nullptr));
 }
 
 template <int MODE>
@@ -837,14 +879,14 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
         const PathQueue cur = B.q[level & 1u], next = B.q[(level & 1u) ^ 1u];
         // (any-hit programs: the fast launch first when the structure's builders kept the geometry flags per primitive -- anyhit_seed)
         const bool seeded = B.any_hit_programs && wh_anyhit_env() != 2 && wh_trace_on_pool(bvh, opts) &&
-                            (bvh.inst ? bvh.inst_flags != 0u : (wh_anyhit_env() == 3 && bvh.prim_flags != nullptr));
+                            (bvh.inst != nullptr || wh_anyhit_env() == 3);
         if (B.any_hit_programs && !seeded) launch_wh_trace<0>(st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, B.hits, nullptr, opts);
         else
             launch_trace_closest(st, bvh, cur.ray_o, cur.ray_d, 1, &ctr->n_cur, n_paths, B.hits, ctr, opts,
                                  MIPT_RAY_FLAG_CULL_BACK_FACING_TRIANGLES);          // traceRadiance, whitted_cuda.h:110
         if (seeded) {
             uint32_t* const open_list = reinterpret_cast<uint32_t*>(B.group);          // (the group records are written by the shade launch that follows)
-            hipLaunchKernelGGL(k_wh_seed, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, c, bvh, &ctr->n_cur, n_paths, (const float4*)B.hits, open_list, ctr);
+            hipLaunchKernelGGL(k_wh_seed, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_cur, n_paths, (const float4*)B.hits, open_list, ctr);
             launch_wh_trace<0>(st, c, bvh, cur.ray_o, cur.ray_d, &ctr->n_open, n_paths, B.hits, nullptr, opts, open_list);
         }
         WhLevel L{};

@@ -515,8 +515,8 @@ def _alpha_frames_match_the_oracle(gltf, w, h, subframes, persistent=None, deep=
         s = st.context.launch_stats()
         tot_c += s["closest_rays"]; tot_s += s["shadow_rays"]
         st.params.subframe_index += 1
-    if deep is not None:
-        assert (st.context.accel_info(st.handle)["depth"] > 8) == deep        # which form of the any-hit kernels ran (wh_trace_on_pool)
+    if deep:
+        assert st.context.accel_info(st.handle)["depth"] > 8                   # the entry-pool form of the any-hit kernels ran (wh_trace_on_pool)
     nodes, tris = st.context.accel_export(st.handle)
     sc, mats, lts, mat, normals = _oracle_for_state(st, nodes, tris)
     for m, sm in zip(mats, st.scene.materials()):
