@@ -117,7 +117,12 @@ __device__ __forceinline__ uint32_t pool_pack(int ref, uint32_t slot)
     const uint32_t desc = ~(uint32_t)ref;
     return 0x80000000u | ((desc >> 4) << 8) | (((desc - 1u) & 3u) << 6) | slot;
 }
-constexpr int kAhLevels = 3;     // AH kernels: a traversal can keep a ray's 3 nearest candidates (keys only: level l of slot s at sh_best[l * 64 + s], over the
+// (2 / 3 / 5 / 8 levels, 1080p over 782 k alpha-textured triangles: BLEND everywhere 24.8 / 20.8 / 17.9 / 17.3 ms, hard-alpha MASK 2.81 / 2.74 / 2.86 /
+//  3.20 ms, boxes MASK 2.16 / 2.15 / 2.24 / 2.52 ms: three fit the merge words and cost the scenes whose rays end early nothing)
+#ifndef MIPT_AH_LEVELS
+#define MIPT_AH_LEVELS 3
+#endif
+constexpr int kAhLevels = MIPT_AH_LEVELS;     // AH kernels: a traversal can keep a ray's 3 nearest candidates (keys only: level l of slot s at sh_best[l * 64 + s], over the
                                  // merge words sh_u / sh_v / sh_done, which the AH kernels do not use -- they re-test a candidate's triangle for u, v)
 constexpr unsigned long long kAhOccludedKey = 0x007fffffull << 32;      // ord_bits(-inf) in the t half: below every key of a real candidate (t > tmin)
 __device__ __forceinline__ uint32_t ord_bits(float f) { const uint32_t b = f2u(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }

@@ -368,8 +368,9 @@ __global__ __launch_bounds__(256) void k_wh_seed(WhConsts c, DeviceBvh bvh, cons
 template <int MODE, int Q>
 __global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
 {
+    constexpr int kLevelWords = kAhLevels * 128 > 384 ? kAhLevels * 128 : 384;      // the candidate levels behind the pool (3 fit the merge words)
     constexpr int kPoolCap = MIPT_WH_AH_ROWS * 64 - 384;
-    __shared__ uint32_t stk[MIPT_WH_AH_ROWS * 64];
+    __shared__ uint32_t stk[MIPT_WH_AH_ROWS * 64 - 384 + kLevelWords];
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
@@ -407,8 +408,9 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k_wh_trace_pool_inst(WhConsts c, WhTraceArgs a)
 {
     constexpr int kRows = 24;
+    constexpr int kLevelWords = kAhLevels * 128 > 384 ? kAhLevels * 128 : 384;
     constexpr int kCap = (kRows * 64 - 384) / 2;
-    __shared__ __attribute__((aligned(16))) uint2 stk2[kRows * 32];
+    __shared__ __attribute__((aligned(16))) uint2 stk2[(kRows * 64 - 384 + kLevelWords) / 2];
     uint32_t* const words = reinterpret_cast<uint32_t*>(stk2);
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(words + 2 * kCap);
     float* const sh_u = reinterpret_cast<float*>(words + 2 * kCap + 128);
