@@ -260,6 +260,8 @@ struct WhBuffers {                 // launch storage owned by the context
     uint32_t* n_levels;            // per pixel
     uint32_t max_levels;           // 1 without BLEND materials, MAX_TRACE_DEPTH with
     bool any_hit_programs;         // a MASK / BLEND material exists: traversal runs the any-hit programs
+    uint32_t* live_ring;           // pinned host words (4): the number of rays a level leaves for the next one, written by k_wh_advance ...
+    void* const* ring_events;      // ... and 4 hipEvent_t recorded behind it: the host stops launching levels two behind the first empty one (null: all levels)
 };
 void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_paths, const DeviceBvh& bvh, const WhGeometry& geo,
                  const MiptMaterialData* d_materials, uint32_t n_materials, const WhTexture* d_textures, uint32_t n_textures,

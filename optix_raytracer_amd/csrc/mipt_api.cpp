@@ -1791,6 +1791,7 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     B.max_levels = ctx->wh_blend ? 8u : 1u;                     // whitted::MAX_TRACE_DEPTH
     B.levels = ctx->wh_blend ? ctx->wh_levels : ctx->result;
     B.any_hit_programs = ctx->wh_any_hit;
+    B.live_ring = ctx->h_pinned; B.ring_events = reinterpret_cast<void* const*>(ctx->ring_ev);
     whitted_run(st, *p, n_paths, device_bvh(acc), ctx->wh_geo, ctx->d_wh_materials, ctx->n_wh_materials, ctx->d_wh_textures,
                 ctx->n_wh_textures, B, ctx->d_ctr, trace_opts(ctx));
     ctx->last_bounces = B.max_levels; ctx->bounces_on_device = false;

@@ -781,10 +781,13 @@ __global__ __launch_bounds__(1024) void k_wh_gather(uint32_t K, WhLevel L, const
     block_add64(&ctr->shadow_rays, traced, &s_traced);                                      // occlusion rays really cast: one atomic per 1024 groups
 }
 
-__global__ void k_wh_advance(DeviceCounters* c)
+__global__ void k_wh_advance(DeviceCounters* c, uint32_t* host_live)
 {
     const uint32_t i = threadIdx.x;
-    if (i == 0) { c->closest_rays += c->n_next; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; c->n_open = 0; }
+    if (i == 0) {
+        if (host_live) *host_live = c->n_next;                  // (pinned host memory: what the next level will find)
+        c->closest_rays += c->n_next; c->n_cur = c->n_next; c->n_next = 0; c->n_shadow = 0; c->bounce = 0; c->n_open = 0;
+    }
     if (i < kNumSegments) { c->cursor_closest[i * kCursorStride] = 0; c->cursor_shadow[i * kCursorStride] = 0; }
 }
 
@@ -901,7 +904,19 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
             launch_trace_any(st, bvh, B.sh.ray_o, B.sh.ray_d, 1, &ctr->n_shadow, n_paths * K, B.flags, nullptr, nullptr, ctr, opts);
         hipLaunchKernelGGL(k_wh_gather, dim3((blocks + 3u) / 4u), dim3(1024), 0, st, K, L, (const uint32_t*)B.flags,
                            B.any_hit_programs ? (const float*)B.flags : (const float*)nullptr, ctr);
-        hipLaunchKernelGGL(k_wh_advance, dim3(1), dim3(64), 0, st, ctr);
+        // Levels beyond the deepest chain of BLEND surfaces find empty queues and cost seven launches each: the count a level leaves behind
+        // goes to a pinned ring, and the host reads it two levels later (the stream never drains) and stops behind the first empty level
+        // (run_wavefront's scheme; the 14-triangle alpha fixture, 8 levels of which 3 carry rays: 0.56 -> 0.52 ms per 1080p subframe).
+        constexpr uint32_t kRing = 4u, kLag = 2u;
+        const bool lagged = B.live_ring != nullptr && B.ring_events != nullptr && B.max_levels > kLag + 1u;
+        hipLaunchKernelGGL(k_wh_advance, dim3(1), dim3(64), 0, st, ctr, lagged ? B.live_ring + level % kRing : (uint32_t*)nullptr);
+        if (lagged) {
+            (void)hipEventRecord((hipEvent_t)B.ring_events[level % kRing], st);
+            if (level >= kLag) {
+                const uint32_t old = (level - kLag) % kRing;
+                if (hipEventSynchronize((hipEvent_t)B.ring_events[old]) == hipSuccess && B.live_ring[old] == 0u) break;
+            }
+        }
     }
     const uint32_t pb = (n_pixels + 255u) / 256u;
     hipLaunchKernelGGL(k_wh_resolve, dim3(pb), dim3(256), 0, st, c, (const float4*)B.levels, (const uint32_t*)B.n_levels, (float4*)p.accum_buffer,
