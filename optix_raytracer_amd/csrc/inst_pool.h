@@ -168,7 +168,9 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
     uint32_t y0 = ent.y, y1 = ent.y, y2 = ent.y, y3 = ent.y;
     int npush = 0;
     if (do_inner) {
-        const Slab4i b = slab_children4i(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
+        float tmn_b = tmn, tcur_b = tcur;                     // the box tests' interval (AH: a little wider, ah_box_interval; nood of the space the entry is in)
+        if (AH != 0) ah_box_interval(nx, ny, nz, tmn, tcur, tmn_b, tcur_b);
+        const Slab4i b = slab_children4i(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn_b, tcur_b);
         npush = b.n;                                          // push1 = the nearest (ends on top), push0 the next, then push2, push3
         int ref[4] = { b.ref[0], b.ref[1], b.ref[2], b.ref[3] };
         uint32_t yy[4] = { ent.y, ent.y, ent.y, ent.y };

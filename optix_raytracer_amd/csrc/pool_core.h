@@ -124,6 +124,19 @@ __device__ __forceinline__ uint32_t pool_pack(int ref, uint32_t slot)
 #endif
 constexpr int kAhLevels = MIPT_AH_LEVELS;     // AH kernels: a traversal can keep a ray's 3 nearest candidates (keys only: level l of slot s at sh_best[l * 64 + s], over the
                                  // merge words sh_u / sh_v / sh_done, which the AH kernels do not use -- they re-test a candidate's triangle for u, v)
+// AH kernels: the interval the BOX tests of a traversal use, a little wider than the ray's.  A traversal of the any-hit kernels starts at
+// tmin = the t of the candidate the program just ignored and is pruned at a candidate's t, and a box that holds a candidate within
+// rounding of such a t (a coincident surface, a decal a few ulps in front) can fail its slab test by an ulp although the triangle test --
+// which decides, and is exact about the key -- would pass.  The oracle's traversal never stands at such a t (it collects a ray's
+// candidates from the ray's own tmin in one walk), so the two would part ways.  Wider box intervals only weaken pruning.  The margin:
+// 2^-19 of the magnitudes that enter a slab distance (box * idir - origin * idir).  (Boxes rounded outward to fp16, node formats 1 and 2,
+// hide this; fp32 boxes -- format 0, scenes that do not suit fp16 boxes -- do not: tests/test_whitted.py runs both.)
+__device__ __forceinline__ void ah_box_interval(const float nx, const float ny, const float nz, const float tmn, const float tcur, float& tmn_b, float& tcur_b)
+{
+    const float mg = (__builtin_fabsf(nx) + __builtin_fabsf(ny) + __builtin_fabsf(nz)) * 1.9073486e-6f;
+    tmn_b = tmn - (mg + __builtin_fabsf(tmn) * 1.9073486e-6f);
+    tcur_b = tcur == -__builtin_inff() ? tcur : tcur + (mg + __builtin_fabsf(tcur) * 1.9073486e-6f);
+}
 constexpr unsigned long long kAhOccludedKey = 0x007fffffull << 32;      // ord_bits(-inf) in the t half: below every key of a real candidate (t > tmin)
 __device__ __forceinline__ uint32_t ord_bits(float f) { const uint32_t b = f2u(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }
 __device__ __forceinline__ float    ord_float(uint32_t k) { return u2f(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }

@@ -189,8 +189,10 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
                  n2 = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
     uint32_t push0 = 0u, push1 = 0u, push2 = 0u, push3 = 0u;
     int npush = 0;
+    float tmn_b = tmn, tcur_b = tcur;                         // the box tests' interval (AH: a little wider, ah_box_interval)
+    if (AH != 0) ah_box_interval(nx, ny, nz, tmn, tcur, tmn_b, tcur_b);
     if (Q == 2 && do_inner) {
-        const Slab4 b = slab_children4(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
+        const Slab4 b = slab_children4(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn_b, tcur_b);
         npush = b.n;                                          // push1 = the nearest (ends on top), push0 the next, then push2, push3
         if (b.n > 0) push1 = pool_pack(b.ref[0], slot);
         if (b.n > 1) push0 = pool_pack(b.ref[1], slot);
@@ -198,7 +200,7 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
         if (b.n > 3) push3 = pool_pack(b.ref[3], slot);
     }
     if (Q != 2 && do_inner) {
-        const SlabOut b = slab_children<Q>(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn, tcur);
+        const SlabOut b = slab_children<Q>(q0, q1, q2, q3, ix, iy, iz, nx, ny, nz, tmn_b, tcur_b);
         const bool h0 = b.tn0 <= b.tf0, h1 = b.tn1 <= b.tf1;
         const int c0 = b.c0, c1 = b.c1;
         if (h0 && h1) {

@@ -467,6 +467,11 @@ __global__ __launch_bounds__(64) void k_wh_trace(WhConsts c, WhTraceArgs a)
             Trav T;
             trav_init(T, make_float4(ro.x, ro.y, ro.z, tmin), rd);
             uint32_t gflags_best = 0u;
+            float best = T.tbest;                                  // exact: the triangle tests' bound; T.tmin / T.tbest: the box tests' (ah_box_interval)
+            const float tmax = T.tmax;
+            float box_lo, box_hi;
+            ah_box_interval(T.nood.x, T.nood.y, T.nood.z, tmin, best, box_lo, box_hi);
+            T.tmin = box_lo; T.tbest = box_hi;
             while (T.node != kSentinel) {
                 while (T.node >= 0) visit_inner(T, bvh.nodes, stk);
                 if (T.node == kSentinel) break;
@@ -487,16 +492,20 @@ __global__ __launch_bounds__(64) void k_wh_trace(WhConsts c, WhTraceArgs a)
                     const float t = fdot(e2, q) * inv;
                     if (!(u >= 0.0f && v >= 0.0f && u + v <= 1.0f)) continue;
                     const uint32_t prim = f2u(ta.w), gflags = f2u(tb.w);
-                    if (!((t > T.tmin || (t == T.tmin && prim > skip)) && t < T.tmax)) continue;
+                    if (!((t > tmin || (t == tmin && prim > skip)) && t < tmax)) continue;
                     if (MODE == 0 && det < 0.0f && (gflags & 4u) == 0u) continue;            // back face of a single-sided triangle
                     if (MODE != 0 && (gflags & 1u) != 0u) { occlusion = 0.0f; T.prim = 0xffffffffu; T.sp = 0; T.node = kSentinel; break; }   // no program: occluded, wherever it lies
-                    if (t < T.tbest || (t == T.tbest && prim < T.prim)) { T.tbest = t; T.prim = prim; T.u = u; T.v = v; gflags_best = gflags; }
+                    if (t < best || (t == best && prim < T.prim)) {
+                        best = t; T.prim = prim; T.u = u; T.v = v; gflags_best = gflags;
+                        ah_box_interval(T.nood.x, T.nood.y, T.nood.z, tmin, best, box_lo, box_hi);
+                        T.tbest = box_hi;
+                    }
                 }
                 T.node = stk.pop(T.sp);
             }
             if (T.prim == 0xffffffffu) break;
-            if (anyhit_step<MODE>(c, gflags_best, T.prim, T.u, T.v, occlusion)) { rec = make_float4(T.tbest, u2f(T.prim), T.u, T.v); open = false; }
-            else { tmin = T.tbest; skip = T.prim; }
+            if (anyhit_step<MODE>(c, gflags_best, T.prim, T.u, T.v, occlusion)) { rec = make_float4(best, u2f(T.prim), T.u, T.v); open = false; }
+            else { tmin = best; skip = T.prim; }
         }
         if (MODE == 0) a.hits[ray] = rec;
         else           a.attenuation[ray] = occlusion;
@@ -530,7 +539,9 @@ __global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, WhTraceArgs a)
             int node = 0;
             bool dead = false;                                  // MODE 1: a candidate without program was met
             while (node != kSentinel && !dead) {
-                while (node >= 0) node = step_inner(bvh.nodes, node, W, tmin, tbest, stk, sp, 0);
+                float w_lo, w_hi;                                   // the box tests' interval, a little wider than the ray's (ah_box_interval)
+                ah_box_interval(W.nood.x, W.nood.y, W.nood.z, tmin, tbest, w_lo, w_hi);
+                while (node >= 0) node = step_inner(bvh.nodes, node, W, w_lo, w_hi, stk, sp, 0);
                 if (node == kSentinel) break;
                 const uint32_t idesc = ~(uint32_t)node, ifirst = idesc >> 4, icnt = idesc & 15u;
                 for (uint32_t k = 0; k < icnt && !dead; ++k) {
@@ -543,7 +554,9 @@ __global__ __launch_bounds__(64) void k_wh_trace_inst(WhConsts c, WhTraceArgs a)
                     const int base = sp;
                     int mn = 0;
                     while (mn != kSentinel && !dead) {
-                        while (mn >= 0) mn = step_inner(in.nodes, mn, O, tmin, tbest, stk, sp, base);
+                        float o_lo, o_hi;
+                        ah_box_interval(O.nood.x, O.nood.y, O.nood.z, tmin, tbest, o_lo, o_hi);
+                        while (mn >= 0) mn = step_inner(in.nodes, mn, O, o_lo, o_hi, stk, sp, base);
                         if (mn == kSentinel) break;
                         const uint32_t desc = ~(uint32_t)mn, first = desc >> 4, cnt = desc & 15u;
                         for (uint32_t i = 0; i < cnt; ++i) {

@@ -549,15 +549,20 @@ def test_alpha_modes_and_culling_match_the_oracle(tmp_path, w, h, subframes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stack,tess,persistent", [(7, 1, None), (24, 1, None), (7, 24, None), (24, 24, None), (24, 24, 2)])
-def test_deferred_any_hit_programs_over_many_layers(tmp_path, stack, tess, persistent):
+@pytest.mark.parametrize("stack,tess,persistent,node_format", [(7, 1, None, 2), (24, 1, None, 2), (7, 24, None, 2), (24, 24, None, 2), (24, 24, 2, 2),
+                                                               (24, 1, None, 0), (24, 24, None, 0), (24, 24, None, 1)])
+def test_deferred_any_hit_programs_over_many_layers(tmp_path, monkeypatch, stack, tess, persistent, node_format):
     """The any-hit programs run deferred, a ray's candidates in the order of (t, primitive index) (whitted_kernels.hip): a closest-hit
     traversal finds the next candidate, the program runs on it, and an ignored candidate becomes the continuation key (tmin = t; at
     equal t only primitives above the ignored one count).  7 / 24 more panes, every fifth one TWICE -- coincident surfaces, candidates
     at bit-equal t -- so occlusion rays from the ground cross up to 30 attenuating surfaces and camera rays run into the depth limit.
     tess = 24: the ground as 1 152 triangles, a tree deep enough for the ENTRY-POOL form (k_wh_trace_pool; trees of up to 8 levels take
     the one-ray-per-thread form by themselves); persistent = 2 pins that form for the deep tree too.  Every frame equals the oracle's --
-    which COLLECTS the candidates of a ray, SORTS them and multiplies -- bit for bit."""
+    which COLLECTS the candidates of a ray, SORTS them and multiplies -- bit for bit.
+    node_format 0: fp32 boxes.  The panes are flat, so their boxes have NO thickness, and a traversal that starts at the t of an ignored
+    candidate stands within rounding of the coincident twin's box: the box tests of these kernels use a slightly wider interval
+    (ah_box_interval) -- without it 300-800 pixels of these frames differ.  (Formats 1 / 2 round boxes outward to fp16 and hide it.)"""
+    monkeypatch.setenv("MIPT_NODE_FORMAT", str(node_format))
     _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path, stack=stack, tess=tess), 120, 80, 2, persistent=persistent, deep=tess > 1)
 
 
