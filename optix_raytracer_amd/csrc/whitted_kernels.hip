@@ -211,9 +211,9 @@ __device__ __forceinline__ uint32_t prim_material(const WhConsts& c, uint32_t pr
 // restarts for rays through many surfaces.  The pool reports keys only; u, v and the geometry flags of a key come from testing its
 // triangle again (candidate_record: the builders' primitive -> record tables).
 // Measured, 1080p subframe over 2 000 instances / 782 k triangles, ALL of them alpha-textured (tools/bench_alpha.py,
-// profiles/r03_bench_alpha.txt): MASK materials with hard alpha (a ray ends at the first solid texel) 2.74 ms against 1.10 ms for the
+// profiles/r03_bench_alpha.txt): MASK materials with hard alpha (a ray ends at the first solid texel) 2.22 ms against 1.10 ms for the
 // same scene with opaque materials; BLEND films everywhere -- an occlusion ray crosses 7 attenuating surfaces on average, up to 78, and
-// none ends it, so every ray is traversed to its end -- 20.8 ms (one candidate per traversal: 33.8) against round 2's 45.5 ms.
+// none ends it, so every ray is traversed to its end -- 19.1 ms (one candidate per traversal, 32 rays per wave: 33.8) against round 2's 45.5 ms.
 // Tried for the occlusion rays and dropped: ONE traversal that records every candidate of the interval (16 records per ray,
 // narrower windows for rays with more) and then sorts -- without a running closest hit nothing prunes the traversal, and the rays that
 // end early pay for the whole interval: 20 ms on the MASK scene, 40-76 ms on the BLEND scene.
@@ -254,12 +254,15 @@ __device__ __forceinline__ bool anyhit_step(const WhConsts& c, uint32_t gflags, 
 }
 
 // rays per wave, from the ray count the DEVICE knows (a level's queue length; the host only knows the capacity): a chunk's traversals
-// run one after the other, so a launch of few rays finishes sooner with few rays per wave -- all 64 lanes serve them
+// run one after the other, so a launch of few rays finishes sooner with few rays per wave -- all 64 lanes serve them.  Big launches take
+// 64 (1080p over 782 k triangles, everything MASK / boxes MASK / BLEND everywhere: one level 2.74 / 2.17 / 21.0 ms with 32, 2.27 / 1.75 /
+// 19.0 with 64; two levels, whose pool entries are twice as wide, with a pool of 40 LDS rows instead of 24 -- 64 rays overfill the
+// smaller one: 3.69 / 2.90 / 29.0 ms with 32 rays and 24 rows, 2.95 / 2.33 / 26.7 with 64 and 40; one level gains nothing from more rows).
 __device__ __forceinline__ uint32_t ah_rays_per_wave(uint32_t fixed, uint32_t n, uint32_t cus)
 {
     if (fixed != 0u) return fixed;
     const uint32_t q = n / (cus * 64u);
-    return q >= 32u ? 32u : (q >= 16u ? 16u : (q >= 8u ? 8u : 4u));
+    return q >= 64u ? 64u : (q >= 32u ? 32u : (q >= 16u ? 16u : (q >= 8u ? 8u : 4u)));
 }
 
 struct WhTraceArgs {
@@ -365,6 +368,9 @@ __global__ __launch_bounds__(256) void k_wh_seed(WhConsts c, DeviceBvh bvh, cons
 #ifndef MIPT_WH_AH_ROWS
 #define MIPT_WH_AH_ROWS 24
 #endif
+#ifndef MIPT_WH_INST_ROWS
+#define MIPT_WH_INST_ROWS 40       // (two-level pool entries are 8 bytes: 40 rows hold what 64 rays per wave need, ah_rays_per_wave)
+#endif
 template <int MODE, int Q>
 __global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
 {
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
 template <int MODE>
 __global__ __launch_bounds__(64) void k_wh_trace_pool_inst(WhConsts c, WhTraceArgs a)
 {
-    constexpr int kRows = 24;
+    constexpr int kRows = MIPT_WH_INST_ROWS;
     constexpr int kLevelWords = kAhLevels * 128 > 384 ? kAhLevels * 128 : 384;
     constexpr int kCap = (kRows * 64 - 384) / 2;
     __shared__ __attribute__((aligned(16))) uint2 stk2[(kRows * 64 - 384 + kLevelWords) / 2];
