@@ -339,6 +339,48 @@ def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, persistent
     MV.cleanup(st)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_level", [False, True])
+def test_any_hit_forms_agree_on_a_large_scene(tmp_path, two_level):
+    """A scene of 300 instances / 117 k alpha-textured triangles (BLEND films + MASK fences) at 960x540, three subframes: the entry-pool
+    form of the any-hit kernels (64 rays per wave, three candidates per traversal after the first, radiance rays seeded by the tiled
+    launch over the two-level structure) and the one-ray-per-thread form (one candidate per traversal) must give the same frame bit for
+    bit -- every candidate of every ray in the order of (t, primitive), whatever the traversal's shape."""
+    import torch
+    import _png_fixture as PF
+    from optix_raytracer_amd import meshviewer as MV
+    from optix_raytracer_amd import scenes
+    from optix_raytracer_amd import _lib as L
+    rng = np.random.default_rng(21)
+    film = np.zeros((8, 8, 4), np.int64); film[..., :3] = rng.integers(60, 255, (8, 8, 3)); film[..., 3] = rng.integers(40, 230, (8, 8))
+    fence = np.zeros((8, 8, 4), np.int64); fence[..., :3] = 200; fence[..., 3] = np.where((np.add.outer(np.arange(8), np.arange(8)) % 3) == 0, 0, 255)
+    path = scenes.write_instanced_gltf(tmp_path / "instanced_alpha_large.gltf", n_instances=300, seed=5,
+                                       alpha_textures=(PF.encode(film, 6, 8)[0], PF.encode(fence, 6, 8)[0]))
+    w, h = 960, 540
+    frames = {}
+    for form in ("pool", "walk"):
+        st = MV.MeshViewerState()
+        MV.loadScene(st, path, two_level=two_level)
+        if form == "walk":
+            st.context.set_option(L.OPT_PERSISTENT, 2)
+        MV.initCameraState(st)
+        MV.initLaunchParams(st, w, h)
+        out = MV.OutputBuffer(w, h, st.device)
+        for _ in range(3):
+            MV.updateState(st)
+            MV.launchSubframe(out, st)
+            st.params.subframe_index += 1
+        assert st.context.accel_info(st.handle)["depth"] > 8
+        frames[form] = (st.accum.cpu().numpy().copy(), st.context.launch_stats())
+        MV.cleanup(st)
+    a, b = frames["pool"][0], frames["walk"][0]
+    assert np.isfinite(a).all() and a[..., :3].max() > 0.05
+    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32))
+    assert bad.size == 0, "first differing pixel %s: pool %s walk %s (%d differ)" % (bad[0], a[tuple(bad[0][:2])], b[tuple(bad[0][:2])], len(bad))
+    assert frames["pool"][1]["closest_rays"] == frames["walk"][1]["closest_rays"] > w * h
+    assert frames["pool"][1]["shadow_rays"] == frames["walk"][1]["shadow_rays"] > 0
+
+
 @pytest.mark.parametrize("form", [1, 2])
 def test_every_traversal_form_gives_the_same_records(tmp_path, monkeypatch, form):
     """Round 3: three forms walk a two-level structure -- tiles of 64 rays, one ray per lane with the object-space ray in registers, then
