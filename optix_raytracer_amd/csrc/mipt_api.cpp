@@ -959,7 +959,7 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = 1;
     a->d_prim_slot = d_slot;
     if ((e = finish_blob(ctx, a)) != hipSuccess) { free_accel(a); return ctx->fail(MIPT_ERROR_HIP, "device BVH build: %s", hipGetErrorString(e)); }
-    a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u + (size_t)n * 4u;         // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table
+    a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u + (size_t)n * 4u + (d_slot ? (size_t)n * 4u : 0u);   // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table + the primitive -> record table
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
@@ -1073,7 +1073,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
         free_accel(a);
         return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "accel upload failed: %s", hipGetErrorString(e));
     }
-    a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)a->num_nodes * 96u + mb;             // the whole allocation: nodes | triangles | pad | room for both node mirrors, + the SBT index table
+    a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)a->num_nodes * 96u + mb + (a->d_prim_slot ? (size_t)n_tris * 4u : 0u);   // the whole allocation: nodes | triangles | pad | room for both node mirrors, + the SBT index table + the primitive -> record table
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
     *handle_out = h;
