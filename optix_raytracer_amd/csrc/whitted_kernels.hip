@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t prim_material(const WhConsts& c, uint32_t pr
 // Measured, 1080p subframe over 2 000 instances / 782 k triangles, ALL of them alpha-textured (tools/bench_alpha.py,
 // profiles/r03_bench_alpha.txt): MASK materials with hard alpha (a ray ends at the first solid texel) 2.22 ms against 1.10 ms for the
 // same scene with opaque materials; BLEND films everywhere -- an occlusion ray crosses 7 attenuating surfaces on average, up to 78, and
-// none ends it, so every ray is traversed to its end -- 19.1 ms (one candidate per traversal, 32 rays per wave: 33.8) against round 2's 45.5 ms.
+// none ends it, so every ray is traversed to its end -- 18.0 ms (one candidate per traversal, 32 rays per wave: 33.8) against round 2's 45.5 ms.
 // Tried for the occlusion rays and dropped: ONE traversal that records every candidate of the interval (16 records per ray,
 // narrower windows for rays with more) and then sorts -- without a running closest hit nothing prunes the traversal, and the rays that
 // end early pay for the whole interval: 20 ms on the MASK scene, 40-76 ms on the BLEND scene.
@@ -271,6 +271,7 @@ struct WhTraceArgs {
     const uint32_t* n_ptr; uint32_t n_max;
     float4* hits; float* attenuation;
     uint32_t ppw, cus;             // ppw 0: chosen on the device (ah_rays_per_wave)
+    uint32_t first_k;              // candidates a ray's FIRST traversal asks for (1; kAhLevels for the occlusion rays of scenes with BLEND materials)
     const uint32_t* open_list;     // MODE 0, seeded launch: the rays to trace (k_wh_seed; n_ptr counts them), each from beyond the candidate in hits[ray]
 };
 
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
         const bool mine = (uint32_t)lane < ppw && ray < n;
         if (MODE == 0 && a.open_list != nullptr && mine) ray = a.open_list[ray];
         Trav T;
-        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu; T.ahk = 1u;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu; T.ahk = a.first_k;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[ray], a.ray_d[ray]);
         if (MODE == 0 && a.open_list != nullptr && mine) { const float4 h = a.hits[ray]; T.tmin = h.x; T.skip = f2u(h.y); T.ahk = (uint32_t)kAhLevels; }      // beyond the ignored candidate
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(64) void k_wh_trace_pool_inst(WhConsts c, WhTraceAr
         const bool mine = (uint32_t)lane < ppw && ray < n;
         if (MODE == 0 && a.open_list != nullptr && mine) ray = a.open_list[ray];
         Trav T;
-        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu; T.ahk = 1u;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f; T.skip = 0xffffffffu; T.ahk = a.first_k;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
         if (mine) trav_init(T, a.ray_o[ray], a.ray_d[ray]);
         if (MODE == 0 && a.open_list != nullptr && mine) { const float4 h = a.hits[ray]; T.tmin = h.x; T.skip = f2u(h.y); T.ahk = (uint32_t)kAhLevels; }      // beyond the ignored candidate
@@ -857,13 +858,15 @@ static bool wh_trace_on_pool(const DeviceBvh& bvh, const TraceOpts& o)
 
 template <int MODE>
 static void launch_wh_trace(hipStream_t st, const WhConsts& c, const DeviceBvh& bvh, const float4* ray_o, const float4* ray_d, const uint32_t* n_ptr,
-                            uint32_t n_max, float4* hits, float* attenuation, const TraceOpts& o, const uint32_t* open_list = nullptr)
+                            uint32_t n_max, float4* hits, float* attenuation, const TraceOpts& o, const uint32_t* open_list = nullptr, bool blend = false)
 {
     if (n_max == 0u) return;
     static const int e_ppw = [] { const char* e = std::getenv("MIPT_WH_AH_PPW"); return e ? std::atoi(e) : 0; }();
     WhTraceArgs a{};
     a.bvh = bvh; a.ray_o = ray_o; a.ray_d = ray_d; a.n_ptr = n_ptr; a.n_max = n_max; a.hits = hits; a.attenuation = attenuation;
     a.open_list = open_list;
+    static const int e_k = [] { const char* e = std::getenv("MIPT_WH_AH_FIRST"); return e ? std::atoi(e) : 0; }();      // (experiments: 1 / kAhLevels everywhere)
+    a.first_k = e_k >= 1 && e_k <= kAhLevels ? (uint32_t)e_k : (MODE == 1 && blend ? (uint32_t)kAhLevels : 1u);
     const bool pool = wh_trace_on_pool(bvh, o);
     if (!pool) {
         const int tblocks = o.blocks > 0 ? o.blocks : 4096;
@@ -918,7 +921,7 @@ void whitted_run(hipStream_t st, const MiptWhittedLaunchParams& p, uint32_t n_pa
         L.level = level; L.n_pixels = n_pixels; L.bound = n_paths;
         hipLaunchKernelGGL(k_wh_shade, dim3(blocks), dim3(256), 0, st, c, L, ctr);
         hipLaunchKernelGGL(k_wh_scale, dim3(1), dim3(64), 0, st, ctr, K);
-        if (B.any_hit_programs) launch_wh_trace<1>(st, c, bvh, B.sh.ray_o, B.sh.ray_d, &ctr->n_shadow, n_paths * K, nullptr, (float*)B.flags, opts);
+        if (B.any_hit_programs) launch_wh_trace<1>(st, c, bvh, B.sh.ray_o, B.sh.ray_d, &ctr->n_shadow, n_paths * K, nullptr, (float*)B.flags, opts, nullptr, B.max_levels > 1u);
         else
             launch_trace_any(st, bvh, B.sh.ray_o, B.sh.ray_d, 1, &ctr->n_shadow, n_paths * K, B.flags, nullptr, nullptr, ctr, opts);
         hipLaunchKernelGGL(k_wh_gather, dim3((blocks + 3u) / 4u), dim3(1024), 0, st, K, L, (const uint32_t*)B.flags,
