@@ -372,8 +372,15 @@ __global__ __launch_bounds__(256) void k_wh_seed(WhConsts c, DeviceBvh bvh, cons
 #ifndef MIPT_WH_INST_ROWS
 #define MIPT_WH_INST_ROWS 40       // (two-level pool entries are 8 bytes: 40 rows hold what 64 rays per wave need, ah_rays_per_wave)
 #endif
+// (experiments: 7 waves per SIMD -- 72 VGPRs -- change nothing, 2.27 / 1.80 / 18.6 ms on the three alpha scenes; 20 LDS rows cost 30-50 %
+//  with 64 rays per wave: the pool runs full)
+#ifdef MIPT_WH_AH_WAVES
+#define MIPT_WH_AH_ATTR __attribute__((amdgpu_waves_per_eu(MIPT_WH_AH_WAVES, MIPT_WH_AH_WAVES)))
+#else
+#define MIPT_WH_AH_ATTR
+#endif
 template <int MODE, int Q>
-__global__ __launch_bounds__(64) void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
+__global__ __launch_bounds__(64) MIPT_WH_AH_ATTR void k_wh_trace_pool(WhConsts c, WhTraceArgs a)
 {
     constexpr int kLevelWords = kAhLevels * 128 > 384 ? kAhLevels * 128 : 384;      // the candidate levels behind the pool (3 fit the merge words)
     constexpr int kPoolCap = MIPT_WH_AH_ROWS * 64 - 384;
