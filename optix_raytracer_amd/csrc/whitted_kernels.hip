@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void k_wh_resolve(WhConsts c, const float4* le
 // whose packed entries fit, a two-level structure in its arena form), else one ray per thread.  MIPT_WH_ANYHIT=walk forces the
 // latter (tests compare the two).  Rays per wave: chosen on the device from the queue's length (ah_rays_per_wave).
 // MIPT_WH_ANYHIT = walk: one ray per thread (what structures without the pool's mirrors get); unseeded / seeded: never / wherever the
-// flag tables exist a fast closest-hit launch in front of the radiance rays (default: over two-level structures, where it gains)
+// record tables exist a fast closest-hit launch in front of the radiance rays (default: over two-level structures, where it gains)
 static int wh_anyhit_env()
 {
     static const int v = [] { const char* e = std::getenv("MIPT_WH_ANYHIT"); return !e ? 0 : (std::strcmp(e, "walk") == 0 ? 1 : (std::strcmp(e, "unseeded") == 0 ? 2 : (std::strcmp(e, "seeded") == 0 ? 3 : 0))); }();
