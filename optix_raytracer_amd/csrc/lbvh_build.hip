@@ -7,6 +7,8 @@
 // which builder made the tree (closest hit: min t, tie -> lowest primitive).
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 #include "kernels.h"
 #include "detmath.h"
 
@@ -226,6 +228,163 @@ __global__ __launch_bounds__(64) void k_lbvh_treelets(const uint32_t* __restrict
     }
 }
 
+// ---- SAH clusters (round 3, experiment MIPT_LBVH_CLUSTERS): the treelet pass one level up -----------------------------------------------
+// The ITEMS of this pass are the subtrees the treelet pass has rebuilt (and single triangles hanging off bigger nodes): children of
+// nodes over more than kTreelet triangles that are not such nodes themselves.  A radix-tree node with at most 64 items below it whose
+// parent has more is a CLUSTER: one wave collects its items (a depth-first walk over the cluster's own inner nodes, whose slots it then
+// reuses), takes each item's box as the union of its triangles' boxes and its weight as its triangle count, and rebuilds the tree
+// over the items top down with the same full-sweep SAH (cost = area(left) * triangles(left) + area(right) * triangles(right)).  Items
+// keep their own subtrees and their place in the triangle order; above them ranges are no longer contiguous, which nothing after this
+// pass needs (leaf folding looks at ranges of at most leaf_max triangles; everything else follows the child / parent links) -- a
+// cluster node's range holds its triangle COUNT.  The cluster's root keeps its slot, so the link from above stays.
+// `big`: one byte per radix-tree node, 1 = above the item layer of this pass (first pass: over more than kTreelet triangles; each further
+// pass: the big nodes with more than 64 items below them -- what lies above the clusters the pass before has made)
+__global__ __launch_bounds__(256) void k_cluster_first_big(const int* range_lo, const int* range_hi, int n_inner, uint8_t* big)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n_inner) big[i] = range_hi[i] - range_lo[i] + 1 > kTreelet ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_cluster_next_big(const uint32_t* cnt, int n_inner, uint8_t* big)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n_inner) big[i] = big[i] != 0u && cnt[i] > (uint32_t)kTreelet ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_cluster_counts(const int* left, const int* right, const uint8_t* big, const int* parent_inner, int n_inner, uint32_t* cnt)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner || big[i] == 0u) return;
+    uint32_t items = 0u;
+    const int ch[2] = { left[i], right[i] };
+    for (int k = 0; k < 2; ++k) if (ch[k] < 0 || big[ch[k]] == 0u) ++items;
+    if (items == 0u) return;
+    int a = i;
+    for (int guard = 0; a >= 0 && guard < 4096; ++guard) { atomicAdd(&cnt[a], items); a = parent_inner[a]; }
+}
+
+__global__ __launch_bounds__(256) void k_cluster_roots(const uint8_t* big, const int* parent_inner, const uint32_t* cnt, int n_inner, uint32_t* roots, uint32_t* n_roots)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_inner || big[i] == 0u) return;
+    const uint32_t c = cnt[i];
+    if (c < 3u || c > (uint32_t)kTreelet) return;
+    const int p = parent_inner[i];
+    if (p >= 0 && cnt[p] <= (uint32_t)kTreelet) return;              // inside a cluster, not its root
+    roots[atomicAdd(n_roots, 1u)] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(64) void k_lbvh_clusters(const uint32_t* __restrict__ roots, const uint32_t* __restrict__ n_roots, const uint8_t* __restrict__ big,
+                                                      const Box6* __restrict__ prim_boxes, const uint32_t* __restrict__ sorted_prims, const Box6* __restrict__ node_boxes,
+                                                      int* left, int* right, int* parent_inner, int* parent_leaf, int* range_lo, int* range_hi)
+{
+    __shared__ float s_box[64][8];                                    // a record per position: box, item reference (bits), triangle count
+    __shared__ int s_items[64], s_slots[64], s_stack[64], s_n[2];
+    const int lane = (int)threadIdx.x;
+    const uint32_t n_t = *n_roots;
+    for (uint32_t t = blockIdx.x; t < n_t; t += gridDim.x) {
+        const int R = (int)roots[t];
+        __syncthreads();
+        if (lane == 0) {
+            int ni = 0, ns = 0, sp = 0;
+            s_stack[sp++] = R;
+            while (sp > 0 && ns < 64) {
+                const int x = s_stack[--sp];
+                s_slots[ns++] = x;
+                const int ch[2] = { right[x], left[x] };
+                for (int k = 0; k < 2; ++k) {
+                    const int c = ch[k];
+                    const bool item = c < 0 || big[c] == 0u;
+                    if (item) { if (ni < 64) s_items[ni] = c; ++ni; } else if (sp < 64) s_stack[sp++] = c; else ni = 1 << 20;
+                }
+            }
+            s_n[0] = sp == 0 ? ni : 1 << 20; s_n[1] = ns;
+        }
+        __syncthreads();
+        const int n = s_n[0];
+        if (n < 3 || n > 64 || s_n[1] != n - 1) continue;              // (never by construction: leave the cluster as it is)
+        const bool valid = lane < n;
+        int ref = valid ? s_items[lane] : 0;
+        float b[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        float wt = 0.0f;
+        if (valid) {
+            const Box6 u = ref < 0 ? prim_boxes[sorted_prims[~ref]] : node_boxes[ref];      // (an item's subtree is not touched by this pass: its fitted box stands)
+            for (int k = 0; k < 3; ++k) { b[k] = u.lo[k]; b[3 + k] = u.hi[k]; }
+            wt = ref < 0 ? 1.0f : (float)(range_hi[ref] - range_lo[ref] + 1);
+        }
+        int sa = 0, sb = n - 1, sp = -1, ss = 0;                       // my segment; the node above it (-1: the cluster's root is made first) and the side
+        int m_root = 0;
+        __syncthreads();
+        for (int level = 0; level < kTreelet; ++level) {
+            const bool active = valid && sb > sa;
+            if (__ballot(active) == 0ull) break;
+            float best_cost = __builtin_inff(); int best_m = sa, best_axis = 0;
+            int pos_axis[3] = { lane, lane, lane };
+            for (int axis = 0; axis < 3; ++axis) {
+                const float key = b[axis] + b[3 + axis];
+                int rank = 0;
+                for (int k = 0; k < kTreelet; ++k) {
+                    const float kk = __shfl(key, k, 64);
+                    rank += (k >= sa && k <= sb && (kk < key || (kk == key && k < lane))) ? 1 : 0;
+                }
+                const int pos = sa + rank;
+                pos_axis[axis] = pos;
+                if (valid) { for (int c = 0; c < 6; ++c) s_box[pos][c] = b[c]; s_box[pos][7] = wt; }
+                __syncthreads();
+                float L[6], Rr[6], wl = valid ? s_box[lane][7] : 0.0f, wr = wl;
+                for (int c = 0; c < 6; ++c) { L[c] = valid ? s_box[lane][c] : 0.f; Rr[c] = L[c]; }
+                __syncthreads();
+                for (int d = 1; d < kTreelet; d <<= 1) {              // union / weight of positions sa .. j (L, wl) and j .. sb (R, wr)
+                    for (int c = 0; c < 6; ++c) {
+                        const float u = __shfl_up(L[c], d, 64), w = __shfl_down(Rr[c], d, 64);
+                        if (lane - d >= sa) L[c] = c < 3 ? fminf(L[c], u) : fmaxf(L[c], u);
+                        if (lane + d <= sb) Rr[c] = c < 3 ? fminf(Rr[c], w) : fmaxf(Rr[c], w);
+                    }
+                    const float ul = __shfl_up(wl, d, 64), ur = __shfl_down(wr, d, 64);
+                    if (lane - d >= sa) wl += ul;
+                    if (lane + d <= sb) wr += ur;
+                }
+                float Rn[6];
+                for (int c = 0; c < 6; ++c) Rn[c] = __shfl_down(Rr[c], 1, 64);      // positions j + 1 .. sb
+                const float wrn = __shfl_down(wr, 1, 64);
+                float cost = __builtin_inff();
+                if (active && lane < sb) cost = box_area6(L) * wl + box_area6(Rn) * wrn;
+                float seg_cost = __builtin_inff(); int seg_m = sa;
+                for (int k = 0; k < kTreelet; ++k) {
+                    const float ck = __shfl(cost, k, 64);
+                    if (k >= sa && k < sb && ck < seg_cost) { seg_cost = ck; seg_m = k; }
+                }
+                if (seg_cost < best_cost) { best_cost = seg_cost; best_m = seg_m; best_axis = axis; }
+            }
+            if (active && !(best_cost < __builtin_inff())) { best_m = (sa + sb) >> 1; best_axis = 0; }
+            const int to = active ? (best_axis == 0 ? pos_axis[0] : (best_axis == 1 ? pos_axis[1] : pos_axis[2])) : lane;
+            if (valid) { for (int c = 0; c < 6; ++c) s_box[to][c] = b[c]; s_box[to][6] = __int_as_float(ref); s_box[to][7] = wt; }
+            __syncthreads();
+            if (valid) { for (int c = 0; c < 6; ++c) b[c] = s_box[lane][c]; ref = __float_as_int(s_box[lane][6]); wt = s_box[lane][7]; }
+            __syncthreads();
+            float seg_w = 0.0f;                                          // the segment's triangle count (the new node's range words)
+            for (int k = 0; k < kTreelet; ++k) { const float wk = __shfl(wt, k, 64); if (k >= sa && k <= sb && k < n) seg_w += wk; }
+            if (level == 0) m_root = __shfl(best_m, 0, 64);            // one segment at level 0: every lane has the same split
+            if (active) {
+                const int mi = level == 0 ? 0 : (best_m == m_root ? 0 : (best_m == 0 ? m_root : best_m));   // slot of the split after position best_m (the root's is slot 0)
+                const int N = s_slots[mi];
+                if (lane == best_m && sp >= 0) {
+                    // (the cluster's root keeps its range -- still the contiguous run of its triangles -- and its place under its parent; a node
+                    //  inside the cluster covers no contiguous run any more: its range holds a COUNT, never small enough to be folded into a leaf)
+                    range_lo[N] = 0; range_hi[N] = ((int)seg_w > kTreelet ? (int)seg_w : kTreelet + 1) - 1;
+                    parent_inner[N] = sp;
+                    if (ss == 0) left[sp] = N; else right[sp] = N;
+                }
+                if (lane <= best_m) { sb = best_m; ss = 0; } else { sa = best_m + 1; ss = 1; }
+                sp = N;
+                if (sa == sb) {                                         // a single item: its link
+                    if (ss == 0) left[sp] = ref; else right[sp] = ref;
+                    if (ref < 0) parent_leaf[~ref] = sp; else parent_inner[ref] = sp;
+                }
+            }
+        }
+    }
+}
+
 // ---- bottom-up passes without fences ---------------------------------------------------------------------------------------------
 // Round 2 fitted boxes with "the second thread to arrive at a node computes it and climbs on": every step of the climb needs an
 // agent-scope release / acquire pair (__threadfence = L2 write-back + invalidate, microseconds each on a chip of eight L2s), and
@@ -349,7 +508,9 @@ __global__ __launch_bounds__(256) void k_lbvh_depth(const int* parent_inner, con
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (k >= n) return;
     uint32_t d = 0;
-    for (int node = parent_leaf[k]; node >= 0; node = parent_inner[node]) d += emit[node];
+    int guard = 0;
+    for (int node = parent_leaf[k]; node >= 0 && guard < 65536; node = parent_inner[node], ++guard) d += emit[node];
+    if (guard >= 65536) d = 0xffffu;                               // (a broken parent chain: reported as too deep, the host builder takes over)
     atomicMax(depth, d);
 }
 
@@ -787,7 +948,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     const size_t o_boxes = carve(sizeof(Box6) * n), o_nboxes = carve(sizeof(Box6) * n), o_keys = carve(8ull * n), o_keys2 = carve(8ull * n),
                  o_vals = carve(4ull * n), o_vals2 = carve(4ull * n), o_left = carve(4ull * n), o_right = carve(4ull * n), o_pin = carve(4ull * n),
                  o_plf = carve(4ull * n), o_lo = carve(4ull * n), o_hi = carve(4ull * n), o_arr = carve(4ull * n), o_emit = carve(4ull * n),
-                 o_idx = carve(4ull * n), o_kh = carve(n), o_misc = carve(256);
+                 o_idx = carve(4ull * n), o_kh = carve(n), o_big = carve(n), o_misc = carve(256);
     size_t sort_bytes = 0, scan_bytes = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, st);
@@ -819,15 +980,44 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
         const uint32_t tg = blocks * 4u < 16384u ? blocks * 4u : 16384u;
         hipLaunchKernelGGL(k_lbvh_treelets, dim3(tg), dim3(64), 0, st, idx, misc + 16, boxes, vals2, left, right, pin, plf, rlo, rhi);
     }
-    {   // boxes bottom-up: heights first (one atomic per step), then one launch per height
-        uint8_t* kh = reinterpret_cast<uint8_t*>(tmp + o_kh);
+    const int cluster_levels = sah_treelets && n > (uint32_t)kTreelet * 4u ? [] { const char* e = std::getenv("MIPT_LBVH_CLUSTERS"); return e ? std::atoi(e) : 0; }() : 0;
+    auto fit_boxes = [&](uint8_t* kh, uint8_t* root_h) -> hipError_t {
+        // boxes bottom-up: heights first (one atomic per step), then one launch per height
+        hipError_t fe;
+        if ((fe = hipMemsetAsync(arrived, 0, 4ull * n, st)) != hipSuccess) return fe;
         hipLaunchKernelGGL(k_lbvh_heights, dim3(blocks), dim3(256), 0, st, left, right, pin, n_inner, arrived, kh);
-        uint8_t root_h = 0;
-        if ((e = hipMemcpyAsync(&root_h, kh, 1, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
-        if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
-        if (root_h == 0u || root_h >= 255u) { (void)hipFree(tmp); *num_nodes = 0; *depth = 255u; return hipSuccess; }      // (degenerate input: the host builder takes it)
-        for (uint32_t level = 1; level <= root_h; ++level)
+        if ((fe = hipMemcpyAsync(root_h, kh, 1, hipMemcpyDeviceToHost, st)) != hipSuccess) return fe;
+        if ((fe = hipStreamSynchronize(st)) != hipSuccess) return fe;
+        if (*root_h == 0u || *root_h >= 255u) return hipSuccess;
+        for (uint32_t level = 1; level <= *root_h; ++level)
             hipLaunchKernelGGL(k_lbvh_fit_level, dim3(blocks), dim3(256), 0, st, boxes, vals2, n_inner, left, right, kh, level, nboxes);
+        return hipSuccess;
+    };
+    if (cluster_levels > 0) {
+        // experiment MIPT_LBVH_CLUSTERS = passes: the same SAH over clusters of at most 64 items, one pass per level above the treelets
+        // (reuses `emit` as the item counters, `idx` as the root list, the height bytes as the `big` flags until the final fit)
+        uint8_t* kh = reinterpret_cast<uint8_t*>(tmp + o_kh);
+        uint8_t* big = reinterpret_cast<uint8_t*>(tmp + o_big);
+        uint8_t root_h = 0;
+        if ((e = fit_boxes(kh, &root_h)) != hipSuccess) return fail(e);
+        if (root_h != 0u && root_h < 255u) {
+            hipLaunchKernelGGL(k_cluster_first_big, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, big);
+            for (int pass = 0; pass < cluster_levels && pass < 4; ++pass) {
+                if ((e = hipMemsetAsync(emit, 0, 4ull * n, st)) != hipSuccess) return fail(e);
+                if ((e = hipMemsetAsync(misc + 17, 0, 4, st)) != hipSuccess) return fail(e);
+                hipLaunchKernelGGL(k_cluster_counts, dim3(blocks), dim3(256), 0, st, left, right, big, pin, n_inner, emit);
+                hipLaunchKernelGGL(k_cluster_roots, dim3(blocks), dim3(256), 0, st, big, pin, emit, n_inner, idx, misc + 17);
+                const uint32_t cg = blocks < 16384u ? blocks : 16384u;
+                hipLaunchKernelGGL(k_lbvh_clusters, dim3(cg), dim3(64), 0, st, idx, misc + 17, big, boxes, vals2, nboxes, left, right, pin, plf, rlo, rhi);
+                hipLaunchKernelGGL(k_cluster_next_big, dim3(blocks), dim3(256), 0, st, emit, n_inner, big);
+            }
+        }
+    }
+    {
+        uint8_t* kh = reinterpret_cast<uint8_t*>(tmp + o_kh);
+        uint8_t root_h = 0;
+        if ((e = fit_boxes(kh, &root_h)) != hipSuccess) return fail(e);
+        if (root_h == 0u || root_h >= 255u) { (void)hipFree(tmp); *num_nodes = 0; *depth = 255u; return hipSuccess; }      // (degenerate input: the host builder takes it)
     }
     hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit, sah_treelets, left, right, pin, boxes, vals2, nboxes, 1.2f);
     if ((e = hipcub::DeviceScan::ExclusiveSum(tmp + o_cub, scan_bytes, emit, idx, n_inner, st)) != hipSuccess) return fail(e);
