@@ -280,12 +280,13 @@ def write_textured(tmpdir, seed=3):
     return path
 
 
-def write_alpha(tmpdir, seed=4, stack=0, tess=1):
+def write_alpha(tmpdir, seed=4, stack=0, tess=1, jitter=None):
     """Alpha MASK / BLEND materials, single- and double-sided: a ground, a masked fence, two stacked blend panes (textured
     alpha), an untextured blend pane, and two opaque panes seen from behind (one single sided -> culled for camera rays).
     stack = n: n more horizontal glass panes above the ground, every fifth one TWICE (coincident surfaces: candidates at equal t) --
     occlusion rays from below cross up to n + n // 5 attenuating surfaces.  tess = k: the ground as k x k quads (a tree deep enough for
-    the entry-pool form of the any-hit kernels, which shallow trees do not take)."""
+    the entry-pool form of the any-hit kernels, which shallow trees do not take).  jitter = s: the stacked panes at random heights, sizes and
+    tilts (seed s), a third of them coincident twins of the pane before, materials drawn at random."""
     import _png_fixture as PF
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:8, 0:8]
@@ -318,10 +319,17 @@ def write_alpha(tmpdir, seed=4, stack=0, tess=1):
         for i in range(tess):
             for j in range(tess):
                 quads.append(quad((-3 + c * i, 0, 3 - c * j), (c, 0, 0), (0, 0, -c))); mats_of.append(0)
+    jr = np.random.default_rng(jitter) if jitter is not None else None
+    pane = None
     for k in range(stack):
-        pane = quad((0.9, 0.25 + 0.06 * k, 0.2), (1.8, 0, 0), (0, 0, -2.2))
-        for _ in range(2 if k % 5 == 4 else 1):
-            quads.append(pane); mats_of.append(2 if k % 3 else 1)          # glass, every third one the masked fence texture
+        if jr is None:
+            pane = quad((0.9, 0.25 + 0.06 * k, 0.2), (1.8, 0, 0), (0, 0, -2.2))
+            for _ in range(2 if k % 5 == 4 else 1):
+                quads.append(pane); mats_of.append(2 if k % 3 else 1)          # glass, every third one the masked fence texture
+        else:
+            if pane is None or jr.random() > 0.33:                            # else: a coincident twin of the pane before (another material, perhaps)
+                pane = quad((0.3 + jr.random(), 0.2 + 1.6 * jr.random(), 0.6 * jr.random()), (1.0 + jr.random(), 0.3 * (jr.random() - 0.5), 0), (0, 0.3 * (jr.random() - 0.5), -1.0 - 1.5 * jr.random()))
+            quads.append(pane); mats_of.append(int(jr.integers(1, 4)))          # fence (MASK), glass (BLEND, textured), film (BLEND, untextured)
     parts, views, accs, prims = [], [], [], []
     blob = b""
     for k, qv in enumerate(quads):
@@ -357,6 +365,6 @@ def write_alpha(tmpdir, seed=4, stack=0, tess=1):
         "nodes": [{"mesh": 0}, {"camera": 0, "translation": [0.0, 1.6, 5.0], "rotation": [-0.1305261922, 0.0, 0.0, 0.9914448614]}],
         "scenes": [{"nodes": [0, 1]}], "scene": 0,
     }
-    path = tmpdir / ("alpha.gltf" if not stack and tess == 1 else "alpha_stack%d_%d.gltf" % (stack, tess))
+    path = tmpdir / ("alpha.gltf" if not stack and tess == 1 else "alpha_stack%d_%d_%s.gltf" % (stack, tess, jitter))
     path.write_text(json.dumps(doc))
     return path

@@ -566,6 +566,20 @@ def test_deferred_any_hit_programs_over_many_layers(tmp_path, monkeypatch, stack
     _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path, stack=stack, tess=tess), 120, 80, 2, persistent=persistent, deep=tess > 1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_deferred_any_hit_programs_random_stacks(tmp_path, seed):
+    """30 panes at random heights, sizes and tilts, a third of them coincident twins of the pane before, MASK / textured BLEND / untextured
+    BLEND at random, over the tessellated ground (entry-pool form; seed 4 with fp32 boxes): frames equal the oracle's bit for bit."""
+    import os
+    if seed == 4:
+        os.environ["MIPT_NODE_FORMAT"] = "0"
+    try:
+        _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path, stack=30, tess=20, jitter=seed), 128, 96, 2, deep=True)
+    finally:
+        os.environ.pop("MIPT_NODE_FORMAT", None)
+
+
 @pytest.mark.parametrize("name", ["textured", "alpha"])
 def test_oracle_whitted_golden_fixtures(tmp_path, name):
     """the oracle's Whitted restatement on the generated glTF fixtures equals the committed golden images
