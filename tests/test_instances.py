@@ -276,8 +276,8 @@ def test_any_hit_programs_inside_instances(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("persistent", [None, 2])
-def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, persistent):
+@pytest.mark.parametrize("persistent,seed,n_instances", [(None, 8, 70), (2, 8, 70), (None, 31, 140)])
+def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, persistent, seed, n_instances):
     """The deferred any-hit programs over the two-level structure (k_wh_trace_pool_inst; persistent = 2: k_wh_trace_inst, one ray per
     thread) against the ORACLE's two-level render of the same structure: textured BLEND and MASK materials on the instanced meshes,
     frames, frame buffer and ray counters bit for bit -- candidates in the order of (t, flattened primitive index), t taken with the
@@ -290,7 +290,7 @@ def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, persistent
     rng = np.random.default_rng(12)
     film = np.zeros((8, 8, 4), np.int64); film[..., :3] = rng.integers(60, 255, (8, 8, 3)); film[..., 3] = rng.integers(40, 230, (8, 8))
     fence = np.zeros((8, 8, 4), np.int64); fence[..., :3] = 200; fence[..., 3] = np.where((np.add.outer(np.arange(8), np.arange(8)) % 3) == 0, 0, 255)
-    path = scenes.write_instanced_gltf(tmp_path / "instanced_alpha.gltf", n_instances=70, seed=8,
+    path = scenes.write_instanced_gltf(tmp_path / "instanced_alpha.gltf", n_instances=n_instances, seed=seed,
                                        alpha_textures=(PF.encode(film, 6, 8)[0], PF.encode(fence, 6, 8)[0]))
     w, h = 200, 112
     st = MV.MeshViewerState()
