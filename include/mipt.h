@@ -479,7 +479,11 @@ int mipt_whitted_set_geometry(MiptContext* ctx, const MiptWhittedGeometry* geome
  * of one word per flattened primitive; a corner is taken to world space in the kernel with the arithmetic mipt_scene_flatten uses on
  * the host (and a normal with mipt_scene_flatten_normals'), so frames are bit-identical to those over the flattened arrays.
  * meshes[m].geometry: DEVICE pointers as in MiptWhittedGeometry (caller-owned, alive until the next set_geometry* call), vertices and
- * normals in object space (normals4: {n, 1} or all 0); instances[i].transform: row-major 3x4 object -> world (the OptixInstance's). */
+ * normals in object space (normals4: {n, 1} or all 0); instances[i].transform: row-major 3x4 object -> world (the OptixInstance's).
+ * ORDER: instances[] must list the same instances in the same order, with the same triangle count per mesh, as the records the
+ * traversable of the launch was built from (mipt_accel_build_instances), or -- for a flattened BVH -- as the flatten that made its
+ * vertex buffer.  mipt_whitted_launch checks what the library can see and fails with MIPT_ERROR_INVALID_VALUE otherwise: the total
+ * triangle count against the traversable's, and over an instance structure every instance's first flattened primitive. */
 typedef struct MiptWhittedMesh {
     MiptWhittedGeometry geometry;
     uint32_t            num_triangles;

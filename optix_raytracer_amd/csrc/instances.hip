@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_INST_TI
 {
     constexpr int kWords = kTiledInstRows * 64;
     constexpr int kCap = (kWords - 384) / 2;
-    __shared__ uint32_t lds[kWords];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kWords];                  // (uint2 entries, 64-bit LDS atomics on sh_best)
     uint2* const stk2 = reinterpret_cast<uint2*>(lds);
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(lds + 2 * kCap);
     float* const sh_u = reinterpret_cast<float*>(lds + 2 * kCap + 128);
@@ -280,7 +280,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_INST_TI
     if (a.n_ptr) { const uint32_t m = *a.n_ptr; n = m < n ? m : n; }
     // a lane's pool entries take two words where its stack entries took one: the rows are rewritten in place, so at most 32 lanes may
     // still be busy at the switch (row e is read before (e + 1) * 32 entries = (e + 1) * 64 words are written)
-    const int steal_min = a.steal_min < 32 ? 32 : (a.steal_min < 64 ? a.steal_min : 64);
+    // ... and the pool must hold what they bring: a busy lane has at most stack4 entries on its stack + the one it stands at, and
+    // pool_round_inst keeps psize <= kCap - 120 only if it starts there (the one-level kernel's steal_floor, kernels.hip)
+    const int busy_max = (kCap - 120) / (int)(a.bvh.stack4 + 1u);
+    int steal_min = a.steal_min < 32 ? 32 : (a.steal_min < 64 ? a.steal_min : 64);
+    if (steal_min < 64 - busy_max) steal_min = 64 - busy_max;
     const uint32_t tiles = (n + 63u) >> 6, tiles_seg = (tiles + kNumSegments - 1) / kNumSegments;
     const uint32_t xcd = blockIdx.x & (kNumSegments - 1), waves_seg = gridDim.x / kNumSegments;
 #if MIPT_INST_STATS

@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(64) void k_tail_pool(TailArgs k)
     const bool use_rg = k.rg.ctr != nullptr;
     if (use_rg && blockIdx.x == 0u) { begin_sample(k.rg.ctr, threadIdx.x, k.rg.fc.n_paths, k.rg.n_valid, k.rg.zero_stats); tail_publish_epoch(k.rg.ctr, k.epoch); }
     constexpr int kPoolCap = 24 * 64 - 384;
-    __shared__ uint32_t stk[24 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t stk[24 * 64];                 // (sh_best: 64-bit LDS atomics)
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_TAIL1_W
     const bool use_rg = k.rg.ctr != nullptr;
     if (use_rg && blockIdx.x == 0u) { begin_sample(k.rg.ctr, threadIdx.x, k.rg.fc.n_paths, k.rg.n_valid, k.rg.zero_stats); tail_publish_epoch(k.rg.ctr, k.epoch); }
     constexpr int kPoolCap = 24 * 64 - 384;
-    __shared__ uint32_t stk[24 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t stk[24 * 64];                 // (sh_best: 64-bit LDS atomics)
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
@@ -1559,7 +1559,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const bool use_rg = k.rg.ctr != nullptr;
     if (use_rg && blockIdx.x == 0u) { begin_sample(k.rg.ctr, threadIdx.x, k.rg.fc.n_paths, k.rg.n_valid, k.rg.zero_stats); tail_publish_epoch(k.rg.ctr, k.epoch); }
     constexpr int kCap = 1152;
-    __shared__ uint32_t lds[kCap + 128 + 3 * 64 + 14 * 64];
+    static_assert(kCap % 2 == 0, "sh_best holds 64-bit keys");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kCap + 128 + 3 * 64 + 14 * 64];
     uint32_t* const stk = lds;
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(lds + kCap);
     float* const sh_u = reinterpret_cast<float*>(lds + kCap + 128);
@@ -1701,7 +1702,8 @@ template <int MODE, int Q>
 __global__ __launch_bounds__(64) MIPT_STATIC_ATTR void k_trace_static(TraceArgs a, uint32_t ppw)
 {
     constexpr int kPoolCap = MIPT_STATIC_ROWS * 64 - 384;
-    __shared__ uint32_t stk[MIPT_STATIC_ROWS * 64];
+    static_assert(kPoolCap % 2 == 0, "sh_best holds 64-bit keys");
+    __shared__ __attribute__((aligned(16))) uint32_t stk[MIPT_STATIC_ROWS * 64];
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);

@@ -141,6 +141,8 @@ struct MiptContext {
     WhInstGeo*        d_wh_inst = nullptr;              // mipt_whitted_set_geometry_instanced: instance records, per-mesh tables,
     WhTables*         d_wh_meshes = nullptr;            // instance of every flattened primitive (library copies)
     uint32_t*         d_wh_prim_inst = nullptr;
+    std::vector<uint32_t> wh_inst_base;                 // ... and their first flattened primitive + the total: compared with the structure a launch is given
+    uint64_t          wh_inst_total = 0;
     bool              wh_any_hit = false, wh_blend = false;   // a MASK / BLEND material exists
     float4*           wh_e1 = nullptr;                  // second float4 per occlusion entry (capacity im_cap)
     float4*           wh_group = nullptr;               // per hit (capacity wh_group_cap)
@@ -440,6 +442,8 @@ DeviceBvh device_bvh(const Accel* a)
     return b;
 }
 
+int check_device_faults(MiptContext* ctx);
+
 int check_launch(MiptContext* ctx, const MiptParams* p, unsigned width, unsigned height, unsigned depth, Accel** acc)
 {
     if (!p) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "params is null");
@@ -452,7 +456,8 @@ int check_launch(MiptContext* ctx, const MiptParams* p, unsigned width, unsigned
     if (!*acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
     if ((*acc)->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", p->handle);
     if (!ctx->d_hitgroups || ctx->n_hitgroups == 0) return ctx->fail(MIPT_ERROR_NOT_CONFIGURED, "no hit-group records set (mipt_sbt_set_hitgroups)");
-    return MIPT_SUCCESS;
+    // a fault an EARLIER launch raised (callers that synchronise the stream themselves never pass mipt_sync): reported once, here
+    return check_device_faults(ctx);
 }
 
 FrameConsts make_consts(const MiptContext* c, const MiptParams* p)
@@ -1370,6 +1375,7 @@ int mipt_accel_info(const MiptContext* ctx, unsigned long long handle, MiptAccel
     info->device_bytes = a->bytes;
     info->build_seconds = a->seconds;
     info->node_format = a->node32_off ? a->node_fmt : 0u; info->num_instances = a->is_ias ? (uint32_t)a->gas.size() : 0u;
+    if (a->is_ias && a->inst_fast) info->node_format = 2u;       // the entry-pool arena: BVH4 mirrors of the top level and of every mesh
     info->stack_entries = info->node_format == 2u ? a->stack_need : a->depth;
     info->mirror_nodes = info->node_format == 2u ? a->num_nodes4 : (info->node_format == 1u ? a->num_nodes : 0u);
     return MIPT_SUCCESS;
@@ -1593,6 +1599,7 @@ int mipt_imgui_launch(MiptContext* ctx, void* stream, const MiptImguiParams* p, 
     Accel* acc = find_accel(ctx, p->handle);
     if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
     if (acc->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", p->handle);
+    if (const int frc = check_device_faults(ctx)) return frc;         // raised by an earlier launch, reported once
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
     int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);
@@ -1649,6 +1656,7 @@ static int set_whitted_tables(MiptContext* ctx, const MiptMaterialData* material
     ctx->wh_texels.clear(); ctx->n_wh_textures = 0;
     for (void** p : { (void**)&ctx->d_wh_inst, (void**)&ctx->d_wh_meshes, (void**)&ctx->d_wh_prim_inst }) if (*p) { (void)hipFree(*p); *p = nullptr; }
     ctx->wh_geo = WhGeometry{};
+    ctx->wh_inst_base.clear(); ctx->wh_inst_total = 0;
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_wh_materials, (size_t)num_materials * sizeof(MiptMaterialData)));
     HIPCHK(ctx, hipMemcpy(ctx->d_wh_materials, materials, (size_t)num_materials * sizeof(MiptMaterialData), hipMemcpyHostToDevice));
     ctx->n_wh_materials = num_materials;
@@ -1743,6 +1751,9 @@ int mipt_whitted_set_geometry_instanced(MiptContext* ctx, const MiptWhittedMesh*
     WhGeometry g{};
     g.prim_inst = ctx->d_wh_prim_inst; g.inst = ctx->d_wh_inst; g.meshes = ctx->d_wh_meshes;
     ctx->wh_geo = g;
+    ctx->wh_inst_base.resize(num_instances);
+    for (uint32_t i = 0; i < num_instances; ++i) ctx->wh_inst_base[i] = recs[i].prim_base;
+    ctx->wh_inst_total = total;
     return MIPT_SUCCESS;
 }
 
@@ -1760,6 +1771,15 @@ int mipt_whitted_launch(MiptContext* ctx, void* stream, const MiptWhittedLaunchP
     Accel* acc = find_accel(ctx, p->handle);
     if (!acc) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "params.handle 0x%llx is not a traversable of this context", p->handle);
     if (acc->stale) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instance structure 0x%llx references a mesh that was refitted since it was built: call mipt_accel_update_instances first", p->handle);
+    if (ctx->wh_geo.prim_inst) {
+        // per-instance shading tables are indexed by the hits' flattened primitive numbers: the tables and the structure must count the
+        // same triangles, and over an instance structure every instance must start at the same number (same instances, same order)
+        if (ctx->wh_inst_total != acc->n_prims)
+            return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instanced shading tables hold %llu triangles, traversable 0x%llx has %u", (unsigned long long)ctx->wh_inst_total, p->handle, acc->n_prims);
+        if (acc->is_ias && acc->h_base != ctx->wh_inst_base)
+            return ctx->fail(MIPT_ERROR_INVALID_VALUE, "instanced shading tables do not follow the instance order of traversable 0x%llx (instances / triangles per instance differ)", p->handle);
+    }
+    if (const int frc = check_device_faults(ctx)) return frc;         // raised by an earlier launch, reported once
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint32_t n_paths = ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
     int rc = ensure_capacity(ctx, n_paths, (size_t)width * height);

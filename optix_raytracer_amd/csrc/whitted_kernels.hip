@@ -384,7 +384,8 @@ __global__ __launch_bounds__(64) MIPT_WH_AH_ATTR void k_wh_trace_pool(WhConsts c
 {
     constexpr int kLevelWords = kAhLevels * 128 > 384 ? kAhLevels * 128 : 384;      // the candidate levels behind the pool (3 fit the merge words)
     constexpr int kPoolCap = MIPT_WH_AH_ROWS * 64 - 384;
-    __shared__ uint32_t stk[MIPT_WH_AH_ROWS * 64 - 384 + kLevelWords];
+    static_assert(kPoolCap % 2 == 0, "sh_best holds 64-bit keys: it must start on an even word");
+    __shared__ __attribute__((aligned(16))) uint32_t stk[MIPT_WH_AH_ROWS * 64 - 384 + kLevelWords];
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
     float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
     float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);

@@ -343,6 +343,18 @@ def test_epoch_handshake_timeout_is_reported(monkeypatch):
     acc = st.accum.cpu().numpy()
     a, f, ost = _oracle_scene(scene, st).render(scenes.launch_desc(scene, w, h, 1))
     _assert_pixels(acc, a)
+    # a caller that synchronises the stream itself (bench.py, meshviewer.py via torch) and launches again never passes mipt_sync:
+    # the NEXT launch reports the fault of the one before, once
+    lib, hnd = st.context._lib, st.context._h
+    import ctypes as C
+    st.params.frame_buffer = ob.map()
+    assert lib.mipt_launch(hnd, st.stream.cuda_stream, C.byref(st.params), w, h, 1) == 0       # faults again (the injection is the context's)
+    ob.unmap()
+    torch.cuda.synchronize()
+    st.params.frame_buffer = ob.map()
+    assert lib.mipt_launch(hnd, st.stream.cuda_stream, C.byref(st.params), w, h, 1) == 8       # MIPT_ERROR_INTERNAL: the earlier launch's
+    ob.unmap()
+    torch.cuda.synchronize()
     # a context without the injection never raises it
     PT2, st2 = _state(scene, w, h, 1, 0)
     acc2, _, stats2 = _render_gpu(PT2, st2)

@@ -487,3 +487,114 @@ def test_instanced_shading_tables_give_the_flattened_frame(tmp_path):
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and np.array_equal(f0, f1)
     assert s0["closest_rays"] == s1["closest_rays"] and s0["shadow_rays"] == s1["shadow_rays"] > 0
     assert (a0[..., :3] > 0).mean() > 0.2
+
+
+def test_instanced_tables_must_match_the_traversable(tmp_path):
+    """mipt_whitted_set_geometry_instanced keeps one record per instance and one word per flattened primitive; a launch over a
+    traversable that counts other triangles, or lists its instances in another order, would index those tables out of bounds on the
+    device.  The library owns every count it needs, so mipt_whitted_launch refuses (MIPT_ERROR_INVALID_VALUE) instead."""
+    from optix_raytracer_amd import api
+    from optix_raytracer_amd import meshviewer as MV
+    from optix_raytracer_amd import scenes
+    path = scenes.write_instanced_gltf(tmp_path / "instanced.gltf", n_instances=40, seed=3)
+    st, image = MV.render(path, 96, 64, two_level=True)
+    assert st.instanced_shading
+    out = MV.OutputBuffer(96, 64, st.device)
+    good = st.params.handle
+    fewer = st.context.accel_build_instances(st.instances[:-1])                   # another triangle total
+    st.params.handle = fewer
+    with pytest.raises(api.MiptError) as e:
+        MV.launchSubframe(out, st)
+    assert e.value.code == 1 and "triangles" in str(e.value)
+    # the same instances in another order: the total agrees, the first flattened primitive of an instance does not
+    k = next(i for i in range(1, len(st.instances)) if st.instances[i][0] != st.instances[0][0])
+    swapped = list(st.instances); swapped[0], swapped[k] = swapped[k], swapped[0]
+    st.params.handle = st.context.accel_build_instances(swapped)
+    with pytest.raises(api.MiptError) as e:
+        MV.launchSubframe(out, st)
+    assert e.value.code == 1 and "instance order" in str(e.value)
+    st.params.handle = good                                                        # the structure the tables were made for still renders
+    st.params.subframe_index = 0
+    MV.launchSubframe(out, st)
+    assert np.array_equal(out.getHostPointer(), image)
+    MV.cleanup(st)
+
+
+def _spike_mesh(n, rng):
+    """n triangles whose sizes and positions shrink geometrically: a SAH builder peels them off one or two at a time, so the tree --
+    and a lane's worst-case stack over its BVH4 mirror -- is about as deep as the builder allows"""
+    tri = np.zeros((n, 3, 4), np.float32)
+    for i in range(n):
+        s = 0.82 ** i
+        c = np.array([1.0 - s, 0.15 * np.sin(i * 2.4) * s, 0.15 * np.cos(i * 2.4) * s])
+        tri[i, :, :3] = c + s * 0.45 * rng.normal(size=(3, 3))
+    return tri.reshape(-1, 4)
+
+
+def test_deep_two_level_structure_on_the_tiled_kernel(monkeypatch):
+    """k_trace_tiled_inst empties its lanes' stacks into the wave's entry pool once enough lanes are finished; the pool
+    holds kCap - 120 = 712 entries and a busy lane can bring stack_entries + 1, so with deep stacks fewer lanes may still be busy at the
+    switch (steal floor = 64 - 712 / (stack + 1), as the one-level kernel has it).  Deep meshes under a top level of a hundred
+    overlapping instances: the tiled form (default for this launch size) against the one-ray-per-lane walk and the oracle."""
+    import torch
+    from optix_raytracer_amd import api
+    rng = np.random.default_rng(12)
+    results = []
+    for env in (None, "2"):
+        if env is None:
+            monkeypatch.delenv("MIPT_INST_FORM", raising=False)
+        else:
+            monkeypatch.setenv("MIPT_INST_FORM", env)
+        ctx = api.Context(0)
+        rng = np.random.default_rng(12)
+        # the regime the fix is for: deep enough that the floor moves (stack + 1 > 712 / 32), shallow enough for the tiled form --
+        # the spikes' length is searched, so the test keeps its regime when a builder changes
+        for spike in (40, 34, 46, 28, 52, 22):
+            rng = np.random.default_rng(12)
+            keep, gas = [], []
+            for m in range(2):
+                v = _spike_mesh(spike + 6 * m, rng)
+                dv = torch.from_numpy(np.ascontiguousarray(v)).cuda()
+                keep.append(dv)
+                gas.append(ctx.accel_build([{"vertices": dv.data_ptr(), "num_vertices": v.shape[0], "stride": 16}]))
+            inst = []
+            for i in range(120):
+                q = rng.standard_normal(4); q /= np.linalg.norm(q)
+                w, x, y, z = q
+                R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                              [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                              [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+                xf = np.zeros((3, 4), np.float32)
+                xf[:, :3] = R * rng.uniform(0.6, 1.5, 3)
+                xf[:, 3] = rng.uniform(-1.0, 1.0, 3)                    # all instances overlap: a ray opens many of them
+                inst.append((gas[i % 2], xf))
+            ias = ctx.accel_build_instances(inst)
+            info = ctx.accel_info(ias)
+            if 23 <= info["stack_entries"] <= 31:
+                break
+        assert info["num_instances"] == 120 and 23 <= info["stack_entries"] <= 31, info
+        n = 400000                                                # > 512 rays per CU: the tiled closest-hit form
+        rays = np.zeros((n, 8), np.float32)
+        rays[:, :3] = rng.normal(size=(n, 3)) * 4.0
+        tgt = rng.uniform(-1.2, 1.2, (n, 3))
+        d = tgt - rays[:, :3]
+        rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        rays[:, 3], rays[:, 7] = 1e-3, 1e16
+        d_rays = torch.from_numpy(rays).cuda()
+        d_hits = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+        results.append(d_hits.cpu().numpy())
+        if env is None:
+            nodes, order, inv, base, gas_handles = ctx.accel_export_instances(ias)
+            exports = {int(h): ctx.accel_export(int(h)) for h in set(int(x) for x in gas_handles)}
+            total = int(info["num_triangles"])
+            osc = O.Scene({"vertices": np.zeros((total * 3, 4), np.float32), "mat_index": np.zeros(total, np.uint32),
+                           "emission": np.zeros((1, 3), np.float32), "diffuse": np.ones((1, 3), np.float32)})
+            osc.set_instances(nodes, order, inv, base, [exports[int(h)] for h in gas_handles])
+            sub = slice(0, 60000)
+            t, prim, u, v = osc.trace_closest(rays[sub], O.MODE_INST)
+            h = results[0][sub]
+            assert (prim != 0xffffffff).mean() > 0.3
+            assert np.array_equal(h[:, 1].view(np.uint32), prim) and np.array_equal(h[:, 0].view(np.uint32), t.view(np.uint32))
+        ctx.destroy()
+    assert np.array_equal(results[0].view(np.uint32), results[1].view(np.uint32))
