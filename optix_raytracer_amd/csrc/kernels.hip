@@ -85,7 +85,7 @@ __device__ __forceinline__ bool visit_leaf(Trav& T, const float4* __restrict__ t
 // One step of the lane state machine (see k_trace_stream): every lane loads 64 bytes -- its node, or its next
 // triangle -- then inner lanes do a slab step and leaf lanes one branch-free triangle test.  `sb` is the bottom of
 // the lane's stack (entries below it were given away); shared by k_trace_stream and the bulk phase of k_trace_pool.
-template <int MODE, bool COUNT, int Q = 0, bool TOP = false>
+template <int MODE, bool COUNT, int Q = 0, bool TOP = false, bool SC = false>
 __device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_buffer_rsrc_t blob, uint32_t* stk, int lane, bool has_ray, Trav& T,
                                             int sb, bool cull_back, uint32_t& n_visits, uint32_t& n_tests PROBE_PARAM, const uint32_t* top_lds = nullptr)
 {
@@ -95,7 +95,7 @@ __device__ __forceinline__ void stream_step(const TraceArgs& a, const __amdgpu_b
     const uint32_t ldesc = ~(uint32_t)T.node;
     const uint32_t lfirst = ldesc >> 4, lcnt = ldesc & 15u;
     u32x4 q0, q1, q2, q3;
-    load_step<Q, TOP>(blob, a.bvh, inner, at_leaf && lcnt != 0u, (uint32_t)T.node, lfirst, q0, q1, q2, q3 PROBE_ARG, top_lds);
+    load_step<Q, TOP, SC>(blob, a.bvh, inner, at_leaf && lcnt != 0u, (uint32_t)T.node, lfirst, q0, q1, q2, q3 PROBE_ARG, top_lds);
 #if MIPT_PROBE_VALU > 0
     if (probe_valu(T.tmin) == 12345.678f) T.tbest = 0.0f;                 // never true (tmin is 0.01 or a hit distance)
 #endif
@@ -488,6 +488,9 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
     uint32_t wv_steps = 0u, wv_rounds = 0u;
 #endif
 
+#if MIPT_PROBE_UNI
+    uint32_t pu[6] = { 0u, 0u, 0u, 0u, 0u, 0u };
+#endif
     for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
         // ============================================================ bulk: one ray per lane, one tile at a time
         // Groups of tile_group consecutive tiles (256: two rows of 16x4-pixel tiles at 1080p) are dealt to the XCDs in turn: a
@@ -543,7 +546,21 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
                 if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
                 uint32_t nv_ = 0u, nt_ = 0u;
                 if (use_top) stream_step<MODE, false, Q, TOP>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_ PROBE_ARG, top_lds);
-                else         stream_step<MODE, false, Q>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_ PROBE_ARG);
+                else         stream_step<MODE, false, Q, false, MIPT_SCALAR_TOP != 0>(a, blob, stk, lane, has_ray, T, 0, cull_back, nv_, nt_ PROBE_ARG);
+#if MIPT_PROBE_UNI
+                {   // how coherent are a tile's lanes?  distinct nodes among the inner lanes of this step (counted up to 8)
+                    unsigned long long im = __ballot(has_ray && T.node >= 0);
+                    const bool leafs = __ballot(has_ray && T.node < 0 && T.node != kSentinel) != 0ull;
+                    uint32_t distinct = 0u;
+                    while (im != 0ull && distinct < 8u) {
+                        const int un = __builtin_amdgcn_readlane(T.node, (int)__builtin_ctzll(im));
+                        im &= ~__ballot(has_ray && T.node == un);
+                        ++distinct;
+                    }
+                    pu[0] += 1u; pu[1] += distinct == 1u ? 1u : 0u; pu[2] += (distinct == 1u && !leafs) ? 1u : 0u;
+                    pu[3] += distinct; pu[4] += (distinct >= 1u && distinct <= 2u) ? 1u : 0u; pu[5] += (distinct >= 1u && distinct <= 4u) ? 1u : 0u;
+                }
+#endif
 #if MIPT_PROBE_STAMP
                 ++pw_steps;
 #endif
@@ -615,6 +632,9 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the next tile's stacks overwrite the merge slots
     }
+#if MIPT_PROBE_UNI
+    if (lane == 0) for (int q = 0; q < 6; ++q) atomicAdd(&a.ctr->dbg[q], (unsigned long long)pu[q]);
+#endif
 #if MIPT_PROBE_WAVES
     if (lane == 0 && a.ctr->dbg[0] != 0ull) {
         uint4* rec = reinterpret_cast<uint4*>(a.ctr->dbg[0]);
@@ -691,7 +711,7 @@ __device__ __forceinline__ void begin_sample(DeviceCounters* c, uint32_t i, uint
     if (i == 0) {
         if (zero_stats) {
             unsigned long long* w = &c->closest_rays;
-            for (int k = 0; k < (MIPT_PROBE_STAMP ? 14 : 8); ++k) w[k] = 0ull;     // (dbg[]: only the stamp probe's sums are per launch)
+            for (int k = 0; k < ((MIPT_PROBE_STAMP || MIPT_PROBE_UNI) ? 14 : 8); ++k) w[k] = 0ull;     // (dbg[]: only the stamp probe's sums are per launch)
             tmax = 0ull;
         }
         c->closest_rays += n_valid; c->n_cur = n_paths; c->n_next = 0; c->n_shadow = 0; c->bounce = 0;
@@ -1235,7 +1255,7 @@ __device__ __forceinline__ void tail_load_path(const TailArgs& k, const bool use
 }
 
 template <int Q>
-__global__ __launch_bounds__(64) void k_tail_pool(TailArgs k)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tail_pool(TailArgs k)      // (<= 128 VGPRs: four waves per SIMD, as it has run since round 1)
 {
     const ShadeArgs& a = k.a;
     const uint32_t ppw = k.ppw;
@@ -1425,6 +1445,9 @@ __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, c
                                             unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done, const float* sray,
                                             const int lane, const Trav& T, int& psize)
 {
+    if (Q == 2 && MIPT_QUAD_MAX > 0) {
+        if (psize <= MIPT_QUAD_MAX) { pool_round_quad<3, 7>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, sray, lane, T, psize, false); return; }
+    }
     int k = psize < 64 ? psize : 64;
     const int room = CAP - (Q == 2 ? 120 : 104) - psize;
     if (Q == 2) { if (3 * k > room) k = room > 3 ? room / 3 : 1; }

@@ -35,6 +35,11 @@ namespace mipt {
 #ifndef MIPT_PROBE_WAVES
 #define MIPT_PROBE_WAVES 0
 #endif
+// MIPT_PROBE_UNI: per launch of k_trace_pool, into DeviceCounters::dbg: bulk steps, steps whose inner lanes stand at ONE node, of those
+// the ones without a lane at a leaf, the sum of distinct nodes per step (counted up to 8), steps with <= 2 / <= 4 distinct nodes
+#ifndef MIPT_PROBE_UNI
+#define MIPT_PROBE_UNI 0
+#endif
 #if MIPT_PROBE_STAMP
 #define PROBE_PARAM , unsigned long long& pw_wait
 #define PROBE_ARG , pw_wait
@@ -62,13 +67,44 @@ __device__ __forceinline__ float probe_valu(float seed)
 #endif
 constexpr uint32_t kTopFlag = 0x40000000u, kTopNodes = 64u, kTopWords = kTopNodes * 8u + kTopNodes;     // nodes (8 words each), then their real indices
 
-template <int Q, bool TOP = false>
+// ---- MIPT_SCALAR_TOP: wave-uniform node fetches through the scalar cache (round 4) -------------------------------------------------
+// The rays of a tile start at the root together and keep to common nodes for the first levels (a 16 x 4-pixel tile of primary rays is
+// narrower than the boxes of the top ~ten levels).  A step whose inner lanes ALL stand at one node fetches it with one s_load_dwordx8
+// (scalar data cache, its own path to the L2) instead of two lane-wide buffer loads of 64 equal addresses -- which cost the CU's
+// vector-memory pipeline ~21 cycles each (profiles/r03_micro_vmem.txt), the resource this kernel is bound by.  Lanes at a leaf in such a
+// step fetch their triangle with masked loads as before.  The visiting order is untouched: results and counters are the same bit for bit.
+#ifndef MIPT_SCALAR_TOP
+#define MIPT_SCALAR_TOP 0          // measured SLOWER (round 4: closest-hit kernel 0.347 against 0.337 ms): kept as a probe build
+#endif
+template <int Q, bool TOP = false, bool SC = false>
 __device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, const bool inner_in, const bool tri,
                                           const uint32_t node, const uint32_t lfirst, u32x4& n0, u32x4& n1, u32x4& n2, u32x4& n3 PROBE_PARAM,
                                           const uint32_t* top_lds = nullptr)
 {
 #if MIPT_PROBE_STAMP
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SC && Q == 1 && !TOP) {
+        const unsigned long long im = __ballot(inner_in);
+        if (im != 0ull) {
+            const uint32_t un = (uint32_t)__builtin_amdgcn_readlane((int)node, (int)__builtin_ctzll(im));
+            if (__ballot(inner_in && node != un) == 0ull) {
+                typedef const __attribute__((address_space(4))) u32x4* ConstQ;        // constant address space: selected as s_load
+                const ConstQ p = (ConstQ)((unsigned long long)bvh.nodes + (unsigned long long)bvh.node32_off + ((unsigned long long)un << 5));
+                const u32x4 s0 = p[0], s1 = p[1];
+                n0 = s0; n1 = s1; n2 = u32x4{ 0u, 0u, 0u, 0u }; n3 = n2;
+                if (__ballot(tri) != 0ull) {
+                    if (tri) {
+                        const uint32_t off = bvh.tri_byte_off + lfirst * 48u;
+                        n0 = ldq(blob, off); n1 = ldq(blob, off + 16u); n2 = ldq(blob, off + 32u);
+                    }
+                }
+                asm volatile("" ::: "memory");
+                return;
+            }
+        }
+    }
 #endif
     const bool in_top = TOP && inner_in && (node & kTopFlag) != 0u;
     const bool inner = inner_in && !in_top;
@@ -126,6 +162,140 @@ __device__ __forceinline__ void load_step(const __amdgpu_buffer_rsrc_t blob, con
 }
 
 
+// ---- quad rounds (round 4): a THIN pool -- at most 16 entries -- is served by quads of lanes, one entry per quad ---------------------
+// The kernels that live on the pool are bound by the CHAIN of their rounds wherever waves are thin: the last paths of a Russian-roulette
+// pass (one or two live rays per wave for tens of bounces), a rank's 1/8 shard (rounds a third full), the end of every chunk.  A thin
+// round pays for 64 lanes and uses a few: each busy lane fetches a whole BVH4 node (4 loads), tests four boxes, sorts them and pushes up
+// to four entries in four ballot stages -- ~360 instructions that ONE wave issues at ~4 cycles each, whatever the other lanes do -- and a
+// leaf of k triangles takes k rounds (a lane tests one and pushes the rest).  With <= 16 entries the wave gives every entry a QUAD: lane
+// c of the quad fetches child c's 16-byte piece (one load instruction for the round) and tests that one box; the quad ranks its hit
+// children by entry distance with three DPP quad broadcasts; lane c of a leaf entry tests triangle first + c, so a leaf is ONE round.
+// Same slab and triangle arithmetic, same merge (ds_min_u64 on the order-preserving key); hit records do not depend on the visiting
+// order, so frames and records are unchanged bit for bit (the existing parity tests run every pool kernel both ways: MIPT_QUAD_MAX).
+// SB: slot bits of an entry (6: pool_round; 7: pool_round2, whose bit 6 marks the lane's occlusion ray, kept in LDS: sray).
+// MODE 0 closest / 1, 2 any / 3 per entry by that bit.
+#ifndef MIPT_QUAD_MAX
+#define MIPT_QUAD_MAX 16          // entries (0: never).  A pool of more runs the 64-entry round.
+#endif
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, true));
+}
+
+template <int MODE, int SB>
+__device__ __forceinline__ void pool_round_quad(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint32_t* stk,
+                                                unsigned long long* sh_best, float* sh_u, float* sh_v, uint32_t* sh_done, const float* sray,
+                                                const int lane, const Trav& T, int& psize, const bool cull_back)
+{
+    constexpr uint32_t kSlotMask = (1u << SB) - 1u, kPayMask = (1u << (31 - SB)) - 1u;
+    const int k = psize < 16 ? psize : 16;
+    const int e = lane >> 2;
+    const uint32_t c = (uint32_t)lane & 3u;
+    const bool have = e < k;
+    uint32_t ent = 0u;
+    if (have) ent = stk[psize - 1 - e];
+    psize -= k;
+    const uint32_t slotw = ent & kSlotMask, ls = slotw & 63u;
+    const bool is_s = SB == 7 && have && (slotw & 64u) != 0u;          // pool2: the slot's occlusion ray
+    float ox = shfl_f(T.o.x, ls), oy = shfl_f(T.o.y, ls), oz = shfl_f(T.o.z, ls);
+    float dx = shfl_f(T.d.x, ls), dy = shfl_f(T.d.y, ls), dz = shfl_f(T.d.z, ls);
+    float ix = shfl_f(T.idir.x, ls), iy = shfl_f(T.idir.y, ls), iz = shfl_f(T.idir.z, ls);
+    float nx = shfl_f(T.nood.x, ls), ny = shfl_f(T.nood.y, ls), nz = shfl_f(T.nood.z, ls);
+    float tmn = shfl_f(T.tmin, ls), tmx = shfl_f(T.tmax, ls);
+    if (SB == 7) {
+        if (__ballot(is_s) != 0ull) {
+            if (is_s) {
+                ox = sray[0 * 64 + ls]; oy = sray[1 * 64 + ls]; oz = sray[2 * 64 + ls];
+                dx = sray[3 * 64 + ls]; dy = sray[4 * 64 + ls]; dz = sray[5 * 64 + ls];
+                ix = sray[6 * 64 + ls]; iy = sray[7 * 64 + ls]; iz = sray[8 * 64 + ls];
+                nx = sray[9 * 64 + ls]; ny = sray[10 * 64 + ls]; nz = sray[11 * 64 + ls];
+                tmn = sray[12 * 64 + ls]; tmx = sray[13 * 64 + ls];
+            }
+        }
+    }
+    const bool any_sem = MODE == 3 ? is_s : MODE != 0;                 // this entry's ray ends at its first hit
+    float tcur = tmx;
+    bool live = have;
+    if (have) {
+        if (any_sem) { if (sh_done[ls] != 0u) live = false; }
+        else tcur = ord_float((uint32_t)(sh_best[ls] >> 32));
+    }
+    const bool leaf = (ent >> 31) != 0u;
+    const uint32_t payload = (ent >> SB) & kPayMask;
+    const uint32_t lfirst = payload >> 2, lcnt = (payload & 3u) + 1u;
+    const bool do_inner = live && !leaf;
+    const bool do_tri = live && leaf && c < lcnt;
+    // ------------------------------------------------------------ this round's loads: a child's piece, or a triangle
+    uint32_t off = bvh.node4_off;                                       // idle lanes re-read the root's first piece (a broadcast)
+    if (do_inner) off = bvh.node4_off + (payload << 6) + (c << 4);
+    if (do_tri)   off = bvh.tri_byte_off + (lfirst + c) * 48u;
+    const u32x4 q0 = ldq(blob, off);
+    u32x4 q1 = u32x4{ 0u, 0u, 0u, 0u }, q2 = q1;
+    if (__ballot(do_tri) != 0ull) { if (do_tri) { q1 = ldq(blob, off + 16u); q2 = ldq(blob, off + 32u); } }
+    asm volatile("" ::: "memory");
+    // ------------------------------------------------------------ one box per lane, ranked inside the quad
+    float key = __builtin_inff();
+    int ref = kNoChild;
+    if (do_inner) slab_piece(q0, ix, iy, iz, nx, ny, nz, tmn, tcur, key, ref);
+    const bool hit = key < __builtin_inff();
+    uint32_t rank = 0u;
+    if (MODE == 0 || MODE == 3) {
+        // entries ahead of this one in the quad: a smaller entry distance, or an equal one in a lower lane (all lanes take part in the DPP reads)
+        const float k0 = quad_bcast<0>(key), k1 = quad_bcast<1>(key), k2 = quad_bcast<2>(key), k3 = quad_bcast<3>(key);
+        rank = (k0 < key || (k0 == key && 0u < c) ? 1u : 0u) + (k1 < key || (k1 == key && 1u < c) ? 1u : 0u) +
+               (k2 < key || (k2 == key && 2u < c) ? 1u : 0u) + (k3 < key || (k3 == key && 3u < c) ? 1u : 0u);
+    }
+    // ------------------------------------------------------------ one triangle per lane of a leaf's quad
+    if (do_tri) {
+        const float4 n0 = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), n1 = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
+                     n2 = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
+        const f3 rd = mk3(dx, dy, dz);
+        const f3 e1 = mk3(n1.x, n1.y, n1.z), e2 = mk3(n2.x, n2.y, n2.z);
+        const f3 p = fcross(rd, e2);
+        const float det = fdot(e1, p);
+        const float inv = 1.0f / det;
+        const f3 tv = mk3(ox, oy, oz) - mk3(n0.x, n0.y, n0.z);
+        const float u = fdot(tv, p) * inv;
+        const f3 q = fcross(tv, e1);
+        const float v = fdot(rd, q) * inv;
+        const float t = fdot(e2, q) * inv;
+        const uint32_t prim = f2u(n0.w);
+        const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > tmn && t < tmx &&
+                        (!cull_back || det > 0.0f || (f2u(n1.w) & 4u) != 0u);
+        if (ok) {
+            if (any_sem) sh_done[ls] = 1u;
+            else {
+                const unsigned long long kk = ((unsigned long long)ord_bits(t + 0.0f) << 32) | (unsigned long long)prim;
+                atomicMin(&sh_best[ls], kk);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (*(volatile unsigned long long*)&sh_best[ls] == kk) { sh_u[ls] = u; sh_v[ls] = v; }
+            }
+        }
+    }
+    // ------------------------------------------------------------ pushes: every quad's farthest first, the nearest on top
+    uint32_t word = 0u;
+    if (hit) {
+        if (ref >= 0) word = ((uint32_t)ref << SB) | slotw;
+        else { const uint32_t desc = ~(uint32_t)ref; word = 0x80000000u | ((desc >> 4) << (SB + 2)) | (((desc - 1u) & 3u) << SB) | slotw; }
+    }
+    if (MODE == 0 || MODE == 3) {
+        const unsigned long long m3 = __ballot(hit && rank == 3u), m2 = __ballot(hit && rank == 2u), m1 = __ballot(hit && rank == 1u), m0 = __ballot(hit && rank == 0u);
+        const int c3 = __popcll(m3), c2 = __popcll(m2), c1 = __popcll(m1);
+        if (hit) {
+            const unsigned long long mm = rank == 0u ? m0 : (rank == 1u ? m1 : (rank == 2u ? m2 : m3));
+            const int base = rank == 0u ? c3 + c2 + c1 : (rank == 1u ? c3 + c2 : (rank == 2u ? c3 : 0));
+            stk[psize + base + (int)lane_rank(mm)] = word;
+        }
+        psize += c3 + c2 + c1 + __popcll(m0);
+    } else {
+        const unsigned long long m = __ballot(hit);                      // (an occlusion ray does not care which of its boxes comes first)
+        if (hit) stk[psize + (int)lane_rank(m)] = word;
+        psize += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
 // One round of a wave's entry pool (k_trace_pool's tail phase, k_tail_pool): pop up to 64 packed (entry, ray slot) words,
 // each lane processes one -- an inner node: slab-test both children against the ray's current best t and push the
 // survivors, nearer on top; a leaf reference: test its first triangle and push the rest of the leaf.  The ray of slot s is
@@ -136,6 +306,9 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
                                            const int lane, const Trav& T, int& psize, const bool cull_back PROBE_PARAM)
 {
     constexpr int kPoolCap = CAP;
+    if (Q == 2 && AH == 0 && MIPT_QUAD_MAX > 0) {
+        if (psize <= MIPT_QUAD_MAX) { pool_round_quad<MODE, 6>(blob, bvh, stk, sh_best, sh_u, sh_v, sh_done, nullptr, lane, T, psize, cull_back); return; }
+    }
     // ------------------------------------------------------------ pop up to 64 entries (each lane adds at most one net entry)
     int k = psize < 64 ? psize : 64;
     const int room = kPoolCap - (Q == 2 ? 120 : 104) - psize;  // 64 for ray starts, 40 (BVH4: 56) for a single-lane descent
