@@ -166,6 +166,12 @@ void launch_begin_sample(hipStream_t st, DeviceCounters* ctr, uint32_t n_paths, 
 void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
                  PathQueue cur, float4* result, DeviceCounters* ctr, uint32_t n_max, const void* common_vertices, const struct TraceOpts& o,
                  const struct ResolveJob& resolve, const struct RaygenJob* rg = nullptr, uint32_t epoch = 0u);
+// a one-bounce pass (depth cap 1) whose closest-hit launch would take the tiled form, as ONE launch: tile waves that make their paths,
+// trace them, shade them, trace their occlusion rays and write their pixels (k_frame1) + the next launch's tile order (k_tile_order).
+// false: nothing was launched (the pass does not qualify), the caller runs the wavefront form
+bool launch_frame1(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
+                   float4* result, DeviceCounters* ctr, uint32_t n_paths, const void* common_vertices, const struct TraceOpts& o,
+                   const struct ResolveJob& resolve, const struct RaygenJob& rg, uint32_t epoch, const struct TileOrderJob& order);
 // rg is allowed (the launch makes the pass's primary paths itself: no k_raygen in front of it) when the pool forms of the path kernel run
 bool tail_launch_makes_rays(const DeviceBvh& bvh, const struct TraceOpts& o);
 void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = nullptr);   // host_live: pinned word that receives the new live count

@@ -1365,6 +1365,152 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_TAIL1_W
 #endif
 }
 
+// ---- k_frame1: a one-bounce pass (depth cap 1: the headline frame) as ONE launch of tile waves (round 4) -------------------------------
+// k_trace_pool's tile wave -- raygen for its 64 paths, one ray per lane over the packed BVH2, then the wave's entry pool -- keeps going
+// where the wavefront form ends the kernel: with every lane's hit in registers it shades its 64 paths (shade_path<LAST>, the body of
+// k_shade), traces the tile's occlusion rays (a fifth of the paths on the headline frame: 13 per tile on average, thin rounds -- quad
+// rounds) on the pool over the BVH4 mirror from the root, adds the unoccluded terms in the reference's order and writes the pixels.
+// What it replaces: the shade launch (0.04 ms: as long as the dependent fetches of the paths that hit), the any-hit launch (0.18 ms, its
+// last 40 % a drain with 16 of 25 wave slots occupied), two launch gaps, the hit records, the compact path entries and the shadow queue
+// (written by one kernel, read back by the next).  The occlusion work of a tile now hides behind the other 23 tile waves of its CU.
+// Same arithmetic in the same order per path, so frames are the wavefront form's bit for bit; ray counters from the waves' bins.
+// The next launch's tile order is made by k_tile_order (the job that rode in the shade launch's first workgroups).
+struct Frame1Args {
+    TraceArgs t;               // bvh, steal_min, burst_bulk, tile_group, the tile order tables (ray arrays unused: the kernel makes its rays)
+    TailArgs  k;               // ShadeArgs (hit groups, frame constants, result, resolve), RaygenJob, epoch
+};
+
+template <int ROWS, int Q, int QS>      // Q: node format the closest-hit phases walk (0 fp32 / 1 packed); QS: the occlusion pool's (2: BVH4 mirror)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS <= 24 ? MIPT_TILED_WAVES : 5, ROWS <= 24 ? MIPT_TILED_WAVES : 5)))
+void k_frame1(Frame1Args f)
+{
+    const TraceArgs& a = f.t;
+    const ShadeArgs& sh_a = f.k.a;
+    constexpr int kPoolCap = ROWS * 64 - 384;
+    __shared__ __attribute__((aligned(16))) uint32_t stk[ROWS * 64];
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
+    float* const sh_u = reinterpret_cast<float*>(stk + kPoolCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(stk + kPoolCap + 192);
+    uint32_t* const sh_done = stk + kPoolCap + 320;
+    const int lane = (int)threadIdx.x;
+    if (blockIdx.x == 0u) { begin_sample(f.k.rg.ctr, threadIdx.x, f.k.rg.fc.n_paths, f.k.rg.n_valid, f.k.rg.zero_stats); tail_publish_epoch(f.k.rg.ctr, f.k.epoch); }
+    const uint32_t n = a.n_max;
+    const int steal_floor = 64 - (kPoolCap - 168) / ROWS;
+    const int steal_min = a.steal_min < 64 ? (a.steal_min > steal_floor ? a.steal_min : steal_floor) : 64;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.blob_bytes, 0x00020000);
+    const uint32_t tiles = (n + 63u) >> 6, tiles_seg = (tiles + kNumSegments - 1) / kNumSegments;
+    const uint32_t xcd = blockIdx.x & (kNumSegments - 1), waves_seg = gridDim.x / kNumSegments;
+    Trav T;
+    T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
+    uint32_t n_shadow = 0u, n_iter = 0u;
+    for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
+        uint32_t tile = xcd * tiles_seg + k;
+        if (a.tile_group != 0u) {
+            const uint32_t gq = k / a.tile_group, r = k - gq * a.tile_group;
+            tile = (gq * kNumSegments + xcd) * a.tile_group + r;
+        } else if (k >= tiles_seg) break;
+        if (tile >= tiles) break;
+        if (a.tile_order != nullptr && a.n_order == tiles) {
+            const uint32_t t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[tile]);
+            tile = t2 < tiles ? t2 : tile;
+        }
+        uint32_t cost = 0u;
+        const uint32_t ray = tile * 64u + (uint32_t)lane;
+        // ============================================================ raygen (optixPathTracer.cu:249-281): the path stays in the lane
+        uint32_t slot = kInvalidSlot, seed = 0u;
+        float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool has_ray = false;
+        T.prim = 0xffffffffu; T.node = kSentinel; T.sp = 0;
+        if (ray < n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef const __attribute__((address_space(4))) RaygenJob* JobPtr;
+            JobPtr rp = (JobPtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Frame1Args, k) + offsetof(TailArgs, rg));
+            asm volatile("" : "+s"(rp));
+#else
+            const RaygenJob* rp = &f.k.rg;            // (the host pass only parses this)
+#endif
+            const FrameConsts fc = rp->fc;
+            const uint32_t sample = rp->sample;
+            float4 ro, rd;
+            const bool valid = raygen_path<2>(fc, sample, PathQueue{}, rp->rg_seed, rp->result, ray, ro, rd, slot, seed);
+            if (valid && !(sample == 0u || fc.batch_spp != 0u)) res = rp->result[slot];           // later samples add to the accumulator
+            if (valid) { trav_init(T, ro, rd); has_ray = T.node != kSentinel; }
+        }
+        const bool valid = slot != kInvalidSlot;
+        // ============================================================ closest hit: one ray per lane, then the wave's entry pool (k_trace_pool)
+        while (__popcll(__ballot(!has_ray)) < steal_min) {
+            for (int bi = 0; bi < a.burst_bulk; ++bi) {
+                if (bi != 0 && __ballot(has_ray && T.node != kSentinel) == 0ull) break;
+                uint32_t nv_ = 0u, nt_ = 0u;
+                stream_step<0, false, Q>(a, blob, stk, lane, has_ray, T, 0, false, nv_, nt_ PROBE_ARG);
+                ++cost;
+            }
+            if (has_ray && T.node == kSentinel) has_ray = false;           // its record stays in T
+        }
+        if (__ballot(has_ray) != 0ull) {
+            int psize = 0;
+            for (int e = 0; e < ROWS; ++e) {
+                const bool in = has_ray && T.sp > e;
+                const unsigned long long m = __ballot(in);
+                if (m == 0ull) break;
+                uint32_t v = 0u;
+                if (in) v = stk[e * 64 + lane];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (in) stk[psize + (int)lane_rank(m)] = pool_pack((int)v, (uint32_t)lane);
+                psize += __popcll(m);
+            }
+            {
+                const unsigned long long m = __ballot(has_ray);
+                if (has_ray) stk[psize + (int)lane_rank(m)] = pool_pack(T.node, (uint32_t)lane);
+                psize += __popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | (unsigned long long)T.prim;
+            sh_u[lane] = T.u; sh_v[lane] = T.v; sh_done[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            while (psize > 0) {
+                pool_round<0, kPoolCap, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, psize, false PROBE_ARG);
+                ++cost;
+            }
+            if (has_ray) {
+                const unsigned long long key = sh_best[lane];
+                T.tbest = ord_float((uint32_t)(key >> 32)); T.prim = (uint32_t)key; T.u = sh_u[lane]; T.v = sh_v[lane];
+            }
+        }
+        // ============================================================ shade (optixPathTracer.cu:323-413, shade_path) and the occlusion rays
+        const float4 hit = T.prim != 0xffffffffu ? make_float4(T.tbest, u2f(T.prim), T.u, T.v) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+        ShadeOut o;
+        o.push_next = false; o.push_shadow = false;
+        if (valid) {
+            n_iter = 1u;
+            shade_path<true>(sh_a, hit, make_float4(1.0f, 1.0f, 1.0f, u2f(seed)), slot, 0u, res, o,
+                             [&](float4& o4, float4& d4) { o4 = make_float4(T.o.x, T.o.y, T.o.z, 0.01f); d4 = make_float4(T.d.x, T.d.y, T.d.z, 1e16f); });
+        }
+        const bool sh = valid && o.push_shadow;
+        if (__ballot(sh) != 0ull) {
+            Trav S;
+            trav_init(S, sh ? o.sro : make_float4(0.f, 0.f, 0.f, 1.0f), sh ? o.srd : make_float4(0.f, 0.f, 1.f, 0.0f));
+            const uint2 work = tail_trace<2, QS, kPoolCap>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel);
+            cost += work.x & 0xffffu;
+            if (sh) {
+                ++n_shadow;
+                if (sh_done[lane] == 0u) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
+            }
+        }
+        if (valid) { if (sh_a.resolve.on) resolve_pixel(sh_a.resolve, slot, res); else sh_a.result[slot] = res; }
+        if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) record_tile_cost(a, tile, cost);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the next tile's stacks overwrite the merge slots
+    }
+    tail_await_epoch(f.k.rg.ctr, f.k.epoch);
+    tail_stats(f.k.rg.ctr, 0u, n_shadow, n_iter);
+}
+
+// the next tiled launch's order from this one's cost classes (TileOrderJob): the work of k_shade's first workgroups, for passes without a shade launch
+__global__ __launch_bounds__(kShadeBlock) void k_tile_order(TileOrderJob j)
+{
+    tile_order_job(j, blockIdx.x);
+}
+
 // ---- k_tail_pool_inst: k_tail_pool over a two-level (instance) structure (round 3) ------------------------------------------------------
 // The same loop -- closest hit, shade_path, the occlusion ray, the next bounce -- with the wave's rays traversed on the two-level entry pool
 // (inst_pool.h: 64-bit entries tagged with the instance they belong to).  A path-traced launch over an instance structure used to run
@@ -2062,6 +2208,40 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
     }
     else
         hipLaunchKernelGGL(k_tail, dim3((n_max + 63u) / 64u), dim3(64), 0, st, a);          // (never with rg: tail_launch_makes_rays)
+}
+
+// a one-bounce pass whose closest-hit launch would take the tiled form: ONE launch (k_frame1) + the order job
+bool launch_frame1(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
+                   float4* result, DeviceCounters* ctr, uint32_t n_paths, const void* common_vertices, const TraceOpts& o,
+                   const ResolveJob& resolve, const RaygenJob& rg, uint32_t epoch, const TileOrderJob& order)
+{
+    if (fc.max_depth != 1u || !closest_launch_is_tiled(bvh, n_paths, o) || bvh.node_fmt < 1u) return false;
+    if (o.tiled_bvh4) return false;                       // (the BVH4 experiment of the tiled kernel keeps the wavefront form)
+    Frame1Args f{};
+    TraceArgs& a = f.t;
+    a.bvh = bvh; a.n_max = n_paths; a.ctr = ctr;
+    a.steal_min = o.steal_min; a.burst_bulk = o.burst_bulk; a.burst_dry = o.burst_dry;
+    a.tile_group = o.tile_group > 0 ? (uint32_t)o.tile_group : 0u;
+    a.tile_order = o.tile_order; a.tile_cost = o.tile_cost; a.tile_hist = o.tile_hist; a.n_order = o.n_order; a.class_width_dev = o.class_width_dev;
+    a.class_width = o.class_width ? o.class_width : 6u;
+    f.k.rg = rg; f.k.epoch = epoch;
+    ShadeArgs& s = f.k.a;
+    s.resolve = resolve; s.fc = fc; s.bvh = bvh; s.hitgroups = hitgroups; s.n_hitgroups = n_hitgroups;
+    s.result = result; s.ctr = ctr; s.n_max = n_paths; s.common_vertices = common_vertices;
+    const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
+    unsigned long long want = ((unsigned long long)n_paths + 63ull) / 64ull;
+    want = want < cus * 16ull ? cus * 16ull : (want > cus * 128ull ? cus * 128ull : want);
+    const int blocks = o.blocks_user ? ((o.blocks + kNumSegments - 1) / kNumSegments * kNumSegments) : (int)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
+    const bool deep = bvh.depth > (uint32_t)MIPT_TILED_ROWS;
+    if (bvh.node_fmt == 2) {
+        if (!deep) hipLaunchKernelGGL((k_frame1<MIPT_TILED_ROWS, 1, 2>), dim3(blocks), dim3(64), 0, st, f);
+        else       hipLaunchKernelGGL((k_frame1<32, 1, 2>), dim3(blocks), dim3(64), 0, st, f);
+    } else {
+        if (!deep) hipLaunchKernelGGL((k_frame1<MIPT_TILED_ROWS, 1, 1>), dim3(blocks), dim3(64), 0, st, f);
+        else       hipLaunchKernelGGL((k_frame1<32, 1, 1>), dim3(blocks), dim3(64), 0, st, f);
+    }
+    if (order.n_chunks != 0u) hipLaunchKernelGGL(k_tile_order, dim3(order.n_chunks), dim3(kShadeBlock), 0, st, order);
+    return true;
 }
 
 bool tail_launch_makes_rays(const DeviceBvh& bvh, const TraceOpts& o)

@@ -796,9 +796,13 @@ __global__ __launch_bounds__(256) void k_tlas4_leaves(uint4* nodes4, uint32_t n4
     const int ref = (int)nodes4[i].w;
     uint32_t r4 = 0u;
     if (ref < 0) {                                                              // leaves hold ONE instance each
-        const uint32_t k = order[(~(uint32_t)ref) >> 4];
-        nodes4[i].w = ~((k << 4) | 1u);
-        r4 = inst[k].root4;
+        const uint32_t desc = ~(uint32_t)ref;
+        if ((desc & 15u) == 0u) nodes4[i].w = 0x7fffffffu;                      // the empty second child of a structure of ONE instance: no child (kNoChild)
+        else {
+            const uint32_t k = order[desc >> 4];
+            nodes4[i].w = ~((k << 4) | 1u);
+            r4 = inst[k].root4;
+        }
     }
     root4_out[i] = r4;
 }

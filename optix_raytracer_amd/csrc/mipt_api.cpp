@@ -171,6 +171,9 @@ struct MiptContext {
     int       tail_refill = 1;           // env MIPT_TAIL_REFILL (TraceOpts::tail_refill)
     uint32_t  profile_launch = 0;        // launches since MIPT_OPT_PROFILE was set (mode 3 brackets every 8th)
     int       direct_resolve = 1;        // env MIPT_DIRECT_RESOLVE=0: always a k_resolve launch (A/B)
+    int       frame1 = 0;                // env MIPT_FRAME1=1: one-bounce passes as ONE launch of tile waves (k_frame1).  Measured SLOWER -- headline frame
+                                         // 0.654 against 0.549 ms for the three wavefront launches: the tiles whose rays are long are the tiles that cast
+                                         // occlusion rays, and ~29 more pool rounds behind them lengthen exactly the waves the launch ends on -- so off
     bool      advance_pending = false;   // the last launch ended without its final k_advance step (mipt_get_launch_stats applies it)
     bool      bins_live = false;         // the last launch was the path tracer's: DeviceCounters::bins belong to its statistics
     int       fuse_raygen = 1;           // env MIPT_FUSE_RAYGEN=0: always a k_raygen launch of its own (A/B)
@@ -596,6 +599,24 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
                         fused_raygen ? &rg : nullptr, next_epoch(ctx));
             continue;
         }
+        if (ctx->frame1 && fused_raygen && !batch && !ctx->count_visits && fc.max_depth == 1u) {
+            // a one-bounce pass as ONE launch of tile waves (k_frame1): trace, shade, occlusion rays, pixels -- no shade / any-hit launch
+            TraceOpts o2 = opts;
+            if (tiled_primary) {
+                o2.tile_cost = ctx->d_tile_class; o2.tile_hist = const_cast<uint32_t*>(job.hist); o2.tile_order = ctx->tile_order_valid ? ctx->d_tile_order : nullptr;
+                o2.n_order = job.n_tiles; o2.class_width = ctx->tile_class_width; o2.class_width_dev = job.width;
+                if (!ctx->tile_group_set && o2.tile_order != nullptr) o2.tile_group = 96;
+                if (ctx->tile_order_mode == 2 && ctx->tile_order_valid) { o2.tile_cost = nullptr; job = TileOrderJob{}; }
+            }
+            bool done1 = false;
+            { TimedScope t(ctx, st, T_CLOSEST);
+              done1 = launch_frame1(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, o2, rj, rg,
+                                    next_epoch(ctx), tiled_primary ? job : TileOrderJob{}); }
+            if (done1) {
+                if (tiled_primary && job.n_chunks != 0u) ctx->tile_order_valid = true;
+                continue;
+            }
+        }
         uint32_t bound = n_paths;      // upper bound of the live-path count (it only falls): the latest count the host has seen
         for (uint32_t bounce = 0;; ++bounce) {
             { TimedScope t(ctx, st, T_CLOSEST);
@@ -737,6 +758,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_LBVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->lbvh_leaf = v; }
     if (const char* e = std::getenv("MIPT_TAIL_REFILL")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tail_refill = v; }
     if (const char* e = std::getenv("MIPT_DIRECT_RESOLVE")) c->direct_resolve = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_FRAME1")) c->frame1 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_FUSE_RAYGEN")) c->fuse_raygen = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }
@@ -1176,7 +1198,7 @@ int build_ias(MiptContext* ctx, Accel* a, const MiptInstance* inst, uint32_t n)
     std::vector<MeshSlot> meshes;
     std::unordered_map<unsigned long long, size_t> mesh_of;
     const uint32_t T = (uint32_t)top.nodes.size();
-    bool fast = ctx->node_format == 2 && n >= 2u && T >= 1u;
+    bool fast = ctx->node_format == 2 && n >= 1u && T >= 1u;      // (one instance -- most glTF files -- too: its top level is a root with one child)
     uint64_t n4_total = T, tri_total = 0;
     for (uint32_t k = 0; k < n && fast; ++k) {
         if (mesh_of.count(gas[k])) continue;

@@ -151,6 +151,40 @@ def test_cost_ordered_tiles_change_nothing_but_the_order():
     assert np.array_equal(frames[1][4][0].reshape(-1, 4)[idx].view(np.uint32), acc.view(np.uint32))
 
 
+def test_one_bounce_pass_as_one_launch_gives_the_same_frame(monkeypatch):
+    """MIPT_FRAME1=1 (an experiment kept in the tree: measured slower, off by default): a one-bounce pass as ONE launch of tile waves
+    that make, trace and shade their paths, trace their occlusion rays and write their pixels (k_frame1) -- same arithmetic in the same
+    order per path, so frames and ray counters equal the three wavefront launches' bit for bit, over several progressive subframes (the
+    accumulator lerp), in cost order from the second launch on, and for a rank's shard."""
+    import torch
+    from optix_raytracer_amd import api
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    scene = scenes.random_soup(200_000, seed_tag=9)
+    ns = api.shard_num_samples(1600, 900, 2)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MIPT_FRAME1", mode)
+        st = PT.make_state(scene, 1600, 900, 1, 0, max_depth=1)
+        ob = PT.OutputBuffer(1600, 900, st.device)
+        frames = []
+        for k in range(3):
+            st.params.subframe_index = k
+            PT.launchSubframe(ob, st)
+            frames.append((st.accum.cpu().numpy().copy(), ob.getHostPointer().copy(), st.context.launch_stats()))
+        shard = torch.zeros((ns, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        st.context.launch_shard(st.params, 1600, 900, 1, 2, shard.data_ptr(), stream=st.stream.cuda_stream)
+        st.context.sync()
+        frames.append((shard.cpu().numpy(), None, st.context.launch_stats()))
+        out[mode] = frames
+        PT.cleanupState(st)
+    for (a1, f1, s1), (a0, f0, s0) in zip(out["1"], out["0"]):
+        assert np.array_equal(a1.view(np.uint32), a0.view(np.uint32))
+        assert f1 is None or np.array_equal(f1, f0)
+        assert s1["closest_rays"] == s0["closest_rays"] and s1["shadow_rays"] == s0["shadow_rays"] > 10000 and s1["bounces"] == s0["bounces"]
+
+
 def test_cost_ordered_tiles_of_a_shard(big):
     """a rank's half of the headline frame (world 2: 1.04 M paths, the tiled kernel) walks its tiles in cost order from the
     second launch on, like a full frame; the compact shard buffer must not depend on it"""

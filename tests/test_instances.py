@@ -598,3 +598,43 @@ def test_deep_two_level_structure_on_the_tiled_kernel(monkeypatch):
             assert np.array_equal(h[:, 1].view(np.uint32), prim) and np.array_equal(h[:, 0].view(np.uint32), t.view(np.uint32))
         ctx.destroy()
     assert np.array_equal(results[0].view(np.uint32), results[1].view(np.uint32))
+
+
+def test_single_instance_structure_runs_on_the_fast_kernels():
+    """Most glTF files are ONE mesh under one node (Duck.gltf, the asset BASELINE's config 3 names), and sutil::Scene builds an instance
+    structure for every scene, as the reference does.  Until round 4 a structure of one instance kept the one-ray-per-lane walk; its top
+    level -- a root whose second child is empty -- now gets the entry-pool arena like any other (the empty child becomes `no child` in the
+    BVH4 mirror).  Path-traced frame, counters and 0.2 M hit records (tiled and pool forms) against the oracle's two-level walk."""
+    import os
+    import torch
+    from optix_raytracer_amd import api, scenes
+    duck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "duck", "Duck.gltf")
+    ctx = api.Context(0)
+    flat, ias, gas, inst, keep = _build(ctx, torch, duck)
+    info = ctx.accel_info(ias)
+    assert info["num_instances"] == 1 and len(inst) == 1
+    assert info["node_format"] == 2 and 1 <= info["stack_entries"] <= 31, info          # the arena of the fast kernels exists
+    w, h, spp, depth = 320, 180, 2, 4
+    launch = scenes.launch_desc(flat, w, h, spp)
+    PT, st = _state(ctx, torch, flat, ias, w, h, spp, depth)
+    acc, frame, stats = _render(PT, st)
+    osc = _oracle_two_level(ctx, flat, ias)
+    a, f, ost = osc.render(launch, mode=O.MODE_INST, max_depth=depth, threads=8)
+    assert np.array_equal(acc.view(np.uint32), a.view(np.uint32)) and np.array_equal(frame, f)
+    assert stats["closest_rays"] == ost["closest_rays"] and stats["shadow_rays"] == ost["shadow_rays"] > 100
+    rays = osc.primary_rays(scenes.launch_desc(flat, 640, 360))
+    n = rays.shape[0]
+    assert n > 140000                                           # more than 512 rays per CU: the tiled two-level form
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    ctx.trace_closest(ias, d_rays.data_ptr(), n, d_hits.data_ptr()); ctx.sync()
+    t, prim, u, v = osc.trace_closest(rays, O.MODE_INST)
+    hg = d_hits.cpu().numpy()
+    assert (prim != 0xffffffff).mean() > 0.02
+    assert np.array_equal(hg[:, 1].view(np.uint32), prim) and np.array_equal(hg[:, 0].view(np.uint32), t.view(np.uint32))
+    seg = rays.copy(); seg[:, 7] = 3.0
+    d_seg = torch.from_numpy(seg).cuda()
+    d_occ = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.trace_any(ias, d_seg.data_ptr(), n, d_occ.data_ptr()); ctx.sync()
+    assert np.array_equal(d_occ.cpu().numpy().astype(np.uint8), osc.trace_any(seg, O.MODE_INST))
+    ctx.destroy()
