@@ -33,11 +33,7 @@ __device__ __forceinline__ void prepare(RayO& r)
     r.nood = mk3(-(r.o.x * r.idir.x), -(r.o.y * r.idir.y), -(r.o.z * r.idir.z));
 }
 
-__device__ __forceinline__ f3 xform_vec(const float* m, f3 d)
-{
-    return mk3(__builtin_fmaf(m[2], d.z, __builtin_fmaf(m[1], d.y, m[0] * d.x)), __builtin_fmaf(m[6], d.z, __builtin_fmaf(m[5], d.y, m[4] * d.x)),
-               __builtin_fmaf(m[10], d.z, __builtin_fmaf(m[9], d.y, m[8] * d.x)));
-}
+// (xform_vec: trav_core.h)
 
 // slab test of both children of one 64-byte node; returns the next node (near child, far one pushed) or a popped entry
 __device__ __forceinline__ int step_inner(const float4* __restrict__ nodes, int node, const RayO& r, float tmin, float tbest, const Stack2& stk,

@@ -67,6 +67,8 @@ struct DeviceBvh {
     const uint32_t* prim_slot; // one-level: per ORIGINAL primitive the position of its triangle record (null: not kept by the builder that made this BVH)
     uint32_t inst_slots;       // two-level: every DeviceInstance::prim_slot is set
     uint32_t top_off;          // experiment MIPT_TOP_CACHE: byte offset of the top-of-tree copy of the packed mirror (64 nodes + their real indices); 0 = none
+    const float* xf;           // not null: this is the mesh of an instance structure of ONE instance, walked as an ordinary BVH -- every ray is taken into
+                               // the instance's object space when its traversal starts (trav_init; the 12 floats of DeviceInstance::inv, device memory)
     uint32_t node_fmt;         // 0: fp32 64-byte BVH2 nodes only; 1: + packed 32-byte BVH2 nodes at node32_off (MiptBvhNode32: the boxes of
                                // `nodes` as fp16 -- the two arrays hold the SAME values), walked by every entry-pool kernel; 2: + the BVH4
                                // mirror at node4_off, walked by the kernels that live on the pool alone (static chunks, path kernels)

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64) void k_trace_stream(TraceArgs a)
         if (n_idle == 64 || (n_idle >= refill_min && (!dry || __ballot(nxt_valid && !has_ray) != 0ull))) {
             if (!has_ray && nxt_valid) {
                 ray = nxt_idx;
-                trav_init(T, nxt_o, nxt_d);
+                trav_init(T, nxt_o, nxt_d, a.bvh.xf);
                 sb = 0; shared = false; own = (uint32_t)lane;
                 has_ray = T.node != kSentinel;
                 if (!has_ray) finish_ray<MODE>(a, T, ray, false);      // empty interval: a miss, no BVH access
@@ -530,9 +530,9 @@ void k_trace_pool(TraceArgs a, RaygenJob rg)
                 const PathQueue q = rp->q;
                 float4 ro, rd; uint32_t slot_, seed_;
                 raygen_path<1>(fc, rp->sample, q, rp->rg_seed, rp->result, ray, ro, rd, slot_, seed_);
-                trav_init(T, ro, rd);
+                trav_init(T, ro, rd, a.bvh.xf);
             } else {
-                trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+                trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride], a.bvh.xf);
             }
             has_ray = T.node != kSentinel;
             if (!has_ray) finish_ray<MODE>(a, T, ray, false);      // empty interval: a miss, no BVH access
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64) void k_trace_simple(TraceArgs a)
     for (uint32_t item = blockIdx.x * 64u + threadIdx.x; item < n; item += gridDim.x * 64u) {
         const uint32_t ray = item;
         Trav T;
-        trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+        trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride], a.bvh.xf);
         bool hit = false;
         while (T.node != kSentinel) {
             while (T.node >= 0) {
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
         float4 res = a.result[slot];
         for (;;) {
             Trav T;
-            trav_init(T, ro4, rd4);
+            trav_init(T, ro4, rd4, a.bvh.xf);
             while (T.node != kSentinel) {
                 while (T.node >= 0) visit_inner(T, a.bvh.nodes, stk);
                 if (T.node != kSentinel) { (void)visit_leaf<false>(T, a.bvh.tris, n_tests, false); T.node = stk.pop(T.sp); }
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(64) void k_tail(ShadeArgs a)
             shade_path(a, hit, sa, slot, depth, res, o, [&](float4& o4, float4& d4) { o4 = ro4; d4 = rd4; });
             if (o.push_shadow) {
                 ++n_shadow;
-                trav_init(T, o.sro, o.srd);
+                trav_init(T, o.sro, o.srd, a.bvh.xf);
                 bool occluded = false;
                 while (T.node != kSentinel) {
                     while (T.node >= 0) visit_inner(T, a.bvh.nodes, stk);
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     bool active = slot != kInvalidSlot;
     while (__ballot(active) != 0ull) {
         Trav T;
-        trav_init(T, ro4, rd4);
+        trav_init(T, ro4, rd4, a.bvh.xf);
         tail_trace<0, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, active && T.node != kSentinel);
         const unsigned long long key = sh_best[lane];
         const uint32_t prim = (uint32_t)key;
@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const bool sh = active && o.push_shadow;
         if (__ballot(sh) != 0ull) {
             Trav S;
-            trav_init(S, sh ? o.sro : ro4, sh ? o.srd : rd4);
+            trav_init(S, sh ? o.sro : ro4, sh ? o.srd : rd4, a.bvh.xf);
             tail_trace<2, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel);
             if (sh) {
                 ++n_shadow;
@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_TAIL1_W
     o.push_next = false; o.push_shadow = false;
     {
         Trav T;
-        trav_init(T, ro4, rd4);
+        trav_init(T, ro4, rd4, a.bvh.xf);
         tail_trace<0, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, active && T.node != kSentinel);
         const unsigned long long key = sh_best[lane];
         const uint32_t prim = (uint32_t)key;
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MIPT_TAIL1_W
     const bool sh = active && o.push_shadow;
     if (__ballot(sh) != 0ull) {
         Trav S;
-        trav_init(S, sh ? o.sro : make_float4(0.f, 0.f, 0.f, 1.0f), sh ? o.srd : make_float4(0.f, 0.f, 1.f, 0.0f));
+        trav_init(S, sh ? o.sro : make_float4(0.f, 0.f, 0.f, 1.0f), sh ? o.srd : make_float4(0.f, 0.f, 1.f, 0.0f), a.bvh.xf);
         tail_trace<2, Q>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel);
         if (sh && sh_done[lane] == 0u) { res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z; }      // finish_ray<2>
     }
@@ -1434,7 +1434,7 @@ void k_frame1(Frame1Args f)
             float4 ro, rd;
             const bool valid = raygen_path<2>(fc, sample, PathQueue{}, rp->rg_seed, rp->result, ray, ro, rd, slot, seed);
             if (valid && !(sample == 0u || fc.batch_spp != 0u)) res = rp->result[slot];           // later samples add to the accumulator
-            if (valid) { trav_init(T, ro, rd); has_ray = T.node != kSentinel; }
+            if (valid) { trav_init(T, ro, rd); has_ray = T.node != kSentinel; }      // (launch_frame1 refuses a BVH with xf: shading reads the ray from T)
         }
         const bool valid = slot != kInvalidSlot;
         // ============================================================ closest hit: one ray per lane, then the wave's entry pool (k_trace_pool)
@@ -1489,7 +1489,7 @@ void k_frame1(Frame1Args f)
         const bool sh = valid && o.push_shadow;
         if (__ballot(sh) != 0ull) {
             Trav S;
-            trav_init(S, sh ? o.sro : make_float4(0.f, 0.f, 0.f, 1.0f), sh ? o.srd : make_float4(0.f, 0.f, 1.f, 0.0f));
+            trav_init(S, sh ? o.sro : make_float4(0.f, 0.f, 0.f, 1.0f), sh ? o.srd : make_float4(0.f, 0.f, 1.f, 0.0f), a.bvh.xf);
             const uint2 work = tail_trace<2, QS, kPoolCap>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel);
             cost += work.x & 0xffffu;
             if (sh) {
@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
     while (__ballot(active) != 0ull) {
         Trav T;
-        trav_init(T, ro4, rd4);
+        trav_init(T, ro4, rd4, a.bvh.xf);
         tail_trace_inst<0, kCap>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, active && T.node != kSentinel, false INST_STATS_ARG);
         const unsigned long long key = sh_best[lane];
         const uint32_t prim = (uint32_t)key;
@@ -1558,7 +1558,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const bool sh = active && o.push_shadow;
         if (__ballot(sh) != 0ull) {
             Trav S;
-            trav_init(S, sh ? o.sro : ro4, sh ? o.srd : rd4);
+            trav_init(S, sh ? o.sro : ro4, sh ? o.srd : rd4, a.bvh.xf);
             tail_trace_inst<2, kCap>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, S, sh && S.node != kSentinel, false INST_STATS_ARG);
             if (sh) {
                 ++n_shadow;
@@ -1787,7 +1787,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         Trav T;
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
-        if (active) trav_init(T, ro4, rd4);
+        if (active) trav_init(T, ro4, rd4, a.bvh.xf);
         const bool has_c = active && T.node != kSentinel;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
@@ -1820,7 +1820,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (o.push_shadow) {
                 ++n_shadow;
                 Trav S;
-                trav_init(S, o.sro, o.srd);
+                trav_init(S, o.sro, o.srd, a.bvh.xf);
                 if (S.node != kSentinel) {
                     sray[0 * 64 + lane] = S.o.x;    sray[1 * 64 + lane] = S.o.y;     sray[2 * 64 + lane] = S.o.z;
                     sray[3 * 64 + lane] = S.d.x;    sray[4 * 64 + lane] = S.d.y;     sray[5 * 64 + lane] = S.d.z;
@@ -1894,7 +1894,7 @@ __global__ __launch_bounds__(64) MIPT_STATIC_ATTR void k_trace_static(TraceArgs 
         Trav T;
         T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
         T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
-        if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride]);
+        if (mine) trav_init(T, a.ray_o[(size_t)ray * a.stride], a.ray_d[(size_t)ray * a.stride], a.bvh.xf);
         const uint2 work = tail_trace<MODE, Q, kPoolCap>(blob, a.bvh, stk, sh_best, sh_u, sh_v, sh_done, lane, T, mine && T.node != kSentinel,
                                                MODE == 0 && (a.ray_flags & 16u) != 0u);
         (void)work;
@@ -2215,7 +2215,7 @@ bool launch_frame1(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, 
                    float4* result, DeviceCounters* ctr, uint32_t n_paths, const void* common_vertices, const TraceOpts& o,
                    const ResolveJob& resolve, const RaygenJob& rg, uint32_t epoch, const TileOrderJob& order)
 {
-    if (fc.max_depth != 1u || !closest_launch_is_tiled(bvh, n_paths, o) || bvh.node_fmt < 1u) return false;
+    if (fc.max_depth != 1u || !closest_launch_is_tiled(bvh, n_paths, o) || bvh.node_fmt < 1u || bvh.xf != nullptr) return false;
     if (o.tiled_bvh4) return false;                       // (the BVH4 experiment of the tiled kernel keeps the wavefront form)
     Frame1Args f{};
     TraceArgs& a = f.t;

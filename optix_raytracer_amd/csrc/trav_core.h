@@ -29,10 +29,25 @@ struct Trav {
                                  // candidate's primitive -- candidates AT tmin count when their primitive index is greater
 };
 
-__device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd)
+// rows of a 3x4 matrix times a direction: fmaf(m2, z, fmaf(m1, y, m0 * x)) per row (the instance walk's arithmetic, inst_core.h)
+__device__ __forceinline__ f3 xform_vec(const float* m, f3 d)
+{
+    return mk3(__builtin_fmaf(m[2], d.z, __builtin_fmaf(m[1], d.y, m[0] * d.x)), __builtin_fmaf(m[6], d.z, __builtin_fmaf(m[5], d.y, m[4] * d.x)),
+               __builtin_fmaf(m[10], d.z, __builtin_fmaf(m[9], d.y, m[8] * d.x)));
+}
+
+// xf != null (DeviceBvh::xf: an instance structure of ONE instance walked as its mesh's own BVH): the ray is taken into the instance's
+// object space first -- o' = M o + t, d' = M d, not re-normalised, exactly as the two-level walk does when it enters the instance
+// (instances.hip) -- so that t, u, v and the primitive come out as that walk has them; tmin / tmax carry over.
+__device__ __forceinline__ void trav_init(Trav& T, float4 ro, float4 rd, const float* __restrict__ xf = nullptr)
 {
     T.o = mk3(ro.x, ro.y, ro.z);
     T.d = mk3(rd.x, rd.y, rd.z);
+    if (xf != nullptr) {
+        const f3 m = xform_vec(xf, T.o);
+        T.o = mk3(m.x + xf[3], m.y + xf[7], m.z + xf[11]);
+        T.d = xform_vec(xf, T.d);
+    }
     T.tmin = ro.w; T.tmax = rd.w; T.tbest = rd.w;
     const float eps = 8.27180613e-25f;   // 2^-80: keeps 1/d finite for axis-parallel rays
     const float dx = __builtin_fabsf(T.d.x) > eps ? T.d.x : __builtin_copysignf(eps, T.d.x);

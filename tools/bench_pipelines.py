@@ -13,9 +13,15 @@ from optix_raytracer_amd.pathtracer import OutputBuffer
 tmp = pathlib.Path(tempfile.mkdtemp())
 
 
-def meshviewer(name, path, w, h, reps):
+def meshviewer(name, path, w, h, reps, two_level=False, inst_form=None):
+    """two_level: per-mesh structures + the instance structure (what the reference and the C++ sutil::Scene build); inst_form = 2 pins the
+    one-ray-per-lane walk of the structure (MIPT_INST_FORM: the form a structure of ONE instance ran until round 4)"""
+    if inst_form is not None:
+        os.environ["MIPT_INST_FORM"] = str(inst_form)
+    else:
+        os.environ.pop("MIPT_INST_FORM", None)
     st = MV.MeshViewerState()
-    MV.loadScene(st, str(path))
+    MV.loadScene(st, str(path), two_level=two_level)
     MV.initCameraState(st)
     MV.initLaunchParams(st, w, h)
     out = OutputBuffer(w, h, st.device)
@@ -88,5 +94,12 @@ def _mk(name):
 
 meshviewer("meshviewer: textured fixture (PNG/JPEG textures), 1920x1080", G.write_textured(_mk("t")), 1920, 1080, 10)
 meshviewer("meshviewer: alpha MASK/BLEND fixture (any-hit programs), 1920x1080", G.write_alpha(_mk("al")), 1920, 1080, 10)
+# structures of ONE instance (one mesh under one node: most glTF files), as sutil::Scene builds them: flattened / two-level / two-level on the
+# one-ray-per-lane walk (what such a structure ran until round 4)
+duck = os.path.join(ROOT, "tests", "golden", "duck", "Duck.gltf")
+for label, path in (("Duck.gltf 4.2k tris", duck), ("generated glTF 240k tris", tmp / "b.gltf")):
+    meshviewer("meshviewer: %s, 1920x1080, flattened" % label, path, 1920, 1080, 10)
+    meshviewer("meshviewer: %s, 1920x1080, two-level" % label, path, 1920, 1080, 10, two_level=True)
+    meshviewer("meshviewer: %s, 1920x1080, two-level, per-lane walk" % label, path, 1920, 1080, 10, two_level=True, inst_form=2)
 imgui("imgui_test: 2x200x200-triangle height field, 1024x768 spf 1", 200, 1024, 768, 1, 10)
 imgui("imgui_test: 2x700x700-triangle height field, 1920x1080 spf 4", 700, 1920, 1080, 4, 5)
