@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 3   /* 2: MiptAccelInfo.node_format, MIPT_OPT_NODE_FORMAT, mipt_group_*; 3: mipt_whitted_set_geometry_instanced, mipt_scene_mesh_normals / _texcoords / _colors */
+#define MIPT_ABI_VERSION 4   /* 2: MiptAccelInfo.node_format, MIPT_OPT_NODE_FORMAT, mipt_group_*; 3: mipt_whitted_set_geometry_instanced, mipt_scene_mesh_normals / _texcoords / _colors;
+                                4: MIPT_OPT_BUILD = 2 (device SAH builder, the default) */
 
 typedef enum MiptResult {
     MIPT_SUCCESS                 = 0,
@@ -199,13 +200,16 @@ typedef enum MiptOption {
     MIPT_OPT_BATCH_SAMPLES = 10, /* 0 (default): one wavefront pass per sample, contributions added in the reference's
                                   order (bit-identical to the oracle); 1: all samples_per_launch samples of a launch are
                                   paths of ONE pass with per-sample accumulators (same values to rounding, far fewer passes) */
-    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build: 0 (default) binned SAH on the host cores (155 ms per million triangles);
-                                  1: on the device, as optixAccelBuild -- Morton codes, radix sort, Karras' radix tree, every subtree
-                                  of <= 64 triangles rebuilt by full-sweep SAH (one wave each), leaves by the SAH termination rule:
-                                  4 ms per million triangles (~ PREFER_FAST_BUILD); frames equal the host tree's on evenly spread
-                                  triangles (the headline scene), 10-60 % slower on scenes whose top levels need SAH (large
-                                  triangles, height fields).  1 falls back to 0 for inputs of <= 4 triangles and when the tree is
-                                  deeper than the 32-entry traversal stack */
+    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build, all three in the same node / triangle layout; a render does not depend on it:
+                                  2 (default since ABI 4): on the device, as optixAccelBuild -- top-down binned SAH (32 bins per axis, all open
+                                  ranges of a level at once) down to ranges of 64 triangles, each of which one wave then builds by full-sweep
+                                  SAH; leaves by the SAH termination rule.  12 ms per million triangles, frames within 1 % of those over the
+                                  host builder's tree on every scene measured (profiles/r04_builders.txt), the same tree in every run;
+                                  1: on the device, fastest build (~ PREFER_FAST_BUILD): Morton codes, radix sort, Karras' radix tree, the same
+                                  64-triangle treelets: 3 ms per million triangles, frames equal on evenly spread triangles (the headline
+                                  scene), 10-20 % slower on scenes whose top levels need SAH (large triangles among small ones, height fields);
+                                  0: binned SAH on the host cores (155 ms per million triangles).  1 and 2 fall back to 0 for inputs of
+                                  <= 4 triangles and when their tree is deeper than the 32-entry traversal stack */
     MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late;
                                   half the value when MAX_DEPTH caps the paths), one kernel runs each of them to its
                                   end, a wave per 64 paths, instead of five kernels per bounce; a pass that starts with at

@@ -246,7 +246,7 @@ def load():
         fn = getattr(L, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if L.mipt_abi_version() != 3:
+    if L.mipt_abi_version() != 4:
         raise RuntimeError("libmipt.so ABI version mismatch")
     _lib = L
     return L

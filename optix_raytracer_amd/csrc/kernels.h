@@ -234,7 +234,8 @@ hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d
 hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth);
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets = true,
-                      uint32_t* d_prim_slot = nullptr);       // d_prim_slot: n words, filled with primitive -> position of its triangle record
+                      uint32_t* d_prim_slot = nullptr,        // d_prim_slot: n words, filled with primitive -> position of its triangle record
+                      bool sah_top = false);                  // the levels above the treelets by top-down binned SAH instead of Morton codes (MIPT_OPT_BUILD = 2)
 
 // SDK/cuda/whitted.cu pipeline (whitted_kernels.hip)
 struct WhTables {                  // MiptWhittedGeometry with typed pointers: the shading tables of a flattened scene, or of one mesh

@@ -23,20 +23,32 @@ struct Box6 { float lo[3], hi[3]; };
 
 __global__ __launch_bounds__(256) void k_lbvh_prims(const float* __restrict__ world, uint32_t n, Box6* boxes, uint32_t* scene /* 6 ordered words */)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* v = world + (size_t)i * 9;
-    Box6 b;
-    for (int k = 0; k < 3; ++k) {
-        b.lo[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
-        b.hi[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+    // centroid bounds are enough for the Morton grid (and the root's bins).  Atomics on ONE address from all over the chip take ~70 ns
+    // each: a million of them on six words were 1.07 ms of a 4 ms build, one per wave still 1.0 ms -- so the grid is at most 1024
+    // workgroups, each reduces its triangles in LDS and adds six atomics (round 4)
+    __shared__ uint32_t s_b[6];
+    if (threadIdx.x < 6u) s_b[threadIdx.x] = threadIdx.x < 3u ? 0xffffffffu : 0u;
+    __syncthreads();
+    uint32_t lo[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, hi[3] = { 0u, 0u, 0u };
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* v = world + (size_t)i * 9;
+        Box6 b;
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
+            b.hi[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+        }
+        boxes[i] = b;
+        for (int k = 0; k < 3; ++k) { const uint32_t c = f_ord(0.5f * (b.lo[k] + b.hi[k])); lo[k] = c < lo[k] ? c : lo[k]; hi[k] = c > hi[k] ? c : hi[k]; }
     }
-    boxes[i] = b;
-    for (int k = 0; k < 3; ++k) {                       // centroid bounds are enough for the Morton grid
-        const float c = 0.5f * (b.lo[k] + b.hi[k]);
-        atomicMin(&scene[k], f_ord(c));
-        atomicMax(&scene[3 + k], f_ord(c));
-    }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t a = (uint32_t)__shfl_xor((int)lo[k], off, 64), c = (uint32_t)__shfl_xor((int)hi[k], off, 64);
+            lo[k] = a < lo[k] ? a : lo[k]; hi[k] = c > hi[k] ? c : hi[k];
+        }
+    if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 3; ++k) { atomicMin(&s_b[k], lo[k]); atomicMax(&s_b[3 + k], hi[k]); }
+    __syncthreads();
+    if (threadIdx.x < 3u) atomicMin(&scene[threadIdx.x], s_b[threadIdx.x]);
+    else if (threadIdx.x < 6u) atomicMax(&scene[threadIdx.x], s_b[threadIdx.x]);
 }
 
 __device__ __forceinline__ unsigned long long spread21(unsigned long long x)
@@ -133,11 +145,18 @@ __device__ __forceinline__ Box6 box_union(const Box6& a, const Box6& b)
 // only, so ranges stay contiguous and the leaf folding, emission, depth and height passes that follow see an ordinary tree.
 constexpr int kTreelet = 64;
 
-__global__ __launch_bounds__(256) void k_treelet_roots(const int* range_lo, const int* range_hi, const int* parent_inner, int n_inner, uint32_t* roots, uint32_t* n_roots)
+// order2 != null (the top-down front end, whose partition leaves the triangles of a range in the order the atomics fell): a node over
+// two triangles gets them in the order of their primitive numbers, so that the tree does not depend on the run
+__global__ __launch_bounds__(256) void k_treelet_roots(const int* range_lo, const int* range_hi, const int* parent_inner, int n_inner, uint32_t* roots, uint32_t* n_roots,
+                                                       uint32_t* order2)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n_inner) return;
     const int sz = range_hi[i] - range_lo[i] + 1;
+    if (order2 != nullptr && sz == 2) {
+        const uint32_t a = order2[range_lo[i]], b = order2[range_hi[i]];
+        if (a > b) { order2[range_lo[i]] = b; order2[range_hi[i]] = a; }
+    }
     const int p = parent_inner[i];
     if (sz > kTreelet || sz < 3 || p < 0) return;                     // (the root keeps slot 0; two triangles have one shape)
     if (range_hi[p] - range_lo[p] + 1 <= kTreelet) return;            // inside a treelet, not its root
@@ -147,7 +166,8 @@ __global__ __launch_bounds__(256) void k_treelet_roots(const int* range_lo, cons
 __device__ __forceinline__ float box_area6(const float* b) { const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2]; return dx * dy + dy * dz + dz * dx; }
 
 __global__ __launch_bounds__(64) void k_lbvh_treelets(const uint32_t* __restrict__ roots, const uint32_t* __restrict__ n_roots, const Box6* __restrict__ prim_boxes,
-                                                      uint32_t* sorted_prims, int* left, int* right, int* parent_inner, int* parent_leaf, int* range_lo, int* range_hi)
+                                                      uint32_t* sorted_prims, int* left, int* right, int* parent_inner, int* parent_leaf, int* range_lo, int* range_hi,
+                                                      int by_prim)
 {
     __shared__ float s_box[64][7];                                    // a record per position: box + prim (as bits)
     const int lane = (int)threadIdx.x;
@@ -159,6 +179,16 @@ __global__ __launch_bounds__(64) void k_lbvh_treelets(const uint32_t* __restrict
         const int P = parent_inner[root];
         const bool valid = lane < n;
         uint32_t prim = valid ? sorted_prims[lo + lane] : 0u;
+        if (by_prim) {
+            // the top-down front end leaves a range's triangles in the order its atomics fell: start from the order of the primitive
+            // numbers, so that ties between equal costs fall the same way in every run (the tree is then a function of the input)
+            int rank = 0;
+            for (int k = 0; k < kTreelet; ++k) { const uint32_t pk = (uint32_t)__shfl((int)prim, k, 64); rank += (k < n && pk < prim) ? 1 : 0; }
+            if (valid) s_box[rank][6] = __uint_as_float(prim);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (valid) prim = __float_as_uint(s_box[lane][6]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
         float b[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
         if (valid) { const Box6 pb = prim_boxes[prim]; for (int k = 0; k < 3; ++k) { b[k] = pb.lo[k]; b[3 + k] = pb.hi[k]; } }
         int sa = 0, sb = n - 1, sp = P, ss = left[P] == root ? 0 : 1;  // my segment (positions = lanes), the node above it and the side it hangs on
@@ -383,6 +413,262 @@ __global__ __launch_bounds__(64) void k_lbvh_clusters(const uint32_t* __restrict
             }
         }
     }
+}
+
+// ---- top-down binned SAH on the device (round 4, MIPT_OPT_BUILD = 2) -----------------------------------------------------------------
+// The radix tree cuts space at Morton-code bits; a scene of large triangles among small ones (a hall's walls around its furniture), a
+// height field or a wall is cut where no SAH builder would cut it, and the treelets below repair the last six levels only: frames
+// 10-60 % behind the host tree's (round 3).  This front end replaces {Morton codes, sort, radix tree} by what the host builder does
+// (bvh_build.cpp: binned SAH over the centroid bounds, 16 bins per axis here), level by level over ALL open ranges at once:
+//   k_sah_bin        every triangle of an open range adds its box, its centroid and 1 to its bin on each axis -- in LDS for the range
+//                    the workgroup's chunk starts in (ranges are contiguous, so that is nearly all of a chunk), flushed with one global
+//                    atomic per non-empty word; stragglers of other ranges go to global memory directly
+//   k_sah_split      one thread per open range: sweep the 3 x 16 bins, cheapest area(L) n(L) + area(R) n(R) whose sides still fit under
+//                    the depth cap (the host's rule), else the median; the children's centroid bounds are the union of the bins'
+//                    centroid bounds on their side (no pass of their own); the node takes Karras' numbering -- a node's index is one
+//                    end of its range: the root 0, a left child its LAST position, a right child its FIRST -- so everything after this
+//                    front end (treelets, box fitting, leaf folding, emission) sees an ordinary radix tree
+//   k_sah_partition  every triangle moves to its side of its range (out of place; one atomic per wave, range and side)
+// until no range holds more than 64 triangles; those become TREELETS (the pass above: full-sweep SAH, one wave each).  No sort at all.
+#ifndef MIPT_SAH_BINS
+#define MIPT_SAH_BINS 32          // the host builder's count (16: the headline tree one level deeper, the 4.2 k-triangle glTF 4 % behind the host tree)
+#endif
+constexpr int kSahBins = MIPT_SAH_BINS, kSahBinWords = 7, kSahSegWords = 3 * kSahBins * kSahBinWords;      // per bin: count, box lo / hi (ordered words)
+constexpr uint32_t kSahNone = 0xffffffffu;
+struct SahSeg { int lo, hi, node, depth; uint32_t cb[6]; };                                   // an open range, its node, its centroid bounds (ordered)
+struct SahSplit { int lo, left_count, axis, bin, median; float cb_lo, scale; uint32_t child[2]; };   // child: slot of the side's range in the next level, or kSahNone
+
+__device__ __forceinline__ int sah_bin_of(float c, float cb_lo, float scale)
+{
+    const float t = (c - cb_lo) * scale;
+    int b = t >= 0.0f ? (int)fminf(t, (float)(kSahBins - 1)) : 0;          // (a NaN centroid lands in bin 0)
+    return b < kSahBins ? b : kSahBins - 1;
+}
+__device__ __forceinline__ uint32_t sah_word_identity(int w) { const int k = w % kSahBinWords; return k >= 1 && k <= 3 ? 0xffffffffu : 0u; }
+
+__global__ __launch_bounds__(256) void k_sah_init(uint32_t* bins, size_t words, uint32_t* perm, uint32_t* seg_of, uint32_t n, int* left, int* right, int* rlo, int* rhi)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) bins[i] = sah_word_identity((int)(i % kSahSegWords));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        perm[i] = (uint32_t)i; seg_of[i] = 0u;
+        left[i] = 0x7ffffff0; right[i] = 0x7ffffff0; rlo[i] = 0; rhi[i] = -1;               // an unused slot: no range, not a bottom node
+    }
+}
+
+constexpr int kSahChunk = 2048, kSahTables = 8;
+__global__ __launch_bounds__(256) void k_sah_bin(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ seg_of, const SahSeg* __restrict__ segs, uint32_t n,
+                                                 const Box6* __restrict__ boxes, uint32_t* bins)
+{
+    // LDS bins for up to eight of the open ranges a chunk of 2048 positions touches (near the root that is one range; deep down ranges
+    // are shorter than a chunk): a range claims the table its slot number hashes to, a range that finds its table taken adds to global
+    // memory directly.  One global atomic per non-empty word and table at the end.
+    __shared__ uint32_t s_dir[kSahTables];
+    __shared__ uint32_t s_bins[kSahTables][kSahSegWords];
+    for (uint32_t chunk = blockIdx.x; (size_t)chunk * kSahChunk < n; chunk += gridDim.x) {
+        const uint32_t first = chunk * (uint32_t)kSahChunk;
+        if (threadIdx.x < (uint32_t)kSahTables) s_dir[threadIdx.x] = kSahNone;
+        for (int w = (int)threadIdx.x; w < kSahTables * kSahSegWords; w += 256) (&s_bins[0][0])[w] = sah_word_identity(w % kSahSegWords);
+        __syncthreads();
+        for (uint32_t p = first + threadIdx.x; p < first + (uint32_t)kSahChunk && p < n; p += 256u) {
+            const uint32_t s = seg_of[p];
+            if (s == kSahNone) continue;
+            const SahSeg sg = segs[s];
+            const Box6 b = boxes[perm[p]];
+            const uint32_t h = s & (uint32_t)(kSahTables - 1);
+            uint32_t owner = s_dir[h];
+            if (owner == kSahNone) { owner = atomicCAS(&s_dir[h], kSahNone, s); if (owner == kSahNone) owner = s; }
+            uint32_t* dst = owner == s ? s_bins[h] : bins + (size_t)s * kSahSegWords;
+            uint32_t ob[6];
+            for (int k = 0; k < 3; ++k) { ob[k] = f_ord(b.lo[k]); ob[3 + k] = f_ord(b.hi[k]); }
+            for (int k = 0; k < 3; ++k) {
+                const float cl = f_unord(sg.cb[k]), ext = f_unord(sg.cb[3 + k]) - cl;
+                if (!(ext > 0.0f) || !(ext < 3.0e38f)) continue;              // an axis without extent is not a split axis (bvh_build.cpp: usable[])
+                const int bi = sah_bin_of(0.5f * (b.lo[k] + b.hi[k]), cl, (float)kSahBins / ext);
+                uint32_t* w = dst + (k * kSahBins + bi) * kSahBinWords;
+                atomicAdd(&w[0], 1u);
+                for (int c = 0; c < 3; ++c) { atomicMin(&w[1 + c], ob[c]); atomicMax(&w[4 + c], ob[3 + c]); }
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < kSahTables; ++t) {
+            const uint32_t sid = s_dir[t];
+            if (sid == kSahNone) continue;                                     // (uniform)
+            uint32_t* g = bins + (size_t)sid * kSahSegWords;
+            for (int w = (int)threadIdx.x; w < kSahSegWords; w += 256) {
+                const uint32_t v = s_bins[t][w];
+                if (v == sah_word_identity(w)) continue;
+                const int k = w % kSahBinWords;
+                if (k == 0) atomicAdd(&g[w], v);
+                else if (k <= 3) atomicMin(&g[w], v);
+                else atomicMax(&g[w], v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float sah_area(const uint32_t* lo, const uint32_t* hi)
+{
+    const float dx = f_unord(hi[0]) - f_unord(lo[0]), dy = f_unord(hi[1]) - f_unord(lo[1]), dz = f_unord(hi[2]) - f_unord(lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(64) void k_sah_split(const SahSeg* __restrict__ cur, const uint32_t* __restrict__ n_cur_p, uint32_t* bins, SahSplit* splits, uint32_t* fill,
+                                                  SahSeg* next, uint32_t* n_next, int leaf_max, int depth_cap,
+                                                  int* left, int* right, int* pin, int* plf, int* rlo, int* rhi)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= *n_cur_p) return;
+    const SahSeg sg = cur[s];
+    uint32_t* B = bins + (size_t)s * kSahSegWords;
+    const int cnt = sg.hi - sg.lo + 1;
+    // sides must still fit below the depth cap when split evenly from here on (bvh_build.cpp: capacity()); four levels are left to
+    // the treelets, which split by SAH alone
+    int levels = depth_cap - sg.depth - 1 - 4;
+    levels = levels < 0 ? 0 : (levels > 40 ? 40 : levels);
+    const unsigned long long side_cap = (unsigned long long)leaf_max << levels;
+    float best = __builtin_inff(); int best_axis = -1, best_bin = -1, best_nl = 0;
+    for (int k = 0; k < 3; ++k) {
+        const float cl = f_unord(sg.cb[k]), ext = f_unord(sg.cb[3 + k]) - cl;
+        if (!(ext > 0.0f) || !(ext < 3.0e38f)) continue;
+        float rarea[kSahBins]; uint32_t rcnt[kSahBins];
+        uint32_t lo[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, hi[3] = { 0u, 0u, 0u }, c = 0u;
+        for (int b = kSahBins - 1; b > 0; --b) {
+            const uint32_t* w = B + (k * kSahBins + b) * kSahBinWords;
+            if (w[0] != 0u) for (int a = 0; a < 3; ++a) { lo[a] = w[1 + a] < lo[a] ? w[1 + a] : lo[a]; hi[a] = w[4 + a] > hi[a] ? w[4 + a] : hi[a]; }
+            c += w[0];
+            rarea[b] = c ? sah_area(lo, hi) : 0.0f; rcnt[b] = c;
+        }
+        for (int a = 0; a < 3; ++a) { lo[a] = 0xffffffffu; hi[a] = 0u; }
+        c = 0u;
+        for (int b = 0; b < kSahBins - 1; ++b) {
+            const uint32_t* w = B + (k * kSahBins + b) * kSahBinWords;
+            if (w[0] != 0u) for (int a = 0; a < 3; ++a) { lo[a] = w[1 + a] < lo[a] ? w[1 + a] : lo[a]; hi[a] = w[4 + a] > hi[a] ? w[4 + a] : hi[a]; }
+            c += w[0];
+            const uint32_t nl = c, nr = rcnt[b + 1];
+            if (nl == 0u || nr == 0u) continue;
+            if (nl > side_cap || nr > side_cap) continue;
+            const float cost = sah_area(lo, hi) * (float)nl + rarea[b + 1] * (float)nr;
+            if (cost < best) { best = cost; best_axis = k; best_bin = b; best_nl = (int)nl; }
+        }
+    }
+    SahSplit sp;
+    sp.lo = sg.lo; sp.median = best_axis < 0 ? 1 : 0;
+    sp.left_count = sp.median ? cnt / 2 : best_nl;
+    sp.axis = sp.median ? 0 : best_axis; sp.bin = best_bin;
+    sp.cb_lo = 0.0f; sp.scale = 0.0f;
+    // (the children's centroid bounds: empty here, filled by the partition pass as the triangles take their sides; after a median
+    //  split -- no usable axis -- the parent's)
+    uint32_t cbs[2][6];
+    for (int side = 0; side < 2; ++side) for (int a = 0; a < 6; ++a) cbs[side][a] = sp.median ? sg.cb[a] : (a < 3 ? 0xffffffffu : 0u);
+    if (!sp.median) {
+        const float cl = f_unord(sg.cb[best_axis]), ext = f_unord(sg.cb[3 + best_axis]) - cl;
+        sp.cb_lo = cl; sp.scale = (float)kSahBins / ext;
+    }
+    // the node's children.  A side of one triangle is a leaf link; of two, a node of two leaves; of 3 .. 64, a treelet (its root's slot
+    // and range are set here, the treelet pass builds it); of more, an open range of the next level.
+    const int i = sg.node;
+    for (int side = 0; side < 2; ++side) {
+        const int a = side == 0 ? sg.lo : sg.lo + sp.left_count, b = side == 0 ? sg.lo + sp.left_count - 1 : sg.hi;
+        const int sz = b - a + 1;
+        sp.child[side] = kSahNone;
+        int ref;
+        if (sz == 1) { ref = ~a; plf[a] = i; }
+        else {
+            const int c = side == 0 ? b : a;                                   // a left child is named by its last position, a right child by its first
+            ref = c; pin[c] = i; rlo[c] = a; rhi[c] = b;
+            if (sz == 2) { left[c] = ~a; right[c] = ~b; plf[a] = c; plf[b] = c; }
+            else if (sz > kTreelet) {
+                const uint32_t slot = atomicAdd(n_next, 1u);
+                SahSeg ns; ns.lo = a; ns.hi = b; ns.node = c; ns.depth = sg.depth + 1;
+                for (int q = 0; q < 6; ++q) ns.cb[q] = cbs[side][q];
+                next[slot] = ns;
+                sp.child[side] = slot;
+            }
+        }
+        if (side == 0) left[i] = ref; else right[i] = ref;
+    }
+    splits[s] = sp;
+    fill[2u * s] = 0u; fill[2u * s + 1u] = 0u;
+    for (int w = 0; w < kSahSegWords; ++w) B[w] = sah_word_identity(w);       // the slot's bins, ready for the next level
+}
+
+// A workgroup moves a chunk of 2048 positions.  The ranges a chunk touches claim LDS tables as in k_sah_bin; a triangle takes its rank
+// on its side from an LDS counter and adds its centroid to the side's bounds there; one thread per table then reserves the chunk's
+// places in the range with ONE global atomic per side (and adds the bounds of the sides that stay open), and the triangles move.  A
+// range without a table does all that with global atomics of its own (deep levels: many ranges, little contention).  Atomics on one
+// address cost ~70 ns each whoever issues them: per wave (16 k waves at the root) the fill counters alone took a millisecond.
+constexpr int kSahPerThread = kSahChunk / 256;
+__global__ __launch_bounds__(256) void k_sah_partition(const uint32_t* __restrict__ perm_in, const uint32_t* __restrict__ seg_in, uint32_t* perm_out, uint32_t* seg_out,
+                                                       const SahSplit* __restrict__ splits, uint32_t* fill, const Box6* __restrict__ boxes, uint32_t n, SahSeg* next)
+{
+    __shared__ uint32_t s_dir[kSahTables], s_cnt[kSahTables][2], s_base[kSahTables][2], s_cb[kSahTables][2][6];
+    for (uint32_t chunk = blockIdx.x; (size_t)chunk * kSahChunk < n; chunk += gridDim.x) {
+        const uint32_t first = chunk * (uint32_t)kSahChunk;
+        if (threadIdx.x < (uint32_t)kSahTables) { s_dir[threadIdx.x] = kSahNone; s_cnt[threadIdx.x][0] = 0u; s_cnt[threadIdx.x][1] = 0u; }
+        if (threadIdx.x < (uint32_t)kSahTables * 12u) (&s_cb[0][0][0])[threadIdx.x] = (threadIdx.x % 6u) < 3u ? 0xffffffffu : 0u;
+        __syncthreads();
+        uint32_t prim[kSahPerThread], dest[kSahPerThread], out_seg[kSahPerThread], tab[kSahPerThread];      // tab: table << 1 | side, or kSahNone
+        for (int e = 0; e < kSahPerThread; ++e) {
+            const uint32_t p = first + (uint32_t)e * 256u + threadIdx.x;
+            prim[e] = 0u; dest[e] = kSahNone; out_seg[e] = kSahNone; tab[e] = kSahNone;
+            if (p >= n) continue;
+            const uint32_t s = seg_in[p];
+            prim[e] = perm_in[p]; dest[e] = p;
+            if (s == kSahNone) continue;
+            const SahSplit sp = splits[s];
+            bool goes_left;
+            uint32_t oc[3] = { 0u, 0u, 0u };
+            if (sp.median) goes_left = (int)p - sp.lo < sp.left_count;             // (no usable axis: the order stays, the bounds are the parent's)
+            else {
+                const Box6 b = boxes[prim[e]];
+                goes_left = sah_bin_of(0.5f * (b.lo[sp.axis] + b.hi[sp.axis]), sp.cb_lo, sp.scale) <= sp.bin;
+                for (int k = 0; k < 3; ++k) oc[k] = f_ord(0.5f * (b.lo[k] + b.hi[k]));
+            }
+            const uint32_t side = goes_left ? 0u : 1u, child = sp.child[side];
+            out_seg[e] = child;
+            if (sp.median) continue;
+            const uint32_t h = s & (uint32_t)(kSahTables - 1);
+            uint32_t owner = s_dir[h];
+            if (owner == kSahNone) { owner = atomicCAS(&s_dir[h], kSahNone, s); if (owner == kSahNone) owner = s; }
+            if (owner == s) {
+                dest[e] = atomicAdd(&s_cnt[h][side], 1u);                          // the rank in this chunk's share of the side: the base comes below
+                tab[e] = (h << 1) | side;
+                if (child != kSahNone) for (int k = 0; k < 3; ++k) { atomicMin(&s_cb[h][side][k], oc[k]); atomicMax(&s_cb[h][side][3 + k], oc[k]); }
+            } else {
+                dest[e] = (uint32_t)(sp.lo + (goes_left ? 0 : sp.left_count)) + atomicAdd(&fill[2u * s + side], 1u);
+                if (child != kSahNone) for (int k = 0; k < 3; ++k) { atomicMin(&next[child].cb[k], oc[k]); atomicMax(&next[child].cb[3 + k], oc[k]); }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)kSahTables * 2u) {
+            const uint32_t h = threadIdx.x >> 1, side = threadIdx.x & 1u, sid = s_dir[h], c = s_cnt[h][side];
+            if (sid != kSahNone && c != 0u) {
+                const SahSplit sp = splits[sid];
+                s_base[h][side] = (uint32_t)(sp.lo + (side == 0u ? 0 : sp.left_count)) + atomicAdd(&fill[2u * sid + side], c);
+                const uint32_t child = sp.child[side];
+                if (child != kSahNone) for (int k = 0; k < 3; ++k) { atomicMin(&next[child].cb[k], s_cb[h][side][k]); atomicMax(&next[child].cb[3 + k], s_cb[h][side][3 + k]); }
+            }
+        }
+        __syncthreads();
+        for (int e = 0; e < kSahPerThread; ++e) {
+            if (dest[e] == kSahNone) continue;
+            const uint32_t d = tab[e] != kSahNone ? s_base[tab[e] >> 1][tab[e] & 1u] + dest[e] : dest[e];
+            perm_out[d] = prim[e]; seg_out[d] = out_seg[e];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_sah_root(SahSeg* segs, const uint32_t* scene, uint32_t n, int* pin, int* rlo, int* rhi, uint32_t* counts)
+{
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    SahSeg r; r.lo = 0; r.hi = (int)n - 1; r.node = 0; r.depth = 0;
+    for (int k = 0; k < 6; ++k) r.cb[k] = scene[k];
+    segs[0] = r;
+    pin[0] = -1; rlo[0] = 0; rhi[0] = (int)n - 1;
+    counts[0] = 1u; counts[1] = 0u;
 }
 
 // ---- bottom-up passes without fences ---------------------------------------------------------------------------------------------
@@ -941,7 +1227,7 @@ void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, ui
 // nodes | triangles | 64 B pad (as mipt_accel_build makes for the host builder).  Returns hipSuccess and ok = false
 // when the tree is deeper than depth_cap (the caller falls back to the host builder).
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
-                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets, uint32_t* d_prim_slot)
+                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets, uint32_t* d_prim_slot, bool sah_top)
 {
     *ok = false; *d_blob = nullptr;
     const int n_inner = (int)n - 1;
@@ -953,6 +1239,11 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
                  o_vals = carve(4ull * n), o_vals2 = carve(4ull * n), o_left = carve(4ull * n), o_right = carve(4ull * n), o_pin = carve(4ull * n),
                  o_plf = carve(4ull * n), o_lo = carve(4ull * n), o_hi = carve(4ull * n), o_arr = carve(4ull * n), o_emit = carve(4ull * n),
                  o_idx = carve(4ull * n), o_kh = carve(n), o_big = carve(n), o_misc = carve(256);
+    // the top-down SAH front end (k_sah_*): open ranges of two levels, their splits, fill counters and bins
+    const bool top_down = sah_top && sah_treelets && n > 2u * (uint32_t)kTreelet;
+    const size_t max_segs = top_down ? (size_t)n / (size_t)kTreelet + 4u : 0u;
+    const size_t o_seg0 = carve(max_segs * sizeof(SahSeg)), o_seg1 = carve(max_segs * sizeof(SahSeg)), o_spl = carve(max_segs * sizeof(SahSplit)),
+                 o_fill = carve(max_segs * 8u), o_bins = carve(max_segs * (size_t)kSahSegWords * 4u);
     size_t sort_bytes = 0, scan_bytes = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, st);
@@ -973,16 +1264,43 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     auto fail = [&](hipError_t err) { (void)hipFree(tmp); return err; };
     if ((e = hipMemcpyAsync(misc, init, sizeof init, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
     if ((e = hipMemsetAsync(arrived, 0, 4ull * n, st)) != hipSuccess) return fail(e);
-    hipLaunchKernelGGL(k_lbvh_prims, dim3(blocks), dim3(256), 0, st, d_world, n, boxes, misc);
+    hipLaunchKernelGGL(k_lbvh_prims, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, st, d_world, n, boxes, misc);
+    if (top_down) {
+        // binned SAH, level by level over all open ranges, until none holds more than kTreelet triangles (the comment at k_sah_bin)
+        SahSeg* segs[2] = { (SahSeg*)(tmp + o_seg0), (SahSeg*)(tmp + o_seg1) };
+        SahSplit* splits = (SahSplit*)(tmp + o_spl);
+        uint32_t* fill = (uint32_t*)(tmp + o_fill); uint32_t* bins = (uint32_t*)(tmp + o_bins);
+        uint32_t* perm[2] = { vals, vals2 };
+        uint32_t* seg_of[2] = { (uint32_t*)keys, (uint32_t*)keys2 };
+        uint32_t* counts = misc + 20;                                   // [0] / [1]: open ranges of the current / next level (alternating)
+        hipLaunchKernelGGL(k_sah_init, dim3(2048), dim3(256), 0, st, bins, max_segs * (size_t)kSahSegWords, perm[0], seg_of[0], n, left, right, rlo, rhi);
+        hipLaunchKernelGGL(k_sah_root, dim3(1), dim3(64), 0, st, segs[0], misc, n, pin, rlo, rhi, counts);
+        uint32_t n_cur = 1u;
+        int cur = 0;
+        const uint32_t chunks = (n + (uint32_t)kSahChunk - 1u) / (uint32_t)kSahChunk;
+        for (int level = 0; n_cur != 0u; ++level) {
+            if (level > 96 || n_cur > max_segs) return fail(hipErrorUnknown);         // (cannot happen: every level splits every open range)
+            hipLaunchKernelGGL(k_sah_bin, dim3(chunks < 4096u ? chunks : 4096u), dim3(256), 0, st, perm[cur], seg_of[cur], segs[cur], n, boxes, bins);
+            hipLaunchKernelGGL(k_sah_split, dim3((n_cur + 63u) / 64u), dim3(64), 0, st, segs[cur], counts + cur, bins, splits, fill, segs[cur ^ 1], counts + (cur ^ 1),
+                               leaf_max, depth_cap, left, right, pin, plf, rlo, rhi);
+            hipLaunchKernelGGL(k_sah_partition, dim3(chunks < 4096u ? chunks : 4096u), dim3(256), 0, st, perm[cur], seg_of[cur], perm[cur ^ 1], seg_of[cur ^ 1], splits, fill, boxes, n, segs[cur ^ 1]);
+            if ((e = hipMemcpyAsync(&n_cur, counts + (cur ^ 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
+            if ((e = hipMemsetAsync(counts + cur, 0, 4, st)) != hipSuccess) return fail(e);
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
+            cur ^= 1;
+        }
+        if (perm[cur] != vals2 && (e = hipMemcpyAsync(vals2, perm[cur], 4ull * n, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e);
+    } else {
     hipLaunchKernelGGL(k_lbvh_morton, dim3(blocks), dim3(256), 0, st, boxes, n, misc, keys, vals);
     if ((e = hipcub::DeviceRadixSort::SortPairs(tmp + o_cub, sort_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(blocks), dim3(256), 0, st, keys2, (int)n, left, right, pin, plf, rlo, rhi);
+    }
     if (sah_treelets && n > (uint32_t)kTreelet) {
         // the subtrees of at most 64 triangles, rebuilt by SAH (reuses `idx` as the list of their roots until the scan needs it)
         if ((e = hipMemsetAsync(misc + 16, 0, 4, st)) != hipSuccess) return fail(e);
-        hipLaunchKernelGGL(k_treelet_roots, dim3(blocks), dim3(256), 0, st, rlo, rhi, pin, n_inner, idx, misc + 16);
+        hipLaunchKernelGGL(k_treelet_roots, dim3(blocks), dim3(256), 0, st, rlo, rhi, pin, n_inner, idx, misc + 16, top_down ? vals2 : nullptr);
         const uint32_t tg = blocks * 4u < 16384u ? blocks * 4u : 16384u;
-        hipLaunchKernelGGL(k_lbvh_treelets, dim3(tg), dim3(64), 0, st, idx, misc + 16, boxes, vals2, left, right, pin, plf, rlo, rhi);
+        hipLaunchKernelGGL(k_lbvh_treelets, dim3(tg), dim3(64), 0, st, idx, misc + 16, boxes, vals2, left, right, pin, plf, rlo, rhi, top_down ? 1 : 0);
     }
     const int cluster_levels = sah_treelets && n > (uint32_t)kTreelet * 4u ? [] { const char* e = std::getenv("MIPT_LBVH_CLUSTERS"); return e ? std::atoi(e) : 0; }() : 0;
     auto fit_boxes = [&](uint8_t* kh, uint8_t* root_h) -> hipError_t {

@@ -119,7 +119,9 @@ struct MiptContext {
     int      blocks_per_cu = 0;
     int      batch_samples = 0;
     int      persistent = 3;
-    int      build_mode = 0;              // MIPT_OPT_BUILD: 0 (default) host binned SAH, 1 on the device (LBVH + SAH treelets, lbvh_build.hip)
+    int      build_mode = 2;              // MIPT_OPT_BUILD: 2 (default, round 4) on the device, top-down binned SAH + SAH treelets: the host builder's trees at a
+                                          // fourteenth of its time; 1 on the device, Morton codes + radix tree + SAH treelets (fastest build: lbvh_build.hip);
+                                          // 0 host binned SAH (bvh_build.cpp; the fallback of the other two for tiny inputs and trees deeper than the stack)
     int      lbvh_treelets = 1;           // env MIPT_LBVH_TREELETS=0: the plain radix tree (A/B of the SAH treelets, lbvh_build.hip)
     int      lbvh_leaf = 4;               // env MIPT_LBVH_LEAF: subtrees of at most this many triangles become leaves of the device LBVH (1 .. 4)
     int      node_format = 2;             // MIPT_OPT_NODE_FORMAT: 2 fp16 boxes + BVH4 mirror, 1 fp16 boxes + packed 32-byte BVH2 mirror (where the
@@ -769,7 +771,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_TILE_CLASS_INIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }   // adapted from there
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_INST_FORM")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->inst_form = v; }
-    if (const char* e = std::getenv("MIPT_BUILD")) { const int v = std::atoi(e); if (v == 0 || v == 1) c->build_mode = v; }       // MIPT_OPT_BUILD at creation
+    if (const char* e = std::getenv("MIPT_BUILD")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->build_mode = v; }       // MIPT_OPT_BUILD at creation
     if (const char* e = std::getenv("MIPT_LBVH_TREELETS")) c->lbvh_treelets = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_LBVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->lbvh_leaf = v; }
     if (const char* e = std::getenv("MIPT_TAIL_REFILL")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tail_refill = v; }
@@ -835,7 +837,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value > (1u << 30)) return c->fail(MIPT_ERROR_INVALID_VALUE, "tail threshold must be 0 (off) .. 2^30 paths");
         c->tail_paths = (uint32_t)value; return MIPT_SUCCESS;
     case MIPT_OPT_BUILD:
-        if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH) or 1 (device LBVH)");
+        if (value > 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH), 1 (device LBVH) or 2 (device SAH)");
         c->build_mode = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_TILE_ORDER:
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "tile order must be 0 (image order) or 1 (by the previous launch's costs)");
@@ -987,19 +989,19 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     float4* blob = nullptr; uint32_t nn = 0, dep = 0; bool ok = false;
     uint32_t* d_slot = nullptr;                                  // primitive -> triangle record (Accel::d_prim_slot)
     if (e == hipSuccess && err == 0u) e = hipMalloc((void**)&d_slot, (size_t)n * 4u);
-    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, ctx->lbvh_leaf, kStackEntries, &blob, &nn, &dep, &ok, ctx->lbvh_treelets != 0, d_slot);
+    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, ctx->lbvh_leaf, kStackEntries, &blob, &nn, &dep, &ok, ctx->lbvh_treelets != 0, d_slot, ctx->build_mode == 2);
     if ((e != hipSuccess || err != 0u || !ok) && d_slot) { (void)hipFree(d_slot); d_slot = nullptr; }
     if (e != hipSuccess) return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e));
     if (err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
     if (!ok) {
-        ctx->log(3, "ACCEL", "device LBVH is %u deep (stack holds %d): falling back to the host builder", dep, kStackEntries);
+        ctx->log(3, "ACCEL", "device-built BVH is %u deep (stack holds %d): falling back to the host builder", dep, kStackEntries);
         return MIPT_SUCCESS;
     }
     uint32_t* d_mats = G.release_mats();
     Accel* a = new Accel();
     const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
     a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
-    a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = 1;
+    a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = ctx->build_mode == 2 ? 2 : 1;
     a->d_prim_slot = d_slot;
     if ((e = finish_blob(ctx, a)) != hipSuccess) { free_accel(a); return ctx->fail(MIPT_ERROR_HIP, "device BVH build: %s", hipGetErrorString(e)); }
     a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u + (size_t)n * 4u + (d_slot ? (size_t)n * 4u : 0u);   // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table + the primitive -> record table
@@ -1007,7 +1009,7 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
     *handle_out = h;
-    ctx->log(4, "ACCEL", "built BVH2 (device LBVH): %u tris, %u nodes, depth %u, %.1f MB, %.4f s", n, nn, dep, (double)a->bytes / 1e6, a->seconds);
+    ctx->log(4, "ACCEL", "built BVH2 (device %s): %u tris, %u nodes, depth %u, %.1f MB, %.4f s", ctx->build_mode == 2 ? "SAH" : "LBVH", n, nn, dep, (double)a->bytes / 1e6, a->seconds);
     return MIPT_SUCCESS;
 }
 
@@ -1016,7 +1018,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     if (!inputs || num_inputs == 0 || !handle_out) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_build: null argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->build_mode == 1) {
+    if (ctx->build_mode == 1 || ctx->build_mode == 2) {
         const int rc = accel_build_device(ctx, inputs, num_inputs, handle_out);
         if (rc != MIPT_SUCCESS || *handle_out != 0ull) return rc;
     }

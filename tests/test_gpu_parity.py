@@ -507,19 +507,22 @@ def test_deep_tree_fills_the_traversal_stacks():
     PT.cleanupState(st)
 
 
-@pytest.mark.parametrize("name,n", [("cornell", 0), ("soup", 40000), ("soup", 7)])
-def test_device_lbvh_build_gives_the_same_pictures(name, n):
-    """MIPT_OPT_BUILD = 1: the linear BVH built on the device is a sound BVH over the same triangles (oracle validation),
-    traversal over it agrees with the oracle walking the same tree, and frames are bit-identical to those over the
-    host's SAH tree -- hit records do not depend on the tree"""
+@pytest.mark.parametrize("name,n,builder", [("cornell", 0, 1), ("soup", 40000, 1), ("soup", 7, 1), ("cornell", 0, 2), ("soup", 40000, 2), ("soup", 130, 2), ("hall", 0, 2)])
+def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path):
+    """MIPT_OPT_BUILD = 1 / 2: the BVH built on the device (1: Morton codes + radix tree + SAH treelets; 2, round 4: top-down binned SAH
+    above the treelets) is a sound BVH over the same triangles (oracle validation), traversal over it agrees with the oracle walking the
+    same tree, and frames are bit-identical to those over the host's SAH tree -- hit records do not depend on the tree"""
     torch = _torch()
     from optix_raytracer_amd import _lib as L
     from optix_raytracer_amd import pathtracer as PT
     from optix_raytracer_amd import scenes
-    scene = scenes.cornell_box() if name == "cornell" else scenes.random_soup(n)
+    if name == "hall":      # large triangles among small ones (walls around boxes): where the Morton cut loses most
+        scene = scenes.from_gltf(scenes.write_rooms_gltf(tmp_path / "hall.gltf", n_boxes=2000))
+    else:
+        scene = scenes.cornell_box() if name == "cornell" else scenes.random_soup(n)
     w, h = 128, 96
     frames, infos = [], []
-    for mode in (0, 1):
+    for mode in (0, builder):
         st = PT.PathTracerState()
         PT.createContext(st, 0)
         st.context.set_option(L.OPT_BUILD, mode)
@@ -533,7 +536,7 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n):
         info = st.context.accel_info(st.gas_handle)
         nodes, tris = st.context.accel_export(st.gas_handle)
         osc = O.Scene(scene).set_bvh(nodes, tris)                       # raises if the tree is not a sound BVH of the scene
-        if mode == 1:
+        if mode != 0:
             rays = osc.primary_rays(scenes.launch_desc(scene, w, h))[::7]
             d_rays = torch.from_numpy(np.ascontiguousarray(rays)).cuda()
             d_hits = torch.zeros((rays.shape[0], 4), dtype=torch.float32, device="cuda")
@@ -542,6 +545,11 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n):
             t, prim, u, v = osc.trace_closest(rays, O.MODE_BVH)
             hits = d_hits.cpu().numpy()
             assert np.array_equal(hits[:, 1].view(np.uint32), prim) and np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
+        if mode == 2:
+            # the top-down front end moves triangles with atomics; the tree must not depend on where they fell: a second build is the same tree
+            PT.buildMeshAccel(st, scene)
+            nodes2, tris2 = st.context.accel_export(st.gas_handle)
+            assert np.array_equal(nodes.view(np.uint32), nodes2.view(np.uint32)) and np.array_equal(tris.view(np.uint32), tris2.view(np.uint32))
         frames.append((acc, frame, stats)); infos.append(info)
         PT.cleanupState(st)
     assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libmipt.so does not export %s" % name
     assert declared == {n for n, _, _ in L.SYMBOLS}, declared ^ {n for n, _, _ in L.SYMBOLS}
-    assert lib.mipt_abi_version() == 3
+    assert lib.mipt_abi_version() == 4
 
 
 # kept struct -> (the reference struct of tests/golden/ref_kat.json "layouts", {reference field: our field})

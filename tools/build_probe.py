@@ -25,9 +25,9 @@ def frames(st, ob, k=20):
     return (time.perf_counter() - t0) / k * 1e3
 
 
-print("%d triangles, %dx%d, depth 1: builder (0 host SAH / 1 device LBVH) x node format" % (n, W, H), flush=True)
+print("%d triangles, %dx%d, depth 1: builder (0 host SAH / 1 device LBVH / 2 device SAH) x node format" % (n, W, H), flush=True)
 only = [tuple(int(x) for x in c.split(":")) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else None     # e.g. "1:2,0:2"
-for mode, fmt in [c for c in [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)] if only is None or c in only]:
+for mode, fmt in [c for c in [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (2, 2)] if only is None or c in only]:
     st = PT.PathTracerState()
     PT.createContext(st, 0)
     st.context.set_option(L.OPT_BUILD, mode)
