@@ -558,7 +558,7 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path):
     assert infos[0]["num_triangles"] == infos[1]["num_triangles"] and infos[1]["depth"] <= 32 and infos[1]["leaf_max"] <= 4
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_accel_update_refits_to_moved_vertices(mode):
     """mipt_accel_update (= OPTIX_BUILD_OPERATION_UPDATE): after the vertices have moved, the refitted tree is a sound BVH of
     the new triangles (oracle validation) and frames over it are bit-identical to frames over a fresh build"""
@@ -913,3 +913,78 @@ def test_in_process_group_renders_the_full_frame():
         grp.launch([states[0].params] * n_dev, w + 8, h)             # size does not match the params
     PT2.cleanupState(ref)
     grp.destroy()
+
+
+def _soup_scene(verts):
+    from optix_raytracer_amd import scenes
+    base = scenes.random_soup(8)
+    n = verts.shape[0] // 3
+    sc = dict(base)
+    sc["vertices"] = np.ascontiguousarray(verts, np.float32)
+    sc["mat_index"] = np.zeros(n, np.uint32)
+    sc["name"] = "degenerate%d" % n
+    return sc
+
+
+@pytest.mark.parametrize("kind", ["identical", "line", "two_clusters", "spikes", "big_and_small"])
+def test_device_sah_builder_on_degenerate_inputs(kind):
+    """The device SAH builder (the default) where binning has nothing to hold on to: thousands of copies of ONE triangle (no centroid
+    extent on any axis: median splits all the way down), triangles along a line (one usable axis), two far clusters (30 of 32 bins
+    empty at the root), geometrically shrinking spikes (the SAH peels them off one by one: deeper than the stack, so the build falls back
+    to the host builder, which caps the depth), large triangles among small ones.  Each tree must be a sound BVH of its scene (oracle
+    validation), and hit records over it equal the brute-force intersector's."""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    rng = np.random.default_rng(21)
+    if kind == "identical":
+        tri = np.array([[0.2, 0.2, 0.5, 0], [0.8, 0.2, 0.5, 0], [0.5, 0.8, 0.5, 0]], np.float32)
+        verts = np.tile(tri, (3000, 1))
+    elif kind == "line":
+        n = 4000
+        c = np.zeros((n, 1, 3), np.float32); c[:, 0, 0] = np.linspace(0, 1, n)
+        c[:, 0, 1] = 0.5; c[:, 0, 2] = 0.5
+        off = np.array([[0, -0.01, 0], [0, 0.01, 0], [0, 0, 0.02]], np.float32)      # every centroid on the line y = 0.5, z = 0.5 + 0.02 / 3
+        verts = np.concatenate([(c + off).reshape(-1, 3), np.zeros((3 * n, 1), np.float32)], 1)
+    elif kind == "two_clusters":
+        n = 6000
+        c = rng.uniform(0, 0.01, (n, 1, 3)).astype(np.float32); c[n // 2:, 0, 0] += 0.99
+        verts = np.concatenate([(c + rng.uniform(-0.002, 0.002, (n, 3, 3))).reshape(-1, 3), np.zeros((3 * n, 1))], 1).astype(np.float32)
+    elif kind == "spikes":
+        n = 400
+        tri = np.zeros((n, 3, 4), np.float32)
+        for i in range(n):
+            s = 0.9 ** i
+            tri[i, :, :3] = np.array([1.0 - s, 0.5, 0.5]) + s * 0.4 * rng.normal(size=(3, 3))
+        verts = tri.reshape(-1, 4)
+    else:
+        n = 20000
+        c = rng.uniform(0, 1, (n, 1, 3))
+        size = np.where(rng.uniform(size=(n, 1, 1)) < 0.01, 0.5, 0.004)
+        verts = np.concatenate([(c + size * rng.uniform(-1, 1, (n, 3, 3))).reshape(-1, 3), np.zeros((3 * n, 1))], 1).astype(np.float32)
+    scene = _soup_scene(verts)
+    st = PT.PathTracerState()
+    PT.createContext(st, 0)
+    assert st.context.get_option(L.OPT_BUILD) == 2
+    PT.buildMeshAccel(st, scene)
+    info = st.context.accel_info(st.gas_handle)
+    assert info["num_triangles"] == verts.shape[0] // 3 and info["depth"] <= 32 and info["leaf_max"] <= 4
+    nodes, tris = st.context.accel_export(st.gas_handle)
+    osc = O.Scene(scene).set_bvh(nodes, tris)                          # raises if the tree is not a sound BVH of the scene
+    n_rays = 20000
+    rays = np.zeros((n_rays, 8), np.float32)
+    rays[:, :3] = rng.uniform(-0.5, 1.5, (n_rays, 3)); rays[:, 2] = -1.0
+    cen = verts[:, :3].reshape(-1, 3, 3).mean(1)                       # half the rays aim at a triangle, half anywhere in the unit cube
+    tgt = np.where(rng.uniform(size=(n_rays, 1)) < 0.5, cen[rng.integers(0, cen.shape[0], n_rays)] + rng.normal(0, 1e-3, (n_rays, 3)), rng.uniform(0, 1, (n_rays, 3)))
+    d = tgt - rays[:, :3]
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 3], rays[:, 7] = 1e-3, 1e16
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros((n_rays, 4), dtype=torch.float32, device="cuda")
+    st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), n_rays, d_hits.data_ptr())
+    st.context.sync()
+    hits = d_hits.cpu().numpy()
+    t, prim, u, v = osc.trace_closest(rays, O.MODE_BRUTE)
+    assert np.array_equal(hits[:, 1].view(np.uint32), prim) and np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
+    assert (prim != 0xffffffff).sum() > 50
+    PT.cleanupState(st)
