@@ -436,7 +436,9 @@ __global__ __launch_bounds__(64) void k_lbvh_clusters(const uint32_t* __restrict
 constexpr int kSahBins = MIPT_SAH_BINS, kSahBinWords = 7, kSahSegWords = 3 * kSahBins * kSahBinWords;      // per bin: count, box lo / hi (ordered words)
 constexpr uint32_t kSahNone = 0xffffffffu;
 struct SahSeg { int lo, hi, node, depth; uint32_t cb[6]; };                                   // an open range, its node, its centroid bounds (ordered)
-struct SahSplit { int lo, left_count, axis, bin, median; float cb_lo, scale; uint32_t child[2]; };   // child: slot of the side's range in the next level, or kSahNone
+struct SahSplit { int lo, left_count, axis, bin, median; float cb_lo, scale; uint32_t child[2], small[2]; };   // child: slot of the side's range in the next level, small: in the
+                                                                                                            // list of ranges one workgroup finishes (k_sah_small); else kSahNone
+constexpr int kSahSmall = 2048;                                  // a range of at most this many triangles leaves the level-by-level loop
 
 __device__ __forceinline__ int sah_bin_of(float c, float cb_lo, float scale)
 {
@@ -514,45 +516,69 @@ __device__ __forceinline__ float sah_area(const uint32_t* lo, const uint32_t* hi
     return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ __launch_bounds__(64) void k_sah_split(const SahSeg* __restrict__ cur, const uint32_t* __restrict__ n_cur_p, uint32_t* bins, SahSplit* splits, uint32_t* fill,
-                                                  SahSeg* next, uint32_t* n_next, int leaf_max, int depth_cap,
-                                                  int* left, int* right, int* pin, int* plf, int* rlo, int* rhi)
+// The sweep of one axis' bins by one wave (lane = bin): inclusive unions of bins 0 .. lane and lane .. last by shuffles, the cost of the
+// split after every bin, the cheapest by a wave minimum (ties to the lower bin).  `bins`: the range's table (global memory or LDS).
+// Returns (in every lane) the cost -- inf when the axis has no extent or no admissible split --, the bin and the triangles on its left.
+__device__ __forceinline__ void sah_sweep_axis(const uint32_t* bins, int k, const SahSeg& sg, int lane, int leaf_max, int depth_cap, float& cost_out, int& bin_out, int& nl_out)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= *n_cur_p) return;
-    const SahSeg sg = cur[s];
-    uint32_t* B = bins + (size_t)s * kSahSegWords;
-    const int cnt = sg.hi - sg.lo + 1;
+    const float cl = f_unord(sg.cb[k]), ext = f_unord(sg.cb[3 + k]) - cl;
+    const bool usable = ext > 0.0f && ext < 3.0e38f;
+    const bool has = lane < kSahBins;
+    const uint32_t* w = bins + (k * kSahBins + (has ? lane : 0)) * kSahBinWords;
+    uint32_t v[kSahBinWords];
+    for (int c = 0; c < kSahBinWords; ++c) v[c] = w[c];                  // all seven words at once: a load that waits for the count costs a round trip per axis
+    uint32_t pc = has ? v[0] : 0u, plo[3], phi[3];
+    for (int c = 0; c < 3; ++c) { plo[c] = has && pc ? v[1 + c] : 0xffffffffu; phi[c] = has && pc ? v[4 + c] : 0u; }
+    uint32_t sc = pc, slo[3] = { plo[0], plo[1], plo[2] }, shi[3] = { phi[0], phi[1], phi[2] };
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t c_up = (uint32_t)__shfl_up((int)pc, off, 64), c_dn = (uint32_t)__shfl_down((int)sc, off, 64);
+        uint32_t lu[3], hu[3], ld[3], hd[3];
+        for (int c = 0; c < 3; ++c) {
+            lu[c] = (uint32_t)__shfl_up((int)plo[c], off, 64); hu[c] = (uint32_t)__shfl_up((int)phi[c], off, 64);
+            ld[c] = (uint32_t)__shfl_down((int)slo[c], off, 64); hd[c] = (uint32_t)__shfl_down((int)shi[c], off, 64);
+        }
+        if (lane >= off) { pc += c_up; for (int c = 0; c < 3; ++c) { plo[c] = lu[c] < plo[c] ? lu[c] : plo[c]; phi[c] = hu[c] > phi[c] ? hu[c] : phi[c]; } }
+        if (lane + off < 64) { sc += c_dn; for (int c = 0; c < 3; ++c) { slo[c] = ld[c] < slo[c] ? ld[c] : slo[c]; shi[c] = hd[c] > shi[c] ? hd[c] : shi[c]; } }
+    }
+    // the split after bin `lane`: left = bins 0 .. lane, right = bins lane + 1 .. last
+    const uint32_t nr = (uint32_t)__shfl_down((int)sc, 1, 64);
+    uint32_t rl[3], rh[3];
+    for (int c = 0; c < 3; ++c) { rl[c] = (uint32_t)__shfl_down((int)slo[c], 1, 64); rh[c] = (uint32_t)__shfl_down((int)shi[c], 1, 64); }
     // sides must still fit below the depth cap when split evenly from here on (bvh_build.cpp: capacity()); four levels are left to
     // the treelets, which split by SAH alone
     int levels = depth_cap - sg.depth - 1 - 4;
     levels = levels < 0 ? 0 : (levels > 40 ? 40 : levels);
     const unsigned long long side_cap = (unsigned long long)leaf_max << levels;
+    float cost = __builtin_inff();
+    if (usable && lane < kSahBins - 1 && pc != 0u && nr != 0u && pc <= side_cap && nr <= side_cap)
+        cost = sah_area(plo, phi) * (float)pc + sah_area(rl, rh) * (float)nr;
+    if (!(cost < __builtin_inff())) cost = __builtin_inff();          // (a NaN area is no candidate)
+    float bc = cost; int bb = lane, bn = (int)pc;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(bc, off, 64); const int ob = __shfl_xor(bb, off, 64), on = __shfl_xor(bn, off, 64);
+        if (oc < bc || (oc == bc && ob < bb)) { bc = oc; bb = ob; bn = on; }
+    }
+    cost_out = bc; bin_out = bb; nl_out = bn;
+}
+
+__global__ __launch_bounds__(64) void k_sah_split(const SahSeg* __restrict__ cur, const uint32_t* __restrict__ n_cur_p, uint32_t* bins, SahSplit* splits, uint32_t* fill,
+                                                  SahSeg* next, uint32_t* n_next, SahSeg* smalls, uint32_t* n_small, int leaf_max, int depth_cap,
+                                                  int* left, int* right, int* pin, int* plf, int* rlo, int* rhi)
+{
+    const uint32_t s = blockIdx.x;                                             // one wave per open range (the sweep: lane = bin)
+    if (s >= *n_cur_p) return;
+    const int lane = (int)threadIdx.x;
+    const SahSeg sg = cur[s];
+    uint32_t* B = bins + (size_t)s * kSahSegWords;
+    const int cnt = sg.hi - sg.lo + 1;
     float best = __builtin_inff(); int best_axis = -1, best_bin = -1, best_nl = 0;
     for (int k = 0; k < 3; ++k) {
-        const float cl = f_unord(sg.cb[k]), ext = f_unord(sg.cb[3 + k]) - cl;
-        if (!(ext > 0.0f) || !(ext < 3.0e38f)) continue;
-        float rarea[kSahBins]; uint32_t rcnt[kSahBins];
-        uint32_t lo[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, hi[3] = { 0u, 0u, 0u }, c = 0u;
-        for (int b = kSahBins - 1; b > 0; --b) {
-            const uint32_t* w = B + (k * kSahBins + b) * kSahBinWords;
-            if (w[0] != 0u) for (int a = 0; a < 3; ++a) { lo[a] = w[1 + a] < lo[a] ? w[1 + a] : lo[a]; hi[a] = w[4 + a] > hi[a] ? w[4 + a] : hi[a]; }
-            c += w[0];
-            rarea[b] = c ? sah_area(lo, hi) : 0.0f; rcnt[b] = c;
-        }
-        for (int a = 0; a < 3; ++a) { lo[a] = 0xffffffffu; hi[a] = 0u; }
-        c = 0u;
-        for (int b = 0; b < kSahBins - 1; ++b) {
-            const uint32_t* w = B + (k * kSahBins + b) * kSahBinWords;
-            if (w[0] != 0u) for (int a = 0; a < 3; ++a) { lo[a] = w[1 + a] < lo[a] ? w[1 + a] : lo[a]; hi[a] = w[4 + a] > hi[a] ? w[4 + a] : hi[a]; }
-            c += w[0];
-            const uint32_t nl = c, nr = rcnt[b + 1];
-            if (nl == 0u || nr == 0u) continue;
-            if (nl > side_cap || nr > side_cap) continue;
-            const float cost = sah_area(lo, hi) * (float)nl + rarea[b + 1] * (float)nr;
-            if (cost < best) { best = cost; best_axis = k; best_bin = b; best_nl = (int)nl; }
-        }
+        float c; int b, nl;
+        sah_sweep_axis(B, k, sg, lane, leaf_max, depth_cap, c, b, nl);
+        if (c < best) { best = c; best_axis = k; best_bin = b; best_nl = nl; }
     }
+    for (int w = lane; w < kSahSegWords; w += 64) B[w] = sah_word_identity(w);           // the slot's bins, ready for the next level
+    if (lane != 0) return;
     SahSplit sp;
     sp.lo = sg.lo; sp.median = best_axis < 0 ? 1 : 0;
     sp.left_count = sp.median ? cnt / 2 : best_nl;
@@ -572,7 +598,7 @@ __global__ __launch_bounds__(64) void k_sah_split(const SahSeg* __restrict__ cur
     for (int side = 0; side < 2; ++side) {
         const int a = side == 0 ? sg.lo : sg.lo + sp.left_count, b = side == 0 ? sg.lo + sp.left_count - 1 : sg.hi;
         const int sz = b - a + 1;
-        sp.child[side] = kSahNone;
+        sp.child[side] = kSahNone; sp.small[side] = kSahNone;
         int ref;
         if (sz == 1) { ref = ~a; plf[a] = i; }
         else {
@@ -580,18 +606,16 @@ __global__ __launch_bounds__(64) void k_sah_split(const SahSeg* __restrict__ cur
             ref = c; pin[c] = i; rlo[c] = a; rhi[c] = b;
             if (sz == 2) { left[c] = ~a; right[c] = ~b; plf[a] = c; plf[b] = c; }
             else if (sz > kTreelet) {
-                const uint32_t slot = atomicAdd(n_next, 1u);
                 SahSeg ns; ns.lo = a; ns.hi = b; ns.node = c; ns.depth = sg.depth + 1;
                 for (int q = 0; q < 6; ++q) ns.cb[q] = cbs[side][q];
-                next[slot] = ns;
-                sp.child[side] = slot;
+                if (sz > kSahSmall) { const uint32_t slot = atomicAdd(n_next, 1u); next[slot] = ns; sp.child[side] = slot; }
+                else                { const uint32_t slot = atomicAdd(n_small, 1u); smalls[slot] = ns; sp.small[side] = slot; }
             }
         }
         if (side == 0) left[i] = ref; else right[i] = ref;
     }
     splits[s] = sp;
     fill[2u * s] = 0u; fill[2u * s + 1u] = 0u;
-    for (int w = 0; w < kSahSegWords; ++w) B[w] = sah_word_identity(w);       // the slot's bins, ready for the next level
 }
 
 // A workgroup moves a chunk of 2048 positions.  The ranges a chunk touches claim LDS tables as in k_sah_bin; a triangle takes its rank
@@ -601,7 +625,7 @@ __global__ __launch_bounds__(64) void k_sah_split(const SahSeg* __restrict__ cur
 // address cost ~70 ns each whoever issues them: per wave (16 k waves at the root) the fill counters alone took a millisecond.
 constexpr int kSahPerThread = kSahChunk / 256;
 __global__ __launch_bounds__(256) void k_sah_partition(const uint32_t* __restrict__ perm_in, const uint32_t* __restrict__ seg_in, uint32_t* perm_out, uint32_t* seg_out,
-                                                       const SahSplit* __restrict__ splits, uint32_t* fill, const Box6* __restrict__ boxes, uint32_t n, SahSeg* next)
+                                                       const SahSplit* __restrict__ splits, uint32_t* fill, const Box6* __restrict__ boxes, uint32_t n, SahSeg* next, SahSeg* smalls)
 {
     __shared__ uint32_t s_dir[kSahTables], s_cnt[kSahTables][2], s_base[kSahTables][2], s_cb[kSahTables][2][6];
     for (uint32_t chunk = blockIdx.x; (size_t)chunk * kSahChunk < n; chunk += gridDim.x) {
@@ -627,6 +651,7 @@ __global__ __launch_bounds__(256) void k_sah_partition(const uint32_t* __restric
                 for (int k = 0; k < 3; ++k) oc[k] = f_ord(0.5f * (b.lo[k] + b.hi[k]));
             }
             const uint32_t side = goes_left ? 0u : 1u, child = sp.child[side];
+            SahSeg* const cbd = child != kSahNone ? &next[child] : (sp.small[side] != kSahNone ? &smalls[sp.small[side]] : nullptr);   // whose centroid bounds this triangle widens
             out_seg[e] = child;
             if (sp.median) continue;
             const uint32_t h = s & (uint32_t)(kSahTables - 1);
@@ -635,10 +660,10 @@ __global__ __launch_bounds__(256) void k_sah_partition(const uint32_t* __restric
             if (owner == s) {
                 dest[e] = atomicAdd(&s_cnt[h][side], 1u);                          // the rank in this chunk's share of the side: the base comes below
                 tab[e] = (h << 1) | side;
-                if (child != kSahNone) for (int k = 0; k < 3; ++k) { atomicMin(&s_cb[h][side][k], oc[k]); atomicMax(&s_cb[h][side][3 + k], oc[k]); }
+                if (cbd != nullptr) for (int k = 0; k < 3; ++k) { atomicMin(&s_cb[h][side][k], oc[k]); atomicMax(&s_cb[h][side][3 + k], oc[k]); }
             } else {
                 dest[e] = (uint32_t)(sp.lo + (goes_left ? 0 : sp.left_count)) + atomicAdd(&fill[2u * s + side], 1u);
-                if (child != kSahNone) for (int k = 0; k < 3; ++k) { atomicMin(&next[child].cb[k], oc[k]); atomicMax(&next[child].cb[3 + k], oc[k]); }
+                if (cbd != nullptr) for (int k = 0; k < 3; ++k) { atomicMin(&cbd->cb[k], oc[k]); atomicMax(&cbd->cb[3 + k], oc[k]); }
             }
         }
         __syncthreads();
@@ -647,8 +672,8 @@ __global__ __launch_bounds__(256) void k_sah_partition(const uint32_t* __restric
             if (sid != kSahNone && c != 0u) {
                 const SahSplit sp = splits[sid];
                 s_base[h][side] = (uint32_t)(sp.lo + (side == 0u ? 0 : sp.left_count)) + atomicAdd(&fill[2u * sid + side], c);
-                const uint32_t child = sp.child[side];
-                if (child != kSahNone) for (int k = 0; k < 3; ++k) { atomicMin(&next[child].cb[k], s_cb[h][side][k]); atomicMax(&next[child].cb[3 + k], s_cb[h][side][3 + k]); }
+                SahSeg* const cbd = sp.child[side] != kSahNone ? &next[sp.child[side]] : (sp.small[side] != kSahNone ? &smalls[sp.small[side]] : nullptr);
+                if (cbd != nullptr) for (int k = 0; k < 3; ++k) { atomicMin(&cbd->cb[k], s_cb[h][side][k]); atomicMax(&cbd->cb[3 + k], s_cb[h][side][3 + k]); }
             }
         }
         __syncthreads();
@@ -661,6 +686,129 @@ __global__ __launch_bounds__(256) void k_sah_partition(const uint32_t* __restric
     }
 }
 
+// ---- ranges of at most 2048 triangles: ONE workgroup takes a range down to its treelets, in LDS -----------------------------------------
+// Level by level the deep levels were the expensive ones (1 M triangles: 0.3-0.8 ms of binning and 0.3-0.4 ms of partition per level from
+// level 8 on, against 0.03 / 0.05 ms at the top): a chunk of 2048 positions then spans dozens of ranges, more than it has LDS tables, and
+// the rest falls back to global atomics.  A range that fits a chunk leaves that loop (k_sah_split puts it on a list) and is finished here:
+// its triangles' numbers in LDS (two copies: the partition is out of place), a stack of open sub-ranges, and per sub-range the same three
+// steps -- bins by LDS atomics, the sweep by one WAVE per axis (lane = bin: prefix and suffix unions by shuffles, the cheapest split by a
+// wave minimum), the partition with LDS counters -- with the same arithmetic and the same tie rules as k_sah_split, so the tree is the one
+// the level-by-level loop would have made.
+__global__ __launch_bounds__(256) void k_sah_small(const SahSeg* __restrict__ list, const uint32_t* __restrict__ n_list, uint32_t* perm, const Box6* __restrict__ boxes,
+                                                   int leaf_max, int depth_cap, int* left, int* right, int* pin, int* plf, int* rlo, int* rhi)
+{
+    constexpr int kStack = 64;
+    __shared__ uint32_t s_perm[2][kSahSmall];
+    __shared__ uint32_t s_bins[kSahSegWords];
+    __shared__ SahSeg s_stack[kStack];                  // lo / hi are positions inside the range here
+    __shared__ uint8_t s_buf[kStack];
+    __shared__ int s_sp;
+    __shared__ SahSeg s_cur; __shared__ int s_cur_buf;
+    __shared__ float s_cost[3]; __shared__ int s_bin[3], s_nl[3];
+    __shared__ int s_axis, s_split_bin, s_left, s_median; __shared__ float s_cb_lo, s_scale;
+    __shared__ uint32_t s_cnt[2], s_cb[2][6];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t item = blockIdx.x; item < *n_list; item += gridDim.x) {
+        const SahSeg root = list[item];
+        const int n = root.hi - root.lo + 1;
+        for (int i = tid; i < n; i += 256) s_perm[0][i] = perm[root.lo + i];
+        if (tid == 0) { SahSeg r = root; r.lo = 0; r.hi = n - 1; s_stack[0] = r; s_buf[0] = 0u; s_sp = 1; }
+        for (;;) {
+            __syncthreads();
+            const int sp = s_sp;                                               // (every thread reads the height before thread 0 changes it)
+            __syncthreads();
+            if (sp == 0) break;
+            if (tid == 0) { s_sp = sp - 1; s_cur = s_stack[sp - 1]; s_cur_buf = s_buf[sp - 1]; }
+            for (int w = tid; w < kSahSegWords; w += 256) s_bins[w] = sah_word_identity(w);
+            __syncthreads();
+            const SahSeg sg = s_cur;
+            const int buf = s_cur_buf, a0 = sg.lo, cnt = sg.hi - sg.lo + 1;
+            // ---- bins
+            for (int i = tid; i < cnt; i += 256) {
+                const Box6 b = boxes[s_perm[buf][a0 + i]];
+                uint32_t ob[6];
+                for (int k = 0; k < 3; ++k) { ob[k] = f_ord(b.lo[k]); ob[3 + k] = f_ord(b.hi[k]); }
+                for (int k = 0; k < 3; ++k) {
+                    const float cl = f_unord(sg.cb[k]), ext = f_unord(sg.cb[3 + k]) - cl;
+                    if (!(ext > 0.0f) || !(ext < 3.0e38f)) continue;
+                    const int bi = sah_bin_of(0.5f * (b.lo[k] + b.hi[k]), cl, (float)kSahBins / ext);
+                    uint32_t* w = s_bins + (k * kSahBins + bi) * kSahBinWords;
+                    atomicAdd(&w[0], 1u);
+                    for (int c = 0; c < 3; ++c) { atomicMin(&w[1 + c], ob[c]); atomicMax(&w[4 + c], ob[3 + c]); }
+                }
+            }
+            __syncthreads();
+            // ---- the sweep: wave k takes axis k, lane b bin b
+            if (wave < 3) {
+                float c; int b, nl;
+                sah_sweep_axis(s_bins, wave, sg, lane, leaf_max, depth_cap, c, b, nl);
+                if (lane == 0) { s_cost[wave] = c; s_bin[wave] = b; s_nl[wave] = nl; }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float best = __builtin_inff(); int ax = -1;
+                for (int k = 0; k < 3; ++k) if (s_cost[k] < best) { best = s_cost[k]; ax = k; }
+                s_median = ax < 0 ? 1 : 0;
+                s_axis = ax < 0 ? 0 : ax; s_split_bin = ax < 0 ? 0 : s_bin[ax];
+                s_left = ax < 0 ? cnt / 2 : s_nl[ax];
+                if (ax >= 0) { const float cl = f_unord(sg.cb[ax]); s_cb_lo = cl; s_scale = (float)kSahBins / (f_unord(sg.cb[3 + ax]) - cl); }
+                s_cnt[0] = 0u; s_cnt[1] = 0u;
+                for (int side = 0; side < 2; ++side) for (int q = 0; q < 6; ++q) s_cb[side][q] = ax < 0 ? sg.cb[q] : (q < 3 ? 0xffffffffu : 0u);
+            }
+            __syncthreads();
+            // ---- the partition (out of place: the other copy)
+            const int left_count = s_left, median = s_median, axis = s_axis, split_bin = s_split_bin;
+            for (int i = tid; i < cnt; i += 256) {
+                const uint32_t prim = s_perm[buf][a0 + i];
+                int dest;
+                if (median) dest = a0 + i;
+                else {
+                    const Box6 b = boxes[prim];
+                    const uint32_t side = sah_bin_of(0.5f * (b.lo[axis] + b.hi[axis]), s_cb_lo, s_scale) <= split_bin ? 0u : 1u;
+                    dest = a0 + (side ? left_count : 0) + (int)atomicAdd(&s_cnt[side], 1u);
+                    for (int k = 0; k < 3; ++k) { const uint32_t oc = f_ord(0.5f * (b.lo[k] + b.hi[k])); atomicMin(&s_cb[side][k], oc); atomicMax(&s_cb[side][3 + k], oc); }
+                }
+                s_perm[buf ^ 1][dest] = prim;
+            }
+            __syncthreads();
+            // ---- the node's children (k_sah_split's cases; positions are the range's, the links the whole array's)
+            if (tid == 0) {
+                const int i = sg.node;
+                for (int side = 0; side < 2; ++side) {
+                    const int a = side == 0 ? a0 : a0 + left_count, b = side == 0 ? a0 + left_count - 1 : sg.hi;
+                    const int sz = b - a + 1, ga = root.lo + a, gb = root.lo + b;
+                    int ref;
+                    if (sz == 1) { ref = ~ga; plf[ga] = i; }
+                    else {
+                        const int c = side == 0 ? gb : ga;
+                        ref = c; pin[c] = i; rlo[c] = ga; rhi[c] = gb;
+                        if (sz == 2) { left[c] = ~ga; right[c] = ~gb; plf[ga] = c; plf[gb] = c; }
+                        else if (sz > kTreelet && s_sp < kStack) {
+                            SahSeg ns; ns.lo = a; ns.hi = b; ns.node = c; ns.depth = sg.depth + 1;
+                            for (int q = 0; q < 6; ++q) ns.cb[q] = s_cb[side][q];
+                            s_stack[s_sp] = ns; s_buf[s_sp] = (uint8_t)(buf ^ 1); ++s_sp;
+                        }
+                        // (a stack that is full -- 64 open sub-ranges of one 2048-triangle range: not with two non-empty sides per split -- would leave
+                        //  the side to the treelet pass as it is, which takes ranges of at most 64 only: it cannot happen, and the depth check after
+                        //  the build would send the input to the host builder if it did)
+                    }
+                    if (side == 0) left[i] = ref; else right[i] = ref;
+                }
+            }
+            // the sides that are finished go home: every position of this sub-range that does not stay open
+            {
+                const int lsz = left_count, rsz = cnt - left_count;
+                for (int i = tid; i < cnt; i += 256) {
+                    const bool in_left = i < lsz;
+                    const int sz = in_left ? lsz : rsz;
+                    if (sz <= kTreelet) perm[root.lo + a0 + i] = s_perm[buf ^ 1][a0 + i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ void k_sah_root(SahSeg* segs, const uint32_t* scene, uint32_t n, int* pin, int* rlo, int* rhi, uint32_t* counts)
 {
     if (threadIdx.x != 0u || blockIdx.x != 0u) return;
@@ -668,7 +816,7 @@ __global__ void k_sah_root(SahSeg* segs, const uint32_t* scene, uint32_t n, int*
     for (int k = 0; k < 6; ++k) r.cb[k] = scene[k];
     segs[0] = r;
     pin[0] = -1; rlo[0] = 0; rhi[0] = (int)n - 1;
-    counts[0] = 1u; counts[1] = 0u;
+    counts[0] = 1u; counts[1] = 0u; counts[2] = 0u;
 }
 
 // ---- bottom-up passes without fences ---------------------------------------------------------------------------------------------
@@ -1243,7 +1391,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     const bool top_down = sah_top && sah_treelets && n > 2u * (uint32_t)kTreelet;
     const size_t max_segs = top_down ? (size_t)n / (size_t)kTreelet + 4u : 0u;
     const size_t o_seg0 = carve(max_segs * sizeof(SahSeg)), o_seg1 = carve(max_segs * sizeof(SahSeg)), o_spl = carve(max_segs * sizeof(SahSplit)),
-                 o_fill = carve(max_segs * 8u), o_bins = carve(max_segs * (size_t)kSahSegWords * 4u);
+                 o_fill = carve(max_segs * 8u), o_bins = carve(max_segs * (size_t)kSahSegWords * 4u), o_small = carve(max_segs * sizeof(SahSeg));
     size_t sort_bytes = 0, scan_bytes = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, st);
@@ -1272,24 +1420,33 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
         uint32_t* fill = (uint32_t*)(tmp + o_fill); uint32_t* bins = (uint32_t*)(tmp + o_bins);
         uint32_t* perm[2] = { vals, vals2 };
         uint32_t* seg_of[2] = { (uint32_t*)keys, (uint32_t*)keys2 };
-        uint32_t* counts = misc + 20;                                   // [0] / [1]: open ranges of the current / next level (alternating)
+        uint32_t* counts = misc + 20;                                   // [0] / [1]: open ranges of the current / next level (alternating); [2]: ranges for k_sah_small
+        SahSeg* smalls = (SahSeg*)(tmp + o_small);
         hipLaunchKernelGGL(k_sah_init, dim3(2048), dim3(256), 0, st, bins, max_segs * (size_t)kSahSegWords, perm[0], seg_of[0], n, left, right, rlo, rhi);
         hipLaunchKernelGGL(k_sah_root, dim3(1), dim3(64), 0, st, segs[0], misc, n, pin, rlo, rhi, counts);
         uint32_t n_cur = 1u;
         int cur = 0;
         const uint32_t chunks = (n + (uint32_t)kSahChunk - 1u) / (uint32_t)kSahChunk;
         for (int level = 0; n_cur != 0u; ++level) {
-            if (level > 96 || n_cur > max_segs) return fail(hipErrorUnknown);         // (cannot happen: every level splits every open range)
+            if (level > 96 || n_cur > max_segs) { (void)hipFree(tmp); *num_nodes = 0; *depth = 255u; return hipSuccess; }   // (every level splits every open range in two non-empty
+                                                                                                                            //  sides, so this does not happen; if it did: ok stays false, the host builder takes the input)
             hipLaunchKernelGGL(k_sah_bin, dim3(chunks < 4096u ? chunks : 4096u), dim3(256), 0, st, perm[cur], seg_of[cur], segs[cur], n, boxes, bins);
-            hipLaunchKernelGGL(k_sah_split, dim3((n_cur + 63u) / 64u), dim3(64), 0, st, segs[cur], counts + cur, bins, splits, fill, segs[cur ^ 1], counts + (cur ^ 1),
-                               leaf_max, depth_cap, left, right, pin, plf, rlo, rhi);
-            hipLaunchKernelGGL(k_sah_partition, dim3(chunks < 4096u ? chunks : 4096u), dim3(256), 0, st, perm[cur], seg_of[cur], perm[cur ^ 1], seg_of[cur ^ 1], splits, fill, boxes, n, segs[cur ^ 1]);
+            hipLaunchKernelGGL(k_sah_split, dim3(n_cur), dim3(64), 0, st, segs[cur], counts + cur, bins, splits, fill, segs[cur ^ 1], counts + (cur ^ 1),
+                               smalls, counts + 2, leaf_max, depth_cap, left, right, pin, plf, rlo, rhi);
+            hipLaunchKernelGGL(k_sah_partition, dim3(chunks < 4096u ? chunks : 4096u), dim3(256), 0, st, perm[cur], seg_of[cur], perm[cur ^ 1], seg_of[cur ^ 1], splits, fill, boxes, n, segs[cur ^ 1], smalls);
             if ((e = hipMemcpyAsync(&n_cur, counts + (cur ^ 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
             if ((e = hipMemsetAsync(counts + cur, 0, 4, st)) != hipSuccess) return fail(e);
             if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
             cur ^= 1;
         }
         if (perm[cur] != vals2 && (e = hipMemcpyAsync(vals2, perm[cur], 4ull * n, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e);
+        uint32_t n_small = 0u;
+        if ((e = hipMemcpyAsync(&n_small, counts + 2, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e);
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
+        if (n_small > max_segs) return fail(hipErrorUnknown);
+        if (n_small != 0u)
+            hipLaunchKernelGGL(k_sah_small, dim3(n_small < 4096u ? n_small : 4096u), dim3(256), 0, st, smalls, counts + 2, vals2, boxes, leaf_max, depth_cap,
+                               left, right, pin, plf, rlo, rhi);
     } else {
     hipLaunchKernelGGL(k_lbvh_morton, dim3(blocks), dim3(256), 0, st, boxes, n, misc, keys, vals);
     if ((e = hipcub::DeviceRadixSort::SortPairs(tmp + o_cub, sort_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, st)) != hipSuccess) return fail(e);
