@@ -203,7 +203,7 @@ typedef enum MiptOption {
     MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build, all three in the same node / triangle layout; a render does not depend on it:
                                   2 (default since ABI 4): on the device, as optixAccelBuild -- top-down binned SAH (32 bins per axis, all open
                                   ranges of a level at once) down to ranges of 64 triangles, each of which one wave then builds by full-sweep
-                                  SAH; leaves by the SAH termination rule.  12 ms per million triangles, frames within 1 % of those over the
+                                  SAH; leaves by the SAH termination rule.  7 ms per million triangles, frames within 2 % of those over the
                                   host builder's tree on every scene measured (profiles/r04_builders.txt), the same tree in every run;
                                   1: on the device, fastest build (~ PREFER_FAST_BUILD): Morton codes, radix sort, Karras' radix tree, the same
                                   64-triangle treelets: 3 ms per million triangles, frames equal on evenly spread triangles (the headline
