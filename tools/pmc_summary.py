@@ -15,7 +15,7 @@ for f in sorted(glob.glob(os.path.join(root, "pass*", "**", "*counter_collection
             name = r["Kernel_Name"]
             if "mipt::" not in name:
                 continue
-            short = name.split("(")[0].replace("void ", "").replace("mipt::", "")
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("mipt::", "")
             acc[short][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 for k in sorted(acc):
     print("==", k)
