@@ -204,7 +204,8 @@ typedef enum MiptOption {
                                   2 (default since ABI 4): on the device, as optixAccelBuild -- top-down binned SAH (32 bins per axis, all open
                                   ranges of a level at once) down to ranges of 64 triangles, each of which one wave then builds by full-sweep
                                   SAH; leaves by the SAH termination rule.  7 ms per million triangles, frames within 2 % of those over the
-                                  host builder's tree on every scene measured (profiles/r04_builders.txt), the same tree in every run;
+                                  host builder's tree on every scene measured (profiles/r04_builders.txt), the same tree in every run; inputs of fewer than
+                                  2048 triangles are built on the host (a device build costs ~0.6 ms of launches whatever its size);
                                   1: on the device, fastest build (~ PREFER_FAST_BUILD): Morton codes, radix sort, Karras' radix tree, the same
                                   64-triangle treelets: 3 ms per million triangles, frames equal on evenly spread triangles (the headline
                                   scene), 10-20 % slower on scenes whose top levels need SAH (large triangles among small ones, height fields);

@@ -257,7 +257,8 @@ namespace sutil {
 // loadScene parses the glTF (mipt_scene_load); finalize() does what Scene::finalize does (Scene.cpp:803-815): creates the
 // context, uploads the geometry, builds the acceleration structures -- one triangle structure per mesh plus the instance
 // structure over them (buildMeshAccels + buildInstanceAccel), or ONE structure over the flattened world-space triangles when
-// asked for (AccelMode::FLATTENED: 1.2-1.3 x faster, twenty times the memory) -- and hands the Whitted programs their geometry (per-mesh
+// asked for (AccelMode::FLATTENED: 1.2-1.3 x faster over MANY instances at twenty times the memory; a scene of ONE instance -- most glTF files -- is
+// walked as its mesh's own BVH either way) -- and hands the Whitted programs their geometry (per-mesh
 // object-space tables + instance records for the two-level form, as the reference's createSBT keeps them; flattened world-space
 // arrays otherwise), material and texture tables.  The programs are fixed-function kernels: pipeline() / sbt() do not exist.
 class Scene {

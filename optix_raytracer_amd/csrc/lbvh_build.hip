@@ -809,14 +809,16 @@ __global__ __launch_bounds__(256) void k_sah_small(const SahSeg* __restrict__ li
     }
 }
 
-__global__ void k_sah_root(SahSeg* segs, const uint32_t* scene, uint32_t n, int* pin, int* rlo, int* rhi, uint32_t* counts)
+// the root range: the first open range of the level loop, or -- a whole input of at most kSahSmall triangles -- the one range of k_sah_small
+__global__ void k_sah_root(SahSeg* segs, SahSeg* smalls, const uint32_t* scene, uint32_t n, int* pin, int* rlo, int* rhi, uint32_t* counts)
 {
     if (threadIdx.x != 0u || blockIdx.x != 0u) return;
     SahSeg r; r.lo = 0; r.hi = (int)n - 1; r.node = 0; r.depth = 0;
     for (int k = 0; k < 6; ++k) r.cb[k] = scene[k];
-    segs[0] = r;
+    const bool small = n <= (uint32_t)kSahSmall;
+    if (small) smalls[0] = r; else segs[0] = r;
     pin[0] = -1; rlo[0] = 0; rhi[0] = (int)n - 1;
-    counts[0] = 1u; counts[1] = 0u; counts[2] = 0u;
+    counts[0] = small ? 0u : 1u; counts[1] = 0u; counts[2] = small ? 1u : 0u;
 }
 
 // ---- bottom-up passes without fences ---------------------------------------------------------------------------------------------
@@ -1423,8 +1425,8 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
         uint32_t* counts = misc + 20;                                   // [0] / [1]: open ranges of the current / next level (alternating); [2]: ranges for k_sah_small
         SahSeg* smalls = (SahSeg*)(tmp + o_small);
         hipLaunchKernelGGL(k_sah_init, dim3(2048), dim3(256), 0, st, bins, max_segs * (size_t)kSahSegWords, perm[0], seg_of[0], n, left, right, rlo, rhi);
-        hipLaunchKernelGGL(k_sah_root, dim3(1), dim3(64), 0, st, segs[0], misc, n, pin, rlo, rhi, counts);
-        uint32_t n_cur = 1u;
+        hipLaunchKernelGGL(k_sah_root, dim3(1), dim3(64), 0, st, segs[0], smalls, misc, n, pin, rlo, rhi, counts);
+        uint32_t n_cur = n <= (uint32_t)kSahSmall ? 0u : 1u;              // (a small input: no level loop, one workgroup builds it)
         int cur = 0;
         const uint32_t chunks = (n + (uint32_t)kSahChunk - 1u) / (uint32_t)kSahChunk;
         for (int level = 0; n_cur != 0u; ++level) {

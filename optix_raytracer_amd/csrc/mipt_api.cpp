@@ -122,6 +122,7 @@ struct MiptContext {
     int      build_mode = 2;              // MIPT_OPT_BUILD: 2 (default, round 4) on the device, top-down binned SAH + SAH treelets: the host builder's trees at a
                                           // fourteenth of its time; 1 on the device, Morton codes + radix tree + SAH treelets (fastest build: lbvh_build.hip);
                                           // 0 host binned SAH (bvh_build.cpp; the fallback of the other two for tiny inputs and trees deeper than the stack)
+    uint32_t build_host_below = 2048;     // MIPT_OPT_BUILD = 2: inputs of fewer triangles go to the host builder (env MIPT_BUILD_HOST_BELOW; 0: everything on the device)
     int      lbvh_treelets = 1;           // env MIPT_LBVH_TREELETS=0: the plain radix tree (A/B of the SAH treelets, lbvh_build.hip)
     int      lbvh_leaf = 4;               // env MIPT_LBVH_LEAF: subtrees of at most this many triangles become leaves of the device LBVH (1 .. 4)
     int      node_format = 2;             // MIPT_OPT_NODE_FORMAT: 2 fp16 boxes + BVH4 mirror, 1 fp16 boxes + packed 32-byte BVH2 mirror (where the
@@ -772,6 +773,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_INST_FORM")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->inst_form = v; }
     if (const char* e = std::getenv("MIPT_BUILD")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->build_mode = v; }       // MIPT_OPT_BUILD at creation
+    if (const char* e = std::getenv("MIPT_BUILD_HOST_BELOW")) { const long v = std::atol(e); if (v >= 0 && v <= (1l << 30)) c->build_host_below = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_LBVH_TREELETS")) c->lbvh_treelets = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_LBVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->lbvh_leaf = v; }
     if (const char* e = std::getenv("MIPT_TAIL_REFILL")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tail_refill = v; }
@@ -1018,7 +1020,11 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     if (!ctx) return MIPT_ERROR_INVALID_VALUE;
     if (!inputs || num_inputs == 0 || !handle_out) return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_build: null argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->build_mode == 1 || ctx->build_mode == 2) {
+    // (the default builder hands inputs of a few thousand triangles to the host builder: a device build is ~0.6 ms of launches, read-backs and
+    //  allocations whatever its size -- 300 triangles: 0.7 against 0.2 ms on the host, break-even near 2 000; the trees are alike)
+    uint64_t n_hint = 0;
+    for (uint32_t k = 0; k < num_inputs; ++k) n_hint += (inputs[k].indices && inputs[k].index_format != 0) ? inputs[k].num_triangles : inputs[k].num_vertices / 3u;
+    if (ctx->build_mode == 1 || (ctx->build_mode == 2 && n_hint >= (uint64_t)ctx->build_host_below)) {
         const int rc = accel_build_device(ctx, inputs, num_inputs, handle_out);
         if (rc != MIPT_SUCCESS || *handle_out != 0ull) return rc;
     }

@@ -508,7 +508,7 @@ def test_deep_tree_fills_the_traversal_stacks():
 
 
 @pytest.mark.parametrize("name,n,builder", [("cornell", 0, 1), ("soup", 40000, 1), ("soup", 7, 1), ("cornell", 0, 2), ("soup", 40000, 2), ("soup", 130, 2), ("hall", 0, 2)])
-def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path):
+def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path, monkeypatch):
     """MIPT_OPT_BUILD = 1 / 2: the BVH built on the device (1: Morton codes + radix tree + SAH treelets; 2, round 4: top-down binned SAH
     above the treelets) is a sound BVH over the same triangles (oracle validation), traversal over it agrees with the oracle walking the
     same tree, and frames are bit-identical to those over the host's SAH tree -- hit records do not depend on the tree"""
@@ -516,6 +516,7 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path):
     from optix_raytracer_amd import _lib as L
     from optix_raytracer_amd import pathtracer as PT
     from optix_raytracer_amd import scenes
+    monkeypatch.setenv("MIPT_BUILD_HOST_BELOW", "0")          # (the default builder hands inputs below 2048 triangles to the host: here everything is built on the device)
     if name == "hall":      # large triangles among small ones (walls around boxes): where the Morton cut loses most
         scene = scenes.from_gltf(scenes.write_rooms_gltf(tmp_path / "hall.gltf", n_boxes=2000))
     else:
@@ -927,7 +928,7 @@ def _soup_scene(verts):
 
 
 @pytest.mark.parametrize("kind", ["identical", "line", "two_clusters", "spikes", "big_and_small"])
-def test_device_sah_builder_on_degenerate_inputs(kind):
+def test_device_sah_builder_on_degenerate_inputs(kind, monkeypatch):
     """The device SAH builder (the default) where binning has nothing to hold on to: thousands of copies of ONE triangle (no centroid
     extent on any axis: median splits all the way down), triangles along a line (one usable axis), two far clusters (30 of 32 bins
     empty at the root), geometrically shrinking spikes (the SAH peels them off one by one: deeper than the stack, so the build falls back
@@ -963,6 +964,7 @@ def test_device_sah_builder_on_degenerate_inputs(kind):
         size = np.where(rng.uniform(size=(n, 1, 1)) < 0.01, 0.5, 0.004)
         verts = np.concatenate([(c + size * rng.uniform(-1, 1, (n, 3, 3))).reshape(-1, 3), np.zeros((3 * n, 1))], 1).astype(np.float32)
     scene = _soup_scene(verts)
+    monkeypatch.setenv("MIPT_BUILD_HOST_BELOW", "0")
     st = PT.PathTracerState()
     PT.createContext(st, 0)
     assert st.context.get_option(L.OPT_BUILD) == 2
