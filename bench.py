@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--steal-min", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the bounded CPU-baseline sample")
+    ap.add_argument("--builder", type=int, default=3,
+                    help="MIPT_OPT_BUILD for the scene's BVH (the build is outside the timed region, as BASELINE.json's metric has it): 3 = host SAH with "
+                         "spatial splits, the best tree for a static scene (default here; ~3 s per million triangles); 2 = the library's default, "
+                         "on the device in 7 ms; 1 = device Morton; 0 = host SAH.  The environment's MIPT_BUILD wins (A/B runs).")
     return ap.parse_args()
 
 
@@ -301,6 +305,7 @@ def main():
 
     w, h = args.width, args.height
     scene = scenes.random_soup(args.tris)
+    os.environ.setdefault("MIPT_BUILD", str(args.builder))          # read when the context is created
     t0 = time.perf_counter()
     st = PT.make_state(scene, w, h, SPP, local_rank, max_depth=args.max_depth)
     build_s = time.perf_counter() - t0
@@ -515,8 +520,11 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[3]: %d random triangles in the unit cube, %dx%d spp=%d, max depth %d "
-                                   "(primary + NEE shadow ray), BVH2 %d nodes depth %d, node format %d (%d mirror nodes, stack %d)" % (
-                                       args.tris, w, h, SPP, args.max_depth, info["num_nodes"], info["depth"], info["node_format"], info["mirror_nodes"], info["stack_entries"]),
+                                   "(primary + NEE shadow ray), BVH2 %d nodes depth %d over %d triangle records (builder %s: %s), node format %d (%d mirror nodes, stack %d)" % (
+                                       args.tris, w, h, SPP, args.max_depth, info["num_nodes"], info["depth"], info["num_triangles"], os.environ.get("MIPT_BUILD"),
+                                       {"0": "host binned SAH", "1": "device Morton + SAH treelets", "2": "device binned SAH + SAH treelets",
+                                        "3": "host binned SAH with spatial splits"}.get(os.environ.get("MIPT_BUILD"), "?"),
+                                       info["node_format"], info["mirror_nodes"], info["stack_entries"]),
                        "rays_per_frame": rays_total, "closest_rays": counts["closest_rays"] if world == 1 else None,
                        "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather%s" % (
                            world, " (frame k's gather overlaps frame k+1's tracing)" if args.overlap else ""),

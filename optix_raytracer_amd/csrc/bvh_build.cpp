@@ -14,7 +14,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <future>
+#include <mutex>
 #include <limits>
 
 namespace mipt {
@@ -194,6 +196,220 @@ struct Builder {
     }
 };
 
+// ---- spatial splits (SBVH; Stich, Friedrich, Dietrich 2009): MIPT_OPT_BUILD = 3 -----------------------------------------------------
+// The object-split builder above puts every triangle into exactly one leaf, so where triangles are as large as the gaps between them
+// (the headline soup: edges of ~0.01 at a spacing of 0.01) sibling boxes overlap all the way down and a ray that enters the cloud walks
+// every one of the overlapping subtrees around its first hit -- ~150 node visits for a ray that hits, where the tree is 20 levels deep.
+// A SPATIAL split cuts the node's box by a plane instead: a triangle that straddles the plane is referenced on BOTH sides, each side
+// with the bounds of the part of the triangle that lies there.  Children then do not overlap (along that axis), at the price of
+// duplicated references (capped: `extra` references per triangle in all).  Per node both kinds of split are priced by the same
+// surface-area heuristic and the cheaper one is taken; spatial splits are only tried where the object split's children overlap
+// noticeably (area of the overlap > 1e-5 of the root's).
+// Reference boxes are CONSERVATIVE: the clip of a triangle against a slab is computed in double and rounded outward to float, then
+// cut by the reference's own box (which bounds the part of the triangle the ancestors' planes left) -- a point of the triangle inside
+// the node's region is inside the box of the reference that region holds, so a ray that meets the triangle there passes that leaf's
+// boxes, and hit records stay what a brute-force intersector gives (closest hit: min t, tie -> lowest primitive).
+struct Ref { uint32_t prim; Box box; };
+
+inline float f_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; }
+inline float f_up(double x)   { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; }
+
+// bounds of { p in triangle : a <= p[k] <= b }, cut by `within`; false when empty
+bool clip_tri(const float* v, int k, double a, double b, const Box& within, Box& out)
+{
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    bool any = false;
+    auto add = [&](const double* p) { any = true; for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], p[c]); hi[c] = std::max(hi[c], p[c]); } };
+    for (int i = 0; i < 3; ++i) {
+        const float* pf = v + 3 * i; const float* qf = v + 3 * ((i + 1) % 3);
+        const double p[3] = { pf[0], pf[1], pf[2] }, q[3] = { qf[0], qf[1], qf[2] };
+        if (p[k] >= a && p[k] <= b) add(p);
+        for (int side = 0; side < 2; ++side) {
+            const double pl = side == 0 ? a : b;
+            if ((p[k] < pl && q[k] > pl) || (p[k] > pl && q[k] < pl)) {
+                const double t = (pl - p[k]) / (q[k] - p[k]);
+                double x[3] = { p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1]), p[2] + t * (q[2] - p[2]) };
+                x[k] = pl;
+                add(x);
+            }
+        }
+    }
+    if (!any) return false;
+    for (int c = 0; c < 3; ++c) {
+        out.lo[c] = std::max(within.lo[c], f_down(lo[c]));
+        out.hi[c] = std::min(within.hi[c], f_up(hi[c]));
+        if (!(out.lo[c] <= out.hi[c])) return false;
+    }
+    return true;
+}
+
+struct SNode { Box box[2]; int32_t child[2]; std::vector<uint32_t> leaf[2]; };      // child >= 0: node index; -1: a leaf of leaf[c]
+
+struct SbvhBuilder {
+    const float* verts = nullptr;
+    int leaf_max = 4, depth_cap = 32;
+    float root_area = 0.0f;
+    std::atomic<int> tasks{ 0 };
+    int max_tasks = 0;
+    std::deque<SNode> nodes;
+    std::mutex mu;
+
+    uint64_t capacity(int levels) const { if (levels < 0) return 0; if (levels > 40) levels = 40; return (uint64_t)leaf_max << levels; }
+    int alloc() { std::lock_guard<std::mutex> g(mu); nodes.emplace_back(); return (int)nodes.size() - 1; }
+    SNode& node(int i) { std::lock_guard<std::mutex> g(mu); return nodes[(size_t)i]; }      // (deque: references stay valid while others append)
+
+    // builds the subtree over `refs` (consumed); returns its node index, or -1 when the references should be one leaf.  `budget`: references
+    // the spatial splits of this subtree may add -- handed down in proportion to the children's sizes, so that the tree does not depend on
+    // which thread built what
+    int build(std::vector<Ref>& refs, int depth, bool force_inner, long long budget)
+    {
+        const uint32_t n = (uint32_t)refs.size();
+        if (!force_inner && n <= 1) return -1;
+        Box bounds; bounds.reset(); Box cb; cb.reset();
+        for (const Ref& r : refs) {
+            bounds.grow(r.box);
+            const float c[3] = { 0.5f * (r.box.lo[0] + r.box.hi[0]), 0.5f * (r.box.lo[1] + r.box.hi[1]), 0.5f * (r.box.lo[2] + r.box.hi[2]) };
+            cb.grow(c);
+        }
+        const uint64_t side_cap = capacity(depth_cap - depth - 1);
+        // ---- object split: binned SAH over the references' centres (as Builder::sah_split)
+        float obj_cost = std::numeric_limits<float>::infinity(); int obj_axis = -1, obj_bin = -1;
+        Box obj_l, obj_r; obj_l.reset(); obj_r.reset();
+        float scale[3]; bool usable[3];
+        for (int k = 0; k < 3; ++k) { const float ext = cb.hi[k] - cb.lo[k]; usable[k] = ext > 0.0f && std::isfinite(ext); scale[k] = usable[k] ? (float)kBins / ext : 0.0f; }
+        auto bin_of = [&](const Ref& r, int k) { int b = (int)((0.5f * (r.box.lo[k] + r.box.hi[k]) - cb.lo[k]) * scale[k]); return b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b); };
+        if (n >= 2) {
+            Box bbox[3][kBins]; uint32_t bcnt[3][kBins];
+            for (int k = 0; k < 3; ++k) for (int b = 0; b < kBins; ++b) { bbox[k][b].reset(); bcnt[k][b] = 0; }
+            for (const Ref& r : refs) for (int k = 0; k < 3; ++k) if (usable[k]) { const int b = bin_of(r, k); bcnt[k][b]++; bbox[k][b].grow(r.box); }
+            for (int k = 0; k < 3; ++k) {
+                if (!usable[k]) continue;
+                Box rbox[kBins]; uint32_t rcnt[kBins];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bbox[k][b]); c += bcnt[k][b]; rbox[b] = acc; rcnt[b] = c; }
+                acc.reset(); c = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bbox[k][b]); c += bcnt[k][b];
+                    const uint32_t nl = c, nr = rcnt[b + 1];
+                    if (nl == 0 || nr == 0 || nl > side_cap || nr > side_cap) continue;
+                    const float cost = acc.half_area() * (float)nl + rbox[b + 1].half_area() * (float)nr;
+                    if (cost < obj_cost) { obj_cost = cost; obj_axis = k; obj_bin = b; obj_l = acc; obj_r = rbox[b + 1]; }
+                }
+            }
+        }
+        const float area = bounds.half_area();
+        if (!force_inner && n <= (uint32_t)leaf_max) {
+            if (obj_axis < 0) return -1;
+            if (!(area > 0.0f) || obj_cost / area + kNodeCost >= (float)n) return -1;        // keep the leaf unless splitting pays for the extra node
+        }
+        // ---- spatial split: only where the object split leaves its children overlapping, with references to spare, and depth to spare
+        float sp_cost = std::numeric_limits<float>::infinity(); int sp_axis = -1; float sp_plane = 0.0f;
+        const uint64_t sp_cap = capacity(depth_cap - depth - 1 - 3);
+        bool try_spatial = n > (uint32_t)leaf_max && budget > 0 && (uint64_t)n <= sp_cap;
+        if (try_spatial && obj_axis >= 0) {
+            Box ov;
+            for (int c = 0; c < 3; ++c) { ov.lo[c] = std::max(obj_l.lo[c], obj_r.lo[c]); ov.hi[c] = std::min(obj_l.hi[c], obj_r.hi[c]); }
+            const bool overlap = ov.lo[0] <= ov.hi[0] && ov.lo[1] <= ov.hi[1] && ov.lo[2] <= ov.hi[2];
+            try_spatial = overlap && ov.half_area() > 1e-5f * root_area;
+        }
+        if (try_spatial) {
+            for (int k = 0; k < 3; ++k) {
+                const double lo = bounds.lo[k], ext = (double)bounds.hi[k] - lo;
+                if (!(ext > 0.0) || !std::isfinite(ext)) continue;
+                const double width = ext / kBins;
+                Box sbox[kBins]; uint32_t enter[kBins], leave[kBins];
+                for (int b = 0; b < kBins; ++b) { sbox[b].reset(); enter[b] = 0; leave[b] = 0; }
+                auto sbin = [&](float x) { int b = (int)(((double)x - lo) / width); return b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b); };
+                for (const Ref& r : refs) {
+                    const int b0 = sbin(r.box.lo[k]), b1 = sbin(r.box.hi[k]);
+                    enter[b0]++; leave[b1]++;
+                    if (b0 == b1) { sbox[b0].grow(r.box); continue; }
+                    const float* v = verts + (size_t)r.prim * 9;
+                    for (int b = b0; b <= b1; ++b) {
+                        Box c;
+                        if (clip_tri(v, k, lo + width * b, lo + width * (b + 1), r.box, c)) sbox[b].grow(c);
+                    }
+                }
+                Box rbox[kBins]; uint32_t rcnt[kBins];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(sbox[b]); c += leave[b]; rbox[b] = acc; rcnt[b] = c; }
+                acc.reset(); c = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(sbox[b]); c += enter[b];
+                    const uint32_t nl = c, nr = rcnt[b + 1];
+                    if (nl == 0 || nr == 0 || nl >= n || nr >= n) continue;                 // (a split that leaves a side with everything makes no progress)
+                    const float cost = acc.half_area() * (float)nl + rbox[b + 1].half_area() * (float)nr;
+                    if (cost < sp_cost) { sp_cost = cost; sp_axis = k; sp_plane = (float)(lo + width * (b + 1)); }
+                }
+            }
+        }
+        std::vector<Ref> L, R;
+        bool done = false;
+        if (sp_axis >= 0 && sp_cost < obj_cost) {
+            const int k = sp_axis;
+            long long added = 0;
+            for (const Ref& r : refs) {
+                if (r.box.hi[k] <= sp_plane) L.push_back(r);
+                else if (r.box.lo[k] >= sp_plane) R.push_back(r);
+                else {
+                    const float* v = verts + (size_t)r.prim * 9;
+                    Ref a = r, b = r;
+                    const bool hl = clip_tri(v, k, -1e300, (double)sp_plane, r.box, a.box), hr = clip_tri(v, k, (double)sp_plane, 1e300, r.box, b.box);
+                    if (hl) L.push_back(a);
+                    if (hr) R.push_back(b);
+                    if (!hl && !hr) L.push_back(r);                                        // (cannot be: the reference's box straddles the plane)
+                    if (hl && hr) ++added;
+                }
+            }
+            if (!L.empty() && !R.empty() && L.size() < n && R.size() < n && L.size() <= side_cap && R.size() <= side_cap && added <= budget) {
+                budget -= added;
+                done = true;
+            } else { L.clear(); R.clear(); }
+        }
+        if (!done && obj_axis >= 0) {
+            for (const Ref& r : refs) (bin_of(r, obj_axis) <= obj_bin ? L : R).push_back(r);
+            done = !L.empty() && !R.empty();
+            if (!done) { L.clear(); R.clear(); }
+        }
+        if (!done) {
+            if (n < 2) { L = refs; }                                                        // forced root over 0 / 1 triangles: child 1 empty
+            else {
+                int ax = 0; float w = -1.0f;
+                for (int k = 0; k < 3; ++k) { const float e = cb.hi[k] - cb.lo[k]; if (e > w) { w = e; ax = k; } }
+                const size_t mid = n / 2;
+                std::nth_element(refs.begin(), refs.begin() + (long)mid, refs.end(), [&](const Ref& a, const Ref& b) {
+                    const float ca = a.box.lo[ax] + a.box.hi[ax], cb2 = b.box.lo[ax] + b.box.hi[ax];
+                    return ca < cb2 || (ca == cb2 && a.prim < b.prim);
+                });
+                L.assign(refs.begin(), refs.begin() + (long)mid); R.assign(refs.begin() + (long)mid, refs.end());
+            }
+        }
+        std::vector<Ref>().swap(refs);
+        const int me = alloc();
+        Box bl, br; bl.reset(); br.reset();
+        for (const Ref& r : L) bl.grow(r.box);
+        for (const Ref& r : R) br.grow(r.box);
+        if (R.empty()) std::memset(&br, 0, sizeof br);
+        if (L.empty()) std::memset(&bl, 0, sizeof bl);
+        std::vector<uint32_t> lp, rp;                                                        // the sides' primitives, should they become leaves
+        for (const Ref& r : L) lp.push_back(r.prim);
+        for (const Ref& r : R) rp.push_back(r.prim);
+        const long long bl_budget = L.size() + R.size() ? (long long)((double)budget * (double)L.size() / (double)(L.size() + R.size())) : 0, br_budget = budget - bl_budget;
+        std::future<int> fut; bool spawned = false;
+        if (n > 32768 && tasks.load(std::memory_order_relaxed) < max_tasks) {
+            tasks.fetch_add(1); spawned = true;
+            fut = std::async(std::launch::async, [this, &L, depth, bl_budget] { const int r = build(L, depth + 1, false, bl_budget); tasks.fetch_sub(1); return r; });
+        }
+        const int cr = build(R, depth + 1, false, br_budget);
+        const int cl = spawned ? fut.get() : build(L, depth + 1, false, bl_budget);
+        SNode& nd = node(me);
+        nd.box[0] = bl; nd.box[1] = br; nd.child[0] = cl; nd.child[1] = cr;
+        if (cl < 0) nd.leaf[0] = std::move(lp);
+        if (cr < 0) nd.leaf[1] = std::move(rp);
+        return me;
+    }
+};
+
 void put_child(MiptBvhNode& n, int which, const Box& b, int32_t ref)
 {
     if (which == 0) {
@@ -268,6 +484,65 @@ bool build_bvh(const float* world_verts, uint32_t n_tris, int leaf_max, int dept
         // push child 1 first so child 0's subtree follows its parent in memory
         if (tn.slot[1] != UINT32_MAX) stack.push_back({ tn.slot[1], child_out[1], it.depth + 1 });
         if (tn.slot[0] != UINT32_MAX) stack.push_back({ tn.slot[0], child_out[0], it.depth + 1 });
+    }
+    out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return out.depth <= (uint32_t)depth_cap;
+}
+
+// MIPT_OPT_BUILD = 3: binned SAH with spatial splits (the comment at struct Ref).  `extra`: references the spatial splits may add, as a
+// fraction of the triangle count.  Leaves of up to 15 references would be possible; the traversal kernels' pool wants at most 4.
+bool build_sbvh(const float* world_verts, uint32_t n_tris, int leaf_max, int depth_cap, int n_threads, float extra, HostBvh& out)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    if (const char* e = std::getenv("MIPT_BVH_NODE_COST")) kNodeCost = (float)std::atof(e);
+    if (leaf_max < 1 || leaf_max > 15 || depth_cap < 1 || n_tris >= (1u << 26)) return false;
+    SbvhBuilder B;
+    B.verts = world_verts; B.leaf_max = leaf_max; B.depth_cap = depth_cap; B.max_tasks = n_threads > 1 ? n_threads - 1 : 0;
+    if ((uint64_t)n_tris > B.capacity(depth_cap)) return false;
+    std::vector<Ref> refs(n_tris);
+    Box all; all.reset();
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        const float* v = world_verts + (size_t)i * 9;
+        Box b; b.reset(); b.grow(v); b.grow(v + 3); b.grow(v + 6);
+        refs[i].prim = i; refs[i].box = b; all.grow(b);
+    }
+    B.root_area = all.half_area();
+    const int root = B.build(refs, 0, /*force_inner=*/true, (long long)((double)n_tris * (double)extra));
+    if (root < 0) return false;
+    // emission: DFS preorder (a node's first child follows it), triangles in leaf order, duplicates and all
+    out.nodes.clear(); out.tris.clear();
+    out.nodes.reserve(B.nodes.size()); out.tris.reserve((size_t)n_tris + (size_t)((double)n_tris * extra));
+    out.depth = 0; out.leaf_max = (uint32_t)leaf_max;
+    struct Item { int src; uint32_t out_index, depth; };
+    std::vector<Item> stack;
+    out.nodes.emplace_back();
+    stack.push_back({ root, 0u, 1u });
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        const SNode& sn = B.nodes[(size_t)it.src];
+        if (it.depth > out.depth) out.depth = it.depth;
+        int32_t refs2[2]; uint32_t child_out[2] = { 0, 0 };
+        for (int c = 0; c < 2; ++c) {
+            if (sn.child[c] >= 0) { child_out[c] = (uint32_t)out.nodes.size(); out.nodes.emplace_back(); refs2[c] = (int32_t)child_out[c]; }
+            else {
+                const uint32_t first = (uint32_t)out.tris.size();
+                if (sn.leaf[c].size() > 15u || first >= (1u << 27)) return false;
+                for (uint32_t p : sn.leaf[c]) {
+                    const float* v = world_verts + (size_t)p * 9;
+                    MiptBvhTri t{};
+                    for (int k = 0; k < 3; ++k) { t.v0[k] = v[k]; t.e1[k] = v[3 + k] - v[k]; t.e2[k] = v[6 + k] - v[k]; }
+                    t.prim = p;
+                    out.tris.push_back(t);
+                }
+                refs2[c] = ~(int32_t)((first << 4) | (uint32_t)sn.leaf[c].size());
+            }
+        }
+        MiptBvhNode& nd = out.nodes[it.out_index];
+        std::memset(&nd, 0, sizeof nd);
+        put_child(nd, 0, sn.box[0], refs2[0]);
+        put_child(nd, 1, sn.box[1], refs2[1]);
+        if (sn.child[1] >= 0) stack.push_back({ sn.child[1], child_out[1], it.depth + 1 });
+        if (sn.child[0] >= 0) stack.push_back({ sn.child[0], child_out[0], it.depth + 1 });
     }
     out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return out.depth <= (uint32_t)depth_cap;

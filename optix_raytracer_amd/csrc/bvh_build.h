@@ -22,4 +22,8 @@ struct HostBvh {
 // Returns false if n_tris cannot be represented within depth_cap.
 bool build_bvh(const float* world_verts, uint32_t n_tris, int leaf_max, int depth_cap, int n_threads, HostBvh& out);
 
+// The same with spatial splits (SBVH): triangles that straddle a split plane are referenced on both sides, so `tris` holds more records than
+// there are triangles (at most n_tris * (1 + extra)); false also when the tree is deeper than depth_cap.
+bool build_sbvh(const float* world_verts, uint32_t n_tris, int leaf_max, int depth_cap, int n_threads, float extra, HostBvh& out);
+
 }  // namespace mipt

@@ -60,7 +60,7 @@ struct Accel {
     HostBvh   host;                // scratch of the host builder (emptied after the upload)
     uint32_t  num_nodes = 0, num_tris = 0, depth = 0, leaf_max = 0;
     double    seconds = 0.0;
-    int       builder = 0;         // 0 host binned SAH, 1 device LBVH
+    int       builder = 0;         // 0 host binned SAH, 1 device LBVH, 2 device SAH, 3 host SAH with spatial splits (num_tris > n_prims: references)
     float4*   d_nodes = nullptr;   // one allocation: nodes | triangles | 64 B pad
     float4*   d_tris  = nullptr;   // = d_nodes + num_nodes * 4
     uint32_t  tri_byte_off = 0;    // 0 when the blob does not fit 32-bit offsets (then no streaming kernel)
@@ -122,6 +122,7 @@ struct MiptContext {
     int      build_mode = 2;              // MIPT_OPT_BUILD: 2 (default, round 4) on the device, top-down binned SAH + SAH treelets: the host builder's trees at a
                                           // fourteenth of its time; 1 on the device, Morton codes + radix tree + SAH treelets (fastest build: lbvh_build.hip);
                                           // 0 host binned SAH (bvh_build.cpp; the fallback of the other two for tiny inputs and trees deeper than the stack)
+    float    sbvh_extra = 0.5f;           // MIPT_OPT_BUILD = 3: references the spatial splits may add, as a fraction of the triangle count (env MIPT_SBVH_EXTRA)
     uint32_t build_host_below = 2048;     // MIPT_OPT_BUILD = 2: inputs of fewer triangles go to the host builder (env MIPT_BUILD_HOST_BELOW; 0: everything on the device)
     int      lbvh_treelets = 1;           // env MIPT_LBVH_TREELETS=0: the plain radix tree (A/B of the SAH treelets, lbvh_build.hip)
     int      lbvh_leaf = 4;               // env MIPT_LBVH_LEAF: subtrees of at most this many triangles become leaves of the device LBVH (1 .. 4)
@@ -772,7 +773,8 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_TILE_CLASS_INIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }   // adapted from there
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_INST_FORM")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->inst_form = v; }
-    if (const char* e = std::getenv("MIPT_BUILD")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->build_mode = v; }       // MIPT_OPT_BUILD at creation
+    if (const char* e = std::getenv("MIPT_BUILD")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) c->build_mode = v; }
+    if (const char* e = std::getenv("MIPT_SBVH_EXTRA")) { const double v = std::atof(e); if (v >= 0.0 && v <= 8.0) c->sbvh_extra = (float)v; }       // MIPT_OPT_BUILD at creation
     if (const char* e = std::getenv("MIPT_BUILD_HOST_BELOW")) { const long v = std::atol(e); if (v >= 0 && v <= (1l << 30)) c->build_host_below = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_LBVH_TREELETS")) c->lbvh_treelets = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_LBVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->lbvh_leaf = v; }
@@ -839,7 +841,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value > (1u << 30)) return c->fail(MIPT_ERROR_INVALID_VALUE, "tail threshold must be 0 (off) .. 2^30 paths");
         c->tail_paths = (uint32_t)value; return MIPT_SUCCESS;
     case MIPT_OPT_BUILD:
-        if (value > 2) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH), 1 (device LBVH) or 2 (device SAH)");
+        if (value > 3) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH), 1 (device LBVH), 2 (device SAH) or 3 (host SAH with spatial splits)");
         c->build_mode = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_TILE_ORDER:
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "tile order must be 0 (image order) or 1 (by the previous launch's costs)");
@@ -1094,12 +1096,20 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     std::vector<uint32_t> prim_slot;
     hipError_t e = hipSuccess;
     {
-        if (!build_bvh(world.data(), n_tris, 4, kStackEntries, default_build_threads(), a->host)) {
+        // MIPT_OPT_BUILD = 3: spatial splits (bvh_build.cpp, build_sbvh): triangles may be referenced by several leaves; an input it cannot take
+        // (a tree deeper than the stack) goes to the object-split builder like every other
+        bool spatial = ctx->build_mode == 3 && n_tris > 4u && build_sbvh(world.data(), n_tris, 4, kStackEntries, default_build_threads(), ctx->sbvh_extra, a->host);
+        if (spatial && (a->host.tris.size() >= (1u << 23) || a->host.nodes.size() >= (1u << 25))) spatial = false;      // (beyond the entry pool's packed words)
+        if (!spatial && !build_bvh(world.data(), n_tris, 4, kStackEntries, default_build_threads(), a->host)) {
             delete a;
             return ctx->fail(MIPT_ERROR_BVH_TOO_DEEP, "BVH over %u triangles does not fit a %d-entry traversal stack", n_tris, kStackEntries);
         }
+        a->builder = spatial ? 3 : 0;
         for (MiptBvhTri& t : a->host.tris) t.pad1 = gflags[t.prim];
-        if (a->host.tris.size() == n_tris) { prim_slot.resize(n_tris); for (uint32_t i = 0; i < n_tris; ++i) prim_slot[a->host.tris[i].prim] = i; }
+        if (a->host.tris.size() >= n_tris && n_tris) {            // primitive -> one of its triangle records (the first: spatial splits leave several)
+            prim_slot.assign(n_tris, 0xffffffffu);
+            for (uint32_t i = 0; i < (uint32_t)a->host.tris.size(); ++i) { uint32_t& sl = prim_slot[a->host.tris[i].prim]; if (sl == 0xffffffffu) sl = i; }
+        }
         nb = a->host.nodes.size() * sizeof(MiptBvhNode);
         tb = std::max<size_t>(a->host.tris.size(), 1) * sizeof(MiptBvhTri);
         e = hipMalloc((void**)&a->d_nodes, nb + tb + 64 + 256 + 8192 + a->host.nodes.size() * 96u);      // + room for the node mirrors (finish_blob)
@@ -1128,7 +1138,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
     *handle_out = h;
-    ctx->log(4, "ACCEL", "built BVH2 (%s): %u tris, %u nodes, depth %u, %.1f MB, %.3f s", a->builder ? "device LBVH" : "host SAH", n_tris,
+    ctx->log(4, "ACCEL", "built BVH2 (%s): %u tris, %u nodes, depth %u, %.1f MB, %.3f s", a->builder == 3 ? "host SAH with spatial splits" : "host SAH", n_tris,
              a->num_nodes, a->depth, (double)a->bytes / 1e6, a->seconds);
     return MIPT_SUCCESS;
 }
@@ -1370,6 +1380,8 @@ int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBui
     Accel* a = find_accel(ctx, handle);
     if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
     if (a->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "0x%llx is an instance structure: use mipt_accel_update_instances", handle);
+    if (a->builder == 3)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0x%llx was built with spatial splits (MIPT_OPT_BUILD = 3): its leaves hold clipped references, which a refit cannot keep -- build it again", handle);
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());                         // launches that still read the old boxes

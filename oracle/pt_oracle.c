@@ -571,9 +571,14 @@ int orc_scene_set_bvh(OrcScene* s, const void* nodes, uint32_t n_nodes, const vo
 }
 
 /* every prim appears exactly once, child boxes contain their triangles, refs in range,
- * depth < STACK_MAX.  Returns 0 when sound. */
+ * depth < STACK_MAX.  Returns 0 when sound.
+ * A tree with MORE triangle records than the scene has triangles was built with spatial splits (MIPT_OPT_BUILD = 3): a triangle may then
+ * be referenced by several leaves, each bounding only the part of it that lies in the leaf's region -- there every primitive must
+ * appear at least once and every reference's leaf box must overlap its triangle's bounds (what can be said without redoing the
+ * builder's clipping; that such a tree loses no hit is what the tests check against the brute-force intersector). */
 static int validate_rec(const OrcScene* s, int32_t ref, const Box* bound, uint8_t* seen, int depth, int* maxd)
 {
+    const int spatial = s->n_leaf_tris > s->n_tris;
     if (depth > *maxd) *maxd = depth;
     if (depth >= STACK_MAX - 1) return -10;
     if (ref < 0) {
@@ -581,14 +586,21 @@ static int validate_rec(const OrcScene* s, int32_t ref, const Box* bound, uint8_
         if (first + cnt > s->n_leaf_tris) return -11;
         for (uint32_t i = first; i < first + cnt; ++i) {
             const Tri48* t = &s->tris[i];
-            if (t->prim >= s->n_tris || seen[t->prim]) return -12;
+            if (t->prim >= s->n_tris || (seen[t->prim] && !spatial)) return -12;
             seen[t->prim] = 1;
             const float* v = s->verts + (size_t)t->prim * 12;
-            for (int c = 0; c < 3; ++c)
+            if (!spatial) {
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < 3; ++k) {
+                        float x = v[c * 4 + k];
+                        if (x < bound->lo[k] || x > bound->hi[k]) return -13;
+                    }
+            } else {
                 for (int k = 0; k < 3; ++k) {
-                    float x = v[c * 4 + k];
-                    if (x < bound->lo[k] || x > bound->hi[k]) return -13;
+                    const float tlo = fminf(v[k], fminf(v[4 + k], v[8 + k])), thi = fmaxf(v[k], fmaxf(v[4 + k], v[8 + k]));
+                    if (thi < bound->lo[k] || tlo > bound->hi[k]) return -13;
                 }
+            }
             for (int k = 0; k < 3; ++k) {
                 if (t->v0[k] != v[k] || t->e1[k] != v[4 + k] - v[k] || t->e2[k] != v[8 + k] - v[k]) return -14;
             }

@@ -42,6 +42,41 @@ def test_headline_frame_matches_oracle(big):
     assert stats["shadow_rays"] == ost["shadow_rays"] > 100000
 
 
+def test_headline_frame_over_a_tree_with_spatial_splits(big, monkeypatch):
+    """MIPT_OPT_BUILD = 3 (what bench.py builds): the headline scene's tree with spatial splits -- triangles that straddle a split plane
+    are referenced on both sides, each reference bounding its part of the triangle conservatively -- must lose no hit: the full frame,
+    the frame buffer and the ray counters at depth 1, and 40 000 pixels at depth 8, equal those over the default builder's tree bit for bit;
+    the oracle walks the exported tree (more triangle records than triangles) to the same frame."""
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT2
+    from optix_raytracer_amd import scenes
+    PT, st, ob, scene = big
+    acc, frame, stats = _render(PT, st, ob)
+    monkeypatch.setenv("MIPT_BUILD", "3")
+    st3 = PT2.make_state(scene, 1920, 1080, 1, 0, max_depth=1)
+    monkeypatch.delenv("MIPT_BUILD")
+    ob3 = PT2.OutputBuffer(1920, 1080, st3.device)
+    acc3, frame3, stats3 = _render(PT2, st3, ob3)
+    info = st3.context.accel_info(st3.gas_handle)
+    assert 1_000_000 < info["num_triangles"] <= 1_500_001 and info["depth"] <= 32 and info["leaf_max"] <= 4
+    assert np.array_equal(acc3.view(np.uint32), acc.view(np.uint32)) and np.array_equal(frame3, frame)
+    assert stats3["closest_rays"] == stats["closest_rays"] and stats3["shadow_rays"] == stats["shadow_rays"]
+    nodes, tris = st3.context.accel_export(st3.gas_handle)
+    osc = O.Scene(scene).set_bvh(nodes, tris)
+    a, f, ost = osc.render(scenes.launch_desc(scene, 1920, 1080, 1), max_depth=1, threads=16)
+    assert np.array_equal(acc3.view(np.uint32), a.view(np.uint32)) and np.array_equal(frame3, f)
+    for s_ in (st, st3):
+        s_.context.set_option(L.OPT_MAX_DEPTH, 8)
+    a8, _, s8 = _render(PT, st, ob)
+    b8, _, t8 = _render(PT2, st3, ob3)
+    st.context.set_option(L.OPT_MAX_DEPTH, 1)
+    assert np.array_equal(a8.view(np.uint32), b8.view(np.uint32)) and s8["closest_rays"] == t8["closest_rays"] and s8["shadow_rays"] == t8["shadow_rays"]
+    with pytest.raises(Exception) as e:                          # clipped references cannot be refitted
+        st3.context.accel_update(st3.gas_handle, [{"vertices": st3.d_vertices.data_ptr(), "num_vertices": 3_000_000, "stride": 16}])
+    assert "spatial" in str(e.value)
+    PT2.cleanupState(st3)
+
+
 def test_headline_determinism_and_kernel_variants(big):
     from optix_raytracer_amd import _lib as L
     PT, st, ob, scene = big
