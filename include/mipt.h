@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define MIPT_ABI_VERSION 4   /* 2: MiptAccelInfo.node_format, MIPT_OPT_NODE_FORMAT, mipt_group_*; 3: mipt_whitted_set_geometry_instanced, mipt_scene_mesh_normals / _texcoords / _colors;
-                                4: MIPT_OPT_BUILD = 2 (device SAH builder, the default) */
+                                4: MIPT_OPT_BUILD = 2 (device SAH builder, the default) and 3 (host SAH with spatial splits) */
 
 typedef enum MiptResult {
     MIPT_SUCCESS                 = 0,
@@ -209,6 +209,12 @@ typedef enum MiptOption {
                                   1: on the device, fastest build (~ PREFER_FAST_BUILD): Morton codes, radix sort, Karras' radix tree, the same
                                   64-triangle treelets: 3 ms per million triangles, frames equal on evenly spread triangles (the headline
                                   scene), 10-20 % slower on scenes whose top levels need SAH (large triangles among small ones, height fields);
+                                  3: binned SAH with SPATIAL SPLITS on the host cores (SBVH: a triangle that straddles a split plane is referenced
+                                  on both sides, each reference with the conservatively clipped bounds of its part; at most 50 % more triangle
+                                  records, env MIPT_SBVH_EXTRA): the best tree for a static scene (~ PREFER_FAST_TRACE) -- frames over scenes of
+                                  triangles as large as the gaps between them 6-7 % faster (the headline scene 0.557 -> 0.520 ms), 0-3 % elsewhere
+                                  -- at ~3 s per million triangles; MiptAccelInfo::num_triangles then counts RECORDS; such a tree cannot be
+                                  refitted (mipt_accel_update fails: build it again);
                                   0: binned SAH on the host cores (155 ms per million triangles).  1 and 2 fall back to 0 for inputs of
                                   <= 4 triangles and when their tree is deeper than the 32-entry traversal stack */
     MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late;
