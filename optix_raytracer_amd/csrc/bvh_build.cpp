@@ -348,18 +348,43 @@ struct SbvhBuilder {
         if (sp_axis >= 0 && sp_cost < obj_cost) {
             const int k = sp_axis;
             long long added = 0;
+            // the references that lie on one side go there; the straddlers are clipped, and then each is looked at once more ("reference
+            // unsplitting", Stich et al. 4.4): whole on the left, whole on the right, or split -- whichever is cheapest with the sides as they
+            // stand (env MIPT_SBVH_UNSPLIT=0: always split)
+            static const bool unsplit = [] { const char* e = std::getenv("MIPT_SBVH_UNSPLIT"); return e ? std::atoi(e) != 0 : true; }();
+            struct Straddler { Ref whole, a, b; bool hl, hr; };
+            std::vector<Straddler> st;
+            Box BL, BR; BL.reset(); BR.reset();
             for (const Ref& r : refs) {
-                if (r.box.hi[k] <= sp_plane) L.push_back(r);
-                else if (r.box.lo[k] >= sp_plane) R.push_back(r);
+                if (r.box.hi[k] <= sp_plane) { L.push_back(r); BL.grow(r.box); }
+                else if (r.box.lo[k] >= sp_plane) { R.push_back(r); BR.grow(r.box); }
                 else {
                     const float* v = verts + (size_t)r.prim * 9;
-                    Ref a = r, b = r;
-                    const bool hl = clip_tri(v, k, -1e300, (double)sp_plane, r.box, a.box), hr = clip_tri(v, k, (double)sp_plane, 1e300, r.box, b.box);
-                    if (hl) L.push_back(a);
-                    if (hr) R.push_back(b);
-                    if (!hl && !hr) L.push_back(r);                                        // (cannot be: the reference's box straddles the plane)
-                    if (hl && hr) ++added;
+                    Straddler s2; s2.whole = r; s2.a = r; s2.b = r;
+                    s2.hl = clip_tri(v, k, -1e300, (double)sp_plane, r.box, s2.a.box); s2.hr = clip_tri(v, k, (double)sp_plane, 1e300, r.box, s2.b.box);
+                    if (s2.hl) BL.grow(s2.a.box);
+                    if (s2.hr) BR.grow(s2.b.box);
+                    st.push_back(s2);
                 }
+            }
+            size_t NL = L.size(), NR = R.size();
+            for (const Straddler& s2 : st) { NL += s2.hl ? 1u : 0u; NR += s2.hr ? 1u : 0u; }
+            for (const Straddler& s2 : st) {
+                if (!s2.hl && !s2.hr) { L.push_back(s2.whole); continue; }                  // (cannot be: the reference's box straddles the plane)
+                if (!s2.hl) { R.push_back(s2.b); continue; }
+                if (!s2.hr) { L.push_back(s2.a); continue; }
+                int choice = 0;                                                             // 0 split, 1 all left, 2 all right
+                if (unsplit) {
+                    Box bl1 = BL, br2 = BR; bl1.grow(s2.whole.box); br2.grow(s2.whole.box);
+                    const float c_split = BL.half_area() * (float)NL + BR.half_area() * (float)NR;
+                    const float c_left = bl1.half_area() * (float)NL + BR.half_area() * (float)(NR - 1);
+                    const float c_right = BL.half_area() * (float)(NL - 1) + br2.half_area() * (float)NR;
+                    if (c_left < c_split && c_left <= c_right && NR > 1) choice = 1;
+                    else if (c_right < c_split && NL > 1) choice = 2;
+                }
+                if (choice == 1)      { L.push_back(s2.whole); BL.grow(s2.whole.box); --NR; }
+                else if (choice == 2) { R.push_back(s2.whole); BR.grow(s2.whole.box); --NL; }
+                else                  { L.push_back(s2.a); R.push_back(s2.b); ++added; }
             }
             if (!L.empty() && !R.empty() && L.size() < n && R.size() < n && L.size() <= side_cap && R.size() <= side_cap && added <= budget) {
                 budget -= added;

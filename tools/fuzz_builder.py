@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the device SAH builder (MIPT_OPT_BUILD = 2, the default): random scenes of many shapes -- clustered, planar,
-needle-thin, with duplicates and with coordinates of very different magnitudes -- each built twice on the device (the trees must be the
-same bytes) and once on the host; the device tree must be a sound BVH of the scene (the oracle's validator) no deeper than the stack,
+"""Differential fuzz of the device SAH builder (MIPT_OPT_BUILD = 2, the default) and of the host builder with spatial splits (3): random scenes of many shapes -- clustered, planar,
+needle-thin, with duplicates and with coordinates of very different magnitudes -- each built twice by either builder (the trees must be the
+same bytes) and once by the plain host builder; each tree must be a sound BVH of the scene (the oracle's validator) no deeper than the stack,
 and 30 000 rays traced over it must give the host tree's hit records and occlusion flags bit for bit.
 usage (GPU box): python tools/fuzz_builder.py [first_seed] [count]       round 4: seeds 0-39, no failure."""
 import os
@@ -59,13 +59,13 @@ for seed in range(first, first + count):
         dv = torch.from_numpy(verts).cuda()
         inp = [{"vertices": dv.data_ptr(), "num_vertices": verts.shape[0], "stride": 16}]
         res = {}
-        for mode in (2, 0):
+        for mode in (2, 3, 0):
             ctx = api.Context(0)
             ctx.set_option(L.OPT_BUILD, mode)
             h = ctx.accel_build(inp)
             info = ctx.accel_info(h)
             nodes, tris = ctx.accel_export(h)
-            if mode == 2:
+            if mode != 0:
                 h2 = ctx.accel_build(inp)
                 nodes2, tris2 = ctx.accel_export(h2)
                 assert np.array_equal(nodes.view(np.uint32), nodes2.view(np.uint32)) and np.array_equal(tris.view(np.uint32), tris2.view(np.uint32)), "two builds differ"
@@ -89,11 +89,13 @@ for seed in range(first, first + count):
             ctx.trace_closest(h, d_rays.data_ptr(), m, d_hits.data_ptr()); ctx.trace_any(h, d_seg.data_ptr(), m, d_occ.data_ptr()); ctx.sync()
             res[mode] = (d_hits.cpu().numpy(), d_occ.cpu().numpy(), info)
             ctx.destroy()
-        assert np.array_equal(res[2][0].view(np.uint32), res[0][0].view(np.uint32)), "hit records differ"
-        assert np.array_equal(res[2][1], res[0][1]), "occlusion flags differ"
-        print("seed %3d kind %d n %6d ok: %d nodes depth %d (host %d / %d), %d hits, build %.2f ms (host %.1f)" % (
+        for mode in (2, 3):
+            assert np.array_equal(res[mode][0].view(np.uint32), res[0][0].view(np.uint32)), "hit records differ (builder %d)" % mode
+            assert np.array_equal(res[mode][1], res[0][1]), "occlusion flags differ (builder %d)" % mode
+        print("seed %3d kind %d n %6d ok: %d nodes depth %d (host %d / %d; spatial %d / %d over %d records), %d hits, build %.2f ms (host %.1f, spatial %.1f)" % (
             seed, kind, n, res[2][2]["num_nodes"], res[2][2]["depth"], res[0][2]["num_nodes"], res[0][2]["depth"],
-            int((res[2][0][:, 0] >= 0).sum()), res[2][2]["build_seconds"] * 1e3, res[0][2]["build_seconds"] * 1e3), flush=True)
+            res[3][2]["num_nodes"], res[3][2]["depth"], res[3][2]["num_triangles"],
+            int((res[2][0][:, 0] >= 0).sum()), res[2][2]["build_seconds"] * 1e3, res[0][2]["build_seconds"] * 1e3, res[3][2]["build_seconds"] * 1e3), flush=True)
     except Exception as e:                              # noqa: BLE001
         bad += 1
         print("seed %3d kind %d n %6d FAILED: %s" % (seed, kind, n, str(e)[:300]), flush=True)
