@@ -411,6 +411,38 @@ def main():
         step()                               # leave the context in its steady state again
     fence()
 
+    # ---- the same frames over the tree the library's DEFAULT builder makes (MIPT_OPT_BUILD = 2, on the device), beside the headline number:
+    # `value` is measured over the tree --builder asks for (3: spatial splits); one GPU, plain launches only
+    default_builder = None
+    if world == 1 and not sharded and os.environ.get("MIPT_BUILD") != "2":
+        keep_env = os.environ.get("MIPT_BUILD")
+        os.environ["MIPT_BUILD"] = "2"
+        try:
+            st2 = PT.make_state(scene, w, h, SPP, local_rank, max_depth=args.max_depth)
+            info2 = st2.context.accel_info(st2.gas_handle)
+            frame2 = torch.zeros((h, w, 4), dtype=torch.uint8, device=st2.device)
+            st2.params.frame_buffer = frame2.data_ptr(); st2.params.subframe_index = 0
+            torch.cuda.synchronize()
+            for _ in range(max(args.warmup, 5)):
+                st2.context.launch(st2.params, w, h, 1, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            n2 = max(args.steps, 20)
+            t2 = time.perf_counter()
+            for _ in range(n2):
+                st2.context.launch(st2.params, w, h, 1, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t2) / n2 * 1e3
+            default_builder = {"ms_per_step": round(ms2, 4), "bvh_build_s": round(info2["build_seconds"], 4),
+                               "tree": "BVH2 %d nodes depth %d over %d triangle records (MIPT_OPT_BUILD = 2: device binned SAH + SAH treelets)" % (
+                                   info2["num_nodes"], info2["depth"], info2["num_triangles"]),
+                               "identical_frame": bool(torch.equal(frame2, frame) and torch.equal(st2.accum, st.accum))}
+            PT.cleanupState(st2)
+        finally:
+            if keep_env is None:
+                os.environ.pop("MIPT_BUILD", None)
+            else:
+                os.environ["MIPT_BUILD"] = keep_env
+
     # ---- N > 1 (or --force-shard-path): what a rank's step consists of -- render (mipt_launch_shard on the launch stream), gather (the
     # all-gather on the exchange stream), scatter (mipt_unpermute) -- from events in a few extra, untimed steps; max over ranks below
     per_rank = None
@@ -529,6 +561,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather%s" % (
                            world, " (frame k's gather overlaps frame k+1's tracing)" if args.overlap else ""),
                        "bvh_build_s": round(info["build_seconds"], 3), "setup_s": round(build_s, 3),
+                       "default_builder": default_builder,
                        "first_frame_ms": round(first_frame_ms, 4),
                        "first_frame_is": "median of 5 fenced frames launched with no tile cost order (image order), as after any change of "
                                          "camera size, rank or option; ms_per_step is the steady state of identical progressive frames"},
