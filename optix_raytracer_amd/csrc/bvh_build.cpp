@@ -305,8 +305,10 @@ struct SbvhBuilder {
         // ---- spatial split: only where the object split leaves its children overlapping, with references to spare, and depth to spare
         float sp_cost = std::numeric_limits<float>::infinity(); int sp_axis = -1; float sp_plane = 0.0f;
         const uint64_t sp_cap = capacity(depth_cap - depth - 1 - 3);
+        // (env MIPT_SBVH_FORCE=1, tests: a valid spatial split is taken whether it is cheaper or not -- trees full of shared references)
+        static const bool force = [] { const char* e = std::getenv("MIPT_SBVH_FORCE"); return e && std::atoi(e) != 0; }();
         bool try_spatial = n > (uint32_t)leaf_max && budget > 0 && (uint64_t)n <= sp_cap;
-        if (try_spatial && obj_axis >= 0) {
+        if (try_spatial && obj_axis >= 0 && !force) {
             Box ov;
             for (int c = 0; c < 3; ++c) { ov.lo[c] = std::max(obj_l.lo[c], obj_r.lo[c]); ov.hi[c] = std::min(obj_l.hi[c], obj_r.hi[c]); }
             const bool overlap = ov.lo[0] <= ov.hi[0] && ov.lo[1] <= ov.hi[1] && ov.lo[2] <= ov.hi[2];
@@ -345,7 +347,7 @@ struct SbvhBuilder {
         }
         std::vector<Ref> L, R;
         bool done = false;
-        if (sp_axis >= 0 && sp_cost < obj_cost) {
+        if (sp_axis >= 0 && (sp_cost < obj_cost || force)) {
             const int k = sp_axis;
             long long added = 0;
             // the references that lie on one side go there; the straddlers are clipped, and then each is looked at once more ("reference

@@ -414,7 +414,7 @@ __device__ __forceinline__ void pool_round(const __amdgpu_buffer_rsrc_t blob, co
                 // AH: the slot's kAhLevels least keys, level l the (l + 1)-th: every level takes the minimum of what reaches it and hands
                 // the larger key down -- whatever the interleaving with other lanes' candidates, level l ends as the (l + 1)-th least
 #pragma unroll
-                for (int l = 0; l < kAhLevels; ++l) { const unsigned long long prev = atomicMin(&sh_best[l * 64 + slot], key); key = prev > key ? prev : key; }
+                for (int l = 0; l < kAhLevels; ++l) { const unsigned long long prev = atomicMin(&sh_best[l * 64 + slot], key); key = prev == key ? ~0ull : (prev > key ? prev : key); }     // (prev == key: the SAME candidate through another reference -- a tree with spatial splits -- is there already)
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             } else {
                 atomicMin(&sh_best[slot], key);

@@ -1481,7 +1481,11 @@ static float whitted_trace_occlusion(const OrcScene* s, int mode, const OrcWhitt
     int occluded = sh.hit;                                 /* a candidate without any-hit program */
     if (!occluded && l.n) {
         qsort(l.v, l.n, sizeof(OccCand), occ_order);
-        for (size_t i = 0; i < l.n && !occluded; ++i) occluded = anyhit_occlusion(&c, l.v[i].prim, l.v[i].t, l.v[i].u, l.v[i].v);
+        for (size_t i = 0; i < l.n && !occluded; ++i) {
+            /* a tree with spatial splits (MIPT_OPT_BUILD = 3) references a triangle from several leaves: the same candidate, met twice, counts once */
+            if (i && l.v[i].prim == l.v[i - 1].prim && l.v[i].t == l.v[i - 1].t) continue;
+            occluded = anyhit_occlusion(&c, l.v[i].prim, l.v[i].t, l.v[i].u, l.v[i].v);
+        }
     }
     free(l.v);
     return occluded ? 0.0f : c.occlusion;

@@ -995,3 +995,56 @@ def test_device_sah_builder_on_degenerate_inputs(kind, monkeypatch):
     assert np.array_equal(hits[:, 1].view(np.uint32), prim) and np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
     assert (prim != 0xffffffff).sum() > 50
     PT.cleanupState(st)
+
+
+@pytest.mark.parametrize("name", ["soup", "hall"])
+def test_forced_spatial_splits_lose_no_hit(name, tmp_path, monkeypatch):
+    """MIPT_SBVH_FORCE=1 with a reference budget of four times the triangle count: the host builder takes EVERY valid spatial split, so
+    the tree is full of triangles referenced from several leaves through small clipped boxes -- the hardest case for the claim that the
+    clipped bounds are conservative.  Frames, counters and 60 k hit records must equal those over the plain host tree bit for bit, the
+    records also the brute-force intersector's."""
+    torch = _torch()
+    from optix_raytracer_amd import _lib as L
+    from optix_raytracer_amd import pathtracer as PT
+    from optix_raytracer_amd import scenes
+    # (a soup of triangles five times as large as the gaps between them; the hall: walls and a floor around 1 500 boxes)
+    scene = scenes.random_soup(30000, edge_scale=0.05) if name == "soup" else scenes.from_gltf(scenes.write_rooms_gltf(tmp_path / "hall.gltf", n_boxes=1500))
+    w, h = 160, 120
+    out = {}
+    for mode in (0, 3):
+        if mode == 3:
+            monkeypatch.setenv("MIPT_SBVH_FORCE", "1"); monkeypatch.setenv("MIPT_SBVH_EXTRA", "4")
+        st = PT.PathTracerState()
+        PT.createContext(st, 0)
+        st.context.set_option(L.OPT_BUILD, mode)
+        PT.buildMeshAccel(st, scene)
+        PT.createSBT(st)
+        PT.initLaunchParams(st, w, h, 2)
+        cam = scene["camera"]
+        PT.handleCameraUpdate(st, PT.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], 1.0))
+        st.context.set_option(L.OPT_MAX_DEPTH, 4)
+        acc, frame, stats = _render_gpu(PT, st)
+        info = st.context.accel_info(st.gas_handle)
+        nodes, tris = st.context.accel_export(st.gas_handle)
+        osc = O.Scene(scene).set_bvh(nodes, tris)
+        rays = osc.primary_rays(scenes.launch_desc(scene, 320, 200))[::1]
+        rng = np.random.default_rng(3)
+        extra = np.zeros((20000, 8), np.float32)
+        lo, hi = scene["vertices"][:, :3].min(0), scene["vertices"][:, :3].max(0)
+        extra[:, :3] = lo + rng.uniform(0, 1, (20000, 3)) * (hi - lo)
+        extra[:, 4:7] = rng.normal(size=(20000, 3)); extra[:, 4:7] /= np.linalg.norm(extra[:, 4:7], axis=1, keepdims=True)
+        extra[:, 3], extra[:, 7] = 1e-4, 1e16
+        rays = np.ascontiguousarray(np.concatenate([rays[:40000], extra]), np.float32)
+        d_rays = torch.from_numpy(rays).cuda()
+        d_hits = torch.zeros((rays.shape[0], 4), dtype=torch.float32, device="cuda")
+        st.context.trace_closest(st.gas_handle, d_rays.data_ptr(), rays.shape[0], d_hits.data_ptr()); st.context.sync()
+        out[mode] = (acc, frame, stats, d_hits.cpu().numpy(), info)
+        if mode == 3:
+            assert info["num_triangles"] > 1.15 * out[0][4]["num_triangles"]             # shared references all over the tree
+            t, prim, u, v = osc.trace_closest(rays, O.MODE_BRUTE)
+            hg = out[3][3]
+            assert np.array_equal(hg[:, 1].view(np.uint32), prim) and np.array_equal(hg[:, 0].view(np.uint32), t.view(np.uint32))
+        PT.cleanupState(st)
+    assert np.array_equal(out[0][0].view(np.uint32), out[3][0].view(np.uint32)) and np.array_equal(out[0][1], out[3][1])
+    assert out[0][2]["closest_rays"] == out[3][2]["closest_rays"] and out[0][2]["shadow_rays"] == out[3][2]["shadow_rays"]
+    assert np.array_equal(out[0][3].view(np.uint32), out[3][3].view(np.uint32))

@@ -493,7 +493,7 @@ def test_oracle_blend_depth_limit():
     assert st["closest_rays"] == 8 * 8 * 8
 
 
-def _alpha_frames_match_the_oracle(gltf, w, h, subframes, persistent=None, deep=None):
+def _alpha_frames_match_the_oracle(gltf, w, h, subframes, persistent=None, deep=None, spatial=False):
     import torch
     assert torch.cuda.is_available()
     from optix_raytracer_amd import meshviewer as MV
@@ -517,6 +517,8 @@ def _alpha_frames_match_the_oracle(gltf, w, h, subframes, persistent=None, deep=
         st.params.subframe_index += 1
     if deep:
         assert st.context.accel_info(st.handle)["depth"] > 8                   # the entry-pool form of the any-hit kernels ran (wh_trace_on_pool)
+    if spatial:          # the tree holds more triangle records than the scene has triangles: some are referenced from several leaves
+        assert st.context.accel_info(st.handle)["num_triangles"] > st.scene.info()["num_triangles"]
     nodes, tris = st.context.accel_export(st.handle)
     sc, mats, lts, mat, normals = _oracle_for_state(st, nodes, tris)
     for m, sm in zip(mats, st.scene.materials()):
@@ -564,6 +566,19 @@ def test_deferred_any_hit_programs_over_many_layers(tmp_path, monkeypatch, stack
     (ah_box_interval) -- without it 300-800 pixels of these frames differ.  (Formats 1 / 2 round boxes outward to fp16 and hide it.)"""
     monkeypatch.setenv("MIPT_NODE_FORMAT", str(node_format))
     _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path, stack=stack, tess=tess), 120, 80, 2, persistent=persistent, deep=tess > 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stack,tess,persistent", [(24, 24, None), (24, 24, 2), (7, 1, None)])
+def test_deferred_any_hit_programs_over_a_tree_with_spatial_splits(tmp_path, monkeypatch, stack, tess, persistent):
+    """MIPT_OPT_BUILD = 3: a triangle that straddles a split plane is referenced from several leaves, so a ray can meet the SAME candidate
+    -- the same (t, primitive) key -- through two references.  The program must run on it once: the pool's candidate levels drop a key
+    that is there already (pool_trace.h), the one-ray-per-thread walk continues strictly beyond (t, primitive), and the oracle -- which
+    collects, sorts and multiplies -- skips a repeated candidate.  The stacked panes over the tessellated ground (large quads among
+    small triangles: where spatial splits happen), every frame against the oracle bit for bit."""
+    monkeypatch.setenv("MIPT_BUILD", "3")
+    monkeypatch.setenv("MIPT_SBVH_FORCE", "1")          # every valid spatial split is taken: references are shared wherever a triangle straddles a plane
+    _alpha_frames_match_the_oracle(FX.write_alpha(tmp_path, stack=stack, tess=tess), 120, 80, 2, persistent=persistent, deep=tess > 1, spatial=True)
 
 
 @pytest.mark.gpu
