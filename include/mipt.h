@@ -311,6 +311,9 @@ int mipt_accel_export_instances(const MiptContext* ctx, unsigned long long handl
  * without a GPU.  vertices9: num_triangles * 9 floats (v0 v1 v2, world space). */
 typedef struct MiptHostBvh MiptHostBvh;
 int mipt_host_bvh_create(const float* vertices9, uint32_t num_triangles, MiptHostBvh** out);
+/* the tree of MIPT_OPT_BUILD = 3 (spatial splits; `extra`: added references per triangle at most, 0..4; mipt_host_bvh_info's
+ * num_triangles counts the triangle RECORDS, duplicates included) */
+int mipt_host_bvh_create_spatial(const float* vertices9, uint32_t num_triangles, float extra, MiptHostBvh** out);
 int mipt_host_bvh_info(const MiptHostBvh* bvh, MiptAccelInfo* info);
 int mipt_host_bvh_copy(const MiptHostBvh* bvh, MiptBvhNode* nodes_out, MiptBvhTri* tris_out);
 int mipt_host_bvh_destroy(MiptHostBvh* bvh);

@@ -173,6 +173,7 @@ SYMBOLS = [
     ("mipt_accel_update_instances", C.c_int, [_vp, C.c_ulonglong, _vp, _u32]),
     ("mipt_accel_export_instances", C.c_int, [_vp, C.c_ulonglong, _vp, _vp, _vp, _vp, _vp]),
     ("mipt_host_bvh_create", C.c_int, [_vp, _u32, C.POINTER(_vp)]),
+    ("mipt_host_bvh_create_spatial", C.c_int, [_vp, _u32, C.c_float, C.POINTER(_vp)]),
     ("mipt_host_bvh_info", C.c_int, [_vp, C.POINTER(MiptAccelInfo)]),
     ("mipt_host_bvh_copy", C.c_int, [_vp, _vp, _vp]),
     ("mipt_host_bvh_destroy", C.c_int, [_vp]),

@@ -50,13 +50,17 @@ def shard_pixel(width, height, world, rank, sample):
     return x.value, y.value
 
 
-def host_bvh(vertices4):
+def host_bvh(vertices4, spatial=None):
     """Builds the BVH on the host only (no GPU): returns (nodes (n,16) f32 view of 64-B nodes,
-    tris (m,12) f32 view of 48-B triangles, info dict).  vertices4: (n*3, 4) float32."""
+    tris (m,12) f32 view of 48-B triangles, info dict).  vertices4: (n*3, 4) float32.  spatial: None = the object-split
+    builder; a float = the builder with spatial splits (MIPT_OPT_BUILD = 3) and that many extra references per triangle."""
     lib = L.load()
     v = np.ascontiguousarray(np.asarray(vertices4, np.float32).reshape(-1, 4)[:, :3]).reshape(-1, 9)
     h = C.c_void_p()
-    rc = lib.mipt_host_bvh_create(v.ctypes.data, v.shape[0], C.byref(h))
+    if spatial is None:
+        rc = lib.mipt_host_bvh_create(v.ctypes.data, v.shape[0], C.byref(h))
+    else:
+        rc = lib.mipt_host_bvh_create_spatial(v.ctypes.data, v.shape[0], float(spatial), C.byref(h))
     if rc:
         raise MiptError(rc, lib.mipt_error_name(rc).decode(), "mipt_host_bvh_create")
     try:

@@ -418,9 +418,6 @@ struct SbvhBuilder {
         for (const Ref& r : R) br.grow(r.box);
         if (R.empty()) std::memset(&br, 0, sizeof br);
         if (L.empty()) std::memset(&bl, 0, sizeof bl);
-        std::vector<uint32_t> lp, rp;                                                        // the sides' primitives, should they become leaves
-        for (const Ref& r : L) lp.push_back(r.prim);
-        for (const Ref& r : R) rp.push_back(r.prim);
         const long long bl_budget = L.size() + R.size() ? (long long)((double)budget * (double)L.size() / (double)(L.size() + R.size())) : 0, br_budget = budget - bl_budget;
         std::future<int> fut; bool spawned = false;
         if (n > 32768 && tasks.load(std::memory_order_relaxed) < max_tasks) {
@@ -431,8 +428,8 @@ struct SbvhBuilder {
         const int cl = spawned ? fut.get() : build(L, depth + 1, false, bl_budget);
         SNode& nd = node(me);
         nd.box[0] = bl; nd.box[1] = br; nd.child[0] = cl; nd.child[1] = cr;
-        if (cl < 0) nd.leaf[0] = std::move(lp);
-        if (cr < 0) nd.leaf[1] = std::move(rp);
+        if (cl < 0) for (const Ref& r : L) nd.leaf[0].push_back(r.prim);                   // (a side that stays a leaf: build() left its references alone)
+        if (cr < 0) for (const Ref& r : R) nd.leaf[1].push_back(r.prim);
         return me;
     }
 };

@@ -369,6 +369,7 @@ TraceOpts trace_opts(const MiptContext* c)
 int default_build_threads()
 {
     int threads = (int)std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("MIPT_BUILD_THREADS")) { const int v = std::atoi(e); if (v >= 1) threads = v; }     // (tests: the tree does not depend on it)
     return threads < 1 ? 1 : (threads > 32 ? 32 : threads);
 }
 
@@ -1461,6 +1462,18 @@ int mipt_host_bvh_create(const float* vertices9, uint32_t num_triangles, MiptHos
     if (!out || (num_triangles && !vertices9)) return MIPT_ERROR_INVALID_VALUE;
     MiptHostBvh* h = new MiptHostBvh();
     if (!build_bvh(vertices9, num_triangles, 4, kStackEntries, default_build_threads(), h->bvh)) { delete h; return MIPT_ERROR_BVH_TOO_DEEP; }
+    *out = h;
+    return MIPT_SUCCESS;
+}
+
+int mipt_host_bvh_create_spatial(const float* vertices9, uint32_t num_triangles, float extra, MiptHostBvh** out)
+{
+    if (!out || (num_triangles && !vertices9) || !(extra >= 0.0f) || extra > 4.0f) return MIPT_ERROR_INVALID_VALUE;
+    MiptHostBvh* h = new MiptHostBvh();
+    // (as mipt_accel_build with MIPT_OPT_BUILD = 3: inputs the spatial builder does not take get the object-split tree)
+    const bool ok = (num_triangles > 4u && build_sbvh(vertices9, num_triangles, 4, kStackEntries, default_build_threads(), extra, h->bvh)) ||
+                    build_bvh(vertices9, num_triangles, 4, kStackEntries, default_build_threads(), h->bvh);
+    if (!ok) { delete h; return MIPT_ERROR_BVH_TOO_DEEP; }
     *out = h;
     return MIPT_SUCCESS;
 }

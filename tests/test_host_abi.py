@@ -199,6 +199,56 @@ def test_product_bvh_is_deterministic():
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("name,n", [("cornell", 0), ("soup", 5), ("soup", 7), ("soup", 5000), ("soup", 60000), ("dense", 20000)])
+def test_spatial_split_bvh_is_sound_and_brute_force_equivalent(name, n, monkeypatch):
+    """MIPT_OPT_BUILD = 3 (bvh_build.cpp, build_sbvh): triangles may sit in several leaves, each under boxes that bound the part of the
+    triangle inside that node's region -- the oracle's validator checks exactly that, and no hit is lost or changed against brute force.
+    ("dense": triangles several cells long, where the builder does split; the plain soup's tree at this size has few duplicates)"""
+    if name == "cornell":
+        sc = scenes.cornell_box()
+    elif name == "dense":
+        sc = scenes.random_soup(n, edge_scale=0.05)
+    else:
+        sc = scenes.random_soup(n)
+    n_tris = sc["vertices"].shape[0] // 3
+    nodes, tris, info = api.host_bvh(sc["vertices"], spatial=0.5)
+    assert info["depth"] <= 32 and info["leaf_max"] == 4
+    assert n_tris <= info["num_triangles"] <= int(n_tris * 1.5) + 1
+    prims = tris.view(np.uint32)[:, 3]
+    assert np.array_equal(np.unique(prims), np.arange(n_tris))          # every triangle is referenced
+    if name == "dense":
+        assert info["num_triangles"] > 1.1 * n_tris                      # ... and here many are referenced more than once
+    s = O.Scene(sc).set_bvh(nodes, tris)
+    rng = np.random.default_rng(n + 1)
+    lo, hi = (0.0, 556.0) if name == "cornell" else (-0.3, 1.3)
+    o = rng.uniform(lo, hi, size=(4000, 3))
+    tgt = rng.uniform(lo + 0.3 * (hi - lo), hi - 0.3 * (hi - lo), size=(4000, 3))
+    rays = np.zeros((4000, 8), np.float32)
+    rays[:, :3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, 0.01, tgt - o, 1e16
+    t0, p0, _, _ = s.trace_closest(rays, O.MODE_BRUTE)
+    t1, p1, _, _ = s.trace_closest(rays, O.MODE_BVH)
+    assert np.array_equal(p0, p1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    seg = rays.copy()
+    seg[:, 7] = 0.5
+    assert np.array_equal(s.trace_any(seg, O.MODE_BRUTE), s.trace_any(seg, O.MODE_BVH))
+    # the same tree whatever the number of builder threads (the reference budget is handed down the tree, not drawn from a shared counter)
+    monkeypatch.setenv("MIPT_BUILD_THREADS", "1")
+    nodes1, tris1, _ = api.host_bvh(sc["vertices"], spatial=0.5)
+    assert np.array_equal(nodes.view(np.uint32), nodes1.view(np.uint32)) and np.array_equal(tris.view(np.uint32), tris1.view(np.uint32))
+
+
+def test_spatial_split_budget_is_kept():
+    sc = scenes.random_soup(20000, edge_scale=0.05)
+    n = sc["vertices"].shape[0] // 3
+    for extra in (0.0, 0.1, 1.0):
+        _, tris, info = api.host_bvh(sc["vertices"], spatial=extra)
+        assert n <= info["num_triangles"] <= int(n * (1.0 + extra))
+        if extra == 0.0:
+            assert info["num_triangles"] == n
+    with pytest.raises(api.MiptError):
+        api.host_bvh(sc["vertices"], spatial=-1.0)
+
+
 def test_header_is_plain_c(tmp_path):
     """the drop-in boundary is a C ABI: include/mipt.h compiles as C99 without warnings, and the layouts the reference's
     structs must keep have the sizes SURVEY.md 8a lists"""
