@@ -307,14 +307,21 @@ struct SbvhBuilder {
         const uint64_t sp_cap = capacity(depth_cap - depth - 1 - 3);
         // (env MIPT_SBVH_FORCE=1, tests: a valid spatial split is taken whether it is cheaper or not -- trees full of shared references)
         static const bool force = [] { const char* e = std::getenv("MIPT_SBVH_FORCE"); return e && std::atoi(e) != 0; }();
-        bool try_spatial = n > (uint32_t)leaf_max && budget > 0 && (uint64_t)n <= sp_cap;
+        // (env MIPT_SBVH_MAX_N / MIPT_SBVH_MIN_N, experiments: spatial splits only at nodes of that many references)
+        static const uint32_t sp_max_n = [] { const char* e = std::getenv("MIPT_SBVH_MAX_N"); return e ? (uint32_t)std::atoll(e) : 0xffffffffu; }();
+        static const uint32_t sp_min_n = [] { const char* e = std::getenv("MIPT_SBVH_MIN_N"); return e ? (uint32_t)std::atoll(e) : 0u; }();
+        bool try_spatial = n > (uint32_t)leaf_max && budget > 0 && (uint64_t)n <= sp_cap && n <= sp_max_n && n >= sp_min_n;
         if (try_spatial && obj_axis >= 0 && !force) {
             Box ov;
             for (int c = 0; c < 3; ++c) { ov.lo[c] = std::max(obj_l.lo[c], obj_r.lo[c]); ov.hi[c] = std::min(obj_l.hi[c], obj_r.hi[c]); }
             const bool overlap = ov.lo[0] <= ov.hi[0] && ov.lo[1] <= ov.hi[1] && ov.lo[2] <= ov.hi[2];
             try_spatial = overlap && ov.half_area() > 1e-5f * root_area;
         }
-        if (try_spatial) {
+        // (env MIPT_SBVH_SIMPLE=1, experiment: the only spatial candidate is the object split's own plane, taken whenever it is tried)
+        static const bool simple = [] { const char* e = std::getenv("MIPT_SBVH_SIMPLE"); return e && std::atoi(e) != 0; }();
+        if (try_spatial && simple) {
+            if (obj_axis >= 0) { sp_axis = obj_axis; sp_plane = cb.lo[obj_axis] + (float)(obj_bin + 1) / scale[obj_axis]; sp_cost = -1.0f; }
+        } else if (try_spatial) {
             for (int k = 0; k < 3; ++k) {
                 const double lo = bounds.lo[k], ext = (double)bounds.hi[k] - lo;
                 if (!(ext > 0.0) || !std::isfinite(ext)) continue;

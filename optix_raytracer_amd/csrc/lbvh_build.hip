@@ -7,7 +7,9 @@
 // which builder made the tree (closest hit: min t, tie -> lowest primitive).
 #include <hipcub/hipcub.hpp>
 
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "kernels.h"
 #include "detmath.h"
@@ -821,6 +823,396 @@ __global__ void k_sah_root(SahSeg* segs, SahSeg* smalls, const uint32_t* scene, 
     counts[0] = small ? 0u : 1u; counts[1] = 0u; counts[2] = small ? 1u : 0u;
 }
 
+// ---- spatial splits in the level loop (round 4, MIPT_OPT_BUILD = 4) ---------------------------------------------------------------------
+// What bvh_build.cpp's build_sbvh buys (references that straddle a split plane are cut in two, so the children do not overlap along
+// that axis; 1 M-triangle soup: SAH cost 537 -> 500, the headline frame 0.555 -> 0.52 ms) in its cheapest form, which measured as good as
+// the full algorithm there: the plane is the OBJECT split's own plane (no spatial binning, no chopped clipping of every reference into
+// every bin), and every reference whose box straddles it is cut whenever the split's two sides overlap noticeably and the range has
+// references to spare (`budget`, handed down in proportion to the sides' sizes, as the host builder does).
+// The ITEMS of the builder become references: an id into a pool of (box, primitive) pairs -- ids 0 .. n-1 are the triangles, a cut
+// keeps the id for its left part (the box shrinks in place) and takes a new id for the right part.  Ranges GROW when cut, so the level
+// loop no longer works in place: a range's two sides are counted first (k_sp_count), then given room -- a side that stays open in the next
+// level's buffer, a side of at most `ret_below` references in the buffer of RETIRED ranges -- by a bump allocator (k_sp_alloc), then
+// written (k_sp_partition).  Where ranges lie in those buffers depends on the run; the tree of the ranges (SpNode) does not, and the host
+// lays the retired ranges out in its depth-first order afterwards (a few thousand nodes): positions, Karras' node numbers and links
+// follow from that (k_sp_layout sorts each retired range by primitive number, so the order inside is a function of the input as well).
+// Everything after -- k_sah_small over the retired ranges, treelets, box fitting, emission -- sees n' items with given boxes.
+// A reference's box is the bounds of the part of its triangle inside the cuts so far: the clip is computed in double and rounded
+// outward, then cut by the box it had (bvh_build.cpp: clip_tri), so a point of the triangle inside a node's region lies in the box of the
+// reference that region holds, and hit records stay a brute-force intersector's.
+struct SpSplit {
+    int lo, cnt, axis, bin, median, cut, nl_obj, tnode, depth, budget;
+    float cb_lo, scale, plane;
+    uint32_t child[2], base[2], ret[2];           // child: the side's slot in the next level or kSahNone; base: offset of its room; ret: its retired record or kSahNone
+    uint32_t pcb[6];                              // the range's centroid bounds (a median split hands them to both sides)
+};
+struct SpNode { int parent, child[2]; };          // child >= 0: a node of this list; < 0: ~(index of a retired range)
+struct SpRet { uint32_t off, size, final_off; int parent, side, depth; uint32_t cb[6]; };
+constexpr int kSpTables = 16;
+
+__device__ __forceinline__ float sp_down(double x)
+{
+    float f = (float)x;
+    if ((double)f > x) { uint32_t u = f2u(f); u = f > 0.0f ? u - 1u : (f < 0.0f ? u + 1u : 0x80000001u); f = u2f(u); }
+    return f;
+}
+__device__ __forceinline__ float sp_up(double x)
+{
+    float f = (float)x;
+    if ((double)f < x) { uint32_t u = f2u(f); u = f > 0.0f ? u + 1u : (f < 0.0f ? u - 1u : 0x00000001u); f = u2f(u); }
+    return f;
+}
+// bounds of { p in triangle : p[k] <= pl } (upper = false) or { p[k] >= pl } (upper = true), cut by `within`; false when empty
+__device__ __forceinline__ bool sp_clip_half(const float* __restrict__ v, int k, double pl, bool upper, const Box6& within, Box6& out)
+{
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    bool any = false;
+    for (int i = 0; i < 3; ++i) {
+        const int j = i == 2 ? 0 : i + 1;
+        const double p[3] = { (double)v[3 * i], (double)v[3 * i + 1], (double)v[3 * i + 2] }, q[3] = { (double)v[3 * j], (double)v[3 * j + 1], (double)v[3 * j + 2] };
+        const double pk = k == 0 ? p[0] : (k == 1 ? p[1] : p[2]), qk = k == 0 ? q[0] : (k == 1 ? q[1] : q[2]);
+        if (upper ? pk >= pl : pk <= pl) { any = true; for (int c = 0; c < 3; ++c) { lo[c] = fmin(lo[c], p[c]); hi[c] = fmax(hi[c], p[c]); } }
+        if ((pk < pl && qk > pl) || (pk > pl && qk < pl)) {
+            const double t = (pl - pk) / (qk - pk);
+            double x[3] = { p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1]), p[2] + t * (q[2] - p[2]) };
+            if (k == 0) x[0] = pl; else if (k == 1) x[1] = pl; else x[2] = pl;
+            any = true;
+            for (int c = 0; c < 3; ++c) { lo[c] = fmin(lo[c], x[c]); hi[c] = fmax(hi[c], x[c]); }
+        }
+    }
+    if (!any) return false;
+    bool ok = true;
+    for (int c = 0; c < 3; ++c) {
+        out.lo[c] = fmaxf(within.lo[c], sp_down(lo[c]));
+        out.hi[c] = fminf(within.hi[c], sp_up(hi[c]));
+        ok = ok && out.lo[c] <= out.hi[c];
+    }
+    return ok;
+}
+// where a reference goes when its range is cut at `plane` along `k`: 0 left, 1 right (its box as it is); 2 both (bl, br: the parts);
+// 3 left / 4 right with the clipped box (the box straddles the plane, the triangle inside it does not)
+__device__ __forceinline__ int sp_classify(const Box6& b, int k, float plane, const float* __restrict__ v, Box6& bl, Box6& br)
+{
+    const float lo = k == 0 ? b.lo[0] : (k == 1 ? b.lo[1] : b.lo[2]), hi = k == 0 ? b.hi[0] : (k == 1 ? b.hi[1] : b.hi[2]);
+    if (hi <= plane) return 0;
+    if (lo >= plane) return 1;
+    const bool hl = sp_clip_half(v, k, (double)plane, false, b, bl), hr = sp_clip_half(v, k, (double)plane, true, b, br);
+    if (hl && hr) return 2;
+    if (hl) return 3;
+    if (hr) return 4;
+    return 0;
+}
+
+// the sweep of k_sah_split + the decision to cut.  One wave per open range.
+__global__ __launch_bounds__(64) void k_sp_split(const SahSeg* __restrict__ cur, const int* __restrict__ budgets, const uint32_t* __restrict__ n_cur_p, uint32_t* bins,
+                                                 SpSplit* splits, uint32_t* cnt2, int leaf_max, int depth_cap, float* root_area_p)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= *n_cur_p) return;
+    const int lane = (int)threadIdx.x;
+    const SahSeg sg = cur[s];
+    uint32_t* B = bins + (size_t)s * kSahSegWords;
+    const int cnt = sg.hi - sg.lo + 1;
+    float best = __builtin_inff(); int best_axis = -1, best_bin = -1, best_nl = 0;
+    for (int k = 0; k < 3; ++k) {
+        float c; int b, nl;
+        sah_sweep_axis(B, k, sg, lane, leaf_max, depth_cap, c, b, nl);
+        if (c < best) { best = c; best_axis = k; best_bin = b; best_nl = nl; }
+    }
+    // the two sides' boxes at the chosen split: unions of the bins' boxes (lane = bin again)
+    float ov_area = 0.0f, all_area = 0.0f;
+    if (best_axis >= 0) {
+        const bool has = lane < kSahBins;
+        const uint32_t* w = B + (best_axis * kSahBins + (has ? lane : 0)) * kSahBinWords;
+        uint32_t v[kSahBinWords];
+        for (int c = 0; c < kSahBinWords; ++c) v[c] = w[c];
+        const bool in = has && v[0] != 0u;
+        uint32_t l_lo[3], l_hi[3], r_lo[3], r_hi[3];
+        for (int c = 0; c < 3; ++c) {
+            l_lo[c] = in && lane <= best_bin ? v[1 + c] : 0xffffffffu; l_hi[c] = in && lane <= best_bin ? v[4 + c] : 0u;
+            r_lo[c] = in && lane > best_bin ? v[1 + c] : 0xffffffffu;  r_hi[c] = in && lane > best_bin ? v[4 + c] : 0u;
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t a0 = (uint32_t)__shfl_xor((int)l_lo[c], off, 64), a1 = (uint32_t)__shfl_xor((int)l_hi[c], off, 64);
+                const uint32_t a2 = (uint32_t)__shfl_xor((int)r_lo[c], off, 64), a3 = (uint32_t)__shfl_xor((int)r_hi[c], off, 64);
+                l_lo[c] = a0 < l_lo[c] ? a0 : l_lo[c]; l_hi[c] = a1 > l_hi[c] ? a1 : l_hi[c];
+                r_lo[c] = a2 < r_lo[c] ? a2 : r_lo[c]; r_hi[c] = a3 > r_hi[c] ? a3 : r_hi[c];
+            }
+        uint32_t o_lo[3], o_hi[3], u_lo[3], u_hi[3];
+        bool overlap = true;
+        for (int c = 0; c < 3; ++c) {
+            o_lo[c] = l_lo[c] > r_lo[c] ? l_lo[c] : r_lo[c]; o_hi[c] = l_hi[c] < r_hi[c] ? l_hi[c] : r_hi[c];
+            u_lo[c] = l_lo[c] < r_lo[c] ? l_lo[c] : r_lo[c]; u_hi[c] = l_hi[c] > r_hi[c] ? l_hi[c] : r_hi[c];
+            overlap = overlap && o_lo[c] <= o_hi[c];
+        }
+        ov_area = overlap ? sah_area(o_lo, o_hi) : 0.0f;
+        all_area = sah_area(u_lo, u_hi);
+    }
+    for (int w = lane; w < kSahSegWords; w += 64) B[w] = sah_word_identity(w);           // the slot's bins, ready for the next level
+    if (lane != 0) return;
+    if (sg.depth == 0) *root_area_p = all_area;                                          // (one range at the first level: later launches read it)
+    const float root_area = sg.depth == 0 ? all_area : *root_area_p;
+    SpSplit sp;
+    sp.lo = sg.lo; sp.cnt = cnt; sp.median = best_axis < 0 ? 1 : 0;
+    sp.axis = sp.median ? 0 : best_axis; sp.bin = best_bin; sp.nl_obj = best_nl;
+    sp.tnode = sg.node; sp.depth = sg.depth; sp.budget = budgets[s];
+    sp.cb_lo = 0.0f; sp.scale = 0.0f; sp.plane = 0.0f; sp.cut = 0;
+    for (int q = 0; q < 6; ++q) sp.pcb[q] = sg.cb[q];
+    if (!sp.median) {
+        const float cl = f_unord(sg.cb[best_axis]), ext = f_unord(sg.cb[3 + best_axis]) - cl;
+        sp.cb_lo = cl; sp.scale = (float)kSahBins / ext;
+        sp.plane = cl + (float)(best_bin + 1) / sp.scale;
+        // as build_sbvh: only where the object split leaves its sides overlapping, with references and depth to spare
+        int levels = depth_cap - sg.depth - 1 - 4 - 3;
+        levels = levels < 0 ? 0 : (levels > 40 ? 40 : levels);
+        const unsigned long long sp_cap = (unsigned long long)leaf_max << levels;
+        sp.cut = sp.budget > 0 && cnt > leaf_max && (unsigned long long)cnt <= sp_cap && ov_area > 1e-5f * root_area && sp.plane == sp.plane ? 1 : 0;
+    }
+    for (int side = 0; side < 2; ++side) { sp.child[side] = kSahNone; sp.base[side] = 0u; sp.ret[side] = kSahNone; }
+    splits[s] = sp;
+    cnt2[2u * s] = 0u; cnt2[2u * s + 1u] = 0u;
+}
+
+// how many references each side of a cut range gets (a chunk of 2048 positions per workgroup, LDS counters per range, one global atomic
+// per chunk, range and side)
+__global__ __launch_bounds__(256) void k_sp_count(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ seg_of, const SpSplit* __restrict__ splits, uint32_t n_pos,
+                                                  const Box6* __restrict__ pbox, const uint32_t* __restrict__ pprim, const float* __restrict__ world, uint32_t* cnt2)
+{
+    __shared__ uint32_t s_dir[kSpTables], s_cnt[kSpTables][2];
+    for (uint32_t chunk = blockIdx.x; (size_t)chunk * kSahChunk < n_pos; chunk += gridDim.x) {
+        const uint32_t first = chunk * (uint32_t)kSahChunk;
+        if (threadIdx.x < (uint32_t)kSpTables) { s_dir[threadIdx.x] = kSahNone; s_cnt[threadIdx.x][0] = 0u; s_cnt[threadIdx.x][1] = 0u; }
+        __syncthreads();
+        for (uint32_t p = first + threadIdx.x; p < first + (uint32_t)kSahChunk && p < n_pos; p += 256u) {
+            const uint32_t s = seg_of[p];
+            const SpSplit sp = splits[s];
+            if (!sp.cut) continue;
+            const uint32_t id = ids[p];
+            Box6 bl, br;
+            const int cls = sp_classify(pbox[id], sp.axis, sp.plane, world + (size_t)pprim[id] * 9, bl, br);
+            const bool tl = cls == 0 || cls == 2 || cls == 3, tr = cls == 1 || cls == 2 || cls == 4;
+            const uint32_t h = s & (uint32_t)(kSpTables - 1);
+            uint32_t owner = s_dir[h];
+            if (owner == kSahNone) { owner = atomicCAS(&s_dir[h], kSahNone, s); if (owner == kSahNone) owner = s; }
+            if (owner == s) { if (tl) atomicAdd(&s_cnt[h][0], 1u); if (tr) atomicAdd(&s_cnt[h][1], 1u); }
+            else            { if (tl) atomicAdd(&cnt2[2u * s], 1u); if (tr) atomicAdd(&cnt2[2u * s + 1u], 1u); }
+        }
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)kSpTables * 2u) {
+            const uint32_t h = threadIdx.x >> 1, side = threadIdx.x & 1u, sid = s_dir[h], c = s_cnt[h][side];
+            if (sid != kSahNone && c != 0u) atomicAdd(&cnt2[2u * sid + side], c);
+        }
+        __syncthreads();
+    }
+}
+
+// room for every range's two sides.  cur[0 .. 3]: the bump allocators -- next level's buffer, retired buffer, nodes, retired records
+__global__ __launch_bounds__(256) void k_sp_alloc(SpSplit* splits, const uint32_t* __restrict__ n_cur_p, const uint32_t* __restrict__ cnt2, uint32_t* fill, SahSeg* next,
+                                                  int* next_budget, uint32_t* n_next, uint32_t* cursors, SpNode* tnodes, SpRet* rets, int leaf_max, int depth_cap,
+                                                  int ret_below, uint32_t max_segs, uint32_t max_rets)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= *n_cur_p) return;
+    SpSplit sp = splits[s];
+    int nl, nr, added = 0;
+    if (sp.cut) {
+        nl = (int)cnt2[2u * s]; nr = (int)cnt2[2u * s + 1u]; added = nl + nr - sp.cnt;
+        int levels = depth_cap - sp.depth - 1 - 4;
+        levels = levels < 0 ? 0 : (levels > 40 ? 40 : levels);
+        const long long side_cap = (long long)leaf_max << levels;
+        if (!(nl > 0 && nr > 0 && nl < sp.cnt && nr < sp.cnt && nl <= side_cap && nr <= side_cap && added >= 0 && added <= sp.budget)) sp.cut = 0;
+    }
+    if (!sp.cut) { nl = sp.median ? sp.cnt / 2 : sp.nl_obj; nr = sp.cnt - nl; added = 0; }
+    const int rem = sp.budget - added;
+    const int bud_l = (int)((double)rem * (double)nl / (double)(nl + nr)), bud_r = rem - bud_l;
+    for (int side = 0; side < 2; ++side) {
+        const int sz = side == 0 ? nl : nr;
+        uint32_t cb[6];
+        for (int q = 0; q < 6; ++q) cb[q] = sp.median ? sp.pcb[q] : (q < 3 ? 0xffffffffu : 0u);
+        if (sz > ret_below) {
+            uint32_t slot = atomicAdd(n_next, 1u), tn = atomicAdd(&cursors[2], 1u);
+            const uint32_t base = atomicAdd(&cursors[0], (uint32_t)sz);
+            // (a list that is full: the counters tell the host, which gives the input up; until then everything stays inside the arrays)
+            if (slot >= max_segs) slot = max_segs - 1u;
+            if (tn >= max_rets) tn = max_rets - 1u;
+            sp.child[side] = slot; sp.base[side] = base; sp.ret[side] = kSahNone;
+            SahSeg ns; ns.lo = (int)base; ns.hi = (int)base + sz - 1; ns.node = (int)tn; ns.depth = sp.depth + 1;
+            for (int q = 0; q < 6; ++q) ns.cb[q] = cb[q];
+            next[slot] = ns; next_budget[slot] = side == 0 ? bud_l : bud_r;
+            tnodes[tn].parent = sp.tnode; tnodes[sp.tnode].child[side] = (int)tn;
+        } else {
+            uint32_t r = atomicAdd(&cursors[3], 1u);
+            const uint32_t base = atomicAdd(&cursors[1], (uint32_t)sz);
+            if (r > max_rets) r = max_rets;                                            // (the list holds max_rets + 1 records)
+            sp.child[side] = kSahNone; sp.base[side] = base; sp.ret[side] = r;
+            SpRet rr; rr.off = base; rr.size = (uint32_t)sz; rr.final_off = 0u; rr.parent = sp.tnode; rr.side = side; rr.depth = sp.depth + 1;
+            for (int q = 0; q < 6; ++q) rr.cb[q] = cb[q];
+            rets[r] = rr;
+            tnodes[sp.tnode].child[side] = ~(int)r;
+        }
+    }
+    sp.nl_obj = nl;                                     // (from here on: the left side's size, whichever way the range is split)
+    splits[s] = sp;
+    fill[2u * s] = 0u; fill[2u * s + 1u] = 0u;
+}
+
+// every reference moves to its side(s).  Two passes over a chunk: ranks and bounds first (LDS counters per range and side, the chunk's
+// new ids from one LDS counter), then -- bases known -- the writes; a reference that is cut is clipped in both (no boxes held across).
+__global__ __launch_bounds__(256) void k_sp_partition(const uint32_t* __restrict__ ids_in, const uint32_t* __restrict__ seg_in, uint32_t n_pos, const SpSplit* __restrict__ splits,
+                                                      uint32_t* ids_out, uint32_t* seg_out, uint32_t* retired, uint32_t* fill, Box6* pbox, uint32_t* pprim,
+                                                      const float* __restrict__ world, uint32_t* pool_cursor, uint32_t pool_cap, SahSeg* next, SpRet* rets)
+{
+    __shared__ uint32_t s_dir[kSpTables], s_cnt[kSpTables][2], s_base[kSpTables][2], s_cb[kSpTables][2][6], s_new, s_newbase;
+    for (uint32_t chunk = blockIdx.x; (size_t)chunk * kSahChunk < n_pos; chunk += gridDim.x) {
+        const uint32_t first = chunk * (uint32_t)kSahChunk;
+        if (threadIdx.x < (uint32_t)kSpTables) { s_dir[threadIdx.x] = kSahNone; s_cnt[threadIdx.x][0] = 0u; s_cnt[threadIdx.x][1] = 0u; }
+        if (threadIdx.x < (uint32_t)kSpTables * 12u) (&s_cb[0][0][0])[threadIdx.x] = (threadIdx.x % 6u) < 3u ? 0xffffffffu : 0u;
+        if (threadIdx.x == 0u) s_new = 0u;
+        __syncthreads();
+        uint32_t rank[kSahPerThread][2], newrank[kSahPerThread], tab[kSahPerThread]; int cls[kSahPerThread];
+        for (int e = 0; e < kSahPerThread; ++e) {
+            const uint32_t p = first + (uint32_t)e * 256u + threadIdx.x;
+            cls[e] = -1; rank[e][0] = kSahNone; rank[e][1] = kSahNone; newrank[e] = kSahNone; tab[e] = kSahNone;
+            if (p >= n_pos) continue;
+            const uint32_t s = seg_in[p];
+            const SpSplit sp = splits[s];
+            if (sp.median) { cls[e] = (int)p - sp.lo < sp.nl_obj ? 0 : 1; continue; }       // (no usable axis: the order stays, the bounds are the parent's)
+            const uint32_t id = ids_in[p];
+            const Box6 b = pbox[id];
+            Box6 bl = b, br = b;
+            int c;
+            if (sp.cut) c = sp_classify(b, sp.axis, sp.plane, world + (size_t)pprim[id] * 9, bl, br);
+            else        c = sah_bin_of(0.5f * (b.lo[sp.axis] + b.hi[sp.axis]), sp.cb_lo, sp.scale) <= sp.bin ? 0 : 1;
+            cls[e] = c;
+            const bool tl = c == 0 || c == 2 || c == 3, tr = c == 1 || c == 2 || c == 4;
+            if (c == 2) newrank[e] = atomicAdd(&s_new, 1u);
+            const uint32_t h = s & (uint32_t)(kSpTables - 1);
+            uint32_t owner = s_dir[h];
+            if (owner == kSahNone) { owner = atomicCAS(&s_dir[h], kSahNone, s); if (owner == kSahNone) owner = s; }
+            const bool mine = owner == s;
+            if (mine) tab[e] = h;
+            for (int side = 0; side < 2; ++side) {
+                if (!(side == 0 ? tl : tr)) continue;
+                const Box6& pb = side == 0 ? bl : br;
+                uint32_t oc[3];
+                for (int k = 0; k < 3; ++k) oc[k] = f_ord(0.5f * (pb.lo[k] + pb.hi[k]));
+                uint32_t* cbd = sp.child[side] != kSahNone ? next[sp.child[side]].cb : rets[sp.ret[side]].cb;
+                if (mine) {
+                    rank[e][side] = atomicAdd(&s_cnt[h][side], 1u);
+                    for (int k = 0; k < 3; ++k) { atomicMin(&s_cb[h][side][k], oc[k]); atomicMax(&s_cb[h][side][3 + k], oc[k]); }
+                } else {
+                    rank[e][side] = atomicAdd(&fill[2u * s + side], 1u);
+                    for (int k = 0; k < 3; ++k) { atomicMin(&cbd[k], oc[k]); atomicMax(&cbd[3 + k], oc[k]); }
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)kSpTables * 2u) {
+            const uint32_t h = threadIdx.x >> 1, side = threadIdx.x & 1u, sid = s_dir[h], c = s_cnt[h][side];
+            if (sid != kSahNone && c != 0u) {
+                const SpSplit sp = splits[sid];
+                s_base[h][side] = atomicAdd(&fill[2u * sid + side], c);
+                uint32_t* cbd = sp.child[side] != kSahNone ? next[sp.child[side]].cb : rets[sp.ret[side]].cb;
+                for (int k = 0; k < 3; ++k) { atomicMin(&cbd[k], s_cb[h][side][k]); atomicMax(&cbd[3 + k], s_cb[h][side][3 + k]); }
+            }
+        }
+        if (threadIdx.x == 64u && s_new != 0u) s_newbase = atomicAdd(pool_cursor, s_new);
+        __syncthreads();
+        for (int e = 0; e < kSahPerThread; ++e) {
+            if (cls[e] < 0) continue;
+            const uint32_t p = first + (uint32_t)e * 256u + threadIdx.x;
+            const uint32_t s = seg_in[p];
+            const SpSplit sp = splits[s];
+            const uint32_t id = ids_in[p];
+            int c = cls[e];
+            uint32_t id_r = id;
+            if (c >= 2) {
+                const Box6 b = pbox[id];
+                Box6 bl = b, br = b;
+                sp_classify(b, sp.axis, sp.plane, world + (size_t)pprim[id] * 9, bl, br);
+                if (c == 2) {
+                    id_r = s_newbase + newrank[e];
+                    if (id_r < pool_cap) { pbox[id_r] = br; pprim[id_r] = pprim[id]; }
+                    pbox[id] = bl;
+                } else pbox[id] = c == 3 ? bl : br;
+            }
+            for (int side = 0; side < 2; ++side) {
+                const bool takes = side == 0 ? (c == 0 || c == 2 || c == 3) : (c == 1 || c == 2 || c == 4);
+                if (!takes) continue;
+                uint32_t d;
+                if (sp.median) d = (uint32_t)((int)p - sp.lo - (side ? sp.nl_obj : 0));
+                else d = (tab[e] != kSahNone ? s_base[tab[e]][side] : 0u) + rank[e][side];
+                d += sp.base[side];
+                if (d >= pool_cap) continue;                                     // (cannot be: the budget keeps every buffer inside its room)
+                const uint32_t v = side == 1 && c == 2 ? id_r : id;
+                if (sp.child[side] != kSahNone) { ids_out[d] = v; seg_out[d] = sp.child[side]; }
+                else retired[d] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// a retired range in its final place: sorted by primitive number (the order its references arrived in depends on the run), boxes and
+// primitive numbers gathered, the items numbered by their positions
+__global__ __launch_bounds__(256) void k_sp_layout(const SpRet* __restrict__ rets, uint32_t n_rets, const uint32_t* __restrict__ retired, const Box6* __restrict__ pbox,
+                                                   const uint32_t* __restrict__ pprim, Box6* fbox, uint32_t* fprim, uint32_t* perm)
+{
+    __shared__ unsigned long long s_key[kSahSmall];
+    for (uint32_t r = blockIdx.x; r < n_rets; r += gridDim.x) {
+        const SpRet rr = rets[r];
+        int width = 2;
+        while (width < (int)rr.size) width <<= 1;
+        for (int i = (int)threadIdx.x; i < width; i += 256) {
+            unsigned long long key = ~0ull;
+            if (i < (int)rr.size) { const uint32_t id = retired[rr.off + (uint32_t)i]; key = ((unsigned long long)pprim[id] << 32) | id; }
+            s_key[i] = key;
+        }
+        __syncthreads();
+        for (int k = 2; k <= width; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = (int)threadIdx.x; i < width; i += 256) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long a = s_key[i], b = s_key[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { s_key[i] = b; s_key[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = (int)threadIdx.x; i < (int)rr.size; i += 256) {
+            const uint32_t id = (uint32_t)s_key[i], at = rr.final_off + (uint32_t)i;
+            fbox[at] = pbox[id]; fprim[at] = pprim[id]; perm[at] = at;
+        }
+        __syncthreads();
+    }
+}
+
+// the links the host made from the tree of the ranges (Karras' numbering over the final positions)
+struct SpLink { int node, left, right, parent, lo, hi; };      // left / right = kSpKeep: set by a later pass (k_sah_small, treelets)
+struct SpLeaf { int pos, parent; };
+constexpr int kSpKeep = 0x7ffffff1;
+__global__ __launch_bounds__(256) void k_sp_links(const SpLink* __restrict__ links, uint32_t n_links, const SpLeaf* __restrict__ leaves, uint32_t n_leaves,
+                                                  int* left, int* right, int* pin, int* plf, int* rlo, int* rhi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_links) {
+        const SpLink l = links[i];
+        if (l.left != kSpKeep) left[l.node] = l.left;
+        if (l.right != kSpKeep) right[l.node] = l.right;
+        pin[l.node] = l.parent; rlo[l.node] = l.lo; rhi[l.node] = l.hi;
+    }
+    if (i < n_leaves) plf[leaves[i].pos] = leaves[i].parent;
+}
+
+__global__ __launch_bounds__(256) void k_sp_init(uint32_t* ids, uint32_t* seg_of, uint32_t* pprim, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { ids[i] = i; seg_of[i] = 0u; pprim[i] = i; }
+}
+
 // ---- bottom-up passes without fences ---------------------------------------------------------------------------------------------
 // Round 2 fitted boxes with "the second thread to arrive at a node computes it and climbs on": every step of the climb needs an
 // agent-scope release / acquire pair (__threadfence = L2 write-back + invalidate, microseconds each on a chip of eight L2s), and
@@ -925,11 +1317,12 @@ __global__ __launch_bounds__(256) void k_lbvh_emit(const int* left, const int* r
 }
 
 __global__ __launch_bounds__(256) void k_lbvh_tris(const float* __restrict__ world, const uint32_t* sorted_prims, const uint32_t* gflags, uint32_t n, MiptBvhTri* out,
-                                                  uint32_t* prim_slot)
+                                                  uint32_t* prim_slot, const uint32_t* __restrict__ ref_prim)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const uint32_t p = sorted_prims[k];
+    uint32_t p = sorted_prims[k];
+    if (ref_prim) p = ref_prim[p];                      // (spatial splits: the items are references; one of a triangle's records wins its prim_slot)
     if (prim_slot) prim_slot[p] = k;
     const float* v = world + (size_t)p * 9;
     MiptBvhTri t;
@@ -1376,29 +1769,44 @@ void launch_gather_input(hipStream_t st, const GatherInput& in, float* world, ui
 // d_world: 9 floats per triangle (device); d_gflags: per triangle or null.  On success *d_blob is ONE allocation
 // nodes | triangles | 64 B pad (as mipt_accel_build makes for the host builder).  Returns hipSuccess and ok = false
 // when the tree is deeper than depth_cap (the caller falls back to the host builder).
-hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
-                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets, uint32_t* d_prim_slot, bool sah_top)
+namespace {
+#define SP_TRY(x) do { if ((e = (x)) != hipSuccess) { if (std::getenv("MIPT_BUILD_DEBUG")) std::fprintf(stderr, "lbvh_build.hip:%d: %s\n", __LINE__, hipGetErrorString(e)); return fail(e); } } while (0)
+hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t* d_gflags, const uint32_t n_in, int leaf_max, int depth_cap,
+                           float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets, uint32_t* d_prim_slot, bool sah_top,
+                           float spatial_extra, int ret_below, uint32_t* num_records)
 {
-    *ok = false; *d_blob = nullptr;
-    const int n_inner = (int)n - 1;
-    const uint32_t blocks = (n + 255u) / 256u;
+    *ok = false; *d_blob = nullptr; *num_records = n_in;
+    // spatial splits (the comment at struct SpSplit): the level loop may add up to `sp_budget` references, every array below has room for them
+    const bool top_down = sah_top && sah_treelets && n_in > 2u * (uint32_t)kTreelet;
+    if (ret_below > kSahSmall) ret_below = kSahSmall;
+    if (ret_below < kTreelet) ret_below = kTreelet;
+    const uint32_t sp_budget = top_down && spatial_extra > 0.0f && n_in > (uint32_t)ret_below && n_in < (1u << 22) ? (uint32_t)((double)n_in * (double)spatial_extra) : 0u;
+    const bool spatial = sp_budget != 0u;
+    const uint32_t cap = n_in + sp_budget;
+    uint32_t n = n_in;                                   // the items of the passes after the front end: triangles, or references
+    int n_inner = (int)n - 1;
+    uint32_t blocks = (n + 255u) / 256u;
     char* tmp = nullptr;
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-    const size_t o_boxes = carve(sizeof(Box6) * n), o_nboxes = carve(sizeof(Box6) * n), o_keys = carve(8ull * n), o_keys2 = carve(8ull * n),
-                 o_vals = carve(4ull * n), o_vals2 = carve(4ull * n), o_left = carve(4ull * n), o_right = carve(4ull * n), o_pin = carve(4ull * n),
-                 o_plf = carve(4ull * n), o_lo = carve(4ull * n), o_hi = carve(4ull * n), o_arr = carve(4ull * n), o_emit = carve(4ull * n),
-                 o_idx = carve(4ull * n), o_kh = carve(n), o_big = carve(n), o_misc = carve(256);
+    const size_t o_boxes = carve(sizeof(Box6) * cap), o_nboxes = carve(sizeof(Box6) * cap), o_keys = carve(8ull * cap), o_keys2 = carve(8ull * cap),
+                 o_vals = carve(4ull * cap), o_vals2 = carve(4ull * cap), o_left = carve(4ull * cap), o_right = carve(4ull * cap), o_pin = carve(4ull * cap),
+                 o_plf = carve(4ull * cap), o_lo = carve(4ull * cap), o_hi = carve(4ull * cap), o_arr = carve(4ull * cap), o_emit = carve(4ull * cap),
+                 o_idx = carve(4ull * cap), o_kh = carve(cap), o_big = carve(cap), o_misc = carve(256);
     // the top-down SAH front end (k_sah_*): open ranges of two levels, their splits, fill counters and bins
-    const bool top_down = sah_top && sah_treelets && n > 2u * (uint32_t)kTreelet;
-    const size_t max_segs = top_down ? (size_t)n / (size_t)kTreelet + 4u : 0u;
-    const size_t o_seg0 = carve(max_segs * sizeof(SahSeg)), o_seg1 = carve(max_segs * sizeof(SahSeg)), o_spl = carve(max_segs * sizeof(SahSplit)),
+    const size_t max_segs = top_down ? (size_t)cap / (size_t)kTreelet + 4u : 0u;
+    const size_t o_seg0 = carve(max_segs * sizeof(SahSeg)), o_seg1 = carve(max_segs * sizeof(SahSeg)), o_spl = carve(max_segs * (spatial ? sizeof(SpSplit) : sizeof(SahSplit))),
                  o_fill = carve(max_segs * 8u), o_bins = carve(max_segs * (size_t)kSahSegWords * 4u), o_small = carve(max_segs * sizeof(SahSeg));
+    const size_t max_tn = spatial ? 8u * ((size_t)cap / (size_t)ret_below) + 4096u : 0u;
+    const size_t o_fbox = carve(spatial ? sizeof(Box6) * cap : 0u), o_fprim = carve(spatial ? 4ull * cap : 0u), o_pprim = carve(spatial ? 4ull * cap : 0u),
+                 o_bud0 = carve(max_segs * 4u * (spatial ? 1u : 0u)), o_bud1 = carve(max_segs * 4u * (spatial ? 1u : 0u)), o_cnt2 = carve(max_segs * 8u * (spatial ? 1u : 0u)),
+                 o_tn = carve(max_tn * sizeof(SpNode)), o_ret = carve((max_tn + 1u) * sizeof(SpRet)), o_lnk = carve((2u * max_tn + 2u) * sizeof(SpLink)),
+                 o_lf = carve((max_tn + 1u) * sizeof(SpLeaf));
     size_t sort_bytes = 0, scan_bytes = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, st);
     if (e != hipSuccess) return e;
-    e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, n_inner, st);
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)cap - 1, st);
     if (e != hipSuccess) return e;
     const size_t o_cub = carve(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
     e = hipMalloc((void**)&tmp, off);
@@ -1415,7 +1823,127 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     if ((e = hipMemcpyAsync(misc, init, sizeof init, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
     if ((e = hipMemsetAsync(arrived, 0, 4ull * n, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(k_lbvh_prims, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, st, d_world, n, boxes, misc);
-    if (top_down) {
+    const Box6* item_boxes = boxes;                      // the items' boxes (spatial splits: the references' boxes in their final order)
+    const uint32_t* item_prim = nullptr;                 // ... and their triangles
+    if (spatial) {
+        SahSeg* segs[2] = { (SahSeg*)(tmp + o_seg0), (SahSeg*)(tmp + o_seg1) };
+        int* budgets[2] = { (int*)(tmp + o_bud0), (int*)(tmp + o_bud1) };
+        SpSplit* splits = (SpSplit*)(tmp + o_spl);
+        uint32_t* fill = (uint32_t*)(tmp + o_fill); uint32_t* bins = (uint32_t*)(tmp + o_bins); uint32_t* cnt2 = (uint32_t*)(tmp + o_cnt2);
+        uint32_t* ids[2] = { vals, vals2 };
+        uint32_t* seg_of[2] = { (uint32_t*)keys, (uint32_t*)keys2 };
+        uint32_t* retired = idx;                          // (the root list / scan output later)
+        uint32_t* pprim = (uint32_t*)(tmp + o_pprim);
+        Box6* fbox = (Box6*)(tmp + o_fbox); uint32_t* fprim = (uint32_t*)(tmp + o_fprim);
+        SpNode* tnodes = (SpNode*)(tmp + o_tn); SpRet* rets = (SpRet*)(tmp + o_ret);
+        SahSeg* smalls = (SahSeg*)(tmp + o_small);
+        uint32_t* counts = misc + 20;                     // [0] / [1]: open ranges of the current / next level; [2]: ranges for k_sah_small
+        uint32_t* cursors = misc + 24;                    // [0] next level's buffer, [1] retired buffer, [2] nodes, [3] retired records, [4] the pool of references
+        float* root_area = reinterpret_cast<float*>(misc + 30);
+        hipLaunchKernelGGL(k_sah_init, dim3(2048), dim3(256), 0, st, bins, max_segs * (size_t)kSahSegWords, ids[0], seg_of[0], cap, left, right, rlo, rhi);
+        hipLaunchKernelGGL(k_sp_init, dim3(blocks), dim3(256), 0, st, ids[0], seg_of[0], pprim, n);
+        {
+            // the root: the one open range, node 0 of the tree of ranges
+            struct { uint32_t counts[4]; uint32_t cursors[6]; } h0 = { { 1u, 0u, 0u, 0u }, { 0u, 0u, 1u, 0u, n, 0u } };
+            SP_TRY(hipMemcpyAsync(counts, &h0, sizeof h0, hipMemcpyHostToDevice, st));
+            SahSeg r; r.lo = 0; r.hi = (int)n - 1; r.node = 0; r.depth = 0;
+            SP_TRY(hipMemcpyAsync(&segs[0][0], &r, 16, hipMemcpyHostToDevice, st));
+            SP_TRY(hipMemcpyAsync(segs[0][0].cb, misc, 24, hipMemcpyDeviceToDevice, st));
+            const int b0 = (int)sp_budget;
+            SP_TRY(hipMemcpyAsync(budgets[0], &b0, 4, hipMemcpyHostToDevice, st));
+            const SpNode root_node = { -1, { 0, 0 } };
+            SP_TRY(hipMemcpyAsync(tnodes, &root_node, sizeof root_node, hipMemcpyHostToDevice, st));
+        }
+        uint32_t n_cur = 1u, n_pos = n;
+        int cur = 0;
+        auto soft_fail = [&]() { (void)hipFree(tmp); *num_nodes = 0; *depth = 255u; return hipSuccess; };      // (ok stays false: the caller builds without spatial splits)
+        for (int level = 0; n_cur != 0u; ++level) {
+            if (level > 96 || n_cur > max_segs) return soft_fail();
+            const uint32_t chunks = (n_pos + (uint32_t)kSahChunk - 1u) / (uint32_t)kSahChunk, cg = chunks < 4096u ? chunks : 4096u;
+            hipLaunchKernelGGL(k_sah_bin, dim3(cg), dim3(256), 0, st, ids[cur], seg_of[cur], segs[cur], n_pos, boxes, bins);
+            hipLaunchKernelGGL(k_sp_split, dim3(n_cur), dim3(64), 0, st, segs[cur], budgets[cur], counts + cur, bins, splits, cnt2, leaf_max, depth_cap, root_area);
+            hipLaunchKernelGGL(k_sp_count, dim3(cg), dim3(256), 0, st, ids[cur], seg_of[cur], splits, n_pos, boxes, pprim, d_world, cnt2);
+            SP_TRY(hipMemsetAsync(cursors, 0, 4, st));
+            hipLaunchKernelGGL(k_sp_alloc, dim3((n_cur + 255u) / 256u), dim3(256), 0, st, splits, counts + cur, cnt2, fill, segs[cur ^ 1], budgets[cur ^ 1], counts + (cur ^ 1),
+                               cursors, tnodes, rets, leaf_max, depth_cap, ret_below, (uint32_t)max_segs, (uint32_t)max_tn);
+            hipLaunchKernelGGL(k_sp_partition, dim3(cg), dim3(256), 0, st, ids[cur], seg_of[cur], n_pos, splits, ids[cur ^ 1], seg_of[cur ^ 1], retired, fill, boxes, pprim,
+                               d_world, cursors + 4, cap, segs[cur ^ 1], rets);
+            uint32_t hc[10];
+            SP_TRY(hipMemcpyAsync(hc, counts, sizeof hc, hipMemcpyDeviceToHost, st));
+            SP_TRY(hipStreamSynchronize(st));
+            SP_TRY(hipMemsetAsync(counts + cur, 0, 4, st));
+            n_cur = hc[cur ^ 1]; n_pos = hc[4];
+            if (hc[4] > cap || hc[5] > cap || hc[6] > max_tn || hc[7] > max_tn + 1u || hc[8] > cap || n_cur > max_segs) return soft_fail();      // (the budget keeps the first two and the pool inside; the lists: by construction of max_tn, unless the ranges peel off one by one)
+            cur ^= 1;
+        }
+        // the tree of the ranges -> final positions, Karras' numbers, links
+        uint32_t hc[10];
+        SP_TRY(hipMemcpyAsync(hc, counts, sizeof hc, hipMemcpyDeviceToHost, st));
+        SP_TRY(hipStreamSynchronize(st));
+        const uint32_t n_tn = hc[6], n_ret = hc[7], n_refs = hc[8];
+        if (hc[5] != n_refs || n_ret != n_tn + 1u) return soft_fail();                   // (every reference retired once; a binary tree)
+        std::vector<SpNode> tn(n_tn); std::vector<SpRet> rt(n_ret);
+        SP_TRY(hipMemcpy(tn.data(), tnodes, (size_t)n_tn * sizeof(SpNode), hipMemcpyDeviceToHost));
+        SP_TRY(hipMemcpy(rt.data(), rets, (size_t)n_ret * sizeof(SpRet), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> size(n_tn, 0u), lo(n_tn, 0u); std::vector<int> name(n_tn, 0), pname(n_tn, -1), dep(n_tn, 0);
+        for (uint32_t i = n_tn; i-- > 0u;)                                                // children have larger numbers than their parents
+            for (int side = 0; side < 2; ++side) {
+                const int c = tn[i].child[side];
+                if (c >= 0 ? ((uint32_t)c >= n_tn || (uint32_t)c <= i) : (uint32_t)~c >= n_ret) return soft_fail();
+                size[i] += c >= 0 ? size[(uint32_t)c] : rt[(uint32_t)~c].size;
+            }
+        if (size[0] != n_refs) return soft_fail();
+        std::vector<SpLink> links; std::vector<SpLeaf> leaves; std::vector<SahSeg> small_list;
+        links.reserve(2u * n_tn + 2u); leaves.reserve(n_ret);
+        for (uint32_t i = 0; i < n_tn; ++i) {
+            const int my_lo = (int)lo[i], my_hi = (int)(lo[i] + size[i] - 1u);
+            SpLink L; L.node = name[i]; L.parent = pname[i]; L.lo = my_lo; L.hi = my_hi; L.left = 0; L.right = 0;
+            uint32_t at = lo[i];
+            for (int side = 0; side < 2; ++side) {
+                const int c = tn[i].child[side];
+                const uint32_t sz = c >= 0 ? size[(uint32_t)c] : rt[(uint32_t)~c].size;
+                const int c_lo = (int)at, c_hi = (int)(at + sz - 1u);
+                const int c_name = side == 0 ? c_hi : c_lo;                               // a left child is named by its last position, a right child by its first
+                int ref = c_name;
+                if (c >= 0) { lo[(uint32_t)c] = at; name[(uint32_t)c] = c_name; pname[(uint32_t)c] = name[i]; dep[(uint32_t)c] = dep[i] + 1; }
+                else {
+                    SpRet& r = rt[(uint32_t)~c];
+                    r.final_off = at;
+                    if (sz == 1u) { ref = ~c_lo; leaves.push_back({ c_lo, name[i] }); }
+                    else {
+                        SpLink R; R.node = c_name; R.parent = name[i]; R.lo = c_lo; R.hi = c_hi; R.left = kSpKeep; R.right = kSpKeep;
+                        if (sz == 2u) { R.left = ~c_lo; R.right = ~c_hi; leaves.push_back({ c_lo, c_name }); leaves.push_back({ c_hi, c_name }); }
+                        links.push_back(R);
+                        if (sz > (uint32_t)kTreelet) {
+                            SahSeg sg; sg.lo = c_lo; sg.hi = c_hi; sg.node = c_name; sg.depth = dep[i] + 1;
+                            for (int q = 0; q < 6; ++q) sg.cb[q] = r.cb[q];
+                            small_list.push_back(sg);
+                        }
+                    }
+                }
+                if (side == 0) L.left = ref; else L.right = ref;
+                at += sz;
+            }
+            links.push_back(L);
+        }
+        if (small_list.size() > max_segs || links.size() > 2u * max_tn + 2u || leaves.size() > max_tn + 1u) return soft_fail();
+        SpLink* d_links = (SpLink*)(tmp + o_lnk); SpLeaf* d_leaves = (SpLeaf*)(tmp + o_lf);
+        SP_TRY(hipMemcpy(rets, rt.data(), (size_t)n_ret * sizeof(SpRet), hipMemcpyHostToDevice));
+        SP_TRY(hipMemcpy(d_links, links.data(), links.size() * sizeof(SpLink), hipMemcpyHostToDevice));
+        if (!leaves.empty()) SP_TRY(hipMemcpy(d_leaves, leaves.data(), leaves.size() * sizeof(SpLeaf), hipMemcpyHostToDevice));
+        if (!small_list.empty()) SP_TRY(hipMemcpy(smalls, small_list.data(), small_list.size() * sizeof(SahSeg), hipMemcpyHostToDevice));
+        const uint32_t n_small = (uint32_t)small_list.size();
+        SP_TRY(hipMemcpy(counts + 2, &n_small, 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_sp_layout, dim3(n_ret < 4096u ? n_ret : 4096u), dim3(256), 0, st, rets, n_ret, retired, boxes, pprim, fbox, fprim, vals2);
+        const uint32_t n_l = (uint32_t)(links.size() > leaves.size() ? links.size() : leaves.size());
+        hipLaunchKernelGGL(k_sp_links, dim3((n_l + 255u) / 256u), dim3(256), 0, st, d_links, (uint32_t)links.size(), d_leaves, (uint32_t)leaves.size(), left, right, pin, plf, rlo, rhi);
+        n = n_refs; n_inner = (int)n - 1; blocks = (n + 255u) / 256u;
+        *num_records = n;
+        item_boxes = fbox; item_prim = fprim;
+        if (n_small != 0u)
+            hipLaunchKernelGGL(k_sah_small, dim3(n_small < 4096u ? n_small : 4096u), dim3(256), 0, st, smalls, counts + 2, vals2, item_boxes, leaf_max, depth_cap,
+                               left, right, pin, plf, rlo, rhi);
+    } else if (top_down) {
         // binned SAH, level by level over all open ranges, until none holds more than kTreelet triangles (the comment at k_sah_bin)
         SahSeg* segs[2] = { (SahSeg*)(tmp + o_seg0), (SahSeg*)(tmp + o_seg1) };
         SahSplit* splits = (SahSplit*)(tmp + o_spl);
@@ -1459,7 +1987,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
         if ((e = hipMemsetAsync(misc + 16, 0, 4, st)) != hipSuccess) return fail(e);
         hipLaunchKernelGGL(k_treelet_roots, dim3(blocks), dim3(256), 0, st, rlo, rhi, pin, n_inner, idx, misc + 16, top_down ? vals2 : nullptr);
         const uint32_t tg = blocks * 4u < 16384u ? blocks * 4u : 16384u;
-        hipLaunchKernelGGL(k_lbvh_treelets, dim3(tg), dim3(64), 0, st, idx, misc + 16, boxes, vals2, left, right, pin, plf, rlo, rhi, top_down ? 1 : 0);
+        hipLaunchKernelGGL(k_lbvh_treelets, dim3(tg), dim3(64), 0, st, idx, misc + 16, item_boxes, vals2, left, right, pin, plf, rlo, rhi, top_down ? 1 : 0);
     }
     const int cluster_levels = sah_treelets && n > (uint32_t)kTreelet * 4u ? [] { const char* e = std::getenv("MIPT_LBVH_CLUSTERS"); return e ? std::atoi(e) : 0; }() : 0;
     auto fit_boxes = [&](uint8_t* kh, uint8_t* root_h) -> hipError_t {
@@ -1471,7 +1999,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
         if ((fe = hipStreamSynchronize(st)) != hipSuccess) return fe;
         if (*root_h == 0u || *root_h >= 255u) return hipSuccess;
         for (uint32_t level = 1; level <= *root_h; ++level)
-            hipLaunchKernelGGL(k_lbvh_fit_level, dim3(blocks), dim3(256), 0, st, boxes, vals2, n_inner, left, right, kh, level, nboxes);
+            hipLaunchKernelGGL(k_lbvh_fit_level, dim3(blocks), dim3(256), 0, st, item_boxes, vals2, n_inner, left, right, kh, level, nboxes);
         return hipSuccess;
     };
     if (cluster_levels > 0) {
@@ -1489,7 +2017,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
                 hipLaunchKernelGGL(k_cluster_counts, dim3(blocks), dim3(256), 0, st, left, right, big, pin, n_inner, emit);
                 hipLaunchKernelGGL(k_cluster_roots, dim3(blocks), dim3(256), 0, st, big, pin, emit, n_inner, idx, misc + 17);
                 const uint32_t cg = blocks < 16384u ? blocks : 16384u;
-                hipLaunchKernelGGL(k_lbvh_clusters, dim3(cg), dim3(64), 0, st, idx, misc + 17, big, boxes, vals2, nboxes, left, right, pin, plf, rlo, rhi);
+                hipLaunchKernelGGL(k_lbvh_clusters, dim3(cg), dim3(64), 0, st, idx, misc + 17, big, item_boxes, vals2, nboxes, left, right, pin, plf, rlo, rhi);
                 hipLaunchKernelGGL(k_cluster_next_big, dim3(blocks), dim3(256), 0, st, emit, n_inner, big);
             }
         }
@@ -1500,7 +2028,7 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
         if ((e = fit_boxes(kh, &root_h)) != hipSuccess) return fail(e);
         if (root_h == 0u || root_h >= 255u) { (void)hipFree(tmp); *num_nodes = 0; *depth = 255u; return hipSuccess; }      // (degenerate input: the host builder takes it)
     }
-    hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit, sah_treelets, left, right, pin, boxes, vals2, nboxes, 1.2f);
+    hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit, sah_treelets, left, right, pin, item_boxes, vals2, nboxes, 1.2f);
     if ((e = hipcub::DeviceScan::ExclusiveSum(tmp + o_cub, scan_bytes, emit, idx, n_inner, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(k_lbvh_depth, dim3(blocks), dim3(256), 0, st, pin, plf, emit, (int)n, misc + 8);
     uint32_t last[2] = { 0, 0 }, dep = 0;
@@ -1514,13 +2042,31 @@ hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gf
     const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
     float4* blob = nullptr;
     if ((e = hipMalloc((void**)&blob, nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u)) != hipSuccess) return fail(e);     // + room for the packed nodes
-    hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks), dim3(256), 0, st, left, right, rlo, rhi, n_inner, leaf_max, emit, idx, boxes, vals2, nboxes, (MiptBvhNode*)blob);
-    hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb), d_prim_slot);
+    hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks), dim3(256), 0, st, left, right, rlo, rhi, n_inner, leaf_max, emit, idx, item_boxes, vals2, nboxes, (MiptBvhNode*)blob);
+    hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb), d_prim_slot, item_prim);
     if ((e = hipMemsetAsync((char*)blob + nb + tb, 0, 64, st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }
     if ((e = hipStreamSynchronize(st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }
     (void)hipFree(tmp);
     *d_blob = blob; *ok = true;
     return hipSuccess;
+}
+}  // namespace
+
+// spatial_extra > 0 (MIPT_OPT_BUILD = 4): references the level loop may add by cutting triangles at split planes, as a fraction of the
+// triangle count; ret_below: ranges of at most that many references leave the loop (and are split by objects only from there on).
+// *num_records: the triangle records of the blob (> n when triangles were cut).  An input the spatial front end gives up on is built
+// without it.
+hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
+                      float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets, uint32_t* d_prim_slot, bool sah_top,
+                      float spatial_extra, int ret_below, uint32_t* num_records)
+{
+    uint32_t records_local = n;
+    if (num_records == nullptr) num_records = &records_local;
+    if (spatial_extra > 0.0f) {
+        const hipError_t e = lbvh_build_impl(st, d_world, d_gflags, n, leaf_max, depth_cap, d_blob, num_nodes, depth, ok, sah_treelets, d_prim_slot, sah_top, spatial_extra, ret_below, num_records);
+        if (e != hipSuccess || *ok) return e;
+    }
+    return lbvh_build_impl(st, d_world, d_gflags, n, leaf_max, depth_cap, d_blob, num_nodes, depth, ok, sah_treelets, d_prim_slot, sah_top, 0.0f, ret_below, num_records);
 }
 
 }  // namespace mipt

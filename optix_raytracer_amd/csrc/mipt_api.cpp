@@ -122,6 +122,7 @@ struct MiptContext {
     int      build_mode = 2;              // MIPT_OPT_BUILD: 2 (default, round 4) on the device, top-down binned SAH + SAH treelets: the host builder's trees at a
                                           // fourteenth of its time; 1 on the device, Morton codes + radix tree + SAH treelets (fastest build: lbvh_build.hip);
                                           // 0 host binned SAH (bvh_build.cpp; the fallback of the other two for tiny inputs and trees deeper than the stack)
+    int      split_below = 128;           // MIPT_OPT_BUILD = 4: ranges of at most this many references are split by objects only (env MIPT_SPLIT_BELOW, 64..2048)
     float    sbvh_extra = 0.5f;           // MIPT_OPT_BUILD = 3: references the spatial splits may add, as a fraction of the triangle count (env MIPT_SBVH_EXTRA)
     uint32_t build_host_below = 2048;     // MIPT_OPT_BUILD = 2: inputs of fewer triangles go to the host builder (env MIPT_BUILD_HOST_BELOW; 0: everything on the device)
     int      lbvh_treelets = 1;           // env MIPT_LBVH_TREELETS=0: the plain radix tree (A/B of the SAH treelets, lbvh_build.hip)
@@ -774,7 +775,8 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_TILE_CLASS_INIT")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) c->tile_class_width = (uint32_t)v; }   // adapted from there
     if (const char* e = std::getenv("MIPT_TILED_BVH4")) c->tiled_bvh4 = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_INST_FORM")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->inst_form = v; }
-    if (const char* e = std::getenv("MIPT_BUILD")) { const int v = std::atoi(e); if (v >= 0 && v <= 3) c->build_mode = v; }
+    if (const char* e = std::getenv("MIPT_BUILD")) { const int v = std::atoi(e); if (v >= 0 && v <= 4) c->build_mode = v; }
+    if (const char* e = std::getenv("MIPT_SPLIT_BELOW")) { const int v = std::atoi(e); if (v >= 64 && v <= 2048) c->split_below = v; }
     if (const char* e = std::getenv("MIPT_SBVH_EXTRA")) { const double v = std::atof(e); if (v >= 0.0 && v <= 8.0) c->sbvh_extra = (float)v; }       // MIPT_OPT_BUILD at creation
     if (const char* e = std::getenv("MIPT_BUILD_HOST_BELOW")) { const long v = std::atol(e); if (v >= 0 && v <= (1l << 30)) c->build_host_below = (uint32_t)v; }
     if (const char* e = std::getenv("MIPT_LBVH_TREELETS")) c->lbvh_treelets = std::atoi(e) != 0;
@@ -842,7 +844,7 @@ int mipt_set_option(MiptContext* c, int option, uint64_t value)
         if (value > (1u << 30)) return c->fail(MIPT_ERROR_INVALID_VALUE, "tail threshold must be 0 (off) .. 2^30 paths");
         c->tail_paths = (uint32_t)value; return MIPT_SUCCESS;
     case MIPT_OPT_BUILD:
-        if (value > 3) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH), 1 (device LBVH), 2 (device SAH) or 3 (host SAH with spatial splits)");
+        if (value > 4) return c->fail(MIPT_ERROR_INVALID_VALUE, "builder must be 0 (host SAH), 1 (device LBVH), 2 (device SAH), 3 (host SAH with spatial splits) or 4 (device SAH with spatial splits)");
         c->build_mode = (int)value; return MIPT_SUCCESS;
     case MIPT_OPT_TILE_ORDER:
         if (value > 1) return c->fail(MIPT_ERROR_INVALID_VALUE, "tile order must be 0 (image order) or 1 (by the previous launch's costs)");
@@ -994,7 +996,9 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     float4* blob = nullptr; uint32_t nn = 0, dep = 0; bool ok = false;
     uint32_t* d_slot = nullptr;                                  // primitive -> triangle record (Accel::d_prim_slot)
     if (e == hipSuccess && err == 0u) e = hipMalloc((void**)&d_slot, (size_t)n * 4u);
-    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, ctx->lbvh_leaf, kStackEntries, &blob, &nn, &dep, &ok, ctx->lbvh_treelets != 0, d_slot, ctx->build_mode == 2);
+    uint32_t records = n;                                        // > n when triangles were cut (MIPT_OPT_BUILD = 4)
+    if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, ctx->lbvh_leaf, kStackEntries, &blob, &nn, &dep, &ok, ctx->lbvh_treelets != 0, d_slot, ctx->build_mode >= 2,
+                                                      ctx->build_mode == 4 ? ctx->sbvh_extra : 0.0f, ctx->split_below, &records);
     if ((e != hipSuccess || err != 0u || !ok) && d_slot) { (void)hipFree(d_slot); d_slot = nullptr; }
     if (e != hipSuccess) return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e));
     if (err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
@@ -1004,9 +1008,9 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     }
     uint32_t* d_mats = G.release_mats();
     Accel* a = new Accel();
-    const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)n * sizeof(MiptBvhTri);
+    const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)records * sizeof(MiptBvhTri);
     a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
-    a->num_nodes = nn; a->num_tris = n; a->depth = dep; a->leaf_max = 4; a->builder = ctx->build_mode == 2 ? 2 : 1;
+    a->num_nodes = nn; a->num_tris = records; a->depth = dep; a->leaf_max = 4; a->builder = records > n ? 4 : (ctx->build_mode >= 2 ? 2 : 1);
     a->d_prim_slot = d_slot;
     if ((e = finish_blob(ctx, a)) != hipSuccess) { free_accel(a); return ctx->fail(MIPT_ERROR_HIP, "device BVH build: %s", hipGetErrorString(e)); }
     a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u + (size_t)n * 4u + (d_slot ? (size_t)n * 4u : 0u);   // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table + the primitive -> record table
@@ -1014,7 +1018,8 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
     *handle_out = h;
-    ctx->log(4, "ACCEL", "built BVH2 (device %s): %u tris, %u nodes, depth %u, %.1f MB, %.4f s", ctx->build_mode == 2 ? "SAH" : "LBVH", n, nn, dep, (double)a->bytes / 1e6, a->seconds);
+    ctx->log(4, "ACCEL", "built BVH2 (device %s): %u tris (%u records), %u nodes, depth %u, %.1f MB, %.4f s", a->builder == 4 ? "SAH with spatial splits" : (a->builder == 2 ? "SAH" : "LBVH"), n, records, nn, dep,
+             (double)a->bytes / 1e6, a->seconds);
     return MIPT_SUCCESS;
 }
 
@@ -1027,7 +1032,7 @@ int mipt_accel_build(MiptContext* ctx, const MiptBuildInput* inputs, uint32_t nu
     //  allocations whatever its size -- 300 triangles: 0.7 against 0.2 ms on the host, break-even near 2 000; the trees are alike)
     uint64_t n_hint = 0;
     for (uint32_t k = 0; k < num_inputs; ++k) n_hint += (inputs[k].indices && inputs[k].index_format != 0) ? inputs[k].num_triangles : inputs[k].num_vertices / 3u;
-    if (ctx->build_mode == 1 || (ctx->build_mode == 2 && n_hint >= (uint64_t)ctx->build_host_below)) {
+    if (ctx->build_mode == 1 || ((ctx->build_mode == 2 || ctx->build_mode == 4) && n_hint >= (uint64_t)ctx->build_host_below)) {
         const int rc = accel_build_device(ctx, inputs, num_inputs, handle_out);
         if (rc != MIPT_SUCCESS || *handle_out != 0ull) return rc;
     }
@@ -1381,8 +1386,8 @@ int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBui
     Accel* a = find_accel(ctx, handle);
     if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
     if (a->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "0x%llx is an instance structure: use mipt_accel_update_instances", handle);
-    if (a->builder == 3)
-        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0x%llx was built with spatial splits (MIPT_OPT_BUILD = 3): its leaves hold clipped references, which a refit cannot keep -- build it again", handle);
+    if (a->builder == 3 || a->builder == 4)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0x%llx was built with spatial splits (MIPT_OPT_BUILD = 3 or 4): its leaves hold clipped references, which a refit cannot keep -- build it again", handle);
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());                         // launches that still read the old boxes

@@ -508,7 +508,8 @@ def test_deep_tree_fills_the_traversal_stacks():
 
 
 @pytest.mark.parametrize("name,n,builder", [("cornell", 0, 1), ("soup", 40000, 1), ("soup", 7, 1), ("cornell", 0, 2), ("soup", 40000, 2), ("soup", 130, 2), ("hall", 0, 2),
-                                                    ("cornell", 0, 3), ("soup", 40000, 3), ("soup", 130, 3), ("hall", 0, 3)])
+                                                    ("cornell", 0, 3), ("soup", 40000, 3), ("soup", 130, 3), ("hall", 0, 3),
+                                                    ("cornell", 0, 4), ("soup", 40000, 4), ("soup", 130, 4), ("hall", 0, 4), ("dense", 30000, 4)])
 def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path, monkeypatch):
     """MIPT_OPT_BUILD = 1 / 2: the BVH built on the device (1: Morton codes + radix tree + SAH treelets; 2, round 4: top-down binned SAH
     above the treelets) is a sound BVH over the same triangles (oracle validation), traversal over it agrees with the oracle walking the
@@ -520,6 +521,8 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path, m
     monkeypatch.setenv("MIPT_BUILD_HOST_BELOW", "0")          # (the default builder hands inputs below 2048 triangles to the host: here everything is built on the device)
     if name == "hall":      # large triangles among small ones (walls around boxes): where the Morton cut loses most
         scene = scenes.from_gltf(scenes.write_rooms_gltf(tmp_path / "hall.gltf", n_boxes=2000))
+    elif name == "dense":   # triangles several cells long: where the builders with spatial splits do cut
+        scene = scenes.random_soup(n, edge_scale=0.05)
     else:
         scene = scenes.cornell_box() if name == "cornell" else scenes.random_soup(n)
     w, h = 128, 96
@@ -547,7 +550,7 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path, m
             t, prim, u, v = osc.trace_closest(rays, O.MODE_BVH)
             hits = d_hits.cpu().numpy()
             assert np.array_equal(hits[:, 1].view(np.uint32), prim) and np.array_equal(hits[:, 0].view(np.uint32), t.view(np.uint32))
-        if mode in (2, 3):
+        if mode in (2, 3, 4):
             # the top-down front end moves triangles with atomics (and the host builder with spatial splits runs on several threads); the tree must not depend on where they fell: a second build is the same tree
             PT.buildMeshAccel(st, scene)
             nodes2, tris2 = st.context.accel_export(st.gas_handle)
@@ -557,9 +560,11 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path, m
     assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
     assert np.array_equal(frames[0][1], frames[1][1])
     assert frames[0][2]["closest_rays"] == frames[1][2]["closest_rays"] and frames[0][2]["shadow_rays"] == frames[1][2]["shadow_rays"]
-    if builder == 3:      # spatial splits: triangles referenced by several leaves -- more records than triangles, never fewer
+    if builder in (3, 4): # spatial splits: triangles referenced by several leaves -- more records than triangles, never fewer
         assert infos[0]["num_triangles"] <= infos[1]["num_triangles"] <= 1.5 * infos[0]["num_triangles"] + 1
         assert infos[1]["depth"] <= 32 and infos[1]["leaf_max"] <= 4
+        if name == "dense":
+            assert infos[1]["num_triangles"] > 1.05 * infos[0]["num_triangles"], infos
         return
     assert infos[0]["num_triangles"] == infos[1]["num_triangles"] and infos[1]["depth"] <= 32 and infos[1]["leaf_max"] <= 4
 
