@@ -58,10 +58,11 @@ def parse():
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--steal-min", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the bounded CPU-baseline sample")
-    ap.add_argument("--builder", type=int, default=3,
-                    help="MIPT_OPT_BUILD for the scene's BVH (the build is outside the timed region, as BASELINE.json's metric has it): 3 = host SAH with "
-                         "spatial splits, the best tree for a static scene (default here; ~3 s per million triangles); 2 = the library's default, "
-                         "on the device in 7 ms; 1 = device Morton; 0 = host SAH.  The environment's MIPT_BUILD wins (A/B runs).")
+    ap.add_argument("--builder", type=int, default=4,
+                    help="MIPT_OPT_BUILD for the scene's BVH (the build is outside the timed region, as BASELINE.json's metric has it): 4 = device SAH with "
+                         "spatial splits, the tree for a static scene (default here; what OPTIX_BUILD_FLAG_PREFER_FAST_TRACE asks for; ~12 ms per million "
+                         "triangles); 3 = the same on the host (~3 s); 2 = the library's default, on the device in 7 ms, a tree that can be refitted; "
+                         "1 = device Morton; 0 = host SAH.  The environment's MIPT_BUILD wins (A/B runs).")
     return ap.parse_args()
 
 
@@ -412,7 +413,7 @@ def main():
     fence()
 
     # ---- the same frames over the tree the library's DEFAULT builder makes (MIPT_OPT_BUILD = 2, on the device), beside the headline number:
-    # `value` is measured over the tree --builder asks for (3: spatial splits); one GPU, plain launches only
+    # `value` is measured over the tree --builder asks for (4: spatial splits); one GPU, plain launches only
     default_builder = None
     if world == 1 and not sharded and os.environ.get("MIPT_BUILD") != "2":
         keep_env = os.environ.get("MIPT_BUILD")
@@ -555,7 +556,7 @@ def main():
                                    "(primary + NEE shadow ray), BVH2 %d nodes depth %d over %d triangle records (builder %s: %s), node format %d (%d mirror nodes, stack %d)" % (
                                        args.tris, w, h, SPP, args.max_depth, info["num_nodes"], info["depth"], info["num_triangles"], os.environ.get("MIPT_BUILD"),
                                        {"0": "host binned SAH", "1": "device Morton + SAH treelets", "2": "device binned SAH + SAH treelets",
-                                        "3": "host binned SAH with spatial splits"}.get(os.environ.get("MIPT_BUILD"), "?"),
+                                        "3": "host binned SAH with spatial splits", "4": "device binned SAH with spatial splits + SAH treelets"}.get(os.environ.get("MIPT_BUILD"), "?"),
                                        info["node_format"], info["mirror_nodes"], info["stack_entries"]),
                        "rays_per_frame": rays_total, "closest_rays": counts["closest_rays"] if world == 1 else None,
                        "parallelism": "1 GPU" if world == 1 else "image tiles 8x4 interleaved over %d ranks + RCCL all-gather%s" % (

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define MIPT_ABI_VERSION 4   /* 2: MiptAccelInfo.node_format, MIPT_OPT_NODE_FORMAT, mipt_group_*; 3: mipt_whitted_set_geometry_instanced, mipt_scene_mesh_normals / _texcoords / _colors;
-                                4: MIPT_OPT_BUILD = 2 (device SAH builder, the default) and 3 (host SAH with spatial splits) */
+                                4: MIPT_OPT_BUILD = 2 (device SAH builder, the default), 3 and 4 (host / device SAH with spatial splits), mipt_host_bvh_create_spatial */
 
 typedef enum MiptResult {
     MIPT_SUCCESS                 = 0,
@@ -200,7 +200,7 @@ typedef enum MiptOption {
     MIPT_OPT_BATCH_SAMPLES = 10, /* 0 (default): one wavefront pass per sample, contributions added in the reference's
                                   order (bit-identical to the oracle); 1: all samples_per_launch samples of a launch are
                                   paths of ONE pass with per-sample accumulators (same values to rounding, far fewer passes) */
-    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build, all three in the same node / triangle layout; a render does not depend on it:
+    MIPT_OPT_BUILD        = 12, /* builder of mipt_accel_build, all in the same node / triangle layout; a render does not depend on it:
                                   2 (default since ABI 4): on the device, as optixAccelBuild -- top-down binned SAH (32 bins per axis, all open
                                   ranges of a level at once) down to ranges of 64 triangles, each of which one wave then builds by full-sweep
                                   SAH; leaves by the SAH termination rule.  7 ms per million triangles, frames within 2 % of those over the
@@ -215,6 +215,13 @@ typedef enum MiptOption {
                                   triangles as large as the gaps between them 6-7 % faster (the headline scene 0.557 -> 0.520 ms), 0-3 % elsewhere
                                   -- at ~3 s per million triangles; MiptAccelInfo::num_triangles then counts RECORDS; such a tree cannot be
                                   refitted (mipt_accel_update fails: build it again);
+                                  4: spatial splits ON THE DEVICE (~ PREFER_FAST_TRACE at the cost of a build): builder 2 whose level loop cuts the
+                                  triangles that straddle a split plane in two wherever the split's sides overlap (the plane is the object
+                                  split's own; clipped bounds in double, rounded outward; the same reference budget, MIPT_SBVH_EXTRA), down to
+                                  ranges of 128 references (env MIPT_SPLIT_BELOW), which are then split by objects only: builder 3's frames
+                                  (the headline scene 0.519 against 0.516 ms) from a build of ~12 ms per million triangles instead of ~3 s; the
+                                  same tree in every run; num_triangles counts RECORDS and mipt_accel_update fails, as for 3; an input it gives up
+                                  on (more than 4 M triangles, lists that overflow) is built as by 2;
                                   0: binned SAH on the host cores (155 ms per million triangles).  1 and 2 fall back to 0 for inputs of
                                   <= 4 triangles and when their tree is deeper than the 32-entry traversal stack */
     MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late;

@@ -359,11 +359,13 @@ int orc_scene_set_instances(OrcScene* s, const void* tlas_nodes, uint32_t n_tlas
         memcpy(in->inv, inv12 + (size_t)i * 12, 48);
         in->prim_base = prim_base[i];
         in->n_nodes = gas_n_nodes[i]; in->n_tris = gas_n_tris[i];
-        if ((uint64_t)in->prim_base + in->n_tris > s->n_tris) return 2;      /* flattened ids must index the scene's arrays */
         in->nodes = (Node64*)malloc((size_t)in->n_nodes * sizeof(Node64));
         in->tris = (Tri48*)malloc((size_t)(in->n_tris ? in->n_tris : 1) * sizeof(Tri48));
         memcpy(in->nodes, gas_nodes[i], (size_t)in->n_nodes * sizeof(Node64));
         memcpy(in->tris, gas_tris[i], (size_t)in->n_tris * sizeof(Tri48));
+        /* flattened ids must index the scene's arrays (a mesh built with spatial splits holds more records than primitives: the
+         * largest primitive number counts, not the number of records) */
+        for (uint32_t k = 0; k < in->n_tris; ++k) if ((uint64_t)in->prim_base + in->tris[k].prim >= s->n_tris) return 2;
     }
     for (uint32_t i = 0; i < n_inst; ++i) if (order[i] >= n_inst) return 3;
     return 0;

@@ -42,8 +42,9 @@ def test_headline_frame_matches_oracle(big):
     assert stats["shadow_rays"] == ost["shadow_rays"] > 100000
 
 
-def test_headline_frame_over_a_tree_with_spatial_splits(big, monkeypatch):
-    """MIPT_OPT_BUILD = 3 (what bench.py builds): the headline scene's tree with spatial splits -- triangles that straddle a split plane
+@pytest.mark.parametrize("builder", [4, 3])
+def test_headline_frame_over_a_tree_with_spatial_splits(big, monkeypatch, builder):
+    """MIPT_OPT_BUILD = 4 (what bench.py builds; 3: the same on the host): the headline scene's tree with spatial splits -- triangles that straddle a split plane
     are referenced on both sides, each reference bounding its part of the triangle conservatively -- must lose no hit: the full frame,
     the frame buffer and the ray counters at depth 1, and 40 000 pixels at depth 8, equal those over the default builder's tree bit for bit;
     the oracle walks the exported tree (more triangle records than triangles) to the same frame."""
@@ -52,7 +53,7 @@ def test_headline_frame_over_a_tree_with_spatial_splits(big, monkeypatch):
     from optix_raytracer_amd import scenes
     PT, st, ob, scene = big
     acc, frame, stats = _render(PT, st, ob)
-    monkeypatch.setenv("MIPT_BUILD", "3")
+    monkeypatch.setenv("MIPT_BUILD", str(builder))
     st3 = PT2.make_state(scene, 1920, 1080, 1, 0, max_depth=1)
     monkeypatch.delenv("MIPT_BUILD")
     ob3 = PT2.OutputBuffer(1920, 1080, st3.device)
@@ -65,6 +66,11 @@ def test_headline_frame_over_a_tree_with_spatial_splits(big, monkeypatch):
     osc = O.Scene(scene).set_bvh(nodes, tris)
     a, f, ost = osc.render(scenes.launch_desc(scene, 1920, 1080, 1), max_depth=1, threads=16)
     assert np.array_equal(acc3.view(np.uint32), a.view(np.uint32)) and np.array_equal(frame3, f)
+    if builder == 4:             # the device builder moves references with atomics: a second build is the same tree all the same
+        PT2.buildMeshAccel(st3, scene)
+        nodes2, tris2 = st3.context.accel_export(st3.gas_handle)
+        assert np.array_equal(nodes.view(np.uint32), nodes2.view(np.uint32)) and np.array_equal(tris.view(np.uint32), tris2.view(np.uint32))
+        del nodes2, tris2
     for s_ in (st, st3):
         s_.context.set_option(L.OPT_MAX_DEPTH, 8)
     a8, _, s8 = _render(PT, st, ob)

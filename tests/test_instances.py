@@ -76,16 +76,24 @@ def _render(PT, st):
     return st.accum.cpu().numpy(), ob.getHostPointer(), st.context.launch_stats()
 
 
-def test_two_level_structure_matches_the_oracle_and_the_flattened_scene(tmp_path):
+@pytest.mark.parametrize("builder", [None, 4])
+def test_two_level_structure_matches_the_oracle_and_the_flattened_scene(tmp_path, monkeypatch, builder):
+    """builder = 4: the meshes built on the device with spatial splits (MIPT_OPT_BUILD = 4) -- their leaves hold more triangle records
+    than the meshes have triangles, the hit records are the same"""
     import torch
     assert torch.cuda.is_available()
     from optix_raytracer_amd import _lib as L
     from optix_raytracer_amd import api, scenes
     path = scenes.write_instanced_gltf(tmp_path / "instanced.gltf")
+    if builder is not None:
+        monkeypatch.setenv("MIPT_BUILD", str(builder)); monkeypatch.setenv("MIPT_BUILD_HOST_BELOW", "0")
     ctx = api.Context(0)
     flat, ias, gas, inst, keep = _build(ctx, torch, path)
     info = ctx.accel_info(ias)
     assert info["num_instances"] == len(inst) == 151 and info["num_triangles"] == flat["vertices"].shape[0] // 3
+    if builder == 4:
+        meshes = scenes.gltf_two_level(api.Scene(path))[0]
+        assert sum(ctx.accel_info(g)["num_triangles"] for g in gas) > sum(v.shape[0] // 3 for v, _ in meshes)
     w, h, spp, depth = 320, 180, 2, 4
     launch = scenes.launch_desc(flat, w, h, spp)
     # ---- (a) GPU over the two-level structure == the oracle's two-level walk, bit for bit (frames, counters, visit counts)
@@ -276,8 +284,8 @@ def test_any_hit_programs_inside_instances(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("persistent,seed,n_instances", [(None, 8, 70), (2, 8, 70), (None, 31, 140)])
-def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, persistent, seed, n_instances):
+@pytest.mark.parametrize("persistent,seed,n_instances,builder", [(None, 8, 70, None), (2, 8, 70, None), (None, 31, 140, None), (None, 8, 70, 4), (2, 31, 140, 4)])
+def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, monkeypatch, persistent, seed, n_instances, builder):
     """The deferred any-hit programs over the two-level structure (k_wh_trace_pool_inst; persistent = 2: k_wh_trace_inst, one ray per
     thread) against the ORACLE's two-level render of the same structure: textured BLEND and MASK materials on the instanced meshes,
     frames, frame buffer and ray counters bit for bit -- candidates in the order of (t, flattened primitive index), t taken with the
@@ -293,6 +301,8 @@ def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, persistent
     path = scenes.write_instanced_gltf(tmp_path / "instanced_alpha.gltf", n_instances=n_instances, seed=seed,
                                        alpha_textures=(PF.encode(film, 6, 8)[0], PF.encode(fence, 6, 8)[0]))
     w, h = 200, 112
+    if builder is not None:       # the meshes under the instances built with spatial splits: a candidate met through two references counts once
+        monkeypatch.setenv("MIPT_BUILD", str(builder)); monkeypatch.setenv("MIPT_BUILD_HOST_BELOW", "0")
     st = MV.MeshViewerState()
     MV.loadScene(st, path, two_level=True)
     if persistent is not None:
@@ -312,6 +322,9 @@ def test_any_hit_programs_inside_instances_match_the_oracle(tmp_path, persistent
     verts, mat = st.scene.flatten()
     flat = {"vertices": verts, "mat_index": np.zeros(mat.shape[0], np.uint32), "emission": np.zeros((1, 3), np.float32), "diffuse": np.ones((1, 3), np.float32)}
     osc = _oracle_two_level(ctx, flat, st.handle)
+    if builder == 4:
+        gas_handles = set(int(x) for x in ctx.accel_export_instances(st.handle)[4])
+        assert sum(ctx.accel_info(g)["num_triangles"] for g in gas_handles) > sum(int(ctx.accel_export(g)[1].view(np.uint32)[:, 3].max()) + 1 for g in gas_handles)
     gf = MV.geometry_flags(st.materials)
     osc.set_prim_flags(gf[np.minimum(mat, len(gf) - 1)])
     mats = [{"base_color": list(m.base_color), "metallic": m.metallic, "roughness": m.roughness, "emissive_factor": list(m.emissive_factor),

@@ -25,9 +25,9 @@ def frames(st, ob, k=20):
     return (time.perf_counter() - t0) / k * 1e3
 
 
-print("%d triangles, %dx%d, depth 1: builder (0 host SAH / 1 device LBVH / 2 device SAH) x node format" % (n, W, H), flush=True)
+print("%d triangles, %dx%d, depth 1: builder (0 host SAH / 1 device LBVH / 2 device SAH / 3, 4 host, device SAH with spatial splits) x node format" % (n, W, H), flush=True)
 only = [tuple(int(x) for x in c.split(":")) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else None     # e.g. "1:2,0:2"
-for mode, fmt in [c for c in [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (2, 2)] if only is None or c in only]:
+for mode, fmt in [c for c in [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (2, 2), (4, 2), (3, 2)] if only is None or c in only]:
     st = PT.PathTracerState()
     PT.createContext(st, 0)
     st.context.set_option(L.OPT_BUILD, mode)
@@ -43,6 +43,11 @@ for mode, fmt in [c for c in [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (2
     ob = PT.OutputBuffer(W, H, st.device)
     ms = frames(st, ob)
     info = st.context.accel_info(st.gas_handle)
+    if mode in (3, 4):       # spatial splits: clipped references, no refit
+        print("builder %d format %d (in effect %d, %d mirror nodes, stack %d): build %8.2f ms (call incl. upload %7.1f ms), %d nodes depth %d over %d records, frame %.3f ms | no refit (spatial splits)" % (
+            mode, fmt, info["node_format"], info["mirror_nodes"], info["stack_entries"], info["build_seconds"] * 1e3, wall * 1e3, info["num_nodes"], info["depth"], info["num_triangles"], ms), flush=True)
+        PT.cleanupState(st)
+        continue
     # refit to slightly moved vertices (mipt_accel_update), then the frame again
     rng = np.random.default_rng(3)
     v = np.array(scene["vertices"], np.float32, copy=True)

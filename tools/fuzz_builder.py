@@ -59,7 +59,7 @@ for seed in range(first, first + count):
         dv = torch.from_numpy(verts).cuda()
         inp = [{"vertices": dv.data_ptr(), "num_vertices": verts.shape[0], "stride": 16}]
         res = {}
-        for mode in (2, 3, 0):
+        for mode in (2, 3, 4, 0):
             ctx = api.Context(0)
             ctx.set_option(L.OPT_BUILD, mode)
             h = ctx.accel_build(inp)
@@ -89,13 +89,15 @@ for seed in range(first, first + count):
             ctx.trace_closest(h, d_rays.data_ptr(), m, d_hits.data_ptr()); ctx.trace_any(h, d_seg.data_ptr(), m, d_occ.data_ptr()); ctx.sync()
             res[mode] = (d_hits.cpu().numpy(), d_occ.cpu().numpy(), info)
             ctx.destroy()
-        for mode in (2, 3):
+        for mode in (2, 3, 4):
             assert np.array_equal(res[mode][0].view(np.uint32), res[0][0].view(np.uint32)), "hit records differ (builder %d)" % mode
             assert np.array_equal(res[mode][1], res[0][1]), "occlusion flags differ (builder %d)" % mode
-        print("seed %3d kind %d n %6d ok: %d nodes depth %d (host %d / %d; spatial %d / %d over %d records), %d hits, build %.2f ms (host %.1f, spatial %.1f)" % (
+        print("seed %3d kind %d n %6d ok: %d nodes depth %d (host %d / %d; spatial %d / %d over %d records; device spatial %d / %d over %d records), %d hits, "
+              "build %.2f ms (host %.1f, spatial %.1f, device spatial %.2f)" % (
             seed, kind, n, res[2][2]["num_nodes"], res[2][2]["depth"], res[0][2]["num_nodes"], res[0][2]["depth"],
-            res[3][2]["num_nodes"], res[3][2]["depth"], res[3][2]["num_triangles"],
-            int((res[2][0][:, 0] >= 0).sum()), res[2][2]["build_seconds"] * 1e3, res[0][2]["build_seconds"] * 1e3, res[3][2]["build_seconds"] * 1e3), flush=True)
+            res[3][2]["num_nodes"], res[3][2]["depth"], res[3][2]["num_triangles"], res[4][2]["num_nodes"], res[4][2]["depth"], res[4][2]["num_triangles"],
+            int((res[2][0][:, 0] >= 0).sum()), res[2][2]["build_seconds"] * 1e3, res[0][2]["build_seconds"] * 1e3, res[3][2]["build_seconds"] * 1e3,
+            res[4][2]["build_seconds"] * 1e3), flush=True)
     except Exception as e:                              # noqa: BLE001
         bad += 1
         print("seed %3d kind %d n %6d FAILED: %s" % (seed, kind, n, str(e)[:300]), flush=True)
