@@ -221,7 +221,7 @@ typedef enum MiptOption {
                                   ranges of 128 references (env MIPT_SPLIT_BELOW), which are then split by objects only: builder 3's frames
                                   (the headline scene 0.519 against 0.516 ms) from a build of ~12 ms per million triangles instead of ~3 s; the
                                   same tree in every run; num_triangles counts RECORDS and mipt_accel_update fails, as for 3; an input it gives up
-                                  on (more than 4 M triangles, lists that overflow) is built as by 2;
+                                  on (lists that overflow) is built as by 2, and the records stay below 2^23 whatever the budget (the entry pool's index width);
                                   0: binned SAH on the host cores (155 ms per million triangles).  1 and 2 fall back to 0 for inputs of
                                   <= 4 triangles and when their tree is deeper than the 32-entry traversal stack */
     MIPT_OPT_TAIL_PATHS   = 13, /* once at most this many paths of a pass are alive (the count is read back two bounces late;

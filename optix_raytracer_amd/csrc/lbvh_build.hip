@@ -1780,7 +1780,9 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
     const bool top_down = sah_top && sah_treelets && n_in > 2u * (uint32_t)kTreelet;
     if (ret_below > kSahSmall) ret_below = kSahSmall;
     if (ret_below < kTreelet) ret_below = kTreelet;
-    const uint32_t sp_budget = top_down && spatial_extra > 0.0f && n_in > (uint32_t)ret_below && n_in < (1u << 22) ? (uint32_t)((double)n_in * (double)spatial_extra) : 0u;
+    // (the entry pool's words hold a 23-bit record index: the records stay below 2^23, whatever the budget asks for)
+    uint32_t sp_budget = top_down && spatial_extra > 0.0f && n_in > (uint32_t)ret_below && n_in < (1u << 23) - 1u ? (uint32_t)fmin((double)n_in * (double)spatial_extra, 4.0e9) : 0u;
+    if (sp_budget > (1u << 23) - 1u - n_in) sp_budget = (1u << 23) - 1u - n_in;
     const bool spatial = sp_budget != 0u;
     const uint32_t cap = n_in + sp_budget;
     uint32_t n = n_in;                                   // the items of the passes after the front end: triangles, or references

@@ -9,7 +9,7 @@ python tools/bench_pipelines.py 2>/dev/null > "$O/${T}_bench_pipelines.txt"; ech
 python tools/bench_instances.py 2>/dev/null > "$O/${T}_bench_instances.txt"; echo instances done
 python tools/bench_inst_pt.py 2>/dev/null > "$O/${T}_bench_inst_pt.txt"; echo inst_pt done
 python tools/shard_probe.py 2>/dev/null > "$O/${T}_shard_probe.txt"; echo shard done
-python tools/build_probe.py 1000000 0:2,1:2,2:2 2>/dev/null > "$O/${T}_build_probe.txt"; echo build done
+python tools/build_probe.py 1000000 0:2,1:2,2:2,4:2 2>/dev/null > "$O/${T}_build_probe.txt"; echo build done
 python tools/soak.py 100 > "$O/${T}_soak.txt" 2>&1; tail -2 "$O/${T}_soak.txt"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${T}_kstats" -- python3 "$R/bench.py" --no-cpu-baseline > "$O/${T}_kstats.log" 2>&1; echo kstats done
