@@ -253,6 +253,9 @@ struct SbvhBuilder {
     int max_tasks = 0;
     std::deque<SNode> nodes;
     std::mutex mu;
+    // test / experiment knobs, read from the environment by build_sbvh at every build
+    bool force = false, unsplit = true, simple = false;
+    uint32_t sp_max_n = 0xffffffffu, sp_min_n = 0u;
 
     uint64_t capacity(int levels) const { if (levels < 0) return 0; if (levels > 40) levels = 40; return (uint64_t)leaf_max << levels; }
     int alloc() { std::lock_guard<std::mutex> g(mu); nodes.emplace_back(); return (int)nodes.size() - 1; }
@@ -306,10 +309,7 @@ struct SbvhBuilder {
         float sp_cost = std::numeric_limits<float>::infinity(); int sp_axis = -1; float sp_plane = 0.0f;
         const uint64_t sp_cap = capacity(depth_cap - depth - 1 - 3);
         // (env MIPT_SBVH_FORCE=1, tests: a valid spatial split is taken whether it is cheaper or not -- trees full of shared references)
-        static const bool force = [] { const char* e = std::getenv("MIPT_SBVH_FORCE"); return e && std::atoi(e) != 0; }();
         // (env MIPT_SBVH_MAX_N / MIPT_SBVH_MIN_N, experiments: spatial splits only at nodes of that many references)
-        static const uint32_t sp_max_n = [] { const char* e = std::getenv("MIPT_SBVH_MAX_N"); return e ? (uint32_t)std::atoll(e) : 0xffffffffu; }();
-        static const uint32_t sp_min_n = [] { const char* e = std::getenv("MIPT_SBVH_MIN_N"); return e ? (uint32_t)std::atoll(e) : 0u; }();
         bool try_spatial = n > (uint32_t)leaf_max && budget > 0 && (uint64_t)n <= sp_cap && n <= sp_max_n && n >= sp_min_n;
         if (try_spatial && obj_axis >= 0 && !force) {
             Box ov;
@@ -318,7 +318,6 @@ struct SbvhBuilder {
             try_spatial = overlap && ov.half_area() > 1e-5f * root_area;
         }
         // (env MIPT_SBVH_SIMPLE=1, experiment: the only spatial candidate is the object split's own plane, taken whenever it is tried)
-        static const bool simple = [] { const char* e = std::getenv("MIPT_SBVH_SIMPLE"); return e && std::atoi(e) != 0; }();
         if (try_spatial && simple) {
             if (obj_axis >= 0) { sp_axis = obj_axis; sp_plane = cb.lo[obj_axis] + (float)(obj_bin + 1) / scale[obj_axis]; sp_cost = -1.0f; }
         } else if (try_spatial) {
@@ -360,7 +359,6 @@ struct SbvhBuilder {
             // the references that lie on one side go there; the straddlers are clipped, and then each is looked at once more ("reference
             // unsplitting", Stich et al. 4.4): whole on the left, whole on the right, or split -- whichever is cheapest with the sides as they
             // stand (env MIPT_SBVH_UNSPLIT=0: always split)
-            static const bool unsplit = [] { const char* e = std::getenv("MIPT_SBVH_UNSPLIT"); return e ? std::atoi(e) != 0 : true; }();
             struct Straddler { Ref whole, a, b; bool hl, hr; };
             std::vector<Straddler> st;
             Box BL, BR; BL.reset(); BR.reset();
@@ -529,6 +527,11 @@ bool build_sbvh(const float* world_verts, uint32_t n_tris, int leaf_max, int dep
     if (leaf_max < 1 || leaf_max > 15 || depth_cap < 1 || n_tris >= (1u << 26)) return false;
     SbvhBuilder B;
     B.verts = world_verts; B.leaf_max = leaf_max; B.depth_cap = depth_cap; B.max_tasks = n_threads > 1 ? n_threads - 1 : 0;
+    if (const char* e = std::getenv("MIPT_SBVH_FORCE")) B.force = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_SBVH_UNSPLIT")) B.unsplit = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_SBVH_SIMPLE")) B.simple = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_SBVH_MAX_N")) B.sp_max_n = (uint32_t)std::atoll(e);
+    if (const char* e = std::getenv("MIPT_SBVH_MIN_N")) B.sp_min_n = (uint32_t)std::atoll(e);
     if ((uint64_t)n_tris > B.capacity(depth_cap)) return false;
     std::vector<Ref> refs(n_tris);
     Box all; all.reset();
