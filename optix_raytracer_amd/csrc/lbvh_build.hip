@@ -1344,7 +1344,8 @@ __global__ __launch_bounds__(256) void k_lbvh_depth(const int* parent_inner, con
 }
 
 // ---- refit (mipt_accel_update): same topology, new vertex positions -------------------------------------------------------
-// triangle records of the existing leaf order from the new world-space vertices
+// triangle records of the existing leaf order from the new world-space vertices (n: the records -- more than there are triangles when the
+// tree was built with spatial splits; a record's primitive number is below the number of triangles, hence below n)
 __global__ __launch_bounds__(256) void k_refit_tris(const float* __restrict__ world, uint32_t n, MiptBvhTri* tris)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1386,21 +1386,21 @@ int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBui
     Accel* a = find_accel(ctx, handle);
     if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
     if (a->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "0x%llx is an instance structure: use mipt_accel_update_instances", handle);
-    if (a->builder == 3 || a->builder == 4)
-        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "0x%llx was built with spatial splits (MIPT_OPT_BUILD = 3 or 4): its leaves hold clipped references, which a refit cannot keep -- build it again", handle);
-
+    // (a tree with spatial splits -- builders 3 and 4: more records than triangles -- is refitted like any other: every record's box becomes the
+    //  box of its WHOLE moved triangle.  The tree stays a sound BVH, hit records stay exact; what the clipped references bought is gone until
+    //  the next build, as a refit of any tree keeps the topology and loses quality)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());                         // launches that still read the old boxes
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGather G;
     const int grc = gather_on_device(ctx, inputs, num_inputs, G, /*keep_mats=*/false, 0);
     if (grc != MIPT_SUCCESS) return grc;
-    if (G.n == 0u || G.n != a->num_tris || a->num_nodes == 0u)
-        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update: the inputs hold %u triangles, the traversable was built from %u", G.n, a->num_tris);
+    if (G.n == 0u || G.n != a->n_prims || a->num_nodes == 0u)
+        return ctx->fail(MIPT_ERROR_INVALID_VALUE, "accel_update: the inputs hold %u triangles, the traversable was built from %u", G.n, a->n_prims);
     if (G.e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(G.e));
     if (G.err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, G.err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
     if (!a->d_height) return ctx->fail(MIPT_ERROR_INTERNAL, "accel_update: the traversable has no height table");
-    hipError_t e = lbvh_refit(nullptr, G.world, G.n, a->d_nodes, a->num_nodes, a->d_tris, a->d_height, a->depth);
+    hipError_t e = lbvh_refit(nullptr, G.world, a->num_tris, a->d_nodes, a->num_nodes, a->d_tris, a->d_height, a->depth);       // (num_tris: the triangle RECORDS)
     if (e == hipSuccess) e = finish_blob(ctx, a);            // the refitted boxes are fp32: round and pack them again
     if (e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(e));
     // an instance structure that references this mesh holds copies of its mirrors and a world box made from its old root box: it has to

@@ -77,9 +77,14 @@ def test_headline_frame_over_a_tree_with_spatial_splits(big, monkeypatch, builde
     b8, _, t8 = _render(PT2, st3, ob3)
     st.context.set_option(L.OPT_MAX_DEPTH, 1)
     assert np.array_equal(a8.view(np.uint32), b8.view(np.uint32)) and s8["closest_rays"] == t8["closest_rays"] and s8["shadow_rays"] == t8["shadow_rays"]
-    with pytest.raises(Exception) as e:                          # clipped references cannot be refitted
-        st3.context.accel_update(st3.gas_handle, [{"vertices": st3.d_vertices.data_ptr(), "num_vertices": 3_000_000, "stride": 16}])
-    assert "spatial" in str(e.value)
+    # a refit (here: to the same vertices) gives every record the box of its WHOLE triangle: a sound tree still, the same frame
+    st3.context.set_option(L.OPT_MAX_DEPTH, 1)
+    st3.context.accel_update(st3.gas_handle, [{"vertices": st3.d_vertices.data_ptr(), "num_vertices": 3_000_000, "stride": 16}])
+    nodes_r, tris_r = st3.context.accel_export(st3.gas_handle)
+    assert np.array_equal(tris_r.view(np.uint32), tris.view(np.uint32))
+    O.Scene(scene).set_bvh(nodes_r, tris_r)
+    acc_r, frame_r, stats_r = _render(PT2, st3, ob3)
+    assert np.array_equal(acc_r.view(np.uint32), acc.view(np.uint32)) and np.array_equal(frame_r, frame) and stats_r["shadow_rays"] == stats["shadow_rays"]
     PT2.cleanupState(st3)
 
 

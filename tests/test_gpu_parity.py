@@ -569,15 +569,17 @@ def test_device_lbvh_build_gives_the_same_pictures(name, n, builder, tmp_path, m
     assert infos[0]["num_triangles"] == infos[1]["num_triangles"] and infos[1]["depth"] <= 32 and infos[1]["leaf_max"] <= 4
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_accel_update_refits_to_moved_vertices(mode):
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_accel_update_refits_to_moved_vertices(mode, monkeypatch):
     """mipt_accel_update (= OPTIX_BUILD_OPERATION_UPDATE): after the vertices have moved, the refitted tree is a sound BVH of
-    the new triangles (oracle validation) and frames over it are bit-identical to frames over a fresh build"""
+    the new triangles (oracle validation) and frames over it are bit-identical to frames over a fresh build.  Modes 3 and 4: trees with
+    spatial splits (a dense soup, so that triangles are cut) -- a refit gives every record the box of its whole moved triangle"""
     torch = _torch()
     from optix_raytracer_amd import _lib as L
     from optix_raytracer_amd import pathtracer as PT
     from optix_raytracer_amd import scenes
-    scene = scenes.random_soup(20000)
+    monkeypatch.setenv("MIPT_BUILD_HOST_BELOW", "0")
+    scene = scenes.random_soup(20000, edge_scale=0.05 if mode in (3, 4) else 0.01)
     rng = np.random.default_rng(17)
     moved = dict(scene)
     v = np.array(scene["vertices"], np.float32, copy=True)
@@ -602,6 +604,7 @@ def test_accel_update_refits_to_moved_vertices(mode):
     st = make(scene)
     before = _render_gpu(PT, st)
     info0 = st.context.accel_info(st.gas_handle)
+    assert info0["num_triangles"] > 21000 if mode in (3, 4) else info0["num_triangles"] == 20000
     d_mat = torch.from_numpy(np.ascontiguousarray(scene["mat_index"]).astype(np.int32)).cuda()
     st.d_vertices.copy_(torch.from_numpy(v))                      # the hit-group records point at this buffer
     st.context.accel_update(st.gas_handle, [{"vertices": st.d_vertices.data_ptr(), "num_vertices": v.shape[0], "stride": 16,

@@ -43,11 +43,6 @@ for mode, fmt in [c for c in [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (2
     ob = PT.OutputBuffer(W, H, st.device)
     ms = frames(st, ob)
     info = st.context.accel_info(st.gas_handle)
-    if mode in (3, 4):       # spatial splits: clipped references, no refit
-        print("builder %d format %d (in effect %d, %d mirror nodes, stack %d): build %8.2f ms (call incl. upload %7.1f ms), %d nodes depth %d over %d records, frame %.3f ms | no refit (spatial splits)" % (
-            mode, fmt, info["node_format"], info["mirror_nodes"], info["stack_entries"], info["build_seconds"] * 1e3, wall * 1e3, info["num_nodes"], info["depth"], info["num_triangles"], ms), flush=True)
-        PT.cleanupState(st)
-        continue
     # refit to slightly moved vertices (mipt_accel_update), then the frame again
     rng = np.random.default_rng(3)
     v = np.array(scene["vertices"], np.float32, copy=True)
@@ -64,8 +59,8 @@ for mode, fmt in [c for c in [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (2
     upd = (time.perf_counter() - t0) / 5 * 1e3
     ms2 = frames(st, ob)
     info2 = st.context.accel_info(st.gas_handle)
-    print("builder %d format %d (in effect %d, %d mirror nodes, stack %d): build %8.2f ms (call incl. upload %7.1f ms), %d nodes depth %d, frame %.3f ms | "
+    print("builder %d format %d (in effect %d, %d mirror nodes, stack %d): build %8.2f ms (call incl. upload %7.1f ms), %d nodes depth %d over %d records, frame %.3f ms | "
           "refit %6.2f ms, frame %.3f ms (format in effect %d)" % (
               mode, fmt, info["node_format"], info["mirror_nodes"], info["stack_entries"], info["build_seconds"] * 1e3, wall * 1e3,
-              info["num_nodes"], info["depth"], ms, upd, ms2, info2["node_format"]), flush=True)
+              info["num_nodes"], info["depth"], info["num_triangles"], ms, upd, ms2, info2["node_format"]), flush=True)
     PT.cleanupState(st)
