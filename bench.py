@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--builder", type=int, default=4,
                     help="MIPT_OPT_BUILD for the scene's BVH (the build is outside the timed region, as BASELINE.json's metric has it): 4 = device SAH with "
                          "spatial splits, the tree for a static scene (default here; what OPTIX_BUILD_FLAG_PREFER_FAST_TRACE asks for; ~12 ms per million "
-                         "triangles); 3 = the same on the host (~3 s); 2 = the library's default, on the device in 7 ms, a tree that can be refitted; "
+                         "triangles); 3 = the same on the host (~3 s); 2 = the library's default, on the device in 7 ms; "
                          "1 = device Morton; 0 = host SAH.  The environment's MIPT_BUILD wins (A/B runs).")
     return ap.parse_args()
 

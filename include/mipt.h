@@ -213,14 +213,18 @@ typedef enum MiptOption {
                                   on both sides, each reference with the conservatively clipped bounds of its part; at most 50 % more triangle
                                   records, env MIPT_SBVH_EXTRA): the best tree for a static scene (~ PREFER_FAST_TRACE) -- frames over scenes of
                                   triangles as large as the gaps between them 6-7 % faster (the headline scene 0.557 -> 0.520 ms), 0-3 % elsewhere
-                                  -- at ~3 s per million triangles; MiptAccelInfo::num_triangles then counts RECORDS; such a tree cannot be
-                                  refitted (mipt_accel_update fails: build it again);
+                                  -- at ~3 s per million triangles; MiptAccelInfo::num_triangles then counts RECORDS; mipt_accel_update
+                                  gives every record the box of its WHOLE moved triangle (a sound tree, but the overlap the splits removed is back:
+                                  build it again instead);
                                   4: spatial splits ON THE DEVICE (~ PREFER_FAST_TRACE at the cost of a build): builder 2 whose level loop cuts the
                                   triangles that straddle a split plane in two wherever the split's sides overlap (the plane is the object
                                   split's own; clipped bounds in double, rounded outward; the same reference budget, MIPT_SBVH_EXTRA), down to
                                   ranges of 128 references (env MIPT_SPLIT_BELOW), which are then split by objects only: builder 3's frames
                                   (the headline scene 0.519 against 0.516 ms) from a build of ~12 ms per million triangles instead of ~3 s; the
-                                  same tree in every run; num_triangles counts RECORDS and mipt_accel_update fails, as for 3; an input it gives up
+                                  same tree in every run; num_triangles counts RECORDS; mipt_accel_update clips every record's moved triangle to the cell the
+                                  builder cut it to (kept, 24 bytes per record): the same vertices give the same tree back, small motions keep most of
+                                  what the cuts bought (1 M triangles moved by 5 % of their size: 0.549 -> 0.594 ms, a refitted tree of builder 2:
+                                  0.581) -- scenes that are refitted every frame are builder 2's; an input it gives up
                                   on (lists that overflow) is built as by 2, and the records stay below 2^23 whatever the budget (the entry pool's index width);
                                   0: binned SAH on the host cores (155 ms per million triangles).  1 and 2 fall back to 0 for inputs of
                                   <= 4 triangles and when their tree is deeper than the 32-entry traversal stack */

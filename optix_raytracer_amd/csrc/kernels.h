@@ -231,12 +231,13 @@ size_t collapse_bvh4_scratch_bytes(uint32_t nn);
 hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d_height, uint32_t nn, uint32_t depth, void* d_nodes4, uint32_t* n4,
                          uint32_t* stack_need, bool* ok, void* scratch = nullptr, size_t scratch_bytes = 0,
                          uint32_t budget = 32u);       // budget: the most stack entries a lane may need while walking the mirror
-hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth);
+hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth,
+                      const float* d_cells = nullptr);        // n: triangle RECORDS; d_cells: 6 floats per record of a tree built with MIPT_OPT_BUILD = 4, or null
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets = true,
                       uint32_t* d_prim_slot = nullptr,        // d_prim_slot: n words, filled with primitive -> position of its triangle record
                       bool sah_top = false,                   // the levels above the treelets by top-down binned SAH instead of Morton codes (MIPT_OPT_BUILD = 2)
-                      float spatial_extra = 0.0f, int ret_below = 256, uint32_t* num_records = nullptr);      // MIPT_OPT_BUILD = 4: triangles cut at split planes (lbvh_build.hip: struct SpSplit)
+                      float spatial_extra = 0.0f, int ret_below = 256, uint32_t* num_records = nullptr, float** d_cells = nullptr);      // MIPT_OPT_BUILD = 4: triangles cut at split planes (lbvh_build.hip: struct SpSplit)
 
 // SDK/cuda/whitted.cu pipeline (whitted_kernels.hip)
 struct WhTables {                  // MiptWhittedGeometry with typed pointers: the shading tables of a flattened scene, or of one mesh

@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_sp_alloc(SpSplit* splits, const uint32_
 // every reference moves to its side(s).  Two passes over a chunk: ranks and bounds first (LDS counters per range and side, the chunk's
 // new ids from one LDS counter), then -- bases known -- the writes; a reference that is cut is clipped in both (no boxes held across).
 __global__ __launch_bounds__(256) void k_sp_partition(const uint32_t* __restrict__ ids_in, const uint32_t* __restrict__ seg_in, uint32_t n_pos, const SpSplit* __restrict__ splits,
-                                                      uint32_t* ids_out, uint32_t* seg_out, uint32_t* retired, uint32_t* fill, Box6* pbox, uint32_t* pprim,
+                                                      uint32_t* ids_out, uint32_t* seg_out, uint32_t* retired, uint32_t* fill, Box6* pbox, uint32_t* pprim, Box6* pcell,
                                                       const float* __restrict__ world, uint32_t* pool_cursor, uint32_t pool_cap, SahSeg* next, SpRet* rets)
 {
     __shared__ uint32_t s_dir[kSpTables], s_cnt[kSpTables][2], s_base[kSpTables][2], s_cb[kSpTables][2][6], s_new, s_newbase;
@@ -1132,10 +1132,17 @@ __global__ __launch_bounds__(256) void k_sp_partition(const uint32_t* __restrict
                 Box6 bl = b, br = b;
                 sp_classify(b, sp.axis, sp.plane, world + (size_t)pprim[id] * 9, bl, br);
                 if (c == 2) {
+                    // the CELLS of the two parts: the half-spaces of the cuts this triangle has been through.  The cells of a triangle's records
+                    // tile space, so after the triangle has moved (mipt_accel_update) "box of the triangle, cut by the cell" still bounds the part
+                    // of it each record answers for
+                    Box6 cl = pcell[id], cr = cl;
+                    if (sp.axis == 0) { cl.hi[0] = fminf(cl.hi[0], sp.plane); cr.lo[0] = fmaxf(cr.lo[0], sp.plane); }
+                    else if (sp.axis == 1) { cl.hi[1] = fminf(cl.hi[1], sp.plane); cr.lo[1] = fmaxf(cr.lo[1], sp.plane); }
+                    else { cl.hi[2] = fminf(cl.hi[2], sp.plane); cr.lo[2] = fmaxf(cr.lo[2], sp.plane); }
                     id_r = s_newbase + newrank[e];
-                    if (id_r < pool_cap) { pbox[id_r] = br; pprim[id_r] = pprim[id]; }
-                    pbox[id] = bl;
-                } else pbox[id] = c == 3 ? bl : br;
+                    if (id_r < pool_cap) { pbox[id_r] = br; pprim[id_r] = pprim[id]; pcell[id_r] = cr; }
+                    pbox[id] = bl; pcell[id] = cl;
+                } else pbox[id] = c == 3 ? bl : br;             // (the triangle does not reach across the plane inside its cell TODAY: the cell stays)
             }
             for (int side = 0; side < 2; ++side) {
                 const bool takes = side == 0 ? (c == 0 || c == 2 || c == 3) : (c == 1 || c == 2 || c == 4);
@@ -1157,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_sp_partition(const uint32_t* __restrict
 // a retired range in its final place: sorted by primitive number (the order its references arrived in depends on the run), boxes and
 // primitive numbers gathered, the items numbered by their positions
 __global__ __launch_bounds__(256) void k_sp_layout(const SpRet* __restrict__ rets, uint32_t n_rets, const uint32_t* __restrict__ retired, const Box6* __restrict__ pbox,
-                                                   const uint32_t* __restrict__ pprim, Box6* fbox, uint32_t* fprim, uint32_t* perm)
+                                                   const uint32_t* __restrict__ pprim, const Box6* __restrict__ pcell, Box6* fbox, uint32_t* fprim, Box6* fcell, uint32_t* perm)
 {
     __shared__ unsigned long long s_key[kSahSmall];
     for (uint32_t r = blockIdx.x; r < n_rets; r += gridDim.x) {
@@ -1184,7 +1191,7 @@ __global__ __launch_bounds__(256) void k_sp_layout(const SpRet* __restrict__ ret
             }
         for (int i = (int)threadIdx.x; i < (int)rr.size; i += 256) {
             const uint32_t id = (uint32_t)s_key[i], at = rr.final_off + (uint32_t)i;
-            fbox[at] = pbox[id]; fprim[at] = pprim[id]; perm[at] = at;
+            fbox[at] = pbox[id]; fprim[at] = pprim[id]; fcell[at] = pcell[id]; perm[at] = at;
         }
         __syncthreads();
     }
@@ -1207,10 +1214,14 @@ __global__ __launch_bounds__(256) void k_sp_links(const SpLink* __restrict__ lin
     if (i < n_leaves) plf[leaves[i].pos] = leaves[i].parent;
 }
 
-__global__ __launch_bounds__(256) void k_sp_init(uint32_t* ids, uint32_t* seg_of, uint32_t* pprim, uint32_t n)
+__global__ __launch_bounds__(256) void k_sp_init(uint32_t* ids, uint32_t* seg_of, uint32_t* pprim, Box6* pcell, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { ids[i] = i; seg_of[i] = 0u; pprim[i] = i; }
+    if (i >= n) return;
+    ids[i] = i; seg_of[i] = 0u; pprim[i] = i;
+    Box6 c;
+    for (int k = 0; k < 3; ++k) { c.lo[k] = -__builtin_inff(); c.hi[k] = __builtin_inff(); }
+    pcell[i] = c;
 }
 
 // ---- bottom-up passes without fences ---------------------------------------------------------------------------------------------
@@ -1317,11 +1328,12 @@ __global__ __launch_bounds__(256) void k_lbvh_emit(const int* left, const int* r
 }
 
 __global__ __launch_bounds__(256) void k_lbvh_tris(const float* __restrict__ world, const uint32_t* sorted_prims, const uint32_t* gflags, uint32_t n, MiptBvhTri* out,
-                                                  uint32_t* prim_slot, const uint32_t* __restrict__ ref_prim)
+                                                  uint32_t* prim_slot, const uint32_t* __restrict__ ref_prim, const Box6* __restrict__ ref_cell, Box6* cells_out)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t p = sorted_prims[k];
+    if (cells_out) cells_out[k] = ref_cell[p];          // the records' cells, in record order: what a refit cuts the moved triangles' boxes by
     if (ref_prim) p = ref_prim[p];                      // (spatial splits: the items are references; one of a triangle's records wins its prim_slot)
     if (prim_slot) prim_slot[p] = k;
     const float* v = world + (size_t)p * 9;
@@ -1398,7 +1410,8 @@ __global__ __launch_bounds__(256) void k_topo_heights(const MiptBvhNode* nodes, 
 }
 
 // refit, step 1: the boxes of every LEAF child from the new vertices (all nodes at once)
-__global__ __launch_bounds__(256) void k_refit_leaf_slots(MiptBvhNode* nodes, uint32_t nn, const MiptBvhTri* tris, uint32_t nt, const float* __restrict__ world)
+__global__ __launch_bounds__(256) void k_refit_leaf_slots(MiptBvhNode* nodes, uint32_t nn, const MiptBvhTri* tris, uint32_t nt, const float* __restrict__ world,
+                                                          const Box6* __restrict__ cells)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nn) return;
@@ -1412,7 +1425,24 @@ __global__ __launch_bounds__(256) void k_refit_leaf_slots(MiptBvhNode* nodes, ui
             const uint32_t p = tris[first + j].prim;
             if (p >= nt) continue;
             const float* v = world + (size_t)p * 9;
-            for (int c = 0; c < 9; ++c) { const float f = v[c]; lo[c % 3] = fminf(lo[c % 3], f); hi[c % 3] = fmaxf(hi[c % 3], f); }
+            float tl[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, th[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+            for (int c = 0; c < 9; ++c) { const float f = v[c]; tl[c % 3] = fminf(tl[c % 3], f); th[c % 3] = fmaxf(th[c % 3], f); }
+            if (cells) {
+                // a record of a tree with spatial splits answers for the part of its triangle inside its cell.  As the builder made its box:
+                // the triangle's box, cut in turn by the bounds of the triangle's part on the record's side of every plane of the cell (the
+                // bounds of an intersection lie inside the intersection of the bounds) -- for vertices that have not moved, the box the
+                // builder gave it.  A triangle that has left the cell altogether keeps its whole box (a sound, if loose, choice)
+                const Box6 cell = cells[first + j];
+                Box6 b; bool some = true;
+                for (int k = 0; k < 3; ++k) { b.lo[k] = tl[k]; b.hi[k] = th[k]; }
+                for (int k = 0; k < 3 && some; ++k) {
+                    const float pl_hi = k == 0 ? cell.hi[0] : (k == 1 ? cell.hi[1] : cell.hi[2]), pl_lo = k == 0 ? cell.lo[0] : (k == 1 ? cell.lo[1] : cell.lo[2]);
+                    if (pl_hi < 3.0e38f) { Box6 o; some = sp_clip_half(v, k, (double)pl_hi, false, b, o); if (some) b = o; }
+                    if (some && pl_lo > -3.0e38f) { Box6 o; some = sp_clip_half(v, k, (double)pl_lo, true, b, o); if (some) b = o; }
+                }
+                if (some) for (int k = 0; k < 3; ++k) { tl[k] = b.lo[k]; th[k] = b.hi[k]; }
+            }
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], tl[k]); hi[k] = fmaxf(hi[k], th[k]); }
         }
         refit_store_slot(nd, slot, lo, hi);
     }
@@ -1749,13 +1779,14 @@ hipError_t collapse_bvh4(hipStream_t st, const void* d_nodes32, const uint8_t* d
 
 // Refit of an existing tree (same topology) to new world-space vertices: triangle records, the boxes of the leaf children, then the
 // inner children's boxes one height at a time (d_height: topo_heights() of the tree; depth = the root's height).  Asynchronous on st.
-hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth)
+hipError_t lbvh_refit(hipStream_t st, const float* d_world, uint32_t n, float4* d_nodes, uint32_t nn, float4* d_tris, const uint8_t* d_height, uint32_t depth,
+                      const float* d_cells)
 {
     MiptBvhNode* nodes = reinterpret_cast<MiptBvhNode*>(d_nodes);
     MiptBvhTri* tris = reinterpret_cast<MiptBvhTri*>(d_tris);
     const uint32_t blocks = (nn + 255u) / 256u;
     hipLaunchKernelGGL(k_refit_tris, dim3((n + 255u) / 256u), dim3(256), 0, st, d_world, n, tris);
-    hipLaunchKernelGGL(k_refit_leaf_slots, dim3(blocks), dim3(256), 0, st, nodes, nn, tris, n, d_world);
+    hipLaunchKernelGGL(k_refit_leaf_slots, dim3(blocks), dim3(256), 0, st, nodes, nn, tris, n, d_world, reinterpret_cast<const Box6*>(d_cells));
     for (uint32_t level = 2; level <= depth; ++level)
         hipLaunchKernelGGL(k_refit_level, dim3(blocks), dim3(256), 0, st, nodes, nn, d_height, level);
     return hipGetLastError();
@@ -1774,9 +1805,9 @@ namespace {
 #define SP_TRY(x) do { if ((e = (x)) != hipSuccess) { if (std::getenv("MIPT_BUILD_DEBUG")) std::fprintf(stderr, "lbvh_build.hip:%d: %s\n", __LINE__, hipGetErrorString(e)); return fail(e); } } while (0)
 hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t* d_gflags, const uint32_t n_in, int leaf_max, int depth_cap,
                            float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets, uint32_t* d_prim_slot, bool sah_top,
-                           float spatial_extra, int ret_below, uint32_t* num_records)
+                           float spatial_extra, int ret_below, uint32_t* num_records, float** d_cells_out)
 {
-    *ok = false; *d_blob = nullptr; *num_records = n_in;
+    *ok = false; *d_blob = nullptr; *num_records = n_in; *d_cells_out = nullptr;
     // spatial splits (the comment at struct SpSplit): the level loop may add up to `sp_budget` references, every array below has room for them
     const bool top_down = sah_top && sah_treelets && n_in > 2u * (uint32_t)kTreelet;
     if (ret_below > kSahSmall) ret_below = kSahSmall;
@@ -1802,6 +1833,7 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
                  o_fill = carve(max_segs * 8u), o_bins = carve(max_segs * (size_t)kSahSegWords * 4u), o_small = carve(max_segs * sizeof(SahSeg));
     const size_t max_tn = spatial ? 8u * ((size_t)cap / (size_t)ret_below) + 4096u : 0u;
     const size_t o_fbox = carve(spatial ? sizeof(Box6) * cap : 0u), o_fprim = carve(spatial ? 4ull * cap : 0u), o_pprim = carve(spatial ? 4ull * cap : 0u),
+                 o_pcell = carve(spatial ? sizeof(Box6) * cap : 0u), o_fcell = carve(spatial ? sizeof(Box6) * cap : 0u),
                  o_bud0 = carve(max_segs * 4u * (spatial ? 1u : 0u)), o_bud1 = carve(max_segs * 4u * (spatial ? 1u : 0u)), o_cnt2 = carve(max_segs * 8u * (spatial ? 1u : 0u)),
                  o_tn = carve(max_tn * sizeof(SpNode)), o_ret = carve((max_tn + 1u) * sizeof(SpRet)), o_lnk = carve((2u * max_tn + 2u) * sizeof(SpLink)),
                  o_lf = carve((max_tn + 1u) * sizeof(SpLeaf));
@@ -1828,6 +1860,7 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
     hipLaunchKernelGGL(k_lbvh_prims, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, st, d_world, n, boxes, misc);
     const Box6* item_boxes = boxes;                      // the items' boxes (spatial splits: the references' boxes in their final order)
     const uint32_t* item_prim = nullptr;                 // ... and their triangles
+    const Box6* item_cell = nullptr;                     // ... and the cells their boxes were clipped to
     if (spatial) {
         SahSeg* segs[2] = { (SahSeg*)(tmp + o_seg0), (SahSeg*)(tmp + o_seg1) };
         int* budgets[2] = { (int*)(tmp + o_bud0), (int*)(tmp + o_bud1) };
@@ -1838,13 +1871,14 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
         uint32_t* retired = idx;                          // (the root list / scan output later)
         uint32_t* pprim = (uint32_t*)(tmp + o_pprim);
         Box6* fbox = (Box6*)(tmp + o_fbox); uint32_t* fprim = (uint32_t*)(tmp + o_fprim);
+        Box6* pcell = (Box6*)(tmp + o_pcell); Box6* fcell = (Box6*)(tmp + o_fcell);
         SpNode* tnodes = (SpNode*)(tmp + o_tn); SpRet* rets = (SpRet*)(tmp + o_ret);
         SahSeg* smalls = (SahSeg*)(tmp + o_small);
         uint32_t* counts = misc + 20;                     // [0] / [1]: open ranges of the current / next level; [2]: ranges for k_sah_small
         uint32_t* cursors = misc + 24;                    // [0] next level's buffer, [1] retired buffer, [2] nodes, [3] retired records, [4] the pool of references
         float* root_area = reinterpret_cast<float*>(misc + 30);
         hipLaunchKernelGGL(k_sah_init, dim3(2048), dim3(256), 0, st, bins, max_segs * (size_t)kSahSegWords, ids[0], seg_of[0], cap, left, right, rlo, rhi);
-        hipLaunchKernelGGL(k_sp_init, dim3(blocks), dim3(256), 0, st, ids[0], seg_of[0], pprim, n);
+        hipLaunchKernelGGL(k_sp_init, dim3(blocks), dim3(256), 0, st, ids[0], seg_of[0], pprim, pcell, n);
         {
             // the root: the one open range, node 0 of the tree of ranges
             struct { uint32_t counts[4]; uint32_t cursors[6]; } h0 = { { 1u, 0u, 0u, 0u }, { 0u, 0u, 1u, 0u, n, 0u } };
@@ -1869,7 +1903,7 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
             SP_TRY(hipMemsetAsync(cursors, 0, 4, st));
             hipLaunchKernelGGL(k_sp_alloc, dim3((n_cur + 255u) / 256u), dim3(256), 0, st, splits, counts + cur, cnt2, fill, segs[cur ^ 1], budgets[cur ^ 1], counts + (cur ^ 1),
                                cursors, tnodes, rets, leaf_max, depth_cap, ret_below, (uint32_t)max_segs, (uint32_t)max_tn);
-            hipLaunchKernelGGL(k_sp_partition, dim3(cg), dim3(256), 0, st, ids[cur], seg_of[cur], n_pos, splits, ids[cur ^ 1], seg_of[cur ^ 1], retired, fill, boxes, pprim,
+            hipLaunchKernelGGL(k_sp_partition, dim3(cg), dim3(256), 0, st, ids[cur], seg_of[cur], n_pos, splits, ids[cur ^ 1], seg_of[cur ^ 1], retired, fill, boxes, pprim, pcell,
                                d_world, cursors + 4, cap, segs[cur ^ 1], rets);
             uint32_t hc[10];
             SP_TRY(hipMemcpyAsync(hc, counts, sizeof hc, hipMemcpyDeviceToHost, st));
@@ -1937,12 +1971,12 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
         if (!small_list.empty()) SP_TRY(hipMemcpy(smalls, small_list.data(), small_list.size() * sizeof(SahSeg), hipMemcpyHostToDevice));
         const uint32_t n_small = (uint32_t)small_list.size();
         SP_TRY(hipMemcpy(counts + 2, &n_small, 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_sp_layout, dim3(n_ret < 4096u ? n_ret : 4096u), dim3(256), 0, st, rets, n_ret, retired, boxes, pprim, fbox, fprim, vals2);
+        hipLaunchKernelGGL(k_sp_layout, dim3(n_ret < 4096u ? n_ret : 4096u), dim3(256), 0, st, rets, n_ret, retired, boxes, pprim, pcell, fbox, fprim, fcell, vals2);
         const uint32_t n_l = (uint32_t)(links.size() > leaves.size() ? links.size() : leaves.size());
         hipLaunchKernelGGL(k_sp_links, dim3((n_l + 255u) / 256u), dim3(256), 0, st, d_links, (uint32_t)links.size(), d_leaves, (uint32_t)leaves.size(), left, right, pin, plf, rlo, rhi);
         n = n_refs; n_inner = (int)n - 1; blocks = (n + 255u) / 256u;
         *num_records = n;
-        item_boxes = fbox; item_prim = fprim;
+        item_boxes = fbox; item_prim = fprim; item_cell = n_refs > n_in ? fcell : nullptr;
         if (n_small != 0u)
             hipLaunchKernelGGL(k_sah_small, dim3(n_small < 4096u ? n_small : 4096u), dim3(256), 0, st, smalls, counts + 2, vals2, item_boxes, leaf_max, depth_cap,
                                left, right, pin, plf, rlo, rhi);
@@ -2046,30 +2080,39 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
     float4* blob = nullptr;
     if ((e = hipMalloc((void**)&blob, nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u)) != hipSuccess) return fail(e);     // + room for the packed nodes
     hipLaunchKernelGGL(k_lbvh_emit, dim3(blocks), dim3(256), 0, st, left, right, rlo, rhi, n_inner, leaf_max, emit, idx, item_boxes, vals2, nboxes, (MiptBvhNode*)blob);
-    hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb), d_prim_slot, item_prim);
-    if ((e = hipMemsetAsync((char*)blob + nb + tb, 0, 64, st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) { (void)hipFree(blob); return fail(e); }
+    Box6* cells = nullptr;                               // (a tree whose triangles were cut: its records' cells, kept for mipt_accel_update)
+    if (item_cell != nullptr && (e = hipMalloc((void**)&cells, (size_t)n * sizeof(Box6))) != hipSuccess) { (void)hipFree(blob); return fail(e); }
+    hipLaunchKernelGGL(k_lbvh_tris, dim3(blocks), dim3(256), 0, st, d_world, vals2, d_gflags, n, (MiptBvhTri*)((char*)blob + nb), d_prim_slot, item_prim, item_cell, cells);
+    if ((e = hipMemsetAsync((char*)blob + nb + tb, 0, 64, st)) != hipSuccess) { (void)hipFree(blob); if (cells) (void)hipFree(cells); return fail(e); }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) { (void)hipFree(blob); if (cells) (void)hipFree(cells); return fail(e); }
     (void)hipFree(tmp);
-    *d_blob = blob; *ok = true;
+    *d_blob = blob; *ok = true; *d_cells_out = reinterpret_cast<float*>(cells);
     return hipSuccess;
 }
 }  // namespace
 
 // spatial_extra > 0 (MIPT_OPT_BUILD = 4): references the level loop may add by cutting triangles at split planes, as a fraction of the
 // triangle count; ret_below: ranges of at most that many references leave the loop (and are split by objects only from there on).
-// *num_records: the triangle records of the blob (> n when triangles were cut).  An input the spatial front end gives up on is built
-// without it.
+// *num_records: the triangle records of the blob (> n when triangles were cut); *d_cells: then 6 floats per record (its own allocation, the
+// caller's to free): the cell each record's box was clipped to, which lbvh_refit cuts the moved triangles' boxes by.  An input the spatial
+// front end gives up on is built without it.
 hipError_t lbvh_build(hipStream_t st, const float* d_world, const uint32_t* d_gflags, uint32_t n, int leaf_max, int depth_cap,
                       float4** d_blob, uint32_t* num_nodes, uint32_t* depth, bool* ok, bool sah_treelets, uint32_t* d_prim_slot, bool sah_top,
-                      float spatial_extra, int ret_below, uint32_t* num_records)
+                      float spatial_extra, int ret_below, uint32_t* num_records, float** d_cells)
 {
-    uint32_t records_local = n;
+    uint32_t records_local = n; float* cells_local = nullptr;
     if (num_records == nullptr) num_records = &records_local;
+    const bool keep_cells = d_cells != nullptr;
+    if (!keep_cells) d_cells = &cells_local;
+    hipError_t e = hipSuccess;
+    bool done = false;
     if (spatial_extra > 0.0f) {
-        const hipError_t e = lbvh_build_impl(st, d_world, d_gflags, n, leaf_max, depth_cap, d_blob, num_nodes, depth, ok, sah_treelets, d_prim_slot, sah_top, spatial_extra, ret_below, num_records);
-        if (e != hipSuccess || *ok) return e;
+        e = lbvh_build_impl(st, d_world, d_gflags, n, leaf_max, depth_cap, d_blob, num_nodes, depth, ok, sah_treelets, d_prim_slot, sah_top, spatial_extra, ret_below, num_records, d_cells);
+        done = e != hipSuccess || *ok;
     }
-    return lbvh_build_impl(st, d_world, d_gflags, n, leaf_max, depth_cap, d_blob, num_nodes, depth, ok, sah_treelets, d_prim_slot, sah_top, 0.0f, ret_below, num_records);
+    if (!done) e = lbvh_build_impl(st, d_world, d_gflags, n, leaf_max, depth_cap, d_blob, num_nodes, depth, ok, sah_treelets, d_prim_slot, sah_top, 0.0f, ret_below, num_records, d_cells);
+    if (!keep_cells && cells_local) (void)hipFree(cells_local);
+    return e;
 }
 
 }  // namespace mipt

@@ -73,6 +73,7 @@ struct Accel {
     uint32_t  num_nodes4 = 0;
     uint32_t* d_mat   = nullptr;
     uint8_t*  d_height = nullptr;  // height of every node (topology only: made at build time, reused by every refit and by the BVH4 collapse)
+    float*    d_cells = nullptr;        // MIPT_OPT_BUILD = 4, triangles cut: per triangle record the cell its box was clipped to (6 floats): a refit clips to it again
     uint32_t* d_prim_slot = nullptr;    // per ORIGINAL primitive: the position of its triangle record (host builder; null: not kept) -- the Whitted any-hit kernels
                                         // re-test a candidate's triangle through it (u, v, geometry flags of a key they hold)
     uint32_t  n_prims = 0;
@@ -305,6 +306,7 @@ void free_accel(Accel* a)
     if (a->d_mat) (void)hipFree(a->d_mat);
     if (a->d_height) (void)hipFree(a->d_height);
     if (a->d_prim_slot) (void)hipFree(a->d_prim_slot);
+    if (a->d_cells) (void)hipFree(a->d_cells);
     if (a->d_inst) (void)hipFree(a->d_inst);
     if (a->d_order) (void)hipFree(a->d_order);
     delete a;
@@ -997,9 +999,11 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     uint32_t* d_slot = nullptr;                                  // primitive -> triangle record (Accel::d_prim_slot)
     if (e == hipSuccess && err == 0u) e = hipMalloc((void**)&d_slot, (size_t)n * 4u);
     uint32_t records = n;                                        // > n when triangles were cut (MIPT_OPT_BUILD = 4)
+    float* d_cells = nullptr;                                    // ... and then the records' cells
     if (e == hipSuccess && err == 0u) e = lbvh_build(nullptr, d_world, d_gf, n, ctx->lbvh_leaf, kStackEntries, &blob, &nn, &dep, &ok, ctx->lbvh_treelets != 0, d_slot, ctx->build_mode >= 2,
-                                                      ctx->build_mode == 4 ? ctx->sbvh_extra : 0.0f, ctx->split_below, &records);
+                                                      ctx->build_mode == 4 ? ctx->sbvh_extra : 0.0f, ctx->split_below, &records, &d_cells);
     if ((e != hipSuccess || err != 0u || !ok) && d_slot) { (void)hipFree(d_slot); d_slot = nullptr; }
+    if ((e != hipSuccess || err != 0u || !ok) && d_cells) { (void)hipFree(d_cells); d_cells = nullptr; }
     if (e != hipSuccess) return ctx->fail(e == hipErrorOutOfMemory ? MIPT_ERROR_OUT_OF_MEMORY : MIPT_ERROR_HIP, "device BVH build failed: %s", hipGetErrorString(e));
     if (err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
     if (!ok) {
@@ -1011,9 +1015,9 @@ static int accel_build_device(MiptContext* ctx, const MiptBuildInput* inputs, ui
     const size_t nb = (size_t)nn * sizeof(MiptBvhNode), tb = (size_t)records * sizeof(MiptBvhTri);
     a->n_prims = n; a->d_nodes = blob; a->d_tris = blob + nb / sizeof(float4); a->d_mat = d_mats;
     a->num_nodes = nn; a->num_tris = records; a->depth = dep; a->leaf_max = 4; a->builder = records > n ? 4 : (ctx->build_mode >= 2 ? 2 : 1);
-    a->d_prim_slot = d_slot;
+    a->d_prim_slot = d_slot; a->d_cells = d_cells;
     if ((e = finish_blob(ctx, a)) != hipSuccess) { free_accel(a); return ctx->fail(MIPT_ERROR_HIP, "device BVH build: %s", hipGetErrorString(e)); }
-    a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u + (size_t)n * 4u + (d_slot ? (size_t)n * 4u : 0u);   // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table + the primitive -> record table
+    a->bytes = nb + tb + 64 + 256 + 8192 + (size_t)nn * 96u + (size_t)n * 4u + (d_slot ? (size_t)n * 4u : 0u) + (d_cells ? (size_t)records * 24u : 0u);   // the whole allocation (lbvh_build sizes it like the host path) + the SBT index table + the primitive -> record table
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const unsigned long long h = ++ctx->next_handle;
     ctx->accels[h] = a;
@@ -1386,9 +1390,10 @@ int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBui
     Accel* a = find_accel(ctx, handle);
     if (!a) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "unknown traversable 0x%llx", handle);
     if (a->is_ias) return ctx->fail(MIPT_ERROR_INVALID_HANDLE, "0x%llx is an instance structure: use mipt_accel_update_instances", handle);
-    // (a tree with spatial splits -- builders 3 and 4: more records than triangles -- is refitted like any other: every record's box becomes the
-    //  box of its WHOLE moved triangle.  The tree stays a sound BVH, hit records stay exact; what the clipped references bought is gone until
-    //  the next build, as a refit of any tree keeps the topology and loses quality)
+    // (a tree with spatial splits -- builders 3 and 4: more records than triangles -- is refitted like any other.  Builder 4 keeps the CELL every
+    //  record's box was clipped to, and a record's new box is its moved triangle's box cut by that cell: the tree keeps what the cuts bought as
+    //  long as triangles stay near their places.  Builder 3 keeps no cells: every record gets the box of its WHOLE triangle -- a sound tree,
+    //  exact records, but the overlap the splits removed is back until the next build)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());                         // launches that still read the old boxes
     const auto t0 = std::chrono::steady_clock::now();
@@ -1400,7 +1405,7 @@ int mipt_accel_update(MiptContext* ctx, unsigned long long handle, const MiptBui
     if (G.e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(G.e));
     if (G.err != 0u) return ctx->fail(MIPT_ERROR_INVALID_VALUE, G.err == 1u ? "a vertex index is out of range" : "an SBT index is >= num_sbt_records");
     if (!a->d_height) return ctx->fail(MIPT_ERROR_INTERNAL, "accel_update: the traversable has no height table");
-    hipError_t e = lbvh_refit(nullptr, G.world, a->num_tris, a->d_nodes, a->num_nodes, a->d_tris, a->d_height, a->depth);       // (num_tris: the triangle RECORDS)
+    hipError_t e = lbvh_refit(nullptr, G.world, a->num_tris, a->d_nodes, a->num_nodes, a->d_tris, a->d_height, a->depth, a->d_cells);       // (num_tris: the triangle RECORDS)
     if (e == hipSuccess) e = finish_blob(ctx, a);            // the refitted boxes are fp32: round and pack them again
     if (e != hipSuccess) return ctx->fail(MIPT_ERROR_HIP, "accel_update: %s", hipGetErrorString(e));
     // an instance structure that references this mesh holds copies of its mirrors and a world box made from its old root box: it has to

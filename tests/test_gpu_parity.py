@@ -606,6 +606,14 @@ def test_accel_update_refits_to_moved_vertices(mode, monkeypatch):
     info0 = st.context.accel_info(st.gas_handle)
     assert info0["num_triangles"] > 21000 if mode in (3, 4) else info0["num_triangles"] == 20000
     d_mat = torch.from_numpy(np.ascontiguousarray(scene["mat_index"]).astype(np.int32)).cuda()
+    if mode == 4:
+        # a refit to the SAME vertices gives the builder's own boxes back: every record's box is clipped to its cell again, plane by plane
+        nodes0, tris0 = st.context.accel_export(st.gas_handle)
+        st.context.accel_update(st.gas_handle, [{"vertices": st.d_vertices.data_ptr(), "num_vertices": v.shape[0], "stride": 16, "sbt_index_offsets": d_mat.data_ptr()}])
+        nodes1, tris1 = st.context.accel_export(st.gas_handle)
+        assert np.array_equal(tris0.view(np.uint32), tris1.view(np.uint32))
+        diff = (nodes0.view(np.uint32) != nodes1.view(np.uint32)).any(1)
+        assert not diff.any(), "%d of %d nodes differ after a refit to the same vertices" % (int(diff.sum()), nodes0.shape[0])
     st.d_vertices.copy_(torch.from_numpy(v))                      # the hit-group records point at this buffer
     st.context.accel_update(st.gas_handle, [{"vertices": st.d_vertices.data_ptr(), "num_vertices": v.shape[0], "stride": 16,
                                              "sbt_index_offsets": d_mat.data_ptr()}])
