@@ -2065,7 +2065,8 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
         if ((e = fit_boxes(kh, &root_h)) != hipSuccess) return fail(e);
         if (root_h == 0u || root_h >= 255u) { (void)hipFree(tmp); *num_nodes = 0; *depth = 255u; return hipSuccess; }      // (degenerate input: the host builder takes it)
     }
-    hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit, sah_treelets, left, right, pin, item_boxes, vals2, nboxes, 1.2f);
+    hipLaunchKernelGGL(k_lbvh_flags, dim3(blocks), dim3(256), 0, st, rlo, rhi, n_inner, leaf_max, emit, sah_treelets, left, right, pin, item_boxes, vals2, nboxes,
+                       [] { const char* c = std::getenv("MIPT_BVH_NODE_COST"); return c ? (float)std::atof(c) : 1.2f; }());     // (experiments only, as in bvh_build.cpp)
     if ((e = hipcub::DeviceScan::ExclusiveSum(tmp + o_cub, scan_bytes, emit, idx, n_inner, st)) != hipSuccess) return fail(e);
     hipLaunchKernelGGL(k_lbvh_depth, dim3(blocks), dim3(256), 0, st, pin, plf, emit, (int)n, misc + 8);
     uint32_t last[2] = { 0, 0 }, dep = 0;
