@@ -378,7 +378,8 @@ void launch_mode(hipStream_t st, const TraceArgs& a, bool count, const TraceOpts
         const uint32_t g = (uint32_t)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
         // big CLOSEST-hit launches: tiles of 64 rays, one ray per lane first (k_trace_tiled_inst), when a lane's stack over both levels
         // fits its rows.  Any-hit launches keep the pool-only form (as over one-level BVHs: occlusion rays start at scattered points
-        // and the per-lane phase buys them nothing -- 151 instances: 376 against 454 us; 2 001: 762 against 692 us).
+        // and the per-lane phase buys them nothing -- 151 instances: 376 against 454 us; 2 001: 762 against 692 us in round 3; round 4, whole MeshViewer
+        // frames with the tiled form for the occlusion rays too: 150 / 500 / 1 000 / 2 000 instances 0.927 / 1.153 / 1.335 / 1.465 ms against 0.834 / 1.051 / 1.299 / 1.377).
         if (o.inst_form == 0 && MODE == 0 && a.bvh.stack4 + 1u <= (uint32_t)kTiledInstRows && n_est > cus * 512u) {
             TraceArgs b = a;
             b.tile_group = o.tile_group > 0 ? (uint32_t)o.tile_group : 0u;
