@@ -173,7 +173,8 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
 // false: nothing was launched (the pass does not qualify), the caller runs the wavefront form
 bool launch_frame1(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
                    float4* result, DeviceCounters* ctr, uint32_t n_paths, const void* common_vertices, const struct TraceOpts& o,
-                   const struct ResolveJob& resolve, const struct RaygenJob& rg, uint32_t epoch, const struct TileOrderJob& order);
+                   const struct ResolveJob& resolve, const struct RaygenJob& rg, uint32_t epoch, const struct TileOrderJob& order,
+                   const ShadowQueue* defer_to = nullptr);      // not null: the occlusion rays go to this queue (ctr->n_shadow), for the any-hit launch of the wavefront form
 // rg is allowed (the launch makes the pass's primary paths itself: no k_raygen in front of it) when the pool forms of the path kernel run
 bool tail_launch_makes_rays(const DeviceBvh& bvh, const struct TraceOpts& o);
 void launch_advance(hipStream_t st, DeviceCounters* ctr, uint32_t* host_live = nullptr);   // host_live: pinned word that receives the new live count

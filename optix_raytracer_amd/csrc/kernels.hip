@@ -1380,12 +1380,17 @@ struct Frame1Args {
     TailArgs  k;               // ShadeArgs (hit groups, frame constants, result, resolve), RaygenJob, epoch
 };
 
-template <int ROWS, int Q, int QS>      // Q: node format the closest-hit phases walk (0 fp32 / 1 packed); QS: the occlusion pool's (2: BVH4 mirror)
+// DEFER (MIPT_FRAME1 = 2): the tile wave traces and SHADES its paths, and leaves the occlusion rays to the any-hit launch of the wavefront form
+// (shadow queue, one append per tile) -- what is saved is the shade launch, the hit records and the compact path entries.  Bit-identical and
+// SLOWER too: trace + shade 0.436 ms in the tile waves against 0.318 + 0.043 as two launches (frame 0.612 against 0.518).  Not registers (path
+// state made again after the traversal, shading arguments read late: 52 bytes of scratch, none in the loop), not the queue counter (see
+// below): the shading of a tile is a chain of four or five dependent fetches (hit group, vertices, accumulator, pixel) by ONE wave that holds
+// a tile slot meanwhile, in a memory system the traversal keeps saturated -- k_shade runs the same chains 2 M wide at full occupancy.
+template <int ROWS, int Q, int QS, bool DEFER>      // Q: node format the closest-hit phases walk (0 fp32 / 1 packed); QS: the occlusion pool's (2: BVH4 mirror)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROWS <= 24 ? MIPT_TILED_WAVES : 5, ROWS <= 24 ? MIPT_TILED_WAVES : 5)))
 void k_frame1(Frame1Args f)
 {
     const TraceArgs& a = f.t;
-    const ShadeArgs& sh_a = f.k.a;
     constexpr int kPoolCap = ROWS * 64 - 384;
     __shared__ __attribute__((aligned(16))) uint32_t stk[ROWS * 64];
     unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(stk + kPoolCap);
@@ -1403,6 +1408,7 @@ void k_frame1(Frame1Args f)
     Trav T;
     T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
     uint32_t n_shadow = 0u, n_iter = 0u;
+    bool awaited = false;
     for (uint32_t k = blockIdx.x / kNumSegments;; k += waves_seg) {
         uint32_t tile = xcd * tiles_seg + k;
         if (a.tile_group != 0u) {
@@ -1432,11 +1438,10 @@ void k_frame1(Frame1Args f)
             const FrameConsts fc = rp->fc;
             const uint32_t sample = rp->sample;
             float4 ro, rd;
-            const bool valid = raygen_path<2>(fc, sample, PathQueue{}, rp->rg_seed, rp->result, ray, ro, rd, slot, seed);
-            if (valid && !(sample == 0u || fc.batch_spp != 0u)) res = rp->result[slot];           // later samples add to the accumulator
-            if (valid) { trav_init(T, ro, rd); has_ray = T.node != kSentinel; }      // (launch_frame1 refuses a BVH with xf: shading reads the ray from T)
+            uint32_t slot0 = kInvalidSlot, seed0 = 0u;
+            const bool valid0 = raygen_path<2>(fc, sample, PathQueue{}, rp->rg_seed, rp->result, ray, ro, rd, slot0, seed0);
+            if (valid0) { trav_init(T, ro, rd); has_ray = T.node != kSentinel; }      // (launch_frame1 refuses a BVH with xf: shading reads the ray from T)
         }
-        const bool valid = slot != kInvalidSlot;
         // ============================================================ closest hit: one ray per lane, then the wave's entry pool (k_trace_pool)
         while (__popcll(__ballot(!has_ray)) < steal_min) {
             for (int bi = 0; bi < a.burst_bulk; ++bi) {
@@ -1478,6 +1483,35 @@ void k_frame1(Frame1Args f)
             }
         }
         // ============================================================ shade (optixPathTracer.cu:323-413, shade_path) and the occlusion rays
+        // (the path's slot, seed and accumulator are made AGAIN here rather than held in registers across the traversal: the tile kernel
+        //  has none to spare -- 80 VGPRs at six waves per SIMD -- and held values went to scratch inside the loop)
+        if (ray < n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef const __attribute__((address_space(4))) RaygenJob* JobPtr2;
+            JobPtr2 rp = (JobPtr2)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Frame1Args, k) + offsetof(TailArgs, rg));
+            asm volatile("" : "+s"(rp));
+#else
+            const RaygenJob* rp = &f.k.rg;
+#endif
+            const FrameConsts fc = rp->fc;
+            const uint32_t sample = rp->sample;
+            float4 ro, rd;
+            slot = kInvalidSlot;
+            const bool valid2 = raygen_path<2>(fc, sample, PathQueue{}, rp->rg_seed, rp->result, ray, ro, rd, slot, seed);
+            res = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid2 && !(sample == 0u || fc.batch_spp != 0u)) res = rp->result[slot];
+        }
+        const bool valid = slot != kInvalidSlot;
+        // (the shading arguments are read from the kernel-argument segment HERE: held from the kernel's entry they cost the traversal loop its
+        //  scalar registers)
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const __attribute__((address_space(4))) ShadeArgs* ShadePtr;
+        ShadePtr sap = (ShadePtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Frame1Args, k) + offsetof(TailArgs, a));
+        asm volatile("" : "+s"(sap));
+        const ShadeArgs sh_a = *sap;
+#else
+        const ShadeArgs& sh_a = f.k.a;
+#endif
         const float4 hit = T.prim != 0xffffffffu ? make_float4(T.tbest, u2f(T.prim), T.u, T.v) : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
         ShadeOut o;
         o.push_next = false; o.push_shadow = false;
@@ -1487,6 +1521,31 @@ void k_frame1(Frame1Args f)
                              [&](float4& o4, float4& d4) { o4 = make_float4(T.o.x, T.o.y, T.o.z, 0.01f); d4 = make_float4(T.d.x, T.d.y, T.d.z, 1e16f); });
         }
         const bool sh = valid && o.push_shadow;
+        if (DEFER) {
+            // as k_shade: the path ends here; with an occlusion ray pending the any-hit launch finishes the pixel, else it is finished now
+            const unsigned long long ms = __ballot(sh);
+            uint32_t base = 0u;
+            if (ms != 0ull) {
+                // (the first workgroup's begin_sample clears the queue counter: no append before its epoch is seen)
+                if (!awaited) { tail_await_epoch(f.k.rg.ctr, f.k.epoch); awaited = true; }
+                // (6.5 k appends on one counter in 0.3 ms: not what this form waits for -- a probe build with one counter per XCD took the same 0.44 ms)
+                if (lane == 0) base = atomicAdd(&sh_a.ctr->n_shadow, (uint32_t)__popcll(ms));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            }
+            if (valid) {
+                if (sh_a.resolve.on) {
+                    if (sh) { o.sc.w = u2f(f2u(o.sc.w) | 0x80000000u); sh_a.result[slot] = res; }
+                    else resolve_pixel(sh_a.resolve, slot, res);
+                } else sh_a.result[slot] = res;
+                if (sh) {
+                    const uint32_t js = base + lane_rank(ms);
+                    sh_a.shadow.ray_o[js] = o.sro; sh_a.shadow.ray_d[js] = o.srd; sh_a.shadow.contrib[js] = o.sc;
+                }
+            }
+            if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) record_tile_cost(a, tile, cost);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            continue;
+        }
         if (__ballot(sh) != 0ull) {
             Trav S;
             trav_init(S, sh ? o.sro : make_float4(0.f, 0.f, 0.f, 1.0f), sh ? o.srd : make_float4(0.f, 0.f, 1.f, 0.0f), a.bvh.xf);
@@ -1501,8 +1560,8 @@ void k_frame1(Frame1Args f)
         if (lane == 0 && a.tile_cost != nullptr && a.n_order == tiles) record_tile_cost(a, tile, cost);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the next tile's stacks overwrite the merge slots
     }
-    tail_await_epoch(f.k.rg.ctr, f.k.epoch);
-    tail_stats(f.k.rg.ctr, 0u, n_shadow, n_iter);
+    if (!DEFER || !awaited) tail_await_epoch(f.k.rg.ctr, f.k.epoch);
+    if (!DEFER) tail_stats(f.k.rg.ctr, 0u, n_shadow, n_iter);        // (DEFER: the queue bookkeeping of the wavefront form counts the occlusion rays)
 }
 
 // the next tiled launch's order from this one's cost classes (TileOrderJob): the work of k_shade's first workgroups, for passes without a shade launch
@@ -2213,7 +2272,7 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
 // a one-bounce pass whose closest-hit launch would take the tiled form: ONE launch (k_frame1) + the order job
 bool launch_frame1(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, const MiptHitGroupData* hitgroups, uint32_t n_hitgroups,
                    float4* result, DeviceCounters* ctr, uint32_t n_paths, const void* common_vertices, const TraceOpts& o,
-                   const ResolveJob& resolve, const RaygenJob& rg, uint32_t epoch, const TileOrderJob& order)
+                   const ResolveJob& resolve, const RaygenJob& rg, uint32_t epoch, const TileOrderJob& order, const ShadowQueue* defer_to)
 {
     if (fc.max_depth != 1u || !closest_launch_is_tiled(bvh, n_paths, o) || bvh.node_fmt < 1u || bvh.xf != nullptr) return false;
     if (o.tiled_bvh4) return false;                       // (the BVH4 experiment of the tiled kernel keeps the wavefront form)
@@ -2228,17 +2287,21 @@ bool launch_frame1(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, 
     ShadeArgs& s = f.k.a;
     s.resolve = resolve; s.fc = fc; s.bvh = bvh; s.hitgroups = hitgroups; s.n_hitgroups = n_hitgroups;
     s.result = result; s.ctr = ctr; s.n_max = n_paths; s.common_vertices = common_vertices;
+    if (defer_to != nullptr) s.shadow = *defer_to;
     const uint32_t cus = (uint32_t)(o.num_cus > 0 ? o.num_cus : 256);
     unsigned long long want = ((unsigned long long)n_paths + 63ull) / 64ull;
     want = want < cus * 16ull ? cus * 16ull : (want > cus * 128ull ? cus * 128ull : want);
     const int blocks = o.blocks_user ? ((o.blocks + kNumSegments - 1) / kNumSegments * kNumSegments) : (int)((want + kNumSegments - 1) / kNumSegments * kNumSegments);
     const bool deep = bvh.depth > (uint32_t)MIPT_TILED_ROWS;
-    if (bvh.node_fmt == 2) {
-        if (!deep) hipLaunchKernelGGL((k_frame1<MIPT_TILED_ROWS, 1, 2>), dim3(blocks), dim3(64), 0, st, f);
-        else       hipLaunchKernelGGL((k_frame1<32, 1, 2>), dim3(blocks), dim3(64), 0, st, f);
+    if (defer_to != nullptr) {
+        if (!deep) hipLaunchKernelGGL((k_frame1<MIPT_TILED_ROWS, 1, 2, true>), dim3(blocks), dim3(64), 0, st, f);
+        else       hipLaunchKernelGGL((k_frame1<32, 1, 2, true>), dim3(blocks), dim3(64), 0, st, f);
+    } else if (bvh.node_fmt == 2) {
+        if (!deep) hipLaunchKernelGGL((k_frame1<MIPT_TILED_ROWS, 1, 2, false>), dim3(blocks), dim3(64), 0, st, f);
+        else       hipLaunchKernelGGL((k_frame1<32, 1, 2, false>), dim3(blocks), dim3(64), 0, st, f);
     } else {
-        if (!deep) hipLaunchKernelGGL((k_frame1<MIPT_TILED_ROWS, 1, 1>), dim3(blocks), dim3(64), 0, st, f);
-        else       hipLaunchKernelGGL((k_frame1<32, 1, 1>), dim3(blocks), dim3(64), 0, st, f);
+        if (!deep) hipLaunchKernelGGL((k_frame1<MIPT_TILED_ROWS, 1, 1, false>), dim3(blocks), dim3(64), 0, st, f);
+        else       hipLaunchKernelGGL((k_frame1<32, 1, 1, false>), dim3(blocks), dim3(64), 0, st, f);
     }
     if (order.n_chunks != 0u) hipLaunchKernelGGL(k_tile_order, dim3(order.n_chunks), dim3(kShadeBlock), 0, st, order);
     return true;

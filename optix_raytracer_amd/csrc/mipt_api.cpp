@@ -635,9 +635,17 @@ int run_wavefront(MiptContext* ctx, hipStream_t st, const FrameConsts& fc_in, co
             bool done1 = false;
             { TimedScope t(ctx, st, T_CLOSEST);
               done1 = launch_frame1(st, fc, bvh, ctx->d_hitgroups, ctx->n_hitgroups, ctx->result, ctx->d_ctr, n_paths, ctx->common_vertices, o2, rj, rg,
-                                    next_epoch(ctx), tiled_primary ? job : TileOrderJob{}); }
+                                    next_epoch(ctx), tiled_primary ? job : TileOrderJob{}, ctx->frame1 == 2 ? &ctx->sq : nullptr); }
             if (done1) {
                 if (tiled_primary && job.n_chunks != 0u) ctx->tile_order_valid = true;
+                if (ctx->frame1 == 2) {
+                    // MIPT_FRAME1 = 2: the tile waves traced and shaded; the occlusion rays they queued are the wavefront form's any-hit launch
+                    { TimedScope t(ctx, st, T_ANY);
+                      launch_trace_any(st, bvh, ctx->sq.ray_o, ctx->sq.ray_d, 1, &ctx->d_ctr->n_shadow, n_paths, nullptr, ctx->sq.contrib,
+                                       ctx->result, ctx->d_ctr, opts, rj); }
+                    if (s + 1u == passes) advance_in_resolve = true;
+                    else launch_advance(st, ctx->d_ctr, ctx->h_pinned);
+                }
                 continue;
             }
         }
@@ -785,7 +793,7 @@ int mipt_context_create(int hip_device, MiptLogCallback cb, void* cbdata, int lo
     if (const char* e = std::getenv("MIPT_LBVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) c->lbvh_leaf = v; }
     if (const char* e = std::getenv("MIPT_TAIL_REFILL")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tail_refill = v; }
     if (const char* e = std::getenv("MIPT_DIRECT_RESOLVE")) c->direct_resolve = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MIPT_FRAME1")) c->frame1 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_FRAME1")) { const int v = std::atoi(e); c->frame1 = v == 1 || v == 2 ? v : 0; }
     if (const char* e = std::getenv("MIPT_FUSE_RAYGEN")) c->fuse_raygen = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_TILE_ORDER")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->tile_order_mode = v; }
     if (const char* e = std::getenv("MIPT_TILE_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 6) c->tile_shift = v; }

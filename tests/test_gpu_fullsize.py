@@ -209,7 +209,7 @@ def test_one_bounce_pass_as_one_launch_gives_the_same_frame(monkeypatch):
     scene = scenes.random_soup(200_000, seed_tag=9)
     ns = api.shard_num_samples(1600, 900, 2)
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "2", "0"):       # (2: the tile waves trace and shade, the occlusion rays go to the wavefront form's any-hit launch)
         monkeypatch.setenv("MIPT_FRAME1", mode)
         st = PT.make_state(scene, 1600, 900, 1, 0, max_depth=1)
         ob = PT.OutputBuffer(1600, 900, st.device)
@@ -225,7 +225,7 @@ def test_one_bounce_pass_as_one_launch_gives_the_same_frame(monkeypatch):
         frames.append((shard.cpu().numpy(), None, st.context.launch_stats()))
         out[mode] = frames
         PT.cleanupState(st)
-    for (a1, f1, s1), (a0, f0, s0) in zip(out["1"], out["0"]):
+    for (a1, f1, s1), (a0, f0, s0) in list(zip(out["1"], out["0"])) + list(zip(out["2"], out["0"])):
         assert np.array_equal(a1.view(np.uint32), a0.view(np.uint32))
         assert f1 is None or np.array_equal(f1, f0)
         assert s1["closest_rays"] == s0["closest_rays"] and s1["shadow_rays"] == s0["shadow_rays"] > 10000 and s1["bounces"] == s0["bounces"]
