@@ -2090,6 +2090,7 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
     *d_blob = blob; *ok = true; *d_cells_out = reinterpret_cast<float*>(cells);
     return hipSuccess;
 }
+#undef SP_TRY
 }  // namespace
 
 // spatial_extra > 0 (MIPT_OPT_BUILD = 4): references the level loop may add by cutting triangles at split planes, as a fraction of the
