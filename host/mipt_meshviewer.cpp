@@ -5,7 +5,7 @@
 // handleCameraUpdate :235-247, launchSubframe :283-308, sutil::saveImage.  Flags as the sample: --model <file.gltf>, --file | -f,
 // --dim=WxH, --no-gl-interop (accepted, there is no GL here).  Extra flags: --subframes N, --zero-copy (CUDAOutputBufferType::
 // ZERO_COPY), --flattened / --two-level (one BVH over world-space triangles / per-mesh structures under an instance structure,
-// the reference's layout; default: two-level unless a material needs the any-hit programs).
+// the reference's layout; default: sutil::Scene's AUTO -- flattened for scenes of several instances up to 4 M triangles, else two-level).
 #include <cstdio>
 #include <cstdlib>
 #include <iomanip>

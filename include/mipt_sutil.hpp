@@ -257,13 +257,14 @@ namespace sutil {
 // loadScene parses the glTF (mipt_scene_load); finalize() does what Scene::finalize does (Scene.cpp:803-815): creates the
 // context, uploads the geometry, builds the acceleration structures -- one triangle structure per mesh plus the instance
 // structure over them (buildMeshAccels + buildInstanceAccel), or ONE structure over the flattened world-space triangles when
-// asked for (AccelMode::FLATTENED: 1.2-1.3 x faster over MANY instances at twenty times the memory; a scene of ONE instance -- most glTF files -- is
-// walked as its mesh's own BVH either way) -- and hands the Whitted programs their geometry (per-mesh
+// asked for or, by default (AccelMode::AUTO), when the scene has several instances and at most 4 M flattened triangles (FLATTENED: 1.2-1.3 x faster
+// over MANY instances at twenty times the memory; a scene of ONE instance -- most glTF files -- is walked as its mesh's own BVH either way) -- and hands the Whitted programs their geometry (per-mesh
 // object-space tables + instance records for the two-level form, as the reference's createSBT keeps them; flattened world-space
 // arrays otherwise), material and texture tables.  The programs are fixed-function kernels: pipeline() / sbt() do not exist.
 class Scene {
 public:
     enum class AccelMode { AUTO, TWO_LEVEL, FLATTENED };
+    static constexpr uint32_t kAutoFlattenTriangles = 4u << 20;        // ~0.6 GB of structure and shading tables
 
     Scene() = default;
     ~Scene() { cleanup(); }
@@ -298,7 +299,13 @@ public:
     {
         if (!m_scene) throw Exception("Scene::finalize: no scene loaded");
         createContext();
-        m_two_level = m_mode != AccelMode::FLATTENED;              // AUTO: what the reference builds
+        // AUTO.  The reference builds the instance structure for every scene (Scene.cpp:803-815).  Here a scene of ONE instance is walked as its
+        // mesh's own BVH either way, and a scene of MANY instances renders 1.2-1.3 x faster flattened, at the price of one triangle record per
+        // instance and triangle (twenty times the memory of the measured scenes) -- which a 288 GB card pays without noticing up to a few million
+        // triangles: AUTO flattens scenes of several instances whose flattened form has at most kAutoFlattenTriangles, and builds the instance
+        // structure for everything else.  TWO_LEVEL / FLATTENED pin the choice.
+        m_two_level = m_mode == AccelMode::TWO_LEVEL ||
+                      (m_mode == AccelMode::AUTO && (m_info.num_instances <= 1u || m_info.num_triangles > kAutoFlattenTriangles));
         if (m_two_level) { buildMeshAccels(); buildInstanceAccel(); createInstancedTables(); }
         else             { uploadGeometry(); buildFlattenedAccel(); createGeometryTables(); }
     }
