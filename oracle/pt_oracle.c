@@ -576,9 +576,11 @@ int orc_scene_set_bvh(OrcScene* s, const void* nodes, uint32_t n_nodes, const vo
  * depth < STACK_MAX.  Returns 0 when sound.
  * A tree with MORE triangle records than the scene has triangles was built with spatial splits (MIPT_OPT_BUILD = 3): a triangle may then
  * be referenced by several leaves, each bounding only the part of it that lies in the leaf's region -- there every primitive must
- * appear at least once and every reference's leaf box must overlap its triangle's bounds (what can be said without redoing the
- * builder's clipping; that such a tree loses no hit is what the tests check against the brute-force intersector). */
-static int validate_rec(const OrcScene* s, int32_t ref, const Box* bound, uint8_t* seen, int depth, int* maxd)
+ * appear at least once, every reference's leaf box must overlap its triangle's bounds, and the leaf boxes of a triangle's references
+ * must COVER the triangle where it is sampled: its three corners (exactly), its edge midpoints and its centroid (computed in double,
+ * compared with a relative slack of 1e-12) must each lie in the leaf box of one of its references -- what can be said without redoing
+ * the builder's clipping; that such a tree loses no hit is what the tests check against the brute-force intersector. */
+static int validate_rec(const OrcScene* s, int32_t ref, const Box* bound, uint8_t* seen, uint8_t* cover, int depth, int* maxd)
 {
     const int spatial = s->n_leaf_tris > s->n_tris;
     if (depth > *maxd) *maxd = depth;
@@ -602,6 +604,23 @@ static int validate_rec(const OrcScene* s, int32_t ref, const Box* bound, uint8_
                     const float tlo = fminf(v[k], fminf(v[4 + k], v[8 + k])), thi = fmaxf(v[k], fmaxf(v[4 + k], v[8 + k]));
                     if (thi < bound->lo[k] || tlo > bound->hi[k]) return -13;
                 }
+                if (cover) {
+                    /* sample points: corners 0..2, edge midpoints 3..5, centroid 6 */
+                    double pt[7][3];
+                    for (int k = 0; k < 3; ++k) {
+                        const double a = v[k], b = v[4 + k], c = v[8 + k];
+                        pt[0][k] = a; pt[1][k] = b; pt[2][k] = c;
+                        pt[3][k] = 0.5 * (a + b); pt[4][k] = 0.5 * (b + c); pt[5][k] = 0.5 * (c + a); pt[6][k] = (a + b + c) / 3.0;
+                    }
+                    for (int q = 0; q < 7; ++q) {
+                        int in = 1;
+                        for (int k = 0; k < 3; ++k) {
+                            const double slack = q < 3 ? 0.0 : 1e-12 * (fabs(pt[q][k]) + 1e-30);
+                            if (pt[q][k] < (double)bound->lo[k] - slack || pt[q][k] > (double)bound->hi[k] + slack) in = 0;
+                        }
+                        if (in) cover[t->prim] |= (uint8_t)(1u << q);
+                    }
+                }
             }
             for (int k = 0; k < 3; ++k) {
                 if (t->v0[k] != v[k] || t->e1[k] != v[4 + k] - v[k] || t->e2[k] != v[8 + k] - v[k]) return -14;
@@ -613,9 +632,9 @@ static int validate_rec(const OrcScene* s, int32_t ref, const Box* bound, uint8_
     const Node64* n = &s->nodes[ref];
     Box b0 = { { n->c0x[0], n->c0y[0], n->c0z[0] }, { n->c0x[1], n->c0y[1], n->c0z[1] } };
     Box b1 = { { n->c1x[0], n->c1y[0], n->c1z[0] }, { n->c1x[1], n->c1y[1], n->c1z[1] } };
-    int r = validate_rec(s, n->c0, &b0, seen, depth + 1, maxd);
+    int r = validate_rec(s, n->c0, &b0, seen, cover, depth + 1, maxd);
     if (r) return r;
-    return validate_rec(s, n->c1, &b1, seen, depth + 1, maxd);
+    return validate_rec(s, n->c1, &b1, seen, cover, depth + 1, maxd);
 }
 
 int orc_scene_validate_bvh(const OrcScene* cs)
@@ -623,11 +642,13 @@ int orc_scene_validate_bvh(const OrcScene* cs)
     OrcScene* s = (OrcScene*)cs;
     if (!s->nodes || s->n_nodes == 0) return -1;
     uint8_t* seen = (uint8_t*)calloc(s->n_tris ? s->n_tris : 1, 1);
+    uint8_t* cover = s->n_leaf_tris > s->n_tris ? (uint8_t*)calloc(s->n_tris ? s->n_tris : 1, 1) : NULL;      /* spatial splits: sample coverage */
     Box all = { { -INFINITY, -INFINITY, -INFINITY }, { INFINITY, INFINITY, INFINITY } };
     int maxd = 0;
-    int r = validate_rec(s, 0, &all, seen, 0, &maxd);
+    int r = validate_rec(s, 0, &all, seen, cover, 0, &maxd);
     if (!r) for (uint32_t i = 0; i < s->n_tris; ++i) if (!seen[i]) { r = -16; break; }
-    free(seen);
+    if (!r && cover) for (uint32_t i = 0; i < s->n_tris; ++i) if (cover[i] != 0x7fu) { r = -17; break; }
+    free(seen); free(cover);
     if (!r) s->depth = maxd;
     return r;
 }

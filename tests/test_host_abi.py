@@ -237,6 +237,33 @@ def test_spatial_split_bvh_is_sound_and_brute_force_equivalent(name, n, monkeypa
     assert np.array_equal(nodes.view(np.uint32), nodes1.view(np.uint32)) and np.array_equal(tris.view(np.uint32), tris1.view(np.uint32))
 
 
+def test_oracle_validator_rejects_a_spatial_tree_that_does_not_cover_a_triangle():
+    """the checker checks: in a tree with spatial splits the leaf boxes of a triangle's references must cover its corners, edge midpoints and
+    centroid -- a leaf box shrunk to a speck around its triangle's centroid still overlaps the triangle's bounds, and is refused"""
+    sc = scenes.random_soup(20000, edge_scale=0.05)
+    nodes, tris, info = api.host_bvh(sc["vertices"], spatial=0.5)
+    assert info["num_triangles"] > 20000
+    O.Scene(sc).set_bvh(nodes, tris)                                    # sound as built
+    refs = nodes.view(np.int32)[:, 12:14]
+    prim = tris.view(np.uint32)[:, 3]
+    for ni in range(nodes.shape[0]):
+        for side in (0, 1):
+            r = int(refs[ni, side])
+            if r < 0 and ((~r) & 15) == 1:                              # a leaf of one reference
+                first = ((~r) & 0xffffffff) >> 4
+                v = sc["vertices"][3 * prim[first]:3 * prim[first] + 3, :3].astype(np.float64)
+                c = v.mean(0)
+                bad = nodes.copy()
+                cols = ((0, 1), (2, 3), (8, 9)) if side == 0 else ((4, 5), (6, 7), (10, 11))
+                for k, (lo, hi) in enumerate(cols):
+                    bad[ni, lo], bad[ni, hi] = np.float32(c[k] - 1e-6), np.float32(c[k] + 1e-6)
+                with pytest.raises(RuntimeError) as e:
+                    O.Scene(sc).set_bvh(bad, tris)
+                assert "-17" in str(e.value)
+                return
+    raise AssertionError("no single-reference leaf found")
+
+
 def test_spatial_split_budget_is_kept():
     sc = scenes.random_soup(20000, edge_scale=0.05)
     n = sc["vertices"].shape[0] // 3
