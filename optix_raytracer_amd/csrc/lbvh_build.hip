@@ -905,7 +905,7 @@ __device__ __forceinline__ int sp_classify(const Box6& b, int k, float plane, co
 
 // the sweep of k_sah_split + the decision to cut.  One wave per open range.
 __global__ __launch_bounds__(64) void k_sp_split(const SahSeg* __restrict__ cur, const int* __restrict__ budgets, const uint32_t* __restrict__ n_cur_p, uint32_t* bins,
-                                                 SpSplit* splits, uint32_t* cnt2, int leaf_max, int depth_cap, float* root_area_p)
+                                                 SpSplit* splits, uint32_t* cnt2, int leaf_max, int depth_cap, float* root_area_p, float min_overlap)
 {
     const uint32_t s = blockIdx.x;
     if (s >= *n_cur_p) return;
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(64) void k_sp_split(const SahSeg* __restrict__ cur,
         int levels = depth_cap - sg.depth - 1 - 4 - 3;
         levels = levels < 0 ? 0 : (levels > 40 ? 40 : levels);
         const unsigned long long sp_cap = (unsigned long long)leaf_max << levels;
-        sp.cut = sp.budget > 0 && cnt > leaf_max && (unsigned long long)cnt <= sp_cap && ov_area > 1e-5f * root_area && sp.plane == sp.plane ? 1 : 0;
+        sp.cut = sp.budget > 0 && cnt > leaf_max && (unsigned long long)cnt <= sp_cap && ov_area > min_overlap * root_area && sp.plane == sp.plane ? 1 : 0;
     }
     for (int side = 0; side < 2; ++side) { sp.child[side] = kSahNone; sp.base[side] = 0u; sp.ret[side] = kSahNone; }
     splits[s] = sp;
@@ -1898,7 +1898,8 @@ hipError_t lbvh_build_impl(hipStream_t st, const float* d_world, const uint32_t*
             if (level > 96 || n_cur > max_segs) return soft_fail();
             const uint32_t chunks = (n_pos + (uint32_t)kSahChunk - 1u) / (uint32_t)kSahChunk, cg = chunks < 4096u ? chunks : 4096u;
             hipLaunchKernelGGL(k_sah_bin, dim3(cg), dim3(256), 0, st, ids[cur], seg_of[cur], segs[cur], n_pos, boxes, bins);
-            hipLaunchKernelGGL(k_sp_split, dim3(n_cur), dim3(64), 0, st, segs[cur], budgets[cur], counts + cur, bins, splits, cnt2, leaf_max, depth_cap, root_area);
+            hipLaunchKernelGGL(k_sp_split, dim3(n_cur), dim3(64), 0, st, segs[cur], budgets[cur], counts + cur, bins, splits, cnt2, leaf_max, depth_cap, root_area,
+                               [] { const char* c = std::getenv("MIPT_SPLIT_OVERLAP"); return c ? (float)std::atof(c) : 1e-5f; }());     // (experiments: build_sbvh's 1e-5 of the root's area)
             hipLaunchKernelGGL(k_sp_count, dim3(cg), dim3(256), 0, st, ids[cur], seg_of[cur], splits, n_pos, boxes, pprim, d_world, cnt2);
             SP_TRY(hipMemsetAsync(cursors, 0, 4, st));
             hipLaunchKernelGGL(k_sp_alloc, dim3((n_cur + 255u) / 256u), dim3(256), 0, st, splits, counts + cur, cnt2, fill, segs[cur ^ 1], budgets[cur ^ 1], counts + (cur ^ 1),
