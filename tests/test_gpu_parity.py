@@ -638,18 +638,20 @@ def test_accel_update_refits_to_moved_vertices(mode, monkeypatch):
     assert refit[2]["closest_rays"] == fresh[2]["closest_rays"] and refit[2]["shadow_rays"] == fresh[2]["shadow_rays"]
 
 
-def test_entry_pool_beyond_four_million_triangles():
+@pytest.mark.parametrize("builder", [1, 4])
+def test_entry_pool_beyond_four_million_triangles(builder):
     """the pool's packed entries address 2^23 triangles: a scene past the former 2^22 limit still runs on the default
-    kernels and agrees with the oracle walking the same tree"""
+    kernels and agrees with the oracle walking the same tree.  builder 4: spatial splits add records up to that limit and no further
+    (the reference budget is clipped to the index width)"""
     _torch()
     from optix_raytracer_amd import _lib as L
     from optix_raytracer_amd import pathtracer as PT
     from optix_raytracer_amd import scenes
-    n = (1 << 22) + 150_000
-    scene = scenes.random_soup(n, edge_scale=0.004)
+    n = (1 << 22) + 150_000 if builder == 1 else 6_000_000
+    scene = scenes.random_soup(n, edge_scale=0.004 if builder == 1 else 0.008)
     st = PT.PathTracerState()
     PT.createContext(st, 0)
-    st.context.set_option(L.OPT_BUILD, 1)                     # the device builder: a few ms
+    st.context.set_option(L.OPT_BUILD, builder)               # the device builders: milliseconds
     PT.buildMeshAccel(st, scene)
     PT.createSBT(st)
     w, h = 96, 64
@@ -658,7 +660,10 @@ def test_entry_pool_beyond_four_million_triangles():
     PT.handleCameraUpdate(st, PT.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovY"], 1.0))
     st.context.set_option(L.OPT_MAX_DEPTH, 2)
     info = st.context.accel_info(st.gas_handle)
-    assert info["num_triangles"] == n and info["leaf_max"] <= 4
+    if builder == 4:           # 6 M triangles ask for 3 M more references; 2^23 - 1 - 6 M are granted
+        assert n + 1_000_000 < info["num_triangles"] < (1 << 23) and info["leaf_max"] <= 4, info
+    else:
+        assert info["num_triangles"] == n and info["leaf_max"] <= 4
     acc, frame, stats = _render_gpu(PT, st)
     nodes, tris = st.context.accel_export(st.gas_handle)
     assert int(tris[:, 3].view(np.uint32).max()) == n - 1
