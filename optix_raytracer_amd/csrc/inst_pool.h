@@ -76,10 +76,14 @@ __device__ __forceinline__ RayO to_object(const u32x4 m0, const u32x4 m1, const 
 // round inside that instance reads it instead of fetching the instance's matrix (3 of the round's 7 loads) and transforming again.
 // One entry per slot, replaced on a miss; a slot whose entries alternate between instances misses on each change, no more.
 constexpr int kXrWords = 64 * 8;                           // [slot][8]: tag, o'.xyz, d'.xyz, writer
-template <int MODE, int CAP, bool CACHE = false, int AH = 0>
+// TWO (the path kernel's two-rays-per-pass form, k_tail_pool2_inst): a slot holds TWO rays -- its closest-hit ray in the owner lane's registers
+// (T) and the occlusion ray of the bounce before in LDS (sray, as k_tail_pool2 keeps it); bit 31 of an entry's .y says which one the entry
+// belongs to (instance numbers stay below 2^31).  An occlusion entry behaves as MODE 2 (first hit sets sh_done[slot]), a closest-hit
+// entry as MODE 0 (sh_best[slot]).
+template <int MODE, int CAP, bool CACHE = false, int AH = 0, bool TWO = false>
 __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blob, const DeviceBvh& bvh, uint2* stk, unsigned long long* sh_best,
                                                 float* sh_u, float* sh_v, uint32_t* sh_done, const int lane, const Trav& T, int& psize, const bool cull_back INST_STATS_PARAM,
-                                                uint32_t* xr = nullptr)
+                                                uint32_t* xr = nullptr, const float* sray = nullptr)
 {
     int k = psize < 64 ? psize : 64;
     const int room = CAP - 120 - psize;
@@ -89,6 +93,9 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
     if (have) ent = stk[psize - 1 - lane];
     psize -= k;
     uint32_t slot = ent.x & 63u;
+    const uint32_t sbit = TWO ? ent.y & 0x80000000u : 0u;      // the entry belongs to the slot's occlusion ray
+    const bool is_s = TWO && have && sbit != 0u;
+    if (TWO) ent.y &= 0x7fffffffu;
     bool dead = false;
     if (MODE != 0) {                                       // an entry of a ray found occluded in the meantime: take one more from the top
         dead = have && sh_done[slot] != 0u;
@@ -105,12 +112,29 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
     float dx = shfl_f(T.d.x, slot), dy = shfl_f(T.d.y, slot), dz = shfl_f(T.d.z, slot);
     float ix = shfl_f(T.idir.x, slot), iy = shfl_f(T.idir.y, slot), iz = shfl_f(T.idir.z, slot);
     float nx = shfl_f(T.nood.x, slot), ny = shfl_f(T.nood.y, slot), nz = shfl_f(T.nood.z, slot);
-    const float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
+    float tmn = shfl_f(T.tmin, slot), tmx = shfl_f(T.tmax, slot);
+    if (TWO) {
+        if (__ballot(is_s) != 0ull) {
+            if (is_s) {
+                ox = sray[0 * 64 + slot]; oy = sray[1 * 64 + slot]; oz = sray[2 * 64 + slot];
+                dx = sray[3 * 64 + slot]; dy = sray[4 * 64 + slot]; dz = sray[5 * 64 + slot];
+                ix = sray[6 * 64 + slot]; iy = sray[7 * 64 + slot]; iz = sray[8 * 64 + slot];
+                nx = sray[9 * 64 + slot]; ny = sray[10 * 64 + slot]; nz = sray[11 * 64 + slot];
+                tmn = sray[12 * 64 + slot]; tmx = sray[13 * 64 + slot];
+            }
+        }
+    }
     const uint32_t skp = AH != 0 ? shfl_u(T.skip, slot) : 0xffffffffu;       // continuation key of the any-hit-program kernels (Trav::skip)
     const uint32_t ahk = AH != 0 ? shfl_u(T.ahk, slot) : 1u;                 // ... and how many candidates the ray wants from this traversal
     float tcur = tmx;
     bool live = have;
-    if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[(AH != 0 && ahk > 1u ? (kAhLevels - 1) * 64 : 0) + slot] >> 32)); }      // AH: pruned at the last wanted candidate
+    if (TWO) {
+        if (have) {
+            if (is_s) { if (sh_done[slot] != 0u) live = false; }
+            else      tcur = ord_float((uint32_t)(sh_best[slot] >> 32));
+        }
+    }
+    else if (MODE == 0) { if (have) tcur = ord_float((uint32_t)(sh_best[(AH != 0 && ahk > 1u ? (kAhLevels - 1) * 64 : 0) + slot] >> 32)); }      // AH: pruned at the last wanted candidate
     else if (dead) live = false;
     const bool leaf = (ent.x >> 31) != 0u;
     const uint32_t payload = (ent.x >> 6) & 0x1ffffffu;
@@ -165,7 +189,7 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
         }
     }
     uint32_t push0 = 0u, push1 = 0u, push2 = 0u, push3 = 0u;
-    uint32_t y0 = ent.y, y1 = ent.y, y2 = ent.y, y3 = ent.y;
+    uint32_t y0 = ent.y | sbit, y1 = y0, y2 = y0, y3 = y0;
     int npush = 0;
     if (do_inner) {
         float tmn_b = tmn, tcur_b = tcur;                     // the box tests' interval (AH: a little wider, ah_box_interval; nood of the space the entry is in)
@@ -185,12 +209,12 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
                 yy[c] = kk + 1u;
             }
         }
-        if (b.n > 0) { push1 = pool_pack(ref[0], slot); y1 = yy[0]; }
-        if (b.n > 1) { push0 = pool_pack(ref[1], slot); y0 = yy[1]; }
-        if (b.n > 2) { push2 = pool_pack(ref[2], slot); y2 = yy[2]; }
-        if (b.n > 3) { push3 = pool_pack(ref[3], slot); y3 = yy[3]; }
+        if (b.n > 0) { push1 = pool_pack(ref[0], slot); y1 = yy[0] | sbit; }
+        if (b.n > 1) { push0 = pool_pack(ref[1], slot); y0 = yy[1] | sbit; }
+        if (b.n > 2) { push2 = pool_pack(ref[2], slot); y2 = yy[2] | sbit; }
+        if (b.n > 3) { push3 = pool_pack(ref[3], slot); y3 = yy[3] | sbit; }
     }
-    if (do_enter) { push1 = pool_pack((int)rec_word, slot); y1 = lfirst + 1u; npush = 1; }
+    if (do_enter) { push1 = pool_pack((int)rec_word, slot); y1 = (lfirst + 1u) | sbit; npush = 1; }
     if (do_tri) {
         const float4 n0 = make_float4(u2f(q0.x), u2f(q0.y), u2f(q0.z), u2f(q0.w)), n1 = make_float4(u2f(q1.x), u2f(q1.y), u2f(q1.z), u2f(q1.w)),
                      n2 = make_float4(u2f(q2.x), u2f(q2.y), u2f(q2.z), u2f(q2.w));
@@ -208,7 +232,7 @@ __device__ __forceinline__ void pool_round_inst(const __amdgpu_buffer_rsrc_t blo
         const bool ok = det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && (t > tmn || (AH != 0 && t == tmn && prim > skp)) && t < tmx &&
                         (!cull_back || det > 0.0f || (f2u(n1.w) & 4u) != 0u);
         bool stop = false;
-        if (MODE != 0) {
+        if (TWO ? is_s : MODE != 0) {
             if (ok) { sh_done[slot] = 1u; stop = true; }
         } else if (AH == 2 && ok && (f2u(n1.w) & 1u) != 0u) {
             // AH 2 (occlusion rays with any-hit programs): a candidate WITHOUT program ends the ray wherever it lies in the interval -- the

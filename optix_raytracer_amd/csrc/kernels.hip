@@ -1774,6 +1774,91 @@ __device__ __forceinline__ void pool_round2(const __amdgpu_buffer_rsrc_t blob, c
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
+// ---- k_tail_pool2_inst: k_tail_pool2's two rays per pass over a two-level structure (round 4) --------------------------------------------
+// The occlusion ray of bounce b and the closest-hit ray of bounce b + 1 of every path in ONE pass of the two-level pool (inst_pool.h,
+// pool_round_inst<.., TWO>: bit 31 of an entry's instance word names the slot's occlusion ray, which waits in LDS): the chain of
+// dependent pool rounds per bounce is the longer of the two traversals instead of their sum.  The accumulator receives its terms in
+// the reference's order, as in k_tail_pool2 (the light term of bounce b is added after the pass, before bounce b + 1 is shaded).  No refill.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tail_pool2_inst(TailArgs k)
+{
+    const ShadeArgs& a = k.a;
+    const uint32_t ppw = k.ppw;
+    const bool use_rg = k.rg.ctr != nullptr;
+    if (use_rg && blockIdx.x == 0u) { begin_sample(k.rg.ctr, threadIdx.x, k.rg.fc.n_paths, k.rg.n_valid, k.rg.zero_stats); tail_publish_epoch(k.rg.ctr, k.epoch); }
+    constexpr int kRows = 24, kCap = (kRows * 64 - 384) / 2;
+    __shared__ __attribute__((aligned(16))) uint2 stk2[kRows * 32 + 7 * 64];          // + the occlusion rays: 14 words per slot
+    uint32_t* const words = reinterpret_cast<uint32_t*>(stk2);
+    unsigned long long* const sh_best = reinterpret_cast<unsigned long long*>(words + 2 * kCap);
+    float* const sh_u = reinterpret_cast<float*>(words + 2 * kCap + 128);
+    float* const sh_v = reinterpret_cast<float*>(words + 2 * kCap + 192);
+    uint32_t* const sh_done = words + 2 * kCap + 320;
+    float* const sray = reinterpret_cast<float*>(words + kRows * 64);
+    const int lane = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bvh.nodes, 0, (int)a.bvh.inst_blob_bytes, 0x00020000);
+    uint32_t n = a.n_max;
+    if (!use_rg) { const uint32_t m = a.ctr->n_cur; n = m < n ? m : n; }
+    const uint32_t i = blockIdx.x * ppw + threadIdx.x;
+    uint32_t n_closest = 0, n_shadow = 0, n_iter = 0;
+    uint32_t slot = kInvalidSlot, depth = 0;
+    float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4, sa = ro4, res = ro4;
+    if (i < n && threadIdx.x < ppw) tail_load_path(k, use_rg, i, slot, depth, ro4, rd4, sa, res);
+    bool active = slot != kInvalidSlot;
+    bool has_s = false;                          // an occlusion ray of the previous bounce is waiting (in LDS)
+    float cx = 0.f, cy = 0.f, cz = 0.f;          // what it adds when nothing is in its way
+    while (__ballot(active || has_s) != 0ull) {
+        Trav T;
+        T.node = kSentinel; T.sp = 0; T.tbest = 0.0f; T.prim = 0xffffffffu; T.u = 0.0f; T.v = 0.0f;
+        T.o = mk3(0.f, 0.f, 0.f); T.d = T.o; T.idir = T.o; T.nood = T.o; T.tmin = 0.0f; T.tmax = 0.0f;
+        if (active) trav_init(T, ro4, rd4, a.bvh.xf);
+        const bool has_c = active && T.node != kSentinel;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        sh_best[lane] = ((unsigned long long)ord_bits(T.tbest + 0.0f) << 32) | 0xffffffffull;
+        sh_u[lane] = 0.0f; sh_v[lane] = 0.0f; sh_done[lane] = 0u;
+        const unsigned long long mc = __ballot(has_c), ms = __ballot(has_s);
+        if (has_c) stk2[(int)lane_rank(mc)] = make_uint2(pool_pack(0, (uint32_t)lane), 0u);
+        int psize = __popcll(mc);
+        if (has_s) stk2[psize + (int)lane_rank(ms)] = make_uint2(pool_pack(0, (uint32_t)lane), 0x80000000u);
+        psize += __popcll(ms);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        while (psize > 0) pool_round_inst<0, kCap, false, 0, true>(blob, a.bvh, stk2, sh_best, sh_u, sh_v, sh_done, lane, T, psize, false, nullptr, sray);
+        // the previous bounce's light term first: the accumulator gets its terms in the reference's order
+        if (has_s) {
+            if (sh_done[lane] == 0u) { res.x += cx; res.y += cy; res.z += cz; }      // finish_ray<2>
+            has_s = false;
+        }
+        if (active) {
+            const unsigned long long key = sh_best[lane];
+            const uint32_t prim = (uint32_t)key;
+            const float4 hit = prim != 0xffffffffu ? make_float4(ord_float((uint32_t)(key >> 32)), u2f(prim), sh_u[lane], sh_v[lane])
+                                                   : make_float4(-1.0f, u2f(0xffffffffu), 0.0f, 0.0f);
+            ShadeOut o;
+            o.push_next = false; o.push_shadow = false;
+            ++n_iter;
+            shade_path(a, hit, sa, slot, depth, res, o, [&](float4& o4, float4& d4) { o4 = ro4; d4 = rd4; });
+            if (o.push_shadow) {
+                ++n_shadow;
+                Trav S;
+                trav_init(S, o.sro, o.srd, a.bvh.xf);
+                if (S.node != kSentinel) {
+                    sray[0 * 64 + lane] = S.o.x;    sray[1 * 64 + lane] = S.o.y;     sray[2 * 64 + lane] = S.o.z;
+                    sray[3 * 64 + lane] = S.d.x;    sray[4 * 64 + lane] = S.d.y;     sray[5 * 64 + lane] = S.d.z;
+                    sray[6 * 64 + lane] = S.idir.x; sray[7 * 64 + lane] = S.idir.y;  sray[8 * 64 + lane] = S.idir.z;
+                    sray[9 * 64 + lane] = S.nood.x; sray[10 * 64 + lane] = S.nood.y; sray[11 * 64 + lane] = S.nood.z;
+                    sray[12 * 64 + lane] = S.tmin;  sray[13 * 64 + lane] = S.tmax;
+                    has_s = true; cx = o.sc.x; cy = o.sc.y; cz = o.sc.z;
+                } else {
+                    res.x += o.sc.x; res.y += o.sc.y; res.z += o.sc.z;              // an empty interval is not occluded
+                }
+            }
+            active = o.push_next;
+            if (active) { ++n_closest; ro4 = o.nro; rd4 = o.nrd; sa = o.nsa; depth = o.nsb.y; }
+        }
+    }
+    if (slot != kInvalidSlot) { if (a.resolve.on) resolve_pixel(a.resolve, slot, res); else a.result[slot] = res; }
+    if (use_rg) tail_await_epoch(a.ctr, k.epoch);
+    tail_stats(a.ctr, n_closest, n_shadow, n_iter);
+}
+
 template <int Q>
 // `refill` != 0: the launch has fewer waves than ppw-path chunks (one set of resident waves), and a wave whose paths have ended
 // takes new ones from the rest of the queue -- the survivors of a Russian-roulette pass thin out geometrically, and a wave that
@@ -2211,7 +2296,10 @@ void launch_tail(hipStream_t st, const FrameConsts& fc, const DeviceBvh& bvh, co
         uint32_t ppw = ((n_max + slots - 1u) / slots + 15u) & ~15u;
         ppw = ppw < 16u ? 16u : (ppw > 64u ? 64u : ppw);
         k.ppw = ppw;
-        hipLaunchKernelGGL(k_tail_pool_inst, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
+        // more than one bounce: two rays per pass (k_tail_pool2_inst; env MIPT_TAIL_INST2=0: the one-ray form, A/B)
+        static const int e_two = [] { const char* e = std::getenv("MIPT_TAIL_INST2"); return e ? std::atoi(e) : 1; }();
+        if (fc.max_depth != 1u && e_two) hipLaunchKernelGGL(k_tail_pool2_inst, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
+        else                             hipLaunchKernelGGL(k_tail_pool_inst, dim3((n_max + ppw - 1u) / ppw), dim3(64), 0, st, k);
         return;
     }
     // the pool variant needs a BVH that fits k_trace_pool's packed entries; MIPT_OPT_PERSISTENT != 3 selects the plain loop
